@@ -1,0 +1,27 @@
+"""Loader for tests/golden/*.npz (written by oracle/gen_golden.py from the reference build)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+import orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(path):
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    d = meta["param"]
+    prm = orc.Param(**{k: (np.float32(v) if k.startswith("pen_") else int(v)) for k, v in d.items()})
+    return dict(name=os.path.basename(path)[:-4], a=z["a"], f=z["f"], p=z["p"].astype(np.int64), u=z["u"], a_out=z["a_out"],
+                prm=prm, meta=meta)
+
+
+def all_cases(prefix=""):
+    return sorted(glob.glob(os.path.join(GOLD, prefix + "*.npz")))
+
+
+def case_ids(paths):
+    return [os.path.basename(p)[:-4] for p in paths]
