@@ -1,0 +1,133 @@
+/*
+ * mm2gb_chain.h -- C ABI of the MI355X-native chaining library (libmm2gb_chain.so).
+ *
+ * Two layers are exported:
+ *   1. the host-independent core declared here (anchors in, per-anchor score/predecessor or finished chains out);
+ *   2. the reference's own drop-in boundary (init/chain/finish/free_stream_gpu) declared in mm2gb_plutils.h.
+ *
+ * Plain C types only: pointers, sizes, PODs.  "Reference" citations are file:line in the mm2-gb checkout.
+ */
+#ifndef MM2GB_CHAIN_H
+#define MM2GB_CHAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM2GB_VERSION "0.1-mi355x"
+
+/* One anchor; bit-identical to mm128_t (minimap.h:44):
+ *   x = rev<<63 | rid<<32 | ref_pos     y = seg_id<<48 | flags<<40 | q_span<<32 | query_pos   (lchain.c:140-143) */
+typedef struct { uint64_t x, y; } mm2gb_anchor_t;
+
+/* Chaining parameter block; field order and types are those of `Misc` (gpu/plutils.h:33-37) so a Misc can be
+ * passed by pointer cast.  Values are what build_misc() (map.c:393-426) produces. */
+typedef struct {
+	int max_iter, max_dist_x, max_dist_y, max_skip, bw, min_cnt, min_score, is_cdna, n_seg;
+	float chn_pen_gap, chn_pen_skip;
+} mm2gb_misc_t;
+
+/* gpu_config.json, same schema as the reference's presets (gpu/gpu_config.json; parsed at plmem.cu:416-540).
+ * Keys that start with "//" are comments.  Unknown keys are ignored.  Fields absent from a file keep their default. */
+typedef struct {
+	int     num_streams;            /* top level */
+	int     min_n;
+	int64_t long_seg_buffer_size;
+	int64_t max_total_n;            /* may exceed INT32_MAX (plmem.cu:491 reads it as a double) */
+	int     max_read;
+	int     avg_read_n;             /* optional in the reference schema (plmem.cu:497-539) */
+	int     has_max_total_n, has_max_read, has_avg_read_n;
+	struct { int blockdim, cut_check_anchors, anchor_per_block; } range_kernel;
+	struct { int micro_batch, mid_blockdim, short_griddim, long_griddim, mid_griddim,
+	             long_seg_cutoff, mid_seg_cutoff; } score_kernel;
+} mm2gb_config_t;
+
+/* Per-call measurements (device times from HIP events on the engine's stream). */
+typedef struct {
+	int64_t n_anchors, n_reads;
+	int64_t n_pairs;            /* sum of predecessor-window sizes == the reference's "anchor pairs" (planalyze.cu:69-83) */
+	int64_t n_chunks;           /* independent DP work items found by the planner */
+	int64_t n_long_chunks;      /* of those, handled by the workgroup-cooperative LDS kernel */
+	int64_t n_tracked_chunks;   /* of those, run with the max_ii rescue state machine (lchain.c:190-205) */
+	int64_t n_clamped_blocks;   /* planner blocks containing a window cut by max_iter (lchain.c:173) */
+	float   ms_h2d, ms_prep, ms_score, ms_d2h, ms_total;
+} mm2gb_stats_t;
+
+typedef struct mm2gb_engine mm2gb_engine_t;
+
+/* ---- errors: every int-returning call gives 0 on success, negative on failure; text via mm2gb_last_error() ---- */
+const char *mm2gb_last_error(void);
+const char *mm2gb_version(void);
+
+/* ---- configuration (replaces plmem_parse_gpu_config / plmem_config_kernels / plmem_config_batch, plmem.cu:373-540) ---- */
+void mm2gb_config_defaults(mm2gb_config_t *cfg);                       /* tuned for MI355X, see mm2-gb_amd/mi355x_config.json */
+int  mm2gb_config_parse(const char *json_text, mm2gb_config_t *cfg);   /* starts from defaults */
+int  mm2gb_config_load(const char *path, mm2gb_config_t *cfg);
+
+/* ---- engine: one per (process, device); owns streams and device arenas (replaces plmem_stream_initialize,
+ *      plmem.cu:558-624, and the constant uploads plrange.cu:225-239 / plscore.cu:491-502) ---- */
+int  mm2gb_device_count(void);
+mm2gb_engine_t *mm2gb_engine_create(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);
+void mm2gb_engine_destroy(mm2gb_engine_t *eng);
+int  mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc);
+int  mm2gb_engine_device(const mm2gb_engine_t *eng);
+/* make sure arenas can take a micro-batch of this size (grows, never shrinks) */
+int  mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads);
+
+/* ---- score generation: range selection + DP (replaces plrange_async_range_selection, plscore_async_*;
+ *      call chain plchain.cu:346-461).  Reads are concatenated: read r owns anchors [offsets[r], offsets[r+1]).
+ *      f[i]  = best chain score ending at anchor i (lchain.c:202)
+ *      p[i]  = distance back to its predecessor, i - j (0 = no predecessor); int32 because the max_ii rescue
+ *              (lchain.c:196-201) can reach further than the reference GPU path's uint16 (plmem.cuh:30). ---- */
+int mm2gb_score_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                     int32_t *f, int32_t *p, mm2gb_stats_t *stats);
+/* Same, all pointers are DEVICE pointers in the engine's device; enqueued on the engine's compute stream and
+ * returns without synchronising.  Use mm2gb_engine_sync() then mm2gb_engine_stats(). */
+int mm2gb_score_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors,
+                       int64_t n_anchors, int32_t *d_f, int32_t *d_p);
+int mm2gb_engine_sync(mm2gb_engine_t *eng);
+int mm2gb_engine_stats(mm2gb_engine_t *eng, mm2gb_stats_t *stats);
+/* HIP stream handle (hipStream_t) the engine launches on -- for callers that time with their own HIP events. */
+void *mm2gb_engine_stream(mm2gb_engine_t *eng);
+/* time of the score kernels alone for the last mm2gb_score_device call (ms, valid after mm2gb_engine_sync) */
+float mm2gb_engine_last_kernel_ms(mm2gb_engine_t *eng);
+
+/* ---- full chaining of a batch on host buffers: scores on the GPU, then backtrack + compaction
+ *      (replaces plchain_cal_score_async + plchain_post_gpu_helper, plchain.cu:201-464).
+ *      Outputs are malloc'd by the library: u_off[n_reads+1] indexes u[], a_off[n_reads+1] indexes a_out[].
+ *      Free with mm2gb_free(). ---- */
+typedef struct {
+	int64_t *u_off;   uint64_t *u;            /* chains per read: score<<32 | n_anchors (lchain.c:145) */
+	int64_t *a_off;   mm2gb_anchor_t *a;      /* compacted anchors per read, chain by chain (lchain.c:78-111) */
+} mm2gb_chains_t;
+int  mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                      int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats);
+void mm2gb_chains_free(mm2gb_chains_t *out);
+
+/* ---- host post-pass on given f / relative p for ONE read (restates mg_chain_backtrack + compact_a,
+ *      lchain.c:27-111, including the radix_sort_128x order, ksort.h:98-151).  Returns number of chains;
+ *      *u_out / *a_out are malloc'd (NULL when 0).  Exposed for tests and for hosts that keep their own loop. ---- */
+int  mm2gb_backtrack_host(const mm2gb_misc_t *misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                          uint64_t **u_out, mm2gb_anchor_t **a_out);
+void mm2gb_free(void *ptr);
+
+/* ---- synchronous single-read entry with the signature of mg_lchain_dp (mmpriv.h:84-85, lchain.c:148-149):
+ *      consumes a[] (freed with the host's kfree when linked into minimap2, free() otherwise), returns the compacted
+ *      anchors and *_u allocated the same way.  max_skip is ignored: the GPU path is exhaustive (== INT32_MAX). ---- */
+mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc,
+                                float chn_pen_gap, float chn_pen_skip, int is_cdna, int n_seg, int64_t n, mm2gb_anchor_t *a,
+                                int *n_u_, uint64_t **_u, void *km);
+
+/* ---- deterministic synthetic reads for benchmarks (SURVEY 8d recipe; xorshift64* seeded per read id).
+ *      Two-call protocol: count, then fill.  len_lo/len_hi in bases. ---- */
+int64_t mm2gb_synth_count(uint64_t seed, int64_t first_read, int64_t n_reads, int len_lo, int len_hi, int64_t *offsets /* n_reads+1 */);
+int     mm2gb_synth_fill(uint64_t seed, int64_t first_read, int64_t n_reads, int len_lo, int len_hi, const int64_t *offsets,
+                         mm2gb_anchor_t *anchors, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

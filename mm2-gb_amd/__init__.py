@@ -1,0 +1,258 @@
+"""mm2-gb chaining on MI355X: thin ctypes plumbing over libmm2gb_chain.so (HIP kernels + C ABI, include/mm2gb_chain.h).
+
+The directory name carries a hyphen, so load it with
+    importlib.import_module("mm2-gb_amd")
+(or use the `mm2gb_amd` shim module at the repository root).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmm2gb_chain.so")
+INT32_MAX = 2**31 - 1
+
+
+class Misc(C.Structure):
+    """mm2gb_misc_t == Misc (gpu/plutils.h:33-37)."""
+    _fields_ = [("max_iter", C.c_int), ("max_dist_x", C.c_int), ("max_dist_y", C.c_int), ("max_skip", C.c_int),
+                ("bw", C.c_int), ("min_cnt", C.c_int), ("min_score", C.c_int), ("is_cdna", C.c_int), ("n_seg", C.c_int),
+                ("chn_pen_gap", C.c_float), ("chn_pen_skip", C.c_float)]
+
+
+class _RangeCfg(C.Structure):
+    _fields_ = [("blockdim", C.c_int), ("cut_check_anchors", C.c_int), ("anchor_per_block", C.c_int)]
+
+
+class _ScoreCfg(C.Structure):
+    _fields_ = [("micro_batch", C.c_int), ("mid_blockdim", C.c_int), ("short_griddim", C.c_int), ("long_griddim", C.c_int),
+                ("mid_griddim", C.c_int), ("long_seg_cutoff", C.c_int), ("mid_seg_cutoff", C.c_int)]
+
+
+class Config(C.Structure):
+    """mm2gb_config_t: the gpu_config.json schema (gpu/gpu_config.json)."""
+    _fields_ = [("num_streams", C.c_int), ("min_n", C.c_int), ("long_seg_buffer_size", C.c_int64), ("max_total_n", C.c_int64),
+                ("max_read", C.c_int), ("avg_read_n", C.c_int),
+                ("has_max_total_n", C.c_int), ("has_max_read", C.c_int), ("has_avg_read_n", C.c_int),
+                ("range_kernel", _RangeCfg), ("score_kernel", _ScoreCfg)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_anchors", C.c_int64), ("n_reads", C.c_int64), ("n_pairs", C.c_int64), ("n_chunks", C.c_int64),
+                ("n_long_chunks", C.c_int64), ("n_tracked_chunks", C.c_int64), ("n_clamped_blocks", C.c_int64),
+                ("ms_h2d", C.c_float), ("ms_prep", C.c_float), ("ms_score", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Chains(C.Structure):
+    _fields_ = [("u_off", C.POINTER(C.c_int64)), ("u", C.POINTER(C.c_uint64)), ("a_off", C.POINTER(C.c_int64)), ("a", C.c_void_p)]
+
+
+class Mm2gbError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/mm2gb_chain.h and include/mm2gb_plutils.h declare
+CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "mm2gb_config_parse", "mm2gb_config_load",
+                "mm2gb_device_count", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device",
+                "mm2gb_engine_reserve", "mm2gb_score_host", "mm2gb_score_device", "mm2gb_engine_sync", "mm2gb_engine_stats",
+                "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chains_free", "mm2gb_backtrack_host",
+                "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill"]
+BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
+
+
+def lib():
+    """Load libmm2gb_chain.so (built in-tree by `make -C mm2-gb_amd` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mm2gbError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (hipcc, --offload-arch=gfx950); "
+                             "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.mm2gb_last_error.restype = C.c_char_p
+        L.mm2gb_version.restype = C.c_char_p
+        L.mm2gb_config_defaults.argtypes = [C.POINTER(Config)]
+        L.mm2gb_config_defaults.restype = None
+        L.mm2gb_config_parse.argtypes = [C.c_char_p, C.POINTER(Config)]
+        L.mm2gb_config_load.argtypes = [C.c_char_p, C.POINTER(Config)]
+        L.mm2gb_engine_create.restype = C.c_void_p
+        L.mm2gb_engine_create.argtypes = [C.POINTER(Config), C.POINTER(Misc), C.c_int]
+        L.mm2gb_engine_destroy.argtypes = [C.c_void_p]
+        L.mm2gb_engine_destroy.restype = None
+        L.mm2gb_engine_set_misc.argtypes = [C.c_void_p, C.POINTER(Misc)]
+        L.mm2gb_engine_device.argtypes = [C.c_void_p]
+        L.mm2gb_engine_reserve.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.mm2gb_score_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.mm2gb_score_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mm2gb_engine_sync.argtypes = [C.c_void_p]
+        L.mm2gb_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.mm2gb_engine_stream.argtypes = [C.c_void_p]
+        L.mm2gb_engine_stream.restype = C.c_void_p
+        L.mm2gb_engine_last_kernel_ms.argtypes = [C.c_void_p]
+        L.mm2gb_engine_last_kernel_ms.restype = C.c_float
+        L.mm2gb_chain_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Chains), C.POINTER(Stats)]
+        L.mm2gb_chains_free.argtypes = [C.POINTER(Chains)]
+        L.mm2gb_chains_free.restype = None
+        L.mm2gb_backtrack_host.argtypes = [C.POINTER(Misc), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.mm2gb_free.argtypes = [C.c_void_p]
+        L.mm2gb_free.restype = None
+        L.mm2gb_lchain_dp.restype = C.c_void_p
+        L.mm2gb_lchain_dp.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                                      C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p]
+        L.mm2gb_synth_count.restype = C.c_int64
+        L.mm2gb_synth_count.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.mm2gb_synth_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise Mm2gbError(lib().mm2gb_last_error().decode())
+
+
+def default_misc(**kw):
+    """build_misc() for map-ont / no preset (map.c:393-426; options.c:24-36; k = 15)."""
+    d = dict(max_iter=5000, max_dist_x=5000, max_dist_y=5000, max_skip=INT32_MAX, bw=500, min_cnt=3, min_score=40,
+             is_cdna=0, n_seg=1, chn_pen_gap=np.float32(0.8 * 0.01 * 15), chn_pen_skip=np.float32(0.0))
+    d.update(kw)
+    return Misc(**d)
+
+
+def default_config():
+    c = Config()
+    lib().mm2gb_config_defaults(C.byref(c))
+    return c
+
+
+def parse_config(text):
+    c = Config()
+    _check(lib().mm2gb_config_parse(text.encode(), C.byref(c)))
+    return c
+
+
+def load_config(path):
+    c = Config()
+    _check(lib().mm2gb_config_load(os.fsencode(path), C.byref(c)))
+    return c
+
+
+def device_count():
+    return lib().mm2gb_device_count()
+
+
+class Engine:
+    """One chaining engine on one GPU (mm2gb_engine_t)."""
+
+    def __init__(self, misc=None, config=None, device=0):
+        L = lib()
+        self.misc = misc if misc is not None else default_misc()
+        self.config = config if config is not None else default_config()
+        self._h = L.mm2gb_engine_create(C.byref(self.config), C.byref(self.misc), device)
+        if not self._h:
+            raise Mm2gbError(L.mm2gb_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm2gb_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_misc(self, misc):
+        _check(lib().mm2gb_engine_set_misc(self._h, C.byref(misc)))
+        self.misc = misc
+
+    def score(self, anchors, offsets):
+        """Host buffers in, host buffers out.  anchors: (n,2) uint64; offsets: (R+1,) int64.
+        Returns f int32[n], p int32[n] (distance back to the predecessor, 0 = none), stats dict."""
+        a = np.ascontiguousarray(anchors, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = int(off[-1])
+        assert a.shape == (n, 2)
+        f = np.empty(n, dtype=np.int32)
+        p = np.empty(n, dtype=np.int32)
+        st = Stats()
+        _check(lib().mm2gb_score_host(self._h, len(off) - 1, off.ctypes.data, a.ctypes.data, f.ctypes.data, p.ctypes.data, C.byref(st)))
+        return f, p, st.as_dict()
+
+    def score_device(self, n_reads, d_offsets, d_anchors, n_anchors, d_f, d_p):
+        """Raw device pointers (ints); asynchronous on the engine's stream."""
+        _check(lib().mm2gb_score_device(self._h, n_reads, d_offsets, d_anchors, n_anchors, d_f, d_p))
+
+    def sync(self):
+        _check(lib().mm2gb_engine_sync(self._h))
+
+    def stats(self):
+        st = Stats()
+        _check(lib().mm2gb_engine_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def stream(self):
+        return lib().mm2gb_engine_stream(self._h)
+
+    def chain(self, anchors, offsets, threads=1):
+        """Full chaining of a batch: returns list of (u, a_out) per read plus stats."""
+        a = np.ascontiguousarray(anchors, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        R = len(off) - 1
+        out = Chains()
+        st = Stats()
+        _check(lib().mm2gb_chain_host(self._h, R, off.ctypes.data, a.ctypes.data, threads, C.byref(out), C.byref(st)))
+        try:
+            u_off = np.ctypeslib.as_array(out.u_off, shape=(R + 1,)).copy()
+            a_off = np.ctypeslib.as_array(out.a_off, shape=(R + 1,)).copy()
+            u_all = np.ctypeslib.as_array(out.u, shape=(int(u_off[-1]),)).copy() if u_off[-1] else np.zeros(0, np.uint64)
+            a_all = (np.ctypeslib.as_array(C.cast(out.a, C.POINTER(C.c_uint64)), shape=(int(a_off[-1]), 2)).copy()
+                     if a_off[-1] else np.zeros((0, 2), np.uint64))
+        finally:
+            lib().mm2gb_chains_free(C.byref(out))
+        res = [(u_all[u_off[r]:u_off[r + 1]], a_all[a_off[r]:a_off[r + 1]]) for r in range(R)]
+        return res, st.as_dict()
+
+
+def backtrack_host(misc, anchors, f, p_rel):
+    """mm2gb_backtrack_host: backtrack + compaction for one read from f / relative p."""
+    a = np.ascontiguousarray(anchors, dtype=np.uint64)
+    f = np.ascontiguousarray(f, dtype=np.int32)
+    p = np.ascontiguousarray(p_rel, dtype=np.int32)
+    u_ptr = C.c_void_p(0)
+    a_ptr = C.c_void_p(0)
+    L = lib()
+    n_u = L.mm2gb_backtrack_host(C.byref(misc), len(f), a.ctypes.data, f.ctypes.data, p.ctypes.data, C.byref(u_ptr), C.byref(a_ptr))
+    if n_u < 0:
+        raise Mm2gbError(L.mm2gb_last_error().decode())
+    if n_u == 0:
+        return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+    u = np.ctypeslib.as_array(C.cast(u_ptr, C.POINTER(C.c_uint64)), shape=(n_u,)).copy()
+    n_out = int((u & 0xffffffff).sum())
+    a_out = np.ctypeslib.as_array(C.cast(a_ptr, C.POINTER(C.c_uint64)), shape=(n_out, 2)).copy()
+    L.mm2gb_free(u_ptr)
+    L.mm2gb_free(a_ptr)
+    return u, a_out
+
+
+def synth_reads(seed, first_read, n_reads, len_lo, len_hi, threads=8):
+    """Deterministic synthetic reads.  Returns anchors (n,2) uint64 and offsets (R+1,) int64."""
+    L = lib()
+    off = np.zeros(n_reads + 1, dtype=np.int64)
+    n = L.mm2gb_synth_count(seed, first_read, n_reads, len_lo, len_hi, off.ctypes.data)
+    if n < 0:
+        raise Mm2gbError(L.mm2gb_last_error().decode())
+    a = np.empty((n, 2), dtype=np.uint64)
+    _check(L.mm2gb_synth_fill(seed, first_read, n_reads, len_lo, len_hi, off.ctypes.data, a.ctypes.data, threads))
+    return a, off

@@ -1,0 +1,72 @@
+// chain_dev.h -- internal: device-side data layout and kernel launchers of the chaining engine (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mm2gb {
+
+// Scoring constants as the kernels see them (clamps of lchain.c:160-161 already applied by the host).
+struct DevParams {
+	int   max_dist_x, max_dist_y, bw, max_iter, n_seg, is_cdna;
+	int   dq_lim;            // min(max_dist_x, max_dist_y): the single-segment fast path's dq bound
+	float gap, skip;
+};
+
+// bits of DevBatch::flags[0]
+enum : unsigned { FLAG_ANY_SEGID = 1u };
+
+// Planner granularity: anchors per planning block (one k_window workgroup).
+constexpr int PLAN_BLOCK = 1024;
+constexpr int PLAN_THREADS = 256;
+// cost charged per anchor on top of its pairs when ordering chunks (tile bookkeeping is not free)
+constexpr int COST_PER_ANCHOR = 16;
+
+// Everything one micro-batch needs in HBM.  SoA: one array per field, anchors of all reads concatenated.
+struct DevBatch {
+	// inputs
+	const uint4   *raw;        // mm128_t as 4 dwords: x.lo x.hi y.lo y.hi          16 B/anchor
+	const int64_t *offsets;    // n_reads + 1
+	int64_t        n;          // anchors
+	int64_t        n_reads;
+	// SoA (written by k_split_soa)
+	int32_t  *x;               // ref_pos  = (int32)a.x                                4 B
+	int32_t  *y;               // qry_pos  = (int32)a.y                                4 B
+	int32_t  *xhi;             // a.x >> 32 = rev<<31 | rid                            4 B
+	uint16_t *tag;             // seg_id<<8 | q_span                                   2 B
+	// range selection
+	int32_t  *st;              // first predecessor index of each anchor (lchain.c:172-173)   4 B
+	// outputs
+	int32_t  *f;               // score                                                4 B
+	int32_t  *p;               // i - predecessor, 0 = none                            4 B
+	// planner (per PLAN_BLOCK anchors)
+	int32_t  *blk_firstcut;    // smallest i in block with st[i] == i, INT32_MAX if none
+	int64_t  *blk_pairs;       // sum of window sizes in block
+	int32_t  *blk_clamped;     // 1 if any window in block was cut by max_iter
+	int64_t   n_blocks;
+	// chunks (independent runs of anchors between cuts), at most n_blocks of them
+	int32_t  *chunk_start, *chunk_end;
+	int64_t  *chunk_cost;
+	uint8_t  *chunk_track;     // needs the max_ii state machine
+	int32_t  *order;           // chunk ids, most expensive first
+	int32_t  *long_list;       // chunk ids routed to the cooperative kernel
+	// scalars
+	int32_t  *counters;        // [0] n_chunks [1] work cursor (wave kernel) [2] n_long [3] work cursor (long kernel) [4] n_tracked [5] n_clamped_blocks
+	int64_t  *totals;          // [0] total pairs
+	unsigned *flags;           // FLAG_*
+};
+enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_WORDS = 8 };
+
+struct LaunchCfg {
+	int wave_grid;       // workgroups of the wave kernel (persistent)
+	int long_grid;       // workgroups of the cooperative kernel (persistent)
+	int long_threads;    // its block size
+	int64_t long_min_cost;   // chunks at least this expensive ...
+	int     long_min_window; // ... whose mean window is at least this go to the cooperative kernel
+};
+
+void launch_split_soa(const DevBatch &b, hipStream_t s);
+void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s);
+void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s);
+void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s);
+
+} // namespace mm2gb

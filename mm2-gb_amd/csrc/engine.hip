@@ -1,0 +1,280 @@
+// engine.hip -- device arenas, stream and the per-micro-batch launch sequence.
+// Replaces plmem_stream_initialize / plmem_*_memcpy (plmem.cu:12-359, 558-641) and the kernel sequencing of
+// plchain_cal_score_async (plchain.cu:292-464) with a design that never leaves the stream between stages:
+// split -> window(+planner reductions) -> plan -> score are all enqueued back to back, no host sort, no hipMalloc per batch.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include "engine.h"
+
+namespace mm2gb {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(const std::string &msg) { g_err = msg; return -1; }
+const char *last_error_cstr() { return g_err.c_str(); }
+
+int DevBuf::ensure(size_t need)
+{
+	if (need <= bytes) return 0;
+	release();
+	MM2GB_HIP(hipMalloc(&ptr, need));
+	bytes = need;
+	return 0;
+}
+void DevBuf::release()
+{
+	if (ptr) (void)hipFree(ptr);
+	ptr = nullptr; bytes = 0;
+}
+
+int PinnedBuf::ensure(size_t need)
+{
+	if (need <= bytes) return 0;
+	release();
+	MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
+	bytes = need;
+	return 0;
+}
+void PinnedBuf::release()
+{
+	if (ptr) (void)hipHostFree(ptr);
+	ptr = nullptr; bytes = 0;
+}
+
+static DevParams make_params(const mm2gb_misc_t &m)
+{
+	DevParams P;
+	P.max_dist_x = m.max_dist_x; P.max_dist_y = m.max_dist_y; P.bw = m.bw;
+	if (P.max_dist_x < P.bw) P.max_dist_x = P.bw;                      // lchain.c:160
+	if (P.max_dist_y < P.bw && !m.is_cdna) P.max_dist_y = P.bw;        // lchain.c:161
+	P.max_iter = m.max_iter; P.n_seg = m.n_seg; P.is_cdna = m.is_cdna;
+	P.dq_lim = std::min(P.max_dist_x, P.max_dist_y);
+	P.gap = m.chn_pen_gap; P.skip = m.chn_pen_skip;
+	return P;
+}
+
+int Engine::set_misc(const mm2gb_misc_t *m)
+{
+	if (!m) return fail("mm2gb: null misc");
+	if (m->max_iter < 0 || m->bw < 0 || m->max_dist_x < 0 || m->max_dist_y < 0) return fail("mm2gb: negative chaining parameter");
+	misc = *m;
+	params = make_params(misc);
+	return 0;
+}
+
+int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
+{
+	int n_dev = 0;
+	MM2GB_HIP(hipGetDeviceCount(&n_dev));
+	if (dev < 0 || dev >= n_dev) return fail("mm2gb: device " + std::to_string(dev) + " not present (" + std::to_string(n_dev) + " visible)");
+	device = dev;
+	MM2GB_HIP(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	MM2GB_HIP(hipGetDeviceProperties(&prop, device));
+	n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	cfg = *c;
+	if (set_misc(m)) return -1;
+	// persistent grids: config values are workgroup counts, as in the reference schema (score_kernel.*_griddim)
+	launch.wave_grid = cfg.score_kernel.short_griddim > 0 ? cfg.score_kernel.short_griddim : n_cu * 8;
+	launch.long_grid = cfg.score_kernel.long_griddim > 0 ? cfg.score_kernel.long_griddim : n_cu;
+	launch.long_threads = 512;
+	launch.long_min_cost = (int64_t)1 << 62;     // cooperative kernel disabled until it exists
+	launch.long_min_window = 1 << 30;
+	MM2GB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	for (auto &e : ev) MM2GB_HIP(hipEventCreate(&e));
+	MM2GB_HIP(hipHostMalloc((void**)&h_counters, CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
+	MM2GB_HIP(hipHostMalloc((void**)&h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+	if (counters.ensure(CNT_WORDS * sizeof(int32_t)) || totals.ensure(2 * sizeof(int64_t)) || flags.ensure(4 * sizeof(unsigned))) return -1;
+	return 0;
+}
+
+void Engine::shutdown()
+{
+	(void)hipSetDevice(device);
+	if (stream) (void)hipStreamSynchronize(stream);
+	for (DevBuf *b : { &x, &y, &xhi, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &chunk_start, &chunk_end, &chunk_cost,
+	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &raw, &offsets, &f, &p })
+		b->release();
+	if (h_counters) (void)hipHostFree(h_counters);
+	if (h_totals) (void)hipHostFree(h_totals);
+	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+	if (stream) (void)hipStreamDestroy(stream);
+	stream = nullptr; h_counters = nullptr; h_totals = nullptr;
+}
+
+int Engine::reserve(int64_t n, int64_t n_reads, bool host_staging)
+{
+	MM2GB_HIP(hipSetDevice(device));
+	if (n >= ((int64_t)1 << 31) - 2 * PLAN_BLOCK) return fail("mm2gb: a micro-batch is limited to 2^31 anchors (got " + std::to_string(n) + ")");
+	if (n > cap_n || n_reads > cap_reads) {
+		// wait for anything in flight before arenas move
+		MM2GB_HIP(hipStreamSynchronize(stream));
+		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
+		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
+		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 2) || st.ensure(nn * 4)) return -1;
+		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4)) return -1;
+		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
+		    order.ensure(nb * 4) || long_list.ensure(nb * 4)) return -1;
+		cap_n = nn; cap_blocks = nb; cap_reads = std::max(cap_reads, n_reads);
+	}
+	if (host_staging) {
+		if (raw.ensure((size_t)std::max<int64_t>(n, 1) * 16) || f.ensure((size_t)std::max<int64_t>(n, 1) * 4) || p.ensure((size_t)std::max<int64_t>(n, 1) * 4) ||
+		    offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
+	}
+	return 0;
+}
+
+int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p)
+{
+	if (n < 0 || n_reads < 0) return fail("mm2gb: negative batch size");
+	if (reserve(n, n_reads, false)) return -1;
+	DevBatch b;
+	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
+	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (uint16_t*)tag.ptr; b.st = (int32_t*)st.ptr;
+	b.f = d_f; b.p = d_p;
+	b.blk_firstcut = (int32_t*)blk_firstcut.ptr; b.blk_pairs = (int64_t*)blk_pairs.ptr; b.blk_clamped = (int32_t*)blk_clamped.ptr;
+	b.n_blocks = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
+	b.chunk_start = (int32_t*)chunk_start.ptr; b.chunk_end = (int32_t*)chunk_end.ptr; b.chunk_cost = (int64_t*)chunk_cost.ptr;
+	b.chunk_track = (uint8_t*)chunk_track.ptr; b.order = (int32_t*)order.ptr; b.long_list = (int32_t*)long_list.ptr;
+	b.counters = (int32_t*)counters.ptr; b.totals = (int64_t*)totals.ptr; b.flags = (unsigned*)flags.ptr;
+
+	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
+	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 2 * sizeof(int64_t), stream));
+	MM2GB_HIP(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(unsigned), stream));
+	MM2GB_HIP(hipEventRecord(ev[1], stream));
+	if (n > 0) {
+		launch_split_soa(b, stream);
+		launch_window(b, params, stream);
+		launch_plan(b, launch, stream);
+	}
+	MM2GB_HIP(hipEventRecord(ev[2], stream));
+	if (n > 0) launch_score(b, params, launch, stream);
+	MM2GB_HIP(hipEventRecord(ev[3], stream));
+	MM2GB_HIP(hipMemcpyAsync(h_counters, counters.ptr, CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipMemcpyAsync(h_totals, totals.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipGetLastError());
+	last = mm2gb_stats_t();
+	last.n_anchors = n; last.n_reads = n_reads;
+	stats_pending = true;
+	return 0;
+}
+
+int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p)
+{
+	MM2GB_HIP(hipSetDevice(device));
+	if (reserve(n, n_reads, true)) return -1;
+	MM2GB_HIP(hipEventRecord(ev[0], stream));
+	MM2GB_HIP(hipMemcpyAsync(offsets.ptr, h_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
+	if (n > 0) MM2GB_HIP(hipMemcpyAsync(raw.ptr, h_anchors, (size_t)n * 16, hipMemcpyHostToDevice, stream));
+	if (enqueue(n_reads, (const int64_t*)offsets.ptr, (const mm2gb_anchor_t*)raw.ptr, n, (int32_t*)f.ptr, (int32_t*)p.ptr)) return -1;
+	if (n > 0) {
+		MM2GB_HIP(hipMemcpyAsync(h_f, f.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+		MM2GB_HIP(hipMemcpyAsync(h_p, p.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+	}
+	MM2GB_HIP(hipEventRecord(ev[4], stream));
+	timed_h2d = timed_d2h = true;
+	return 0;
+}
+
+int Engine::sync()
+{
+	MM2GB_HIP(hipSetDevice(device));
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	return collect_stats();
+}
+
+int Engine::collect_stats()
+{
+	if (!stats_pending) return 0;
+	stats_pending = false;
+	last.n_pairs = h_totals[0];
+	last.n_chunks = h_counters[CNT_NCHUNK];
+	last.n_long_chunks = h_counters[CNT_NLONG];
+	last.n_tracked_chunks = h_counters[CNT_NTRACK];
+	last.n_clamped_blocks = h_counters[CNT_NCLAMP];
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) last.ms_prep = ms;
+	if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) last.ms_score = ms;
+	if (timed_h2d && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) last.ms_h2d = ms;
+	if (timed_d2h && hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) last.ms_d2h = ms;
+	if (hipEventElapsedTime(&ms, timed_h2d ? ev[0] : ev[1], timed_d2h ? ev[4] : ev[3]) == hipSuccess) last.ms_total = ms;
+	timed_h2d = timed_d2h = false;
+	return 0;
+}
+
+} // namespace mm2gb
+
+using namespace mm2gb;
+
+extern "C" {
+
+const char *mm2gb_last_error(void) { return last_error_cstr(); }
+const char *mm2gb_version(void) { return MM2GB_VERSION; }
+
+int mm2gb_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+mm2gb_engine_t *mm2gb_engine_create(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device)
+{
+	mm2gb_config_t def;
+	if (!cfg) { mm2gb_config_defaults(&def); cfg = &def; }
+	if (!misc) { set_error("mm2gb_engine_create: misc is required"); return nullptr; }
+	mm2gb_engine_t *eng = new mm2gb_engine_t();
+	if (eng->e.init(cfg, misc, device)) { eng->e.shutdown(); delete eng; return nullptr; }
+	return eng;
+}
+
+void mm2gb_engine_destroy(mm2gb_engine_t *eng)
+{
+	if (!eng) return;
+	eng->e.shutdown();
+	delete eng;
+}
+
+int mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc) { return eng ? eng->e.set_misc(misc) : fail("mm2gb: null engine"); }
+int mm2gb_engine_device(const mm2gb_engine_t *eng) { return eng ? eng->e.device : -1; }
+int mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads) { return eng ? eng->e.reserve(n_anchors, n_reads, true) : fail("mm2gb: null engine"); }
+void *mm2gb_engine_stream(mm2gb_engine_t *eng) { return eng ? (void*)eng->e.stream : nullptr; }
+float mm2gb_engine_last_kernel_ms(mm2gb_engine_t *eng) { return eng ? eng->e.last.ms_prep + eng->e.last.ms_score : 0.f; }
+
+int mm2gb_score_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors,
+                       int64_t n_anchors, int32_t *d_f, int32_t *d_p)
+{
+	if (!eng) return fail("mm2gb: null engine");
+	Engine &e = eng->e;
+	MM2GB_HIP(hipSetDevice(e.device));
+	return e.enqueue(n_reads, d_offsets, d_anchors, n_anchors, d_f, d_p);
+}
+
+int mm2gb_engine_sync(mm2gb_engine_t *eng) { return eng ? eng->e.sync() : fail("mm2gb: null engine"); }
+
+int mm2gb_engine_stats(mm2gb_engine_t *eng, mm2gb_stats_t *stats)
+{
+	if (!eng || !stats) return fail("mm2gb: null argument");
+	*stats = eng->e.last;
+	return 0;
+}
+
+int mm2gb_score_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                     int32_t *f, int32_t *p, mm2gb_stats_t *stats)
+{
+	if (!eng) return fail("mm2gb: null engine");
+	if (n_reads < 0 || !offsets) return fail("mm2gb_score_host: bad offsets");
+	Engine &e = eng->e;
+	const int64_t n = offsets[n_reads];
+	if (offsets[0] != 0) return fail("mm2gb_score_host: offsets[0] must be 0");
+	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_score_host: offsets must be non-decreasing");
+	if (n > 0 && (!anchors || !f || !p)) return fail("mm2gb_score_host: null buffer");
+	if (e.enqueue_host(n_reads, offsets, anchors, n, f, p)) return -1;
+	if (e.sync()) return -1;
+	if (stats) *stats = e.last;
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,193 @@
+// host_chain.cpp -- host post-pass of the chaining path: chain extraction from (f, p) and compaction.
+// Behaviour follows mg_chain_backtrack / compact_a (lchain.c:27-111); the ordering of equal scores follows
+// radix_sort_128x (ksort.h:98-151).  Written for reuse across reads by a pool of worker threads: all temporaries live in
+// a BacktrackScratch, only u[] and the compacted a[] are allocated per read (from the host's arena when there is one).
+#include <cstdlib>
+#include <cstring>
+#include <limits.h>
+#include "host_chain.h"
+#include "engine.h"
+
+// Host allocator of minimap2 (kalloc.h:15-18).  Weak: present when linked into the reference host, absent otherwise.
+extern "C" {
+void *kmalloc(void *km, size_t size) __attribute__((weak));
+void  kfree(void *km, void *ptr) __attribute__((weak));
+}
+
+namespace mm2gb {
+
+bool host_kalloc_present() { return kmalloc != nullptr && kfree != nullptr; }
+
+void *HostAlloc::alloc(size_t bytes) const
+{
+	if (use_kalloc) return kmalloc(km, bytes);
+	return malloc(bytes ? bytes : 1);
+}
+void HostAlloc::release(void *ptr) const
+{
+	if (!ptr) return;
+	if (use_kalloc) kfree(km, ptr); else free(ptr);
+}
+
+// ---- the host's sort order --------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t SMALL_RUN = 64;   // RS_MIN_SIZE, ksort.h:98
+
+inline void insertion_run(mm2gb_anchor_t *v, size_t lo, size_t hi)   // ksort.h:105-115
+{
+	for (size_t i = lo + 1; i < hi; ++i) {
+		if (v[i].x < v[i - 1].x) {
+			const mm2gb_anchor_t hold = v[i];
+			size_t j = i;
+			while (j > lo && hold.x < v[j - 1].x) { v[j] = v[j - 1]; --j; }
+			v[j] = hold;
+		}
+	}
+}
+
+// One most-significant-byte-first pass with in-place cycle permutation, then recursion (ksort.h:116-146).
+void flag_pass(mm2gb_anchor_t *v, size_t lo, size_t hi, int shift)
+{
+	size_t head[256], tail[256], first[256];
+	size_t count[256] = { 0 };
+	for (size_t i = lo; i < hi; ++i) ++count[(v[i].x >> shift) & 255];
+	size_t at = lo;
+	for (int k = 0; k < 256; ++k) { first[k] = head[k] = at; at += count[k]; tail[k] = at; }
+	for (int k = 0; k < 256;) {
+		if (head[k] == tail[k]) { ++k; continue; }
+		int dst = (int)((v[head[k]].x >> shift) & 255);
+		if (dst == k) { ++head[k]; continue; }
+		mm2gb_anchor_t carry = v[head[k]];
+		do {
+			const mm2gb_anchor_t moved = carry;
+			carry = v[head[dst]];
+			v[head[dst]++] = moved;
+			dst = (int)((carry.x >> shift) & 255);
+		} while (dst != k);
+		v[head[k]++] = carry;
+	}
+	if (shift == 0) return;
+	const int next = shift > 8 ? shift - 8 : 0;
+	for (int k = 0; k < 256; ++k) {
+		const size_t len = tail[k] - first[k];
+		if (len > SMALL_RUN) flag_pass(v, first[k], tail[k], next);
+		else if (len > 1) insertion_run(v, first[k], tail[k]);
+	}
+}
+
+} // namespace
+
+void sort_by_x_like_host(mm2gb_anchor_t *beg, mm2gb_anchor_t *end)
+{
+	const size_t n = (size_t)(end - beg);
+	if (n <= SMALL_RUN) insertion_run(beg, 0, n);   // ksort.h:149
+	else flag_pass(beg, 0, n, 56);                   // 8 key bytes, top byte first
+}
+
+// ---- backtrack ----------------------------------------------------------------------------------------------
+namespace {
+
+inline int64_t pred_of(const int32_t *p_rel, int64_t i) { return p_rel[i] ? i - p_rel[i] : -1; }
+
+// lchain.c:9-25: walk back from the chain end k until an anchor that is taken, the start of the path, or an X-drop of
+// more than max_drop below the best prefix; returns where the kept part stops.
+int64_t kept_until(int32_t max_drop, int32_t top_score, int64_t start, const int32_t *f, const int32_t *p_rel, int32_t *mark)
+{
+	int64_t i = start, last = -1, best_i = start;
+	int32_t best = 0;
+	if (i < 0 || mark[i] != 0) return i;
+	do {
+		mark[i] = 2;
+		last = i = pred_of(p_rel, i);
+		const int32_t s = i < 0 ? top_score : top_score - f[i];
+		if (s > best) { best = s; best_i = i; }
+		else if (best - s > max_drop) break;
+	} while (i >= 0 && mark[i] == 0);
+	for (i = start; i >= 0 && i != last; i = pred_of(p_rel, i)) mark[i] = 0;   // undo the provisional marks
+	return best_i;
+}
+
+} // namespace
+
+int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                      const HostAlloc &mem, BacktrackScratch &ws, uint64_t **u_out, mm2gb_anchor_t **a_out)
+{
+	*u_out = nullptr; *a_out = nullptr;
+	if (n <= 0) return 0;
+	const int32_t min_sc = misc.min_score, min_cnt = misc.min_cnt;
+	const int32_t max_drop = misc.is_cdna ? INT_MAX : misc.bw;                 // lchain.c:151,162
+
+	// candidates: anchors scoring at least min_sc, ordered by score the way the host orders them (lchain.c:35-41)
+	ws.keyed.clear();
+	for (int64_t i = 0; i < n; ++i)
+		if (f[i] >= min_sc) ws.keyed.push_back(mm2gb_anchor_t{ (uint64_t)(int64_t)f[i], (uint64_t)i });
+	if (ws.keyed.empty()) return 0;
+	sort_by_x_like_host(ws.keyed.data(), ws.keyed.data() + ws.keyed.size());
+
+	ws.mark.assign((size_t)n, 0);
+	ws.picked.clear();
+	ws.chains.clear();
+	// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
+	for (int64_t k = (int64_t)ws.keyed.size() - 1; k >= 0; --k) {
+		const int64_t start = (int64_t)ws.keyed[k].y;
+		if (ws.mark[start] != 0) continue;
+		const int32_t top = (int32_t)ws.keyed[k].x;
+		const size_t n_before = ws.picked.size();
+		const int64_t stop = kept_until(max_drop, top, start, f, p_rel, ws.mark.data());
+		int64_t i;
+		for (i = start; i != stop; i = pred_of(p_rel, i)) { ws.picked.push_back((int32_t)i); ws.mark[i] = 1; }
+		const int32_t sc = i < 0 ? top : top - f[i];
+		const size_t cnt = ws.picked.size() - n_before;
+		if (sc >= min_sc && cnt > 0 && (int64_t)cnt >= min_cnt) ws.chains.push_back((uint64_t)sc << 32 | (uint64_t)cnt);
+		else ws.picked.resize(n_before);
+	}
+	const int n_u = (int)ws.chains.size();
+	if (n_u == 0) return 0;
+
+	// compaction (lchain.c:84-110): each chain start->end, chains ordered by the x of their first anchor
+	const size_t n_v = ws.picked.size();
+	ws.packed.resize(n_v);
+	ws.heads.resize((size_t)n_u);
+	size_t k = 0;
+	for (int c = 0; c < n_u; ++c) {
+		const size_t cnt = (size_t)(uint32_t)ws.chains[c], k0 = k;
+		for (size_t j = 0; j < cnt; ++j) ws.packed[k++] = a[ws.picked[k0 + (cnt - j - 1)]];
+		ws.heads[c].x = ws.packed[k0].x;
+		ws.heads[c].y = (uint64_t)k0 << 32 | (uint64_t)c;
+	}
+	sort_by_x_like_host(ws.heads.data(), ws.heads.data() + n_u);
+	uint64_t *u = (uint64_t*)mem.alloc((size_t)n_u * sizeof(uint64_t));
+	mm2gb_anchor_t *out = (mm2gb_anchor_t*)mem.alloc(n_v * sizeof(mm2gb_anchor_t));
+	k = 0;
+	for (int c = 0; c < n_u; ++c) {
+		const int src = (int)(uint32_t)ws.heads[c].y;
+		const size_t cnt = (size_t)(uint32_t)ws.chains[src];
+		u[c] = ws.chains[src];
+		memcpy(out + k, ws.packed.data() + (ws.heads[c].y >> 32), cnt * sizeof(mm2gb_anchor_t));
+		k += cnt;
+	}
+	*u_out = u; *a_out = out;
+	return n_u;
+}
+
+} // namespace mm2gb
+
+using namespace mm2gb;
+
+extern "C" {
+
+int mm2gb_backtrack_host(const mm2gb_misc_t *misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                         uint64_t **u_out, mm2gb_anchor_t **a_out)
+{
+	if (!misc || !u_out || !a_out || (n > 0 && (!a || !f || !p_rel))) return fail("mm2gb_backtrack_host: null argument");
+	for (int64_t i = 0; i < n; ++i)
+		if (p_rel[i] < 0 || p_rel[i] > i) return fail("mm2gb_backtrack_host: predecessor offset out of range at anchor " + std::to_string(i));
+	BacktrackScratch ws;
+	HostAlloc mem;   // libc: the caller frees with mm2gb_free
+	return backtrack_compact(*misc, n, a, f, p_rel, mem, ws, u_out, a_out);
+}
+
+void mm2gb_free(void *ptr) { free(ptr); }
+
+} // extern "C"

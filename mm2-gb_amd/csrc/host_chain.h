@@ -1,0 +1,40 @@
+// host_chain.h -- internal: host-side post-pass (backtrack + compaction) and allocator plumbing.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "../../include/mm2gb_chain.h"
+
+namespace mm2gb {
+
+// Where results that outlive the call are allocated: the host's kalloc arena when the library is linked into
+// minimap2 (kmalloc/kfree, kalloc.h:15-18), libc otherwise.
+struct HostAlloc {
+	void *km = nullptr;
+	bool use_kalloc = false;
+	void *alloc(size_t bytes) const;
+	void release(void *ptr) const;
+};
+bool host_kalloc_present();
+
+// Reusable scratch for one worker thread.
+struct BacktrackScratch {
+	std::vector<mm2gb_anchor_t> keyed;     // (score, index) pairs to sort -- the reference's z[] (lchain.c:38-41)
+	std::vector<int32_t> mark;             // the reference's t[] (lchain.c:43)
+	std::vector<int32_t> picked;           // the reference's v[] (lchain.c:65)
+	std::vector<uint64_t> chains;          // u[] before it is copied out
+	std::vector<mm2gb_anchor_t> packed;    // compaction buffer b[] (lchain.c:85)
+	std::vector<mm2gb_anchor_t> heads;     // (first x, offset<<32|chain) to order chains (lchain.c:94-99)
+};
+
+// Sort by .x exactly as radix_sort_128x does (ksort.h:98-151 instantiated at misc.c:167-168): equal keys end up in
+// that implementation's order, which decides chain priority.
+void sort_by_x_like_host(mm2gb_anchor_t *beg, mm2gb_anchor_t *end);
+
+// Backtrack (lchain.c:27-76) + compaction (lchain.c:78-111) for one read.
+// p_rel[i] = i - predecessor, 0 = none.  Returns the number of chains; *u_out / *a_out come from `mem`
+// (both NULL when there is no chain).  `a` is only read.
+int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                      const HostAlloc &mem, BacktrackScratch &ws, uint64_t **u_out, mm2gb_anchor_t **a_out);
+
+} // namespace mm2gb

@@ -1,0 +1,345 @@
+// stream_api.cpp -- batch-level host logic above the engine:
+//   * mm2gb_chain_host     : scores on the GPU, then backtrack + compaction on a pool of host threads
+//   * mm2gb_lchain_dp      : single-read entry with the mg_lchain_dp signature (mmpriv.h:84-85)
+//   * init/chain/finish/free_stream_gpu : the reference's drop-in boundary (gpu/plutils.h:98-104; plchain.cu:466-561),
+//     same deferred hand-back protocol (launch batch k, return batch k-1 finished), one engine per stream/thread id.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "../../include/mm2gb_plutils.h"
+#include "engine.h"
+#include "host_chain.h"
+
+// ---- host callbacks (map.c:393, map.c:428); weak so the library also loads without a minimap2 host ----
+extern "C" {
+mm2gb_Misc build_misc(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, const int64_t qlen_sum, const int n_seg) __attribute__((weak));
+void post_chaining_helper(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *read, mm2gb_Misc misc, void *km) __attribute__((weak));
+}
+
+namespace mm2gb {
+
+// Run fn(r, scratch) for r in [0, n) on n_threads threads, dynamic dealing.
+template <typename F>
+static void parallel_reads(int64_t n, int n_threads, F fn)
+{
+	if (n_threads < 1) n_threads = 1;
+	if (n_threads == 1 || n < 2) {
+		BacktrackScratch ws;
+		for (int64_t r = 0; r < n; ++r) fn(r, ws);
+		return;
+	}
+	std::atomic<int64_t> next(0);
+	std::vector<std::thread> pool;
+	for (int t = 0; t < n_threads; ++t)
+		pool.emplace_back([&]() {
+			BacktrackScratch ws;
+			for (;;) {
+				const int64_t r = next.fetch_add(1);
+				if (r >= n) break;
+				fn(r, ws);
+			}
+		});
+	for (auto &th : pool) th.join();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// drop-in boundary state: one slot per stream / host thread id
+// ---------------------------------------------------------------------------------------------------------------
+struct StreamSlot {
+	Engine eng;
+	bool   live = false, busy = false;
+	mm2gb_chain_read_t *reads = nullptr;   // batch in flight (owned by the host)
+	int    n_read = 0;
+	PinnedBuf h_raw, h_f, h_p, h_off;      // staging for the batch in flight (h_off: per-micro-batch offsets, each from 0)
+	std::vector<int64_t> goff;             // offsets of every read in h_raw / h_f / h_p, size n_read + 1
+	std::vector<int64_t> mb_first;         // micro-batch boundaries (read indices), size n_mb + 1
+};
+
+static struct {
+	std::vector<StreamSlot*> slots;
+	mm2gb_config_t cfg;
+	mm2gb_misc_t   misc;
+	int  post_threads = 1;
+	bool ready = false;
+} g_streams;
+
+[[noreturn]] static void die(const std::string &msg)
+{
+	fprintf(stderr, "[Error] %s\n", msg.c_str());   // the reference's style for fatal configuration problems (plmem.cu:390-412)
+	exit(1);
+}
+
+static int devices_for_streams(std::vector<int> &out)
+{
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail("no HIP device visible");
+	// MM2GB_DEVICES=0,1,2 restricts / orders the devices streams are dealt to; default: all visible devices
+	const char *env = getenv("MM2GB_DEVICES");
+	out.clear();
+	if (env && *env) {
+		for (const char *p = env; *p;) {
+			char *end; long d = strtol(p, &end, 10);
+			if (end == p) break;
+			if (d < 0 || d >= n_dev) return fail("MM2GB_DEVICES names device " + std::to_string(d) + " but only " + std::to_string(n_dev) + " are visible");
+			out.push_back((int)d);
+			p = *end == ',' ? end + 1 : end;
+		}
+	}
+	if (out.empty()) for (int d = 0; d < n_dev; ++d) out.push_back(d);
+	return 0;
+}
+
+// Finish the batch in flight on `slot`: wait, extract chains per read, hand the reads back.
+static int finish_slot(StreamSlot &slot, void *km, mm2gb_chain_read_t **reads_out, int *n_out)
+{
+	*reads_out = nullptr; *n_out = 0;
+	if (!slot.busy) return 0;
+	if (slot.eng.sync()) return -1;
+	mm2gb_chain_read_t *reads = slot.reads;
+	const int n_read = slot.n_read;
+	const int64_t *off = slot.goff.data();
+	const int32_t *f = (const int32_t*)slot.h_f.ptr, *p = (const int32_t*)slot.h_p.ptr;
+	HostAlloc mem; mem.km = km; mem.use_kalloc = host_kalloc_present();
+	const mm2gb_misc_t misc = slot.eng.misc;
+	// kalloc arenas are not thread-safe: with the host's allocator, allocation happens on this thread only
+	const int threads = mem.use_kalloc ? 1 : g_streams.post_threads;
+	parallel_reads(n_read, threads, [&](int64_t r, BacktrackScratch &ws) {
+		mm2gb_chain_read_t &rd = reads[r];
+		uint64_t *u = nullptr; mm2gb_anchor_t *a_new = nullptr;
+		const int n_u = backtrack_compact(misc, rd.n, rd.a, f + off[r], p + off[r], mem, ws, &u, &a_new);
+		mem.release(rd.a);                      // compact_a frees the oversized input (lchain.c:108-109, plchain.cu:135)
+		rd.a = a_new; rd.u = u; rd.n_u = n_u;   // a = 0 when nothing chained (plchain.cu:134-137)
+	});
+	slot.busy = false; slot.reads = nullptr; slot.n_read = 0;
+	*reads_out = reads; *n_out = n_read;
+	return 0;
+}
+
+// Launch `reads` on `slot`: pack anchors into pinned memory, enqueue one or more micro-batches, return at once.
+static int launch_slot(StreamSlot &slot, mm2gb_chain_read_t *reads, int n_read)
+{
+	int64_t total = 0;
+	for (int r = 0; r < n_read; ++r) total += reads[r].n > 0 ? reads[r].n : 0;
+	if (slot.h_raw.ensure((size_t)(total + 1) * 16) || slot.h_f.ensure((size_t)(total + 1) * 4) || slot.h_p.ensure((size_t)(total + 1) * 4)) return -1;
+	slot.goff.resize((size_t)n_read + 1);
+	int64_t *off = slot.goff.data();
+	mm2gb_anchor_t *raw = (mm2gb_anchor_t*)slot.h_raw.ptr;
+	off[0] = 0;
+	for (int r = 0; r < n_read; ++r) {
+		const int64_t n = reads[r].n > 0 ? reads[r].n : 0;
+		if (n) memcpy(raw + off[r], reads[r].a, (size_t)n * 16);
+		off[r + 1] = off[r] + n;
+	}
+	// micro-batches: greedy split so each holds at most max_total_n anchors (plchain.cu:356-366); unlike the reference
+	// nothing is ever sent back to the CPU -- a batch simply takes as many micro-batches as it needs
+	const int64_t cap = g_streams.cfg.max_total_n > 0 ? g_streams.cfg.max_total_n : total;
+	slot.mb_first.assign(1, 0);
+	int64_t acc = 0;
+	for (int r = 0; r < n_read; ++r) {
+		const int64_t n = off[r + 1] - off[r];
+		if (acc > 0 && acc + n > cap) { slot.mb_first.push_back(r); acc = 0; }
+		acc += n;
+	}
+	slot.mb_first.push_back(n_read);
+	// every micro-batch needs offsets that start at 0: build them after the global ones
+	const size_t n_mb = slot.mb_first.size() - 1;
+	if (slot.h_off.ensure(((size_t)n_read + n_mb + 1) * 8)) return -1;
+	int64_t *local_off = (int64_t*)slot.h_off.ptr;
+	size_t w = 0;
+	for (size_t m = 0; m < n_mb; ++m) {
+		const int64_t r0 = slot.mb_first[m], r1 = slot.mb_first[m + 1];
+		const size_t base = w;
+		for (int64_t r = r0; r <= r1; ++r) local_off[w++] = off[r] - off[r0];
+		const int64_t n = off[r1] - off[r0];
+		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)slot.h_f.ptr + off[r0], (int32_t*)slot.h_p.ptr + off[r0])) return -1;
+	}
+	slot.reads = reads; slot.n_read = n_read; slot.busy = true;
+	return 0;
+}
+
+static StreamSlot &slot_for(int thread_id)
+{
+	if (!g_streams.ready) die("chain_stream_gpu called before init_stream_gpu");
+	if (thread_id < 0 || thread_id >= (int)g_streams.slots.size())
+		die("thread id " + std::to_string(thread_id) + " has no GPU stream: raise num_streams in the gpu config (have " +
+		    std::to_string(g_streams.slots.size()) + ")");
+	return *g_streams.slots[thread_id];
+}
+
+// default engine for the synchronous single-read surface
+static std::mutex g_default_mu;
+static mm2gb_engine_t *g_default_engine = nullptr;
+
+} // namespace mm2gb
+
+using namespace mm2gb;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// core: whole batch, host buffers
+// ---------------------------------------------------------------------------------------------------------------
+int mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                     int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats)
+{
+	if (!eng || !out || !offsets) return fail("mm2gb_chain_host: null argument");
+	memset(out, 0, sizeof(*out));
+	const int64_t n = offsets[n_reads];
+	std::vector<int32_t> f((size_t)(n > 0 ? n : 1)), p((size_t)(n > 0 ? n : 1));
+	if (mm2gb_score_host(eng, n_reads, offsets, anchors, f.data(), p.data(), stats)) return -1;
+	std::vector<uint64_t*> u_of((size_t)n_reads, nullptr);
+	std::vector<mm2gb_anchor_t*> a_of((size_t)n_reads, nullptr);
+	std::vector<int> nu_of((size_t)n_reads, 0);
+	const mm2gb_misc_t misc = eng->e.misc;
+	HostAlloc mem;
+	parallel_reads(n_reads, n_threads, [&](int64_t r, BacktrackScratch &ws) {
+		nu_of[r] = backtrack_compact(misc, offsets[r + 1] - offsets[r], anchors + offsets[r], f.data() + offsets[r], p.data() + offsets[r],
+		                             mem, ws, &u_of[r], &a_of[r]);
+	});
+	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->u_off[0] = out->a_off[0] = 0;
+	for (int64_t r = 0; r < n_reads; ++r) {
+		int64_t na = 0;
+		for (int k = 0; k < nu_of[r]; ++k) na += (uint32_t)u_of[r][k];
+		out->u_off[r + 1] = out->u_off[r] + nu_of[r];
+		out->a_off[r + 1] = out->a_off[r] + na;
+	}
+	out->u = (uint64_t*)malloc((size_t)(out->u_off[n_reads] + 1) * 8);
+	out->a = (mm2gb_anchor_t*)malloc((size_t)(out->a_off[n_reads] + 1) * 16);
+	for (int64_t r = 0; r < n_reads; ++r) {
+		if (nu_of[r]) {
+			memcpy(out->u + out->u_off[r], u_of[r], (size_t)nu_of[r] * 8);
+			memcpy(out->a + out->a_off[r], a_of[r], (size_t)(out->a_off[r + 1] - out->a_off[r]) * 16);
+		}
+		free(u_of[r]); free(a_of[r]);
+	}
+	return 0;
+}
+
+void mm2gb_chains_free(mm2gb_chains_t *out)
+{
+	if (!out) return;
+	free(out->u_off); free(out->u); free(out->a_off); free(out->a);
+	memset(out, 0, sizeof(*out));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// core: one read, mg_lchain_dp's signature (lchain.c:148-217)
+// ---------------------------------------------------------------------------------------------------------------
+mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int max_iter, int min_cnt, int min_sc,
+                                float chn_pen_gap, float chn_pen_skip, int is_cdna, int n_seg, int64_t n, mm2gb_anchor_t *a,
+                                int *n_u_, uint64_t **_u, void *km)
+{
+	HostAlloc mem; mem.km = km; mem.use_kalloc = host_kalloc_present();
+	if (!mem.use_kalloc && km) { fprintf(stderr, "[Error] mm2gb_lchain_dp: a kalloc arena was passed but the host allocator is not linked\n"); exit(1); }
+	if (_u) *_u = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) { mem.release(a); return 0; }                       // lchain.c:156-159
+	mm2gb_misc_t misc;
+	misc.max_iter = max_iter; misc.max_dist_x = max_dist_x; misc.max_dist_y = max_dist_y; misc.max_skip = max_skip; misc.bw = bw;
+	misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.is_cdna = is_cdna; misc.n_seg = n_seg;
+	misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
+	std::lock_guard<std::mutex> lock(g_default_mu);
+	if (!g_default_engine) {
+		g_default_engine = mm2gb_engine_create(nullptr, &misc, 0);
+		if (!g_default_engine) { fprintf(stderr, "[Error] mm2gb_lchain_dp: %s\n", mm2gb_last_error()); exit(1); }
+	}
+	const int64_t off[2] = { 0, n };
+	std::vector<int32_t> f((size_t)n), p((size_t)n);
+	if (mm2gb_engine_set_misc(g_default_engine, &misc) || mm2gb_score_host(g_default_engine, 1, off, a, f.data(), p.data(), nullptr)) {
+		fprintf(stderr, "[Error] mm2gb_lchain_dp: %s\n", mm2gb_last_error()); exit(1);
+	}
+	BacktrackScratch ws;
+	uint64_t *u = nullptr; mm2gb_anchor_t *out = nullptr;
+	const int n_u = backtrack_compact(misc, n, a, f.data(), p.data(), mem, ws, &u, &out);
+	mem.release(a);                                                          // input is consumed (lchain.c:146,213,109)
+	*n_u_ = n_u; *_u = u;
+	return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the reference's boundary
+// ---------------------------------------------------------------------------------------------------------------
+void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_config_file[], mm2gb_Misc misc)
+{
+	if (g_streams.ready) free_stream_gpu((int)g_streams.slots.size());
+	if (mm2gb_config_load(gpu_config_file, &g_streams.cfg)) die(mm2gb_last_error());
+	mm2gb_config_t &cfg = g_streams.cfg;
+	if (!(cfg.has_max_total_n && cfg.has_max_read)) {
+		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's 46 B/anchor footprint
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) die("cannot query device memory");
+		const double per_anchor = 46.0 + 16.0 / 1024;
+		const double budget = (double)total_b / cfg.num_streams * 0.9 / 2;    // half: staging and outputs live beside the work arenas
+		int64_t n = (int64_t)(budget / per_anchor);
+		if (n > 2000000000LL) n = 2000000000LL;
+		cfg.max_total_n = n;
+		cfg.max_read = (int)std::min<int64_t>(n / std::max(1, cfg.avg_read_n) + 1, 2147483647LL / std::max(1, cfg.score_kernel.micro_batch));
+	}
+	g_streams.misc = misc;
+	const char *pt = getenv("MM2GB_POST_THREADS");
+	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : 1;
+	std::vector<int> devs;
+	if (devices_for_streams(devs)) die(mm2gb_last_error());
+	for (int s = 0; s < cfg.num_streams; ++s) {
+		StreamSlot *slot = new StreamSlot();
+		if (slot->eng.init(&cfg, &misc, devs[(size_t)s % devs.size()])) die(mm2gb_last_error());
+		slot->live = true;
+		g_streams.slots.push_back(slot);
+	}
+	g_streams.ready = true;
+	// what the host accumulates to (plmem.cu:616-617)
+	*max_total_n = (size_t)cfg.max_total_n * (size_t)cfg.score_kernel.micro_batch;
+	*max_reads = (int)std::min<int64_t>((int64_t)cfg.max_read * cfg.score_kernel.micro_batch, 2147483647LL);
+	*min_n = cfg.min_n;
+}
+
+void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t **in_arr_ptr, int *n_read_ptr,
+                      int thread_id, void *km)
+{
+	StreamSlot &slot = slot_for(thread_id);
+	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;   // plchain.cu:500
+	mm2gb_chain_read_t *new_reads = *in_arr_ptr;
+	const int n_new = *n_read_ptr;
+	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
+	if (finish_slot(slot, km, &done, &n_done)) die(mm2gb_last_error());          // plchain.cu:300-305
+	if (slot.eng.set_misc(&misc)) die(mm2gb_last_error());
+	if (new_reads && n_new > 0) { if (launch_slot(slot, new_reads, n_new)) die(mm2gb_last_error()); }
+	*in_arr_ptr = done; *n_read_ptr = n_done;
+	if (done && post_chaining_helper)
+		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:502-507
+}
+
+void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t **batches, int *num_reads,
+                       int num_batch, void *km)
+{
+	StreamSlot &slot = slot_for(num_batch);
+	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;
+	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
+	if (finish_slot(slot, km, &done, &n_done)) die(mm2gb_last_error());
+	if (done && post_chaining_helper)
+		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:539-541
+	*batches = done; *num_reads = n_done;
+}
+
+void free_stream_gpu(int n_threads)
+{
+	(void)n_threads;
+	for (StreamSlot *slot : g_streams.slots) {
+		if (slot->busy) (void)slot->eng.sync();
+		slot->h_raw.release(); slot->h_f.release(); slot->h_p.release(); slot->h_off.release();
+		slot->eng.shutdown();
+		delete slot;
+	}
+	g_streams.slots.clear();
+	g_streams.ready = false;
+	std::lock_guard<std::mutex> lock(g_default_mu);
+	if (g_default_engine) { mm2gb_engine_destroy(g_default_engine); g_default_engine = nullptr; }
+}
+
+} // extern "C"

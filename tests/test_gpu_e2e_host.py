@@ -1,0 +1,56 @@
+"""configs[0]/[1]: the reference's own minimap2 host (built unmodified from /root/reference with -D__AMD_SPLIT_KERNELS__,
+oracle/Makefile target `gpuhost`) running --gpu-chain on top of OUR libmm2gb_chain.so, PAF compared with the PAF the
+reference's CPU path printed for the same inputs (tests/golden/real_*_inf.paf, made with --max-chain-skip=2147483647)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "oracle", "_ref", "minimap2_gpuhost")
+GOLD = os.path.join(ROOT, "tests", "golden")
+CFG = os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json")
+PAIRS = {"mt": ("MT-human.fa", "MT-orang.fa"), "inv": ("t-inv.fa", "q-inv.fa"), "q2": ("t2.fa", "q2.fa")}
+
+needs_host = pytest.mark.skipif(not os.path.exists(HOST), reason="oracle/_ref/minimap2_gpuhost not built (needs the reference checkout at build time)")
+
+
+def run_host(tgt, qry, *extra):
+    cmd = [HOST, "-t", "1", "--gpu-chain", "--gpu-cfg", CFG, *extra, os.path.join(GOLD, "data", tgt), os.path.join(GOLD, "data", qry)]
+    r = subprocess.run(cmd, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout.decode()
+
+
+@needs_host
+@pytest.mark.parametrize("name", sorted(PAIRS))
+def test_paf_diff_empty_vs_cpu_reference(name):
+    tgt, qry = PAIRS[name]
+    want = open(os.path.join(GOLD, f"real_{name}_inf.paf")).read()
+    got = run_host(tgt, qry)
+    assert got == want
+
+
+@needs_host
+def test_paf_with_cigar_alignment_stage_downstream():
+    """-c runs the base-level alignment on the chains we hand back: the compacted a[] / u[] must be usable downstream."""
+    out = run_host("MT-human.fa", "MT-orang.fa", "-c")
+    assert "cg:Z:" in out and out.split("\t")[0] == "MT_orang"
+
+
+@needs_host
+def test_small_micro_batches_and_multiple_batches(tmp_path):
+    """Force several host batches / micro-batches: tiny max_total_n so every read is its own micro-batch."""
+    import json
+    cfg = json.load(open(CFG))
+    cfg["max_total_n"] = 1000
+    cfg["max_read"] = 1
+    cfg["score_kernel"]["micro_batch"] = 1
+    p = tmp_path / "tiny.json"
+    p.write_text(json.dumps(cfg))
+    cmd = [HOST, "-t", "1", "--gpu-chain", "--gpu-cfg", str(p), os.path.join(GOLD, "data", "t-inv.fa"), os.path.join(GOLD, "data", "q-inv.fa")]
+    r = subprocess.run(cmd, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode() == open(os.path.join(GOLD, "real_inv_inf.paf")).read()

@@ -1,0 +1,183 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed reference vectors.
+Bit-exact on every per-anchor score f[] and predecessor p[], and on chains u[] / compacted anchors."""
+import numpy as np
+import pytest
+
+import golden_io
+import orc
+import synth_cases as sc
+
+pytestmark = pytest.mark.gpu
+
+mm = pytest.importorskip("mm2gb_amd")
+
+CASES = golden_io.all_cases()
+
+
+def misc_from(prm):
+    return mm.default_misc(max_iter=prm.max_iter, max_dist_x=prm.max_dist_x, max_dist_y=prm.max_dist_y, max_skip=orc.INT32_MAX,
+                           bw=prm.bw, min_cnt=prm.min_cnt, min_score=prm.min_sc, is_cdna=prm.is_cdna, n_seg=prm.n_seg,
+                           chn_pen_gap=np.float32(prm.pen_gap), chn_pen_skip=np.float32(prm.pen_skip))
+
+
+def rel(p):
+    idx = np.arange(len(p), dtype=np.int64)
+    return np.where(p >= 0, idx - p, 0).astype(np.int32)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    with mm.Engine() as e:
+        yield e
+
+
+def check_batch(engine, a, off, prm, threads=4):
+    engine.set_misc(misc_from(prm))
+    f, p, st = engine.score(a, off)
+    fo, po, pairs = orc.chain_fill_many(a, off, prm, threads=threads)
+    po_rel = np.concatenate([rel(po[off[r]:off[r + 1]]) for r in range(len(off) - 1)]) if len(a) else np.zeros(0, np.int32)
+    bad = np.flatnonzero((f != fo) | (p != po_rel))
+    assert bad.size == 0, f"{bad.size} anchors differ, first at {bad[:5]}: gpu f/p {f[bad[:5]]}/{p[bad[:5]]} oracle {fo[bad[:5]]}/{po_rel[bad[:5]]}"
+    assert st["n_pairs"] == pairs
+    return st
+
+
+@pytest.mark.parametrize("path", CASES, ids=golden_io.case_ids(CASES))
+def test_reference_vectors(engine, path):
+    """Every committed reference vector.  Vectors recorded with a finite max_skip are re-derived with the oracle at
+    max_skip = INT32_MAX (the GPU path is exhaustive by contract); all others are compared to the reference's own f/p."""
+    g = golden_io.load(path)
+    prm = g["prm"]
+    a = g["a"]
+    off = np.array([0, len(a)], dtype=np.int64)
+    engine.set_misc(misc_from(prm))
+    f, p, st = engine.score(a, off)
+    if prm.max_skip == orc.INT32_MAX:
+        assert np.array_equal(f, g["f"]) and np.array_equal(p, rel(g["p"]))
+        res, _ = engine.chain(a, off)
+        assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
+    else:
+        prm.max_skip = orc.INT32_MAX
+        fo, po, _ = orc.chain_fill(a, prm)
+        assert np.array_equal(f, fo) and np.array_equal(p, rel(po))
+
+
+def test_multi_read_batch(engine):
+    a, off = sc.multi_read_batch(40, 3)
+    st = check_batch(engine, a, off, orc.default_param())
+    assert st["n_chunks"] >= 1 and st["n_reads"] == 40
+
+
+def test_reads_never_chain_across_each_other(engine):
+    """Two copies of one read back to back share rid/strand/positions; windows must stop at the read boundary."""
+    one = sc.read_like(15000, 5)
+    a = np.concatenate([one, one, one])
+    off = np.array([0, len(one), 2 * len(one), 3 * len(one)], dtype=np.int64)
+    check_batch(engine, a, off, orc.default_param())
+
+
+def test_empty_and_tiny_inputs(engine):
+    prm = orc.default_param()
+    engine.set_misc(misc_from(prm))
+    f, p, st = engine.score(np.zeros((0, 2), np.uint64), np.array([0], np.int64))
+    assert len(f) == 0 and st["n_pairs"] == 0
+    f, p, st = engine.score(np.zeros((0, 2), np.uint64), np.array([0, 0, 0], np.int64))      # reads without anchors
+    assert len(f) == 0
+    one = sc.noise(1, 3)
+    f, p, _ = engine.score(one, np.array([0, 1], np.int64))
+    assert f.tolist() == [15] and p.tolist() == [0]
+    # ragged: empty reads between non-empty ones
+    r = sc.read_like(4000, 9)
+    a = np.concatenate([r, r])
+    off = np.array([0, 0, len(r), len(r), len(r), 2 * len(r), 2 * len(r)], dtype=np.int64)
+    check_batch(engine, a, off, prm)
+
+
+@pytest.mark.parametrize("kw", [dict(is_cdna=1), dict(n_seg=2), dict(n_seg=2, is_cdna=1), dict(pen_skip=np.float32(0.05)),
+                                dict(bw=100, max_dist_x=50, max_dist_y=60), dict(max_iter=64), dict(max_iter=1), dict(max_dist_y=200),
+                                dict(pen_gap=np.float32(0.0)), dict(pen_gap=np.float32(1.7), pen_skip=np.float32(0.3))])
+def test_parameter_variants(engine, kw):
+    prm = orc.default_param(**kw)
+    a1 = sc.two_segments(500, 21) if kw.get("n_seg", 1) > 1 else sc.read_like(9000, 22)
+    a2 = sc.variable_span(700, 23)
+    a = np.concatenate([a1, a2])
+    off = np.array([0, len(a1), len(a)], dtype=np.int64)
+    check_batch(engine, a, off, prm)
+
+
+def test_saturated_windows_and_rescue(engine):
+    """Windows cut by max_iter and the max_ii rescue, several shapes in one batch."""
+    parts = [sc.rescue_case(n_noise=700, n_chain=40, seed=3), sc.sort_by_x(np.concatenate([sc.repeat_block(900, 31), sc.colinear(300, 32)])),
+             sc.rescue_case(n_noise=260, n_chain=80, seed=4), sc.read_like(6000, 33)]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    st = check_batch(engine, np.concatenate(parts), off, orc.default_param(max_iter=200))
+    assert st["n_tracked_chunks"] >= 1 and st["n_clamped_blocks"] >= 1
+
+
+def test_default_max_iter_repeat_block(engine):
+    a = sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 41), sc.colinear(800, 42), sc.noise(3000, 43)]))
+    st = check_batch(engine, a, np.array([0, len(a)], np.int64), orc.default_param())
+    assert st["n_tracked_chunks"] >= 1
+
+
+def test_synthetic_ont_batch_full_chain(engine):
+    """The bench workload at small scale: 24 reads of 10-100 kb; scores, then chains, against the oracle."""
+    a, off = mm.synth_reads(7, 0, 24, 10_000, 100_000)
+    prm = orc.default_param()
+    check_batch(engine, a, off, prm, threads=8)
+    res, _ = engine.chain(a, off, threads=4)
+    for r in range(len(off) - 1):
+        o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
+        assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), f"read {r}"
+
+
+def test_ultralong_reads_properties(engine):
+    """configs[3]-shaped reads (100-300 kb): oracle on a sample of reads, size-independent properties on all."""
+    a, off = mm.synth_reads(11, 0, 12, 100_000, 300_000)
+    prm = orc.default_param()
+    engine.set_misc(misc_from(prm))
+    f, p, st = engine.score(a, off)
+    # properties: f >= q_span; a predecessor is in the same read, same strand|rid, within max_dist_x, and within the window
+    span = ((a[:, 1] >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64)
+    assert np.all(f >= span)
+    idx = np.arange(len(a))
+    has = p > 0
+    j = idx - p
+    read_of = np.searchsorted(off, idx, side="right") - 1
+    assert np.all(j[has] >= off[read_of[has]])
+    assert np.all((a[idx[has], 0] >> np.uint64(32)) == (a[j[has], 0] >> np.uint64(32)))
+    assert np.all(a[idx[has], 0] - a[j[has], 0] <= 5000)
+    assert np.all(f[has] > span[has]) and np.all(f[~has] == span[~has])
+    # idempotence: same inputs, same outputs
+    f2, p2, _ = engine.score(a, off)
+    assert np.array_equal(f, f2) and np.array_equal(p, p2)
+    # oracle on three reads
+    for r in (0, 5, 11):
+        fo, po, _ = orc.chain_fill(a[off[r]:off[r + 1]], prm)
+        assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
+
+
+def test_lchain_dp_signature_entry():
+    """mm2gb_lchain_dp: same call shape as mg_lchain_dp (lchain.c:148), input consumed, outputs malloc'd."""
+    import ctypes as C
+    g = golden_io.load([p for p in CASES if p.endswith("real_mt_inf_0.npz")][0])
+    L = mm.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    a = np.ascontiguousarray(g["a"])
+    buf = libc.malloc(a.nbytes)
+    C.memmove(buf, a.ctypes.data, a.nbytes)
+    prm = g["prm"]
+    n_u = C.c_int(0)
+    u_ptr = C.c_void_p(0)
+    out = L.mm2gb_lchain_dp(prm.max_dist_x, prm.max_dist_y, prm.bw, prm.max_skip, prm.max_iter, prm.min_cnt, prm.min_sc,
+                            prm.pen_gap, prm.pen_skip, prm.is_cdna, prm.n_seg, len(a), buf, C.byref(n_u), C.byref(u_ptr), None)
+    assert n_u.value == len(g["u"])
+    u = np.ctypeslib.as_array(C.cast(u_ptr, C.POINTER(C.c_uint64)), shape=(n_u.value,)).copy()
+    a_out = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(len(g["a_out"]), 2)).copy()
+    assert np.array_equal(u, g["u"]) and np.array_equal(a_out, g["a_out"])
+    libc.free(u_ptr)
+    libc.free(out)

@@ -1,0 +1,128 @@
+"""CPU-side checks of the product library (no GPU needed): it loads, exports the declared C ABI, parses gpu_config.json
+like the reference, and its host post-pass (backtrack + compaction) reproduces the reference vectors."""
+import ctypes as C
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_io
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+mm = pytest.importorskip("mm2gb_amd")
+
+CASES = golden_io.all_cases()
+
+
+def test_library_exports_every_declared_symbol():
+    L = mm.lib()
+    declared = set()
+    for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+        for m in re.finditer(r"\b((?:mm2gb_|init_stream_gpu|chain_stream_gpu|finish_stream_gpu|free_stream_gpu)\w*)\s*\(", text):
+            declared.add(m.group(1))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert set(mm.CORE_SYMBOLS) | set(mm.BOUNDARY_SYMBOLS) <= declared | set(mm.CORE_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+    assert L.mm2gb_version().decode().startswith("0.")
+
+
+def test_misc_layout_matches_reference_struct():
+    # Misc (gpu/plutils.h:33-37): 9 ints then 2 floats = 44 bytes, passed by value across the boundary
+    assert C.sizeof(mm.Misc) == 44
+    assert mm.Misc.chn_pen_gap.offset == 36 and mm.Misc.max_iter.offset == 0 and mm.Misc.n_seg.offset == 32
+
+
+REF_GPU_DIR = "/root/reference/gpu"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_GPU_DIR), reason="reference presets only exist in the dev container")
+@pytest.mark.parametrize("name", ["gpu_config.json", "a6000_config.json", "gfx1030_config.json", "mi210_below50k_config.json",
+                                  "mi210_over50k_config.json", "orin32GB.json"])
+def test_reference_presets_load_unchanged(name):
+    cfg = mm.load_config(os.path.join(REF_GPU_DIR, name))
+    raw = json.load(open(os.path.join(REF_GPU_DIR, name)))
+    assert cfg.num_streams == raw["num_streams"] and cfg.min_n == raw["min_n"]
+    if "max_total_n" in raw:
+        assert cfg.max_total_n == raw["max_total_n"]          # may exceed INT32_MAX (plmem.cu:491)
+    for k, v in raw["score_kernel"].items():
+        if not k.startswith("//"):
+            assert getattr(cfg.score_kernel, k) == v
+    for k, v in raw["range_kernel"].items():
+        if not k.startswith("//"):
+            assert getattr(cfg.range_kernel, k) == v
+
+
+def test_shipped_mi355x_preset_and_defaults_agree():
+    cfg = mm.load_config(os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json"))
+    d = mm.default_config()
+    assert (cfg.max_total_n, cfg.max_read, cfg.score_kernel.micro_batch) == (d.max_total_n, d.max_read, d.score_kernel.micro_batch)
+    assert cfg.score_kernel.short_griddim == d.score_kernel.short_griddim
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("{", "JSON error"),
+    ('{"num_streams": 1}', "min_n"),
+    ('{"num_streams":1,"min_n":1,"max_total_n":10,"max_read":1,"range_kernel":{"blockdim":1,"cut_check_anchors":1,"anchor_per_block":1}}', "score_kernel"),
+    ('{"num_streams":1,"min_n":1,"range_kernel":{},"score_kernel":{}}', "avg_read_n"),
+    ('[1,2]', "object"),
+])
+def test_config_errors_are_loud(text, msg):
+    with pytest.raises(mm.Mm2gbError, match=msg):
+        mm.parse_config(text)
+
+
+def test_config_comment_keys_and_big_numbers():
+    cfg = mm.parse_config('{"//c":"x","num_streams":2,"min_n":7,"max_total_n":3000000000,"max_read":5,"long_seg_buffer_size":99,'
+                          '"range_kernel":{"blockdim":512,"//k":1,"cut_check_anchors":10,"anchor_per_block":32768},'
+                          '"score_kernel":{"micro_batch":3,"mid_blockdim":512,"short_griddim":1,"long_griddim":2,"mid_griddim":3,'
+                          '"long_seg_cutoff":20,"mid_seg_cutoff":3}}')
+    assert cfg.max_total_n == 3000000000 and cfg.num_streams == 2 and cfg.score_kernel.micro_batch == 3
+    assert cfg.long_seg_buffer_size == 99
+    with pytest.raises(mm.Mm2gbError, match="fail to open"):
+        mm.load_config("/nonexistent/gpu_config.json")
+
+
+@pytest.mark.parametrize("path", CASES, ids=golden_io.case_ids(CASES))
+def test_host_backtrack_matches_reference_vectors(path):
+    """mm2gb_backtrack_host (the product's own post-pass) on the reference's f/p -> the reference's chains."""
+    g = golden_io.load(path)
+    prm = g["prm"]
+    misc = mm.default_misc(bw=prm.bw, min_cnt=prm.min_cnt, min_score=prm.min_sc, is_cdna=prm.is_cdna, n_seg=prm.n_seg)
+    idx = np.arange(len(g["p"]), dtype=np.int64)
+    p_rel = np.where(g["p"] >= 0, idx - g["p"], 0).astype(np.int32)
+    u, a_out = mm.backtrack_host(misc, g["a"], g["f"], p_rel)
+    assert np.array_equal(u, g["u"]) and np.array_equal(a_out, g["a_out"])
+
+
+def test_host_backtrack_rejects_bad_predecessors():
+    misc = mm.default_misc()
+    a = np.zeros((3, 2), np.uint64)
+    with pytest.raises(mm.Mm2gbError, match="out of range"):
+        mm.backtrack_host(misc, a, np.array([50, 50, 50], np.int32), np.array([0, 2, 0], np.int32))
+
+
+def test_synth_is_deterministic_sorted_and_subsettable():
+    a, off = mm.synth_reads(5, 0, 6, 10_000, 100_000, threads=3)
+    b, off_b = mm.synth_reads(5, 0, 6, 10_000, 100_000, threads=1)
+    assert np.array_equal(a, b) and np.array_equal(off, off_b)
+    c, off_c = mm.synth_reads(5, 2, 2, 10_000, 100_000)          # reads 2..3 regenerated alone
+    assert np.array_equal(c, a[off[2]:off[4]])
+    for r in range(6):
+        x = a[off[r]:off[r + 1], 0]
+        assert np.all(x[1:] >= x[:-1])
+    assert ((a[:, 1] >> np.uint64(32)) & np.uint64(0xff) == 15).all()
+    dens = off[-1] / 6 / 55_000
+    assert 0.15 < dens < 0.6       # ~0.24 anchors/bp + repeat blocks
+
+
+def test_synth_matches_oracle_pairs_scale():
+    """The recipe is meant to give a few hundred pairs per anchor, repeats dominating."""
+    a, off = mm.synth_reads(1, 0, 4, 100_000, 300_000)
+    _, _, pairs = orc.chain_fill_many(a, off, orc.default_param(), threads=4)
+    assert 50 < pairs / off[-1] < 3000
