@@ -9,6 +9,7 @@ namespace mm2gb {
 struct DevParams {
 	int   max_dist_x, max_dist_y, bw, max_iter, n_seg, is_cdna;
 	int   dq_lim;            // min(max_dist_x, max_dist_y): the single-segment fast path's dq bound
+	int   lut_last;          // bw + 1: index of the "reject" entry of the penalty table
 	float gap, skip;
 };
 
@@ -53,20 +54,25 @@ struct DevBatch {
 	int32_t  *counters;        // [0] n_chunks [1] work cursor (wave kernel) [2] n_long [3] work cursor (long kernel) [4] n_tracked [5] n_clamped_blocks
 	int64_t  *totals;          // [0] total pairs
 	unsigned *flags;           // FLAG_*
+	const int32_t *lut;        // penalty by dd, lut_last + 1 entries (MODE_LUT only)
 };
 enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_WORDS = 8 };
 
 struct LaunchCfg {
-	int wave_grid;       // workgroups of the wave kernel (persistent)
-	int long_grid;       // workgroups of the cooperative kernel (persistent)
-	int long_threads;    // its block size
+	int score_grid;          // persistent 1024-thread workgroups of k_score
+	int host_mode;           // MODE_* the host's parameters allow (the device may still fall back to MODE_GENERAL)
+	int ring_mask;           // LDS ring of the cooperative mode holds ring_mask+1 scores; -1 = cooperative mode off
 	int64_t long_min_cost;   // chunks at least this expensive ...
-	int     long_min_window; // ... whose mean window is at least this go to the cooperative kernel
+	int     long_min_window; // ... whose mean window is at least this are scored cooperatively
 };
 
 void launch_split_soa(const DevBatch &b, hipStream_t s);
 void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s);
 void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s);
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s);
+void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s);
+size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask);
+int  score_set_lds_limit(size_t bytes);     // hipFuncSetAttribute on every k_score instance
+enum { SCORE_MODE_LUT = 0, SCORE_MODE_FAST = 1, SCORE_MODE_GENERAL = 2 };
 
 } // namespace mm2gb

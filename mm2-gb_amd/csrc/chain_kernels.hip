@@ -161,8 +161,9 @@ __device__ T block_exclusive_scan(T v, T *s_tmp /* PLANNER_THREADS/64 */, T *tot
 __global__ __launch_bounds__(PLANNER_THREADS) void k_plan(DevBatch b, LaunchCfg cfg)
 {
 	__shared__ long long s_tmp[PLANNER_THREADS / WAVE];
-	__shared__ int s_hist[COST_BINS];
-	__shared__ int s_binbase[COST_BINS];
+	__shared__ int s_hist[2][COST_BINS];      // [0] wave-mode chunks, [1] cooperative-mode chunks
+	__shared__ int s_binbase[2][COST_BINS];
+	__shared__ int s_nlong;
 	const int64_t nb = b.n_blocks;
 	const int tid = threadIdx.x;
 	const int64_t per = (nb + PLANNER_THREADS - 1) / PLANNER_THREADS;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(PLANNER_THREADS) void k_plan(DevBatch b, LaunchCfg 
 			kk += b.blk_clamped[k];
 		}
 	}
-	for (int k = tid; k < COST_BINS; k += PLANNER_THREADS) s_hist[k] = 0;
+	for (int k = tid; k < 2 * COST_BINS; k += PLANNER_THREADS) (&s_hist[0][0])[k] = 0;
 	__threadfence_block();
 	__syncthreads();
 
@@ -219,39 +220,51 @@ __global__ __launch_bounds__(PLANNER_THREADS) void k_plan(DevBatch b, LaunchCfg 
 		// the chunk covers its own block .. part of the next chunk's block: count clamps inclusively (superset is safe)
 		const bool track = (nxt_kk + nxt_blk_clamped - kk) > 0;
 		const long long cost = (nxt_pp - pp) + (long long)(end - start) * COST_PER_ANCHOR;
+		// heavy chunks with wide windows go to the cooperative mode (bit 1 of chunk_track)
+		const bool is_long = cfg.ring_mask >= 0 && cost >= cfg.long_min_cost && (long long)(end - start) * cfg.long_min_window <= cost;
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;
-		b.chunk_track[c] = track;
+		b.chunk_track[c] = (uint8_t)((track ? 1 : 0) | (is_long ? 2 : 0));
 		n_track += track;
-		atomicAdd(&s_hist[cost_bin(cost)], 1);
+		atomicAdd(&s_hist[is_long][cost_bin(cost)], 1);
 		nxt_pp = pp; nxt_kk = kk; nxt_start = start; nxt_blk_clamped = b.blk_clamped[blk];
 	}
 	__syncthreads();
 	// descending bin order -> base offsets
-	if (tid == 0) {
+	if (tid < 2) {
 		int acc = 0;
-		for (int k = COST_BINS - 1; k >= 0; --k) { s_binbase[k] = acc; acc += s_hist[k]; }
+		for (int k = COST_BINS - 1; k >= 0; --k) { s_binbase[tid][k] = acc; acc += s_hist[tid][k]; }
+		if (tid == 1) s_nlong = acc;
 	}
 	__syncthreads();
 	for (int64_t c = c0; c < c1; ++c) {
-		const int slot = atomicAdd(&s_binbase[cost_bin(b.chunk_cost[c])], 1);
-		b.order[slot] = (int)c;
+		const int is_long = (b.chunk_track[c] >> 1) & 1;
+		const int slot = atomicAdd(&s_binbase[is_long][cost_bin(b.chunk_cost[c])], 1);
+		(is_long ? b.long_list : b.order)[slot] = (int)c;
 	}
 	if (n_track) atomicAdd(&b.counters[CNT_NTRACK], n_track);
 	if (tid == 0) {
 		b.counters[CNT_NCHUNK] = (int)n_chunks;
 		b.counters[CNT_CURSOR] = 0;
-		b.counters[CNT_NLONG] = 0;
+		b.counters[CNT_NLONG] = s_nlong;
 		b.counters[CNT_LCURSOR] = 0;
 		b.counters[CNT_NCLAMP] = (int)tot_clamps;
 		b.totals[0] = tot_pairs;
 	}
-	(void)cfg;
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// Pair score, lchain.c:113-138.  FAST = single query segment, not cDNA (what --gpu-chain runs: plchain.cu:499-500).
+// Pair score, lchain.c:113-138 (+ mmpriv.h:118-126).  Three builds of the same arithmetic:
+//   MODE_LUT      single query segment, not cDNA, chn_pen_skip == 0 (what --gpu-chain runs with stock presets,
+//                 plchain.cu:499-500): the penalty (int)(gap*dd + .5*log2(dd+1)) depends on dd only and dd <= bw for
+//                 every accepted pair, so it is tabulated once per parameter set BY THE SAME DEVICE CODE as MODE_FAST
+//                 (k_build_lut) and looked up in LDS.  Entry bw+1 is a huge penalty: "dd > bw" rejects by itself.
+//   MODE_FAST     same restriction except chn_pen_skip may be non-zero: penalty computed per pair.
+//   MODE_GENERAL  every branch of comput_sc (segment ids, cDNA, n_seg > 1).
 // --------------------------------------------------------------------------------------------------------------
+enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
+constexpr int LUT_REJECT = 1 << 29;
+
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
 {
 	unsigned u = __float_as_uint(v);
@@ -262,24 +275,55 @@ __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
 	return r;
 }
 
-template <bool FAST>
-__device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int yj, int spanj, int segj, const DevParams &P, int &sc_out)
+// lchain.c:129-130,135 for the single-segment, non-cDNA case
+__device__ __forceinline__ int gap_penalty(int dd, int dg, const DevParams &P)
+{
+	const float lin = P.gap * (float)dd + P.skip * (float)dg;
+	const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
+	return (int)(lin + .5f * lg);
+}
+
+__global__ void k_build_lut(int *lut, DevParams P)
+{
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k > P.lut_last) return;
+	lut[k] = k == P.lut_last ? LUT_REJECT : gap_penalty(k, 0, P);   // skip == 0 here: the dg term is +0.0f
+}
+
+__device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
+{
+	unsigned r;
+	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int yj, int tagj, const DevParams &P, const int *lut, int &sc_out)
 {
 	const int dq = yi - yj;
 	const int dr = xi - xj;                                    // low 32 bits of the 64-bit difference (lchain.c:119)
-	const int ddiff = (int)((unsigned)dr - (unsigned)dq);
-	const int dd = ddiff < 0 ? -ddiff : ddiff;
+	const int spanj = tagj & 0xff;
 	const int dg = dr < dq ? dr : dq;
 	int sc = spanj < dg ? spanj : dg;
-	const float lin = P.gap * (float)dd + P.skip * (float)dg;
-	const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
-	if (FAST) {
+	if (MODE == MODE_LUT) {
+		// accepted pairs have dr >= 0 (same strand|rid, sorted by x) and dq >= 1, so the unsigned |dr-dq| is dd
+		const unsigned dd = abs_diff_u32(dr, dq);
+		const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
+		sc_out = sc - lut[idx];
+		return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0;
+	}
+	const int ddiff = (int)((unsigned)dr - (unsigned)dq);
+	const int dd = ddiff < 0 ? -ddiff : ddiff;
+	if (MODE == MODE_FAST) {
 		const bool ok = (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && dd <= P.bw;
-		if (dd != 0 || dg > spanj) sc -= (int)(lin + .5f * lg);
+		if (dd != 0 || dg > spanj) sc -= gap_penalty(dd, dg, P);
 		sc_out = sc;
 		return ok;
 	} else {
+		const int segj = tagj >> 8;
 		const bool same = segi == segj;
+		const float lin = P.gap * (float)dd + P.skip * (float)dg;
+		const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
 		bool ok = dq > 0 && dq <= P.max_dist_x;
 		if (same && (dr == 0 || dq > P.max_dist_y)) ok = false;
 		if (same && dd > P.bw) ok = false;
@@ -297,126 +341,247 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// One wave works through a chunk [cs, ce) in tiles of 64 anchors, lane L owning anchor i0+L.
-//   best / arg : running maximum in the "threshold" form: best starts at q_span+1 with arg=-1, so "cand >= best" is
-//                the CPU's strict '>' against q_span first and "latest j wins ties" afterwards (predecessors are
-//                visited in ascending j here, descending with strict '>' on the CPU: lchain.c:174-181).
-//   TRACK      : carry the max_ii state machine of lchain.c:189-205 (only chunks with max_iter-clamped windows need it;
-//                elsewhere max_ii always lies inside the window and the extra candidate is a no-op).
+// Tile machinery.  A tile is 64 consecutive anchors of a chunk, lane L owning anchor i0+L ("target").
+//   best / arg : running maximum in "threshold" form: best starts at q_span+1 with arg=-1, so "cand >= best" is the
+//                CPU's strict '>' against q_span first and "latest j wins ties" afterwards (predecessors are visited in
+//                ascending j here; descending with strict '>' on the CPU, lchain.c:174-181).
+// Predecessors ("sources") come 64 at a time, one per lane, and are broadcast lane -> SGPR with v_readlane, so each
+// step scores ONE source against the wave's 64 targets: 64x register reuse of every source, no LDS or memory in the loop.
 // --------------------------------------------------------------------------------------------------------------
-struct Keep { int idx, x, hi, y, tag, f; };   // the remembered best anchor ("max_ii") and its fields, wave-uniform
+struct Target { int x, y, tag, seg, q, st, hi; bool live; };
+struct Keep { int idx, x, hi, y, tag, f; };   // the remembered best anchor ("max_ii", lchain.c:189-205), wave-uniform
 
-template <bool FAST, bool TRACK>
-__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int cs, const int ce)
+// Sources jb+k, k in [k_from, 64), all final.  CHECK: some target windows start inside this block.
+template <int MODE, bool CHECK>
+__device__ __forceinline__ void sweep_block(const Target &T, int jb, int k_from, int sx, int sy, int stg, int sf,
+                                            const DevParams &P, const int *lut, int &best, int &arg)
+{
+	for (int kg = k_from & ~3; kg < WAVE; kg += 4) {
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int k = kg + u, j = jb + k;
+			const int ux = bcast(sx, k), uy = bcast(sy, k), ut = bcast(stg, k), uf = bcast(sf, k);
+			int sc;
+			bool take = pair_score<MODE>(T.x, T.y, T.seg, ux, uy, ut, P, lut, sc);
+			const int cand = sc + uf;
+			take = take && cand >= best;
+			if (CHECK) take = take && j >= T.st;
+			if (take) { best = cand; arg = j; }
+		}
+	}
+}
+
+__device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce, bool want_hi)
+{
+	Target T;
+	const int i = i0 + lane_id();
+	T.live = i < ce;
+	const int il = T.live ? i : ce - 1;
+	T.x = b.x[il]; T.y = b.y[il]; T.tag = b.tag[il];
+	T.hi = want_hi ? b.xhi[il] : 0;
+	T.st = T.live ? b.st[il] : INT_MAX;          // dead lanes never activate
+	T.q = T.tag & 0xff; T.seg = T.tag >> 8;
+	return T;
+}
+
+// Predecessors inside the tile: lane t becomes final at step t and is pushed to the lanes above it.
+// F(j) returns the final score of an anchor of an EARLIER tile (global memory for the wave kernel, LDS ring for the
+// cooperative one); only the rescue state machine needs it.
+template <int MODE, bool TRACK, typename FOld>
+__device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, const int *lut,
+                                        int &best, int &arg, Keep &keep, FOld f_old)
+{
+	const int lane = lane_id(), i = i0 + lane;
+	if (!TRACK) {
+		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
+		unsigned long long need = __ballot(T.live && T.st < i) >> 1;
+		while (need) {
+			const int t = __builtin_ctzll(need);
+			need &= need - 1;
+			const int j = i0 + t;
+			const int ft = bcast(arg < 0 ? T.q : best, t);
+			const int ux = bcast(T.x, t), uy = bcast(T.y, t), ut = bcast(T.tag, t);
+			int sc;
+			const bool ok = pair_score<MODE>(T.x, T.y, T.seg, ux, uy, ut, P, lut, sc);
+			const int cand = sc + ft;
+			if (ok && lane > t && j >= T.st && cand >= best) { best = cand; arg = j; }
+		}
+		return;
+	}
+	for (int t = 0; t < n_here; ++t) {
+		const int j = i0 + t;
+		const int xt = bcast(T.x, t), yt = bcast(T.y, t), tgt = bcast(T.tag, t), ht = bcast(T.hi, t), stt = bcast(T.st, t);
+		// lchain.c:190-195: the remembered anchor fell out of reach (or none yet): arg-max of f over the window,
+		// largest index among equals
+		if (keep.idx < 0 || ht != keep.hi || (unsigned)(xt - keep.x) > (unsigned)P.max_dist_x) {
+			int bf = INT_MIN, bi = -1;
+			for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)
+				const int v = f_old(jj);
+				if (v >= bf) { bf = v; bi = jj; }
+			}
+			if (lane < t && i >= stt) {                                      // finished lanes of this tile
+				const int v = arg < 0 ? T.q : best;
+				if (v >= bf) { bf = v; bi = i; }
+			}
+			for (int off = WAVE / 2; off > 0; off >>= 1) {
+				const int of = __shfl_xor(bf, off), oi = __shfl_xor(bi, off);
+				if (of > bf || (of == bf && oi > bi)) { bf = of; bi = oi; }
+			}
+			keep.idx = first_lane(bi);
+			if (keep.idx >= 0) {
+				keep.f = first_lane(bf);
+				keep.x = b.x[keep.idx]; keep.y = b.y[keep.idx]; keep.tag = b.tag[keep.idx]; keep.hi = ht;
+			}
+		}
+		// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf)
+		if (keep.idx >= 0 && keep.idx < stt - 1) {
+			int sc;
+			const bool ok = pair_score<MODE>(xt, yt, tgt >> 8, keep.x, keep.y, keep.tag, P, lut, sc);
+			if (ok && lane == t) {
+				const int cur = arg < 0 ? T.q : best;
+				if (cur < sc + keep.f) { best = sc + keep.f; arg = keep.idx; }
+			}
+		}
+		const int ft = bcast(arg < 0 ? T.q : best, t);                       // lchain.c:202
+		// lchain.c:204-205 (in reach is guaranteed after the refresh above)
+		if (keep.idx < 0 || keep.f < ft) { keep.idx = j; keep.x = xt; keep.hi = ht; keep.y = yt; keep.tag = tgt; keep.f = ft; }
+		int sc;
+		const bool ok = pair_score<MODE>(T.x, T.y, T.seg, xt, yt, tgt, P, lut, sc);
+		const int cand = sc + ft;
+		if (ok && lane > t && j >= T.st && cand >= best) { best = cand; arg = j; }
+	}
+}
+
+// ---- wave mode: one wave owns the chunk [cs, ce) --------------------------------------------------------------
+template <int MODE, bool TRACK>
+__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, const int cs, const int ce)
 {
 	const int lane = lane_id();
 	Keep keep; keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
-
 	for (int i0 = cs; i0 < ce; i0 += WAVE) {
-		const int i = i0 + lane;
-		const bool live = i < ce;
-		const int il = live ? i : ce - 1;
-		const int xi = b.x[il], yi = b.y[il], tgi = b.tag[il];
-		const int hii = TRACK ? b.xhi[il] : 0;
-		const int sti = live ? b.st[il] : INT_MAX;        // dead lanes never activate
-		const int qi = tgi & 0xff, segi = tgi >> 8;
-		int best = qi + 1, arg = -1;
-
-		// ---- predecessors in earlier tiles: all final, broadcast one by one ----
-		const int tile_lo = first_lane(sti);               // lane 0 has the smallest window start
-		for (int jb = cs + ((tile_lo - cs) & ~(WAVE - 1)); jb < i0; jb += WAVE) {
-			const int js = jb + lane;                      // < i0 <= ce
-			const int sx = b.x[js], sy = b.y[js], stg = b.tag[js], sf = b.f[js];
-			int kg = tile_lo - jb; kg = kg < 0 ? 0 : (kg & ~3);
-			for (; kg < WAVE; kg += 4) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int k = kg + u, j = jb + k;
-					const int ux = bcast(sx, k), uy = bcast(sy, k), ut = bcast(stg, k), uf = bcast(sf, k);
-					int sc;
-					const bool ok = pair_score<FAST>(xi, yi, segi, ux, uy, ut & 0xff, ut >> 8, P, sc);
-					const int cand = sc + uf;
-					if (ok && j >= sti && cand >= best) { best = cand; arg = j; }
-				}
-			}
-		}
-
-		// ---- predecessors inside the tile: lane t becomes final at step t and is pushed to the lanes above it ----
+		const Target T = load_target(b, i0, ce, TRACK);
 		const int n_here = min(WAVE, ce - i0);
-		if (!TRACK) {
-			// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
-			unsigned long long need = __ballot(live && sti < i) >> 1;
-			while (need) {
-				const int t = __builtin_ctzll(need);
-				need &= need - 1;
-				const int j = i0 + t;
-				const int ft = bcast(arg < 0 ? qi : best, t);
-				const int ux = bcast(xi, t), uy = bcast(yi, t), ut = bcast(tgi, t);
-				int sc;
-				const bool ok = pair_score<FAST>(xi, yi, segi, ux, uy, ut & 0xff, ut >> 8, P, sc);
-				const int cand = sc + ft;
-				if (ok && lane > t && j >= sti && cand >= best) { best = cand; arg = j; }
-			}
-		} else {
-			for (int t = 0; t < n_here; ++t) {
-				const int j = i0 + t;
-				const int xt = bcast(xi, t), yt = bcast(yi, t), tgt = bcast(tgi, t), ht = bcast(hii, t), stt = bcast(sti, t);
-				// lchain.c:190-195: the remembered anchor fell out of reach (or none yet): arg-max of f over the window,
-				// largest index among equals
-				if (keep.idx < 0 || ht != keep.hi || (unsigned)(xt - keep.x) > (unsigned)P.max_dist_x) {
-					int bf = INT_MIN, bi = -1;
-					for (int jj = stt + lane; jj < i0; jj += WAVE) {      // earlier tiles (ascending per lane)
-						const int v = b.f[jj];
-						if (v >= bf) { bf = v; bi = jj; }
-					}
-					if (lane < t && i >= stt) {                              // finished lanes of this tile
-						const int v = arg < 0 ? qi : best;
-						if (v >= bf) { bf = v; bi = i; }
-					}
-					for (int off = WAVE / 2; off > 0; off >>= 1) {
-						const int of = __shfl_xor(bf, off), oi = __shfl_xor(bi, off);
-						if (of > bf || (of == bf && oi > bi)) { bf = of; bi = oi; }
-					}
-					keep.idx = first_lane(bi);
-					if (keep.idx >= 0) {
-						keep.f = first_lane(bf);
-						keep.x = b.x[keep.idx]; keep.y = b.y[keep.idx]; keep.tag = b.tag[keep.idx]; keep.hi = ht;
-					}
-				}
-				// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf)
-				if (keep.idx >= 0 && keep.idx < stt - 1) {
-					int sc;
-					const bool ok = pair_score<FAST>(xt, yt, tgt >> 8, keep.x, keep.y, keep.tag & 0xff, keep.tag >> 8, P, sc);
-					if (ok && lane == t) {
-						const int cur = arg < 0 ? qi : best;
-						if (cur < sc + keep.f) { best = sc + keep.f; arg = keep.idx; }
-					}
-				}
-				const int ft = bcast(arg < 0 ? qi : best, t);               // lchain.c:202
-				// lchain.c:204-205 (in reach is guaranteed after the refresh above)
-				if (keep.idx < 0 || keep.f < ft) { keep.idx = j; keep.x = xt; keep.hi = ht; keep.y = yt; keep.tag = tgt; keep.f = ft; }
-				// push
-				int sc;
-				const bool ok = pair_score<FAST>(xi, yi, segi, xt, yt, tgt & 0xff, tgt >> 8, P, sc);
-				const int cand = sc + ft;
-				if (ok && lane > t && j >= sti && cand >= best) { best = cand; arg = j; }
+		int best = T.q + 1, arg = -1;
+		const int tile_lo = first_lane(T.st);                 // lane 0 has the smallest window start
+		const int st_hi = bcast(T.st, n_here - 1);            // the last live lane the largest
+		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
+		if (jb < i0) {
+			int sx = b.x[jb + lane], sy = b.y[jb + lane], stg = b.tag[jb + lane], sf = b.f[jb + lane];
+			for (; jb < i0; jb += WAVE) {
+				// next block's loads are issued before this block is consumed
+				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
+				const int nx = b.x[jn], ny = b.y[jn], ntg = b.tag[jn], nf = b.f[jn];
+				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
+				if (jb >= st_hi) sweep_block<MODE, false>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
+				else sweep_block<MODE, true>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
+				sx = nx; sy = ny; stg = ntg; sf = nf;
 			}
 		}
-		if (live) {
-			b.f[i] = arg < 0 ? qi : best;
+		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, best, arg, keep, [&](int jj) { return b.f[jj]; });
+		if (T.live) {
+			const int i = i0 + lane;
+			b.f[i] = arg < 0 ? T.q : best;
 			b.p[i] = arg < 0 ? 0 : i - arg;
 		}
 	}
 }
 
-// FAST kernel runs only when no anchor carries a segment id; the general one only when some does (or always,
-// when the host already knows the parameters need it).  Exactly one of the two does the work of a batch.
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_score_wave(DevBatch b, DevParams P, int general_always)
+// ---- cooperative mode: the 16 waves of a workgroup pipeline the tiles of ONE heavy chunk ---------------------
+// Wave w takes tiles w, w+16, ...  A tile's sources are swept oldest first, so the only sources that may not be final
+// yet are the most recent tiles': the sweep reaches them last, and by then the waves ahead have normally finished
+// (a tile needs ~(window/64 + 2) block sweeps, its critical dependency is 2 of them).  Final scores travel between
+// waves through an LDS ring indexed by anchor number (the sliding predecessor window, max_iter + slack entries);
+// "tiles done" is a release/acquire counter in LDS.  No block barrier inside a chunk.
+struct CoopShared { int done; int keep[6]; int chunk; };
+
+template <int MODE, bool TRACK>
+__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int *ring, const int ring_mask, CoopShared *sh,
+                           const int cs, const int ce)
 {
+	const int lane = lane_id(), wave = threadIdx.x / WAVE, n_waves = blockDim.x / WAVE;
+	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
+	auto wait_done = [&](int need) {
+		while (__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+	};
+	for (int t = wave; t < n_tiles; t += n_waves) {
+		const int i0 = cs + t * WAVE;
+		const Target T = load_target(b, i0, ce, TRACK);
+		const int n_here = min(WAVE, ce - i0);
+		int best = T.q + 1, arg = -1;
+		const int tile_lo = first_lane(T.st);
+		const int st_hi = bcast(T.st, n_here - 1);
+		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
+		if (jb < i0) {
+			int sx = b.x[jb + lane], sy = b.y[jb + lane], stg = b.tag[jb + lane];
+			for (; jb < i0; jb += WAVE) {
+				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
+				const int nx = b.x[jn], ny = b.y[jn], ntg = b.tag[jn];
+				wait_done((jb - cs) / WAVE + 1);                       // that tile's scores are in the ring
+				const int sf = ring[(jb + lane) & ring_mask];
+				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
+				if (jb >= st_hi) sweep_block<MODE, false>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
+				else sweep_block<MODE, true>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
+				sx = nx; sy = ny; stg = ntg;
+			}
+		}
+		wait_done(t);                                                    // every earlier tile is final
+		Keep keep;
+		if (TRACK) { keep.idx = sh->keep[0]; keep.x = sh->keep[1]; keep.hi = sh->keep[2]; keep.y = sh->keep[3]; keep.tag = sh->keep[4]; keep.f = sh->keep[5]; }
+		else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
+		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, best, arg, keep, [&](int jj) { return ring[jj & ring_mask]; });
+		const int i = i0 + lane;
+		const int fi = arg < 0 ? T.q : best;
+		if (T.live) {
+			ring[i & ring_mask] = fi;
+			b.f[i] = fi;
+			b.p[i] = arg < 0 ? 0 : i - arg;
+		}
+		if (TRACK && lane == 0) { sh->keep[0] = keep.idx; sh->keep[1] = keep.x; sh->keep[2] = keep.hi; sh->keep[3] = keep.y; sh->keep[4] = keep.tag; sh->keep[5] = keep.f; }
+		// publish: ring + keep writes above are ordered before the counter by the release
+		if (lane == 0) __hip_atomic_store(&sh->done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// The score kernel: persistent 1024-thread workgroups (16 waves).  Phase 1: workgroups pull heavy chunks from the long
+// list and run them cooperatively.  Phase 2: every wave pulls ordinary chunks on its own, most expensive first.
+// Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
+// "some anchor carries a segment id" flag found on the device by k_split_soa).
+// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ CoopShared ]
+// --------------------------------------------------------------------------------------------------------------
+constexpr int SCORE_THREADS = 1024;
+
+template <int MODE>
+__global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_mask)
+{
+	extern __shared__ __attribute__((aligned(16))) int smem[];
 	const bool any_seg = (b.flags[0] & FLAG_ANY_SEGID) != 0;
-	if (FAST ? any_seg : (!general_always && !any_seg)) return;
-	const int n_chunks = b.counters[CNT_NCHUNK];
+	const int mode = any_seg ? MODE_GENERAL : host_mode;
+	if (mode != MODE) return;
+	int *lut = smem;
+	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
+	int *ring = smem + lut_words;
+	CoopShared *sh = (CoopShared*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0));
+	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];
+	__syncthreads();
+
+	// phase 1: cooperative
+	const int n_long = b.counters[CNT_NLONG];
+	if (ring_mask >= 0) {
+		while (true) {
+			if (threadIdx.x == 0) { sh->chunk = atomicAdd(&b.counters[CNT_LCURSOR], 1); sh->done = 0; sh->keep[0] = -1; }
+			__syncthreads();
+			const int c = sh->chunk;
+			if (c >= n_long) break;
+			const int ci = b.long_list[c];
+			const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
+			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, ring, ring_mask, sh, cs, ce);
+			else coop_chunk<MODE, false>(b, P, lut, ring, ring_mask, sh, cs, ce);
+			__syncthreads();
+		}
+	}
+	// phase 2: one wave per chunk
+	const int n_chunks = b.counters[CNT_NCHUNK] - n_long;
 	while (true) {
 		int c = 0;
 		if (lane_id() == 0) c = atomicAdd(&b.counters[CNT_CURSOR], 1);
@@ -424,8 +589,8 @@ __global__ __launch_bounds__(256) void k_score_wave(DevBatch b, DevParams P, int
 		if (c >= n_chunks) break;
 		const int ci = b.order[c];
 		const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
-		if (b.chunk_track[ci]) run_chunk<FAST, true>(b, P, cs, ce);
-		else run_chunk<FAST, false>(b, P, cs, ce);
+		if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, cs, ce);
+		else run_chunk<MODE, false>(b, P, lut, cs, ce);
 	}
 }
 
@@ -451,12 +616,33 @@ void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s)
 	hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLANNER_THREADS), 0, s, b, cfg);
 }
 
+void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_build_lut, dim3((P.lut_last + 256) / 256), dim3(256), 0, s, d_lut, P);
+}
+
+size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask)
+{
+	const size_t lut_words = host_mode == MODE_LUT ? (size_t)((P.lut_last + 1 + 3) & ~3) : 0;
+	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + sizeof(CoopShared) + 16;
+}
+
+int score_set_lds_limit(size_t bytes)
+{
+	hipError_t e = hipFuncSetAttribute((const void*)k_score<MODE_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_GENERAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	return e == hipSuccess ? 0 : -1;
+}
+
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s)
 {
 	if (b.n <= 0) return;
-	const bool host_general = P.is_cdna || P.n_seg > 1;
-	if (!host_general) hipLaunchKernelGGL(k_score_wave<true>, dim3(cfg.wave_grid), dim3(256), 0, s, b, P, 0);
-	hipLaunchKernelGGL(k_score_wave<false>, dim3(cfg.wave_grid), dim3(256), 0, s, b, P, host_general ? 1 : 0);
+	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_mask);
+	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_mask);
+	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
+	if (cfg.host_mode == MODE_FAST) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
+	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_mask);
 }
 
 } // namespace mm2gb

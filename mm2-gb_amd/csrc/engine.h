@@ -50,7 +50,7 @@ struct Engine {
 	DevBuf x, y, xhi, tag, st;
 	DevBuf blk_firstcut, blk_pairs, blk_clamped;
 	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list;
-	DevBuf counters, totals, flags;
+	DevBuf counters, totals, flags, lut;
 	// staging for the host-buffer API
 	DevBuf raw, offsets, f, p;
 	// pinned scalars for stats read-back
@@ -60,10 +60,12 @@ struct Engine {
 	mm2gb_stats_t last = {};
 	bool stats_pending = false;
 	bool timed_h2d = false, timed_d2h = false;
+	bool misc_valid = false, coop_disabled = false;
 
 	int  init(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);
 	void shutdown();
 	int  set_misc(const mm2gb_misc_t *m);
+	int  configure_score();
 	int  reserve(int64_t n_anchors, int64_t n_reads, bool host_staging);
 	// host buffers (pinned for true asynchrony): H2D, kernels, D2H enqueued; returns without waiting
 	int  enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p);

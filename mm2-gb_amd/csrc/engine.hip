@@ -51,6 +51,7 @@ static DevParams make_params(const mm2gb_misc_t &m)
 	if (P.max_dist_y < P.bw && !m.is_cdna) P.max_dist_y = P.bw;        // lchain.c:161
 	P.max_iter = m.max_iter; P.n_seg = m.n_seg; P.is_cdna = m.is_cdna;
 	P.dq_lim = std::min(P.max_dist_x, P.max_dist_y);
+	P.lut_last = P.bw + 1;
 	P.gap = m.chn_pen_gap; P.skip = m.chn_pen_skip;
 	return P;
 }
@@ -59,8 +60,35 @@ int Engine::set_misc(const mm2gb_misc_t *m)
 {
 	if (!m) return fail("mm2gb: null misc");
 	if (m->max_iter < 0 || m->bw < 0 || m->max_dist_x < 0 || m->max_dist_y < 0) return fail("mm2gb: negative chaining parameter");
+	const bool changed = !misc_valid || memcmp(&misc, m, sizeof(misc)) != 0;
 	misc = *m;
+	misc_valid = true;
 	params = make_params(misc);
+	if (!changed || !stream) return 0;
+	return configure_score();
+}
+
+// Pick the scoring build and the LDS budget for these parameters; (re)build the penalty table on the device.
+int Engine::configure_score()
+{
+	const bool single = !params.is_cdna && params.n_seg == 1;
+	constexpr int LUT_MAX = 8192;                       // entries; bw above this falls back to per-pair arithmetic
+	if (!single) launch.host_mode = SCORE_MODE_GENERAL;
+	else if (params.skip == 0.0f && params.lut_last + 1 <= LUT_MAX) launch.host_mode = SCORE_MODE_LUT;
+	else launch.host_mode = SCORE_MODE_FAST;
+	// cooperative mode: ring must cover max_iter predecessors plus the tile being written
+	int ring = 1024;
+	while (ring < params.max_iter + 2 * 64 && ring < (1 << 20)) ring <<= 1;
+	launch.ring_mask = ring - 1;
+	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS)
+	if (coop_disabled || score_lds_bytes(params, launch.host_mode, launch.ring_mask) > LDS_BUDGET) launch.ring_mask = -1;
+	const size_t need = std::max(score_lds_bytes(params, launch.host_mode, launch.ring_mask), score_lds_bytes(params, SCORE_MODE_GENERAL, launch.ring_mask));
+	if (score_set_lds_limit(need)) return fail("mm2gb: cannot raise the dynamic LDS limit of the score kernel");
+	if (launch.host_mode == SCORE_MODE_LUT) {
+		if (lut.ensure((size_t)(params.lut_last + 1) * 4)) return -1;
+		launch_build_lut((int*)lut.ptr, params, stream);
+		MM2GB_HIP(hipGetLastError());
+	}
 	return 0;
 }
 
@@ -75,14 +103,17 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	MM2GB_HIP(hipGetDeviceProperties(&prop, device));
 	n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	cfg = *c;
-	if (set_misc(m)) return -1;
-	// persistent grids: config values are workgroup counts, as in the reference schema (score_kernel.*_griddim)
-	launch.wave_grid = cfg.score_kernel.short_griddim > 0 ? cfg.score_kernel.short_griddim : n_cu * 8;
-	launch.long_grid = cfg.score_kernel.long_griddim > 0 ? cfg.score_kernel.long_griddim : n_cu;
-	launch.long_threads = 512;
-	launch.long_min_cost = (int64_t)1 << 62;     // cooperative kernel disabled until it exists
-	launch.long_min_window = 1 << 30;
+	// persistent grid: short_griddim counts 256-thread workgroups in the reference schema; k_score uses 1024-thread ones
+	launch.score_grid = cfg.score_kernel.short_griddim > 0 ? std::max(1, cfg.score_kernel.short_griddim / 4) : n_cu * 2;
+	// long_seg_cutoff is in units of range_kernel.blockdim anchors in the reference (plscore.cu:330); a chunk that long
+	// with windows at least 1024 wide is worth pipelining over a whole workgroup
+	const int64_t long_anchors = (int64_t)std::max(1, cfg.score_kernel.long_seg_cutoff) * std::max(64, cfg.range_kernel.blockdim);
+	launch.long_min_window = 1024;
+	launch.long_min_cost = long_anchors * launch.long_min_window;
+	const char *env = getenv("MM2GB_NO_COOP");
+	coop_disabled = env && *env && *env != '0';
 	MM2GB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	if (set_misc(m)) return -1;
 	for (auto &e : ev) MM2GB_HIP(hipEventCreate(&e));
 	MM2GB_HIP(hipHostMalloc((void**)&h_counters, CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
 	MM2GB_HIP(hipHostMalloc((void**)&h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
@@ -95,7 +126,7 @@ void Engine::shutdown()
 	(void)hipSetDevice(device);
 	if (stream) (void)hipStreamSynchronize(stream);
 	for (DevBuf *b : { &x, &y, &xhi, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &chunk_start, &chunk_end, &chunk_cost,
-	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &raw, &offsets, &f, &p })
+	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &raw, &offsets, &f, &p, &lut })
 		b->release();
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
@@ -139,6 +170,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	b.chunk_start = (int32_t*)chunk_start.ptr; b.chunk_end = (int32_t*)chunk_end.ptr; b.chunk_cost = (int64_t*)chunk_cost.ptr;
 	b.chunk_track = (uint8_t*)chunk_track.ptr; b.order = (int32_t*)order.ptr; b.long_list = (int32_t*)long_list.ptr;
 	b.counters = (int32_t*)counters.ptr; b.totals = (int64_t*)totals.ptr; b.flags = (unsigned*)flags.ptr;
+	b.lut = (const int32_t*)lut.ptr;
 
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
 	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 2 * sizeof(int64_t), stream));
