@@ -105,11 +105,14 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	cfg = *c;
 	// persistent grid: short_griddim counts 256-thread workgroups in the reference schema; k_score uses 1024-thread ones
 	launch.score_grid = cfg.score_kernel.short_griddim > 0 ? std::max(1, cfg.score_kernel.short_griddim / 4) : n_cu * 2;
-	// long_seg_cutoff is in units of range_kernel.blockdim anchors in the reference (plscore.cu:330); a chunk that long
-	// with windows at least 1024 wide is worth pipelining over a whole workgroup
-	const int64_t long_anchors = (int64_t)std::max(1, cfg.score_kernel.long_seg_cutoff) * std::max(64, cfg.range_kernel.blockdim);
-	launch.long_min_window = 1024;
-	launch.long_min_cost = long_anchors * launch.long_min_window;
+	// Chunks whose DP would keep a single wave busy for long are pipelined over a whole workgroup (cooperative mode).
+	// A chunk with mean window W can keep about (W + 128) / 128 waves busy, so the mode pays from a few blocks of window.
+	// long_seg_cutoff / mid_seg_cutoff keep their reference meaning of "cut units" (range_kernel.blockdim anchors,
+	// plscore.cu:330,378): cost threshold = mid_seg_cutoff units of anchors at the minimum window.
+	launch.long_min_window = 128;
+	launch.long_min_cost = (int64_t)std::max(1, cfg.score_kernel.mid_seg_cutoff) * std::max(64, cfg.range_kernel.blockdim) * 1024;
+	if (const char *v = getenv("MM2GB_LONG_MIN_WINDOW")) launch.long_min_window = std::max(1, atoi(v));
+	if (const char *v = getenv("MM2GB_LONG_MIN_COST")) launch.long_min_cost = std::max<int64_t>(1, atoll(v));
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
 	MM2GB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
