@@ -1,0 +1,75 @@
+// valu_rate.hip -- how many SIMD cycles does one wave64 instruction of each kind cost on gfx950 when 8 waves/SIMD issue it
+// back to back?  (Input for DESIGN.md "what bounds the score kernel".)  Build: hipcc --offload-arch=gfx950 -O2 valu_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+#define KERNEL(name, ...)                                                              \
+	__global__ __launch_bounds__(256) void name(int *out, int iters, int a, int b)      \
+	{                                                                                   \
+		int v0 = threadIdx.x + a, v1 = v0 ^ b, v2 = v1 + 3, v3 = v2 * 5, v4 = a, v5 = b, v6 = 7, v7 = 9; \
+		float f0 = v0, f1 = v1, f2 = v2, f3 = v3;                                       \
+		int s0 = 0;                                                                     \
+		for (int it = 0; it < iters; ++it) { REP64(__VA_ARGS__) }                              \
+		out[blockIdx.x * 256 + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + (int)(f0 + f1 + f2 + f3) + s0; \
+	}
+
+KERNEL(k_add_u32,  asm volatile("v_add_u32 %0, %1, %0\n v_add_u32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_sub_u32,  asm volatile("v_sub_u32 %0, %1, %0\n v_sub_u32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_min_u32,  asm volatile("v_min_u32 %0, %1, %0\n v_min_u32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_min3_i32, asm volatile("v_min3_i32 %0, %1, %0, %2\n v_min3_i32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_sad_u32,  asm volatile("v_sad_u32 %0, %1, %0, 0\n v_sad_u32 %2, %3, %2, 0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_lshl_add, asm volatile("v_lshl_add_u32 %0, %1, 2, %0\n v_lshl_add_u32 %2, %3, 2, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_add3,     asm volatile("v_add3_u32 %0, %1, %0, %2\n v_add3_u32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_cndmask,  asm volatile("v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %2, %3, %2, vcc" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "vcc");)
+KERNEL(k_cmp_u32,  asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %2, %3" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "vcc");)
+KERNEL(k_cmp_e64,  asm volatile("v_cmp_gt_u32 s[20:21], %0, %1\n v_cmp_gt_u32 s[22:23], %2, %3" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "s20", "s21", "s22", "s23");)
+KERNEL(k_readlane, asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5" :: "v"(v0), "v"(v1) : "s20", "s21");)
+KERNEL(k_mov,      asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %2, %3" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_add_f32,  asm volatile("v_add_f32 %0, %1, %0\n v_add_f32 %2, %3, %2" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));)
+KERNEL(k_fma_f32,  asm volatile("v_fma_f32 %0, %1, %0, %2\n v_fma_f32 %2, %3, %2, %0" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));)
+KERNEL(k_min_f32,  asm volatile("v_min_f32 %0, %1, %0\n v_min_f32 %2, %3, %2" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));)
+KERNEL(k_cmp_f32,  asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %2, %3" :: "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "vcc");)
+KERNEL(k_cvt_i2f,  asm volatile("v_cvt_f32_i32 %0, %1\n v_cvt_f32_i32 %2, %3" : "+v"(f0), "+v"(v1), "+v"(f2), "+v"(v3));)
+KERNEL(k_pk_add_f32, asm volatile("v_pk_add_f32 %0, %1, %0\n v_pk_add_f32 %2, %3, %2" : "+v"(*(double*)&v0), "+v"(*(double*)&v2), "+v"(*(double*)&v4), "+v"(*(double*)&v6));)
+KERNEL(k_max_i32,  asm volatile("v_max_i32 %0, %1, %0\n v_max_i32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_and_or,   asm volatile("v_and_or_b32 %0, %1, %0, %2\n v_and_or_b32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_ds_read,  { int t; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v0 & 0xff) << 2)); v1 ^= t; })
+KERNEL(k_ds_read_nw, { int t; int u; asm volatile("ds_read_b32 %0, %2\n ds_read_b32 %1, %2 offset:4" : "=v"(t), "=v"(u) : "v"((v0 & 0xff) << 2)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v1 ^= t + u; })
+
+typedef void (*kfn)(int*, int, int, int);
+
+int main()
+{
+	struct { const char *name; kfn fn; } tests[] = {
+		{"v_add_u32", k_add_u32}, {"v_sub_u32", k_sub_u32}, {"v_min_u32", k_min_u32}, {"v_max_i32", k_max_i32}, {"v_min3_i32", k_min3_i32},
+		{"v_sad_u32", k_sad_u32}, {"v_lshl_add_u32", k_lshl_add}, {"v_add3_u32", k_add3}, {"v_and_or_b32", k_and_or}, {"v_cndmask_b32", k_cndmask},
+		{"v_cmp_gt_u32 vcc", k_cmp_u32}, {"v_cmp_gt_u32 sgpr", k_cmp_e64}, {"v_readlane_b32", k_readlane}, {"v_mov_b32", k_mov},
+		{"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_min_f32", k_min_f32}, {"v_cmp_gt_f32", k_cmp_f32}, {"v_cvt_f32_i32", k_cvt_i2f},
+		{"v_pk_add_f32", k_pk_add_f32}, 
+		{"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
+	};
+	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+	const int cus = prop.multiProcessorCount;
+	int *out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const double clk = prop.clockRate * 1e3;   // Hz
+	printf("device %s, %d CUs, clock %.0f MHz; 8 waves/SIMD, 128 instr per loop body\n", prop.name, cus, clk / 1e6);
+	for (auto &t : tests) {
+		const int iters = 20000;
+		for (int rep = 0; rep < 2; ++rep) {
+			hipEventRecord(e0);
+			hipLaunchKernelGGL(t.fn, dim3(cus * 8), dim3(256), 0, 0, out, iters, 1, 2);
+			hipEventRecord(e1); hipEventSynchronize(e1);
+		}
+		float ms; hipEventElapsedTime(&ms, e0, e1);
+		// per SIMD: 8 waves x iters x 128 instructions
+		const double instr = 8.0 * iters * 128;  /* kernels with other bodies: scale by hand */
+		printf("%-28s %8.3f ms  -> %.2f cycles per wave-instruction per SIMD (at nominal clock)\n", t.name, ms, ms * 1e-3 * clk / instr);
+	}
+	return 0;
+}
