@@ -33,7 +33,7 @@ struct DevBatch {
 	int32_t  *x;               // ref_pos  = (int32)a.x                                4 B
 	int32_t  *y;               // qry_pos  = (int32)a.y                                4 B
 	int32_t  *xhi;             // a.x >> 32 = rev<<31 | rid                            4 B
-	uint16_t *tag;             // seg_id<<8 | q_span                                   2 B
+	int32_t  *tag;             // seg_id<<8 | q_span (a dword so the scalar path can fetch it) 4 B
 	// range selection
 	int32_t  *st;              // first predecessor index of each anchor (lchain.c:172-173)   4 B
 	// outputs

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_split_soa(DevBatch b)
 		b.y[i] = (int32_t)v.z;
 		const unsigned span = v.w & 0xffu;        // y>>32 & 0xff      (lchain.c:125)
 		const unsigned seg = (v.w >> 16) & 0xffu; // (y & MM_SEED_SEG_MASK) >> 48 (lchain.c:116)
-		b.tag[i] = (uint16_t)(seg << 8 | span);
+		b.tag[i] = (int32_t)(seg << 8 | span);
 		any_seg |= seg != 0;
 	}
 	if (__ballot(any_seg) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_ANY_SEGID);
@@ -351,22 +351,69 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 struct Target { int x, y, tag, seg, q, st, hi; bool live; };
 struct Keep { int idx, x, hi, y, tag, f; };   // the remembered best anchor ("max_ii", lchain.c:189-205), wave-uniform
 
+// Read-only inputs fetched through the scalar path: a wave-uniform index into constant address space makes the
+// compiler emit s_load_dword* (scalar cache -> SGPRs), which costs no vector-ALU issue slot at all.  Only arrays that no
+// kernel in flight writes may be read this way (x, y, tag: written by k_split_soa in an earlier launch).
+typedef const int __attribute__((address_space(4))) *scalar_i32_ptr;
+__device__ __forceinline__ scalar_i32_ptr as_scalar(const void *p) { return (scalar_i32_ptr)(uintptr_t)p; }
+
 // Sources jb+k, k in [k_from, 64), all final.  CHECK: some target windows start inside this block.
+// x, y and the span/segment tag of each source come through the scalar path; its score f (written by this very kernel)
+// sits in lane k of `sf` and is broadcast with v_readlane.
+struct SrcGroup { int x[4], y[4], t[4]; };
+__device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
+{
+	const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y), st = as_scalar(b.tag);
+	SrcGroup g;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; g.t[u] = st[j0 + u]; }
+	return g;
+}
+
 template <int MODE, bool CHECK>
-__device__ __forceinline__ void sweep_block(const Target &T, int jb, int k_from, int sx, int sy, int stg, int sf,
+__device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, int jb, int k_from, int sf,
                                             const DevParams &P, const int *lut, int &best, int &arg)
 {
-	for (int kg = k_from & ~3; kg < WAVE; kg += 4) {
+	int kg = k_from & ~3;
+	SrcGroup nxt = load_group(b, jb + kg);
+	for (; kg < WAVE; kg += 4) {
+		const SrcGroup g = nxt;
+		const int j0 = jb + kg;
+		if (MODE == MODE_LUT) {
+			// stage 1: geometry and the four table look-ups (issued together so one wait covers them)
+			int dq[4], dr[4], pen[4];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int k = kg + u, j = jb + k;
-			const int ux = bcast(sx, k), uy = bcast(sy, k), ut = bcast(stg, k), uf = bcast(sf, k);
-			int sc;
-			bool take = pair_score<MODE>(T.x, T.y, T.seg, ux, uy, ut, P, lut, sc);
-			const int cand = sc + uf;
-			take = take && cand >= best;
-			if (CHECK) take = take && j >= T.st;
-			if (take) { best = cand; arg = j; }
+			for (int u = 0; u < 4; ++u) {
+				dq[u] = T.y - g.y[u]; dr[u] = T.x - g.x[u];
+				const unsigned dd = abs_diff_u32(dr[u], dq[u]);
+				pen[u] = lut[dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last];
+			}
+			// the next group's scalar loads overlap the arithmetic below (clamped: the last group re-reads itself)
+			nxt = load_group(b, kg + 4 < WAVE ? j0 + 4 : j0);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int j = j0 + u;
+				const int uf = bcast(sf, kg + u);
+				const int span = g.t[u] & 0xff;
+				const int dg = dr[u] < dq[u] ? dr[u] : dq[u];
+				const int cand = (span < dg ? span : dg) - pen[u] + uf;
+				bool take = (unsigned)(dq[u] - 1) < (unsigned)P.dq_lim && dr[u] != 0 && cand >= best;
+				if (CHECK) take = take && j >= T.st;
+				if (take) { best = cand; arg = j; }
+			}
+		} else {
+			nxt = load_group(b, kg + 4 < WAVE ? j0 + 4 : j0);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int j = j0 + u;
+				const int uf = bcast(sf, kg + u);
+				int sc;
+				bool take = pair_score<MODE>(T.x, T.y, T.seg, g.x[u], g.y[u], g.t[u], P, lut, sc);
+				const int cand = sc + uf;
+				take = take && cand >= best;
+				if (CHECK) take = take && j >= T.st;
+				if (take) { best = cand; arg = j; }
+			}
 		}
 	}
 }
@@ -466,15 +513,14 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 		const int st_hi = bcast(T.st, n_here - 1);            // the last live lane the largest
 		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
 		if (jb < i0) {
-			int sx = b.x[jb + lane], sy = b.y[jb + lane], stg = b.tag[jb + lane], sf = b.f[jb + lane];
+			int sf = b.f[jb + lane];
 			for (; jb < i0; jb += WAVE) {
-				// next block's loads are issued before this block is consumed
-				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
-				const int nx = b.x[jn], ny = b.y[jn], ntg = b.tag[jn], nf = b.f[jn];
+				// next block's scores are requested before this block is consumed
+				const int nf = b.f[jb + WAVE < i0 ? jb + WAVE + lane : jb + lane];
 				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
-				if (jb >= st_hi) sweep_block<MODE, false>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
-				else sweep_block<MODE, true>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
-				sx = nx; sy = ny; stg = ntg; sf = nf;
+				if (jb >= st_hi) sweep_block<MODE, false>(b, T, jb, k_from, sf, P, lut, best, arg);
+				else sweep_block<MODE, true>(b, T, jb, k_from, sf, P, lut, best, arg);
+				sf = nf;
 			}
 		}
 		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, best, arg, keep, [&](int jj) { return b.f[jj]; });
@@ -511,18 +557,12 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 		const int tile_lo = first_lane(T.st);
 		const int st_hi = bcast(T.st, n_here - 1);
 		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
-		if (jb < i0) {
-			int sx = b.x[jb + lane], sy = b.y[jb + lane], stg = b.tag[jb + lane];
-			for (; jb < i0; jb += WAVE) {
-				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
-				const int nx = b.x[jn], ny = b.y[jn], ntg = b.tag[jn];
-				wait_done((jb - cs) / WAVE + 1);                       // that tile's scores are in the ring
-				const int sf = ring[(jb + lane) & ring_mask];
-				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
-				if (jb >= st_hi) sweep_block<MODE, false>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
-				else sweep_block<MODE, true>(T, jb, k_from, sx, sy, stg, sf, P, lut, best, arg);
-				sx = nx; sy = ny; stg = ntg;
-			}
+		for (; jb < i0; jb += WAVE) {
+			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring
+			const int sf = ring[(jb + lane) & ring_mask];
+			const int k_from = tile_lo > jb ? tile_lo - jb : 0;
+			if (jb >= st_hi) sweep_block<MODE, false>(b, T, jb, k_from, sf, P, lut, best, arg);
+			else sweep_block<MODE, true>(b, T, jb, k_from, sf, P, lut, best, arg);
 		}
 		wait_done(t);                                                    // every earlier tile is final
 		Keep keep;

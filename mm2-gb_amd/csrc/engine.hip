@@ -147,7 +147,7 @@ int Engine::reserve(int64_t n, int64_t n_reads, bool host_staging)
 		MM2GB_HIP(hipStreamSynchronize(stream));
 		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
 		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
-		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 2) || st.ensure(nn * 4)) return -1;
+		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
 		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4)) return -1;
 		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
 		    order.ensure(nb * 4) || long_list.ensure(nb * 4)) return -1;
@@ -166,7 +166,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	if (reserve(n, n_reads, false)) return -1;
 	DevBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
-	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (uint16_t*)tag.ptr; b.st = (int32_t*)st.ptr;
+	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
 	b.f = d_f; b.p = d_p;
 	b.blk_firstcut = (int32_t*)blk_firstcut.ptr; b.blk_pairs = (int64_t*)blk_pairs.ptr; b.blk_clamped = (int32_t*)blk_clamped.ptr;
 	b.n_blocks = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
