@@ -397,9 +397,10 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 				const int span = g.t[u] & 0xff;
 				const int dg = dr[u] < dq[u] ? dr[u] : dq[u];
 				const int cand = (span < dg ? span : dg) - pen[u] + uf;
-				bool take = (unsigned)(dq[u] - 1) < (unsigned)P.dq_lim && dr[u] != 0 && cand >= best;
-				if (CHECK) take = take && j >= T.st;
-				if (take) { best = cand; arg = j; }
+				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
+				bool take = ((unsigned)(dq[u] - 1) < (unsigned)P.dq_lim) & (dr[u] != 0) & (cand >= best);
+				if (CHECK) take = take & (j >= T.st);
+				best = take ? cand : best; arg = take ? j : arg;
 			}
 		} else {
 			nxt = load_group(b, kg + 4 < WAVE ? j0 + 4 : j0);

@@ -38,6 +38,13 @@ KERNEL(k_cvt_i2f,  asm volatile("v_cvt_f32_i32 %0, %1\n v_cvt_f32_i32 %2, %3" : 
 KERNEL(k_pk_add_f32, asm volatile("v_pk_add_f32 %0, %1, %0\n v_pk_add_f32 %2, %3, %2" : "+v"(*(double*)&v0), "+v"(*(double*)&v2), "+v"(*(double*)&v4), "+v"(*(double*)&v6));)
 KERNEL(k_max_i32,  asm volatile("v_max_i32 %0, %1, %0\n v_max_i32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
 KERNEL(k_and_or,   asm volatile("v_and_or_b32 %0, %1, %0, %2\n v_and_or_b32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_sub_sgpr, asm volatile("v_sub_u32 %0, s20, %0\n v_sub_u32 %1, s21, %1" : "+v"(v0), "+v"(v2));)
+KERNEL(k_subrev_sgpr, asm volatile("v_subrev_u32 %0, s20, %1\n v_subrev_u32 %2, s21, %3" : "=v"(v0), "+v"(v1), "=v"(v2), "+v"(v3));)
+KERNEL(k_cmp_sgpr, asm volatile("v_cmp_gt_u32 vcc, s20, %0\n v_cmp_gt_u32 vcc, s21, %1" :: "v"(v0), "v"(v2) : "vcc");)
+KERNEL(k_min3_sgpr, asm volatile("v_min3_i32 %0, s20, %1, %0\n v_min3_i32 %2, s21, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_cmp_cnd, asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "vcc");)
+KERNEL(k_cnd_only, asm volatile("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %3, %2, %1, vcc" : "=v"(v0), "+v"(v1), "+v"(v2), "=v"(v3));)
+KERNEL(k_readlane_use, asm volatile("v_readlane_b32 s20, %0, 3\n v_add_u32 %1, s20, %1" : "+v"(v0), "+v"(v1) :: "s20");)
 KERNEL(k_ds_read,  { int t; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v0 & 0xff) << 2)); v1 ^= t; })
 KERNEL(k_ds_read_nw, { int t; int u; asm volatile("ds_read_b32 %0, %2\n ds_read_b32 %1, %2 offset:4" : "=v"(t), "=v"(u) : "v"((v0 & 0xff) << 2)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v1 ^= t + u; })
 
@@ -51,7 +58,7 @@ int main()
 		{"v_cmp_gt_u32 vcc", k_cmp_u32}, {"v_cmp_gt_u32 sgpr", k_cmp_e64}, {"v_readlane_b32", k_readlane}, {"v_mov_b32", k_mov},
 		{"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_min_f32", k_min_f32}, {"v_cmp_gt_f32", k_cmp_f32}, {"v_cvt_f32_i32", k_cvt_i2f},
 		{"v_pk_add_f32", k_pk_add_f32}, 
-		{"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
+		{"v_sub_u32 sgpr src", k_sub_sgpr}, {"v_subrev_u32 sgpr src", k_subrev_sgpr}, {"v_cmp vcc, sgpr, v", k_cmp_sgpr}, {"v_min3_i32 sgpr src", k_min3_sgpr}, {"v_cmp + v_cndmask (2 instr)", k_cmp_cnd}, {"v_cndmask indep", k_cnd_only}, {"v_readlane + v_add using it", k_readlane_use}, {"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
 	};
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount;
@@ -69,7 +76,7 @@ int main()
 		float ms; hipEventElapsedTime(&ms, e0, e1);
 		// per SIMD: 8 waves x iters x 128 instructions
 		const double instr = 8.0 * iters * 128;  /* kernels with other bodies: scale by hand */
-		printf("%-28s %8.3f ms  -> %.2f cycles per wave-instruction per SIMD (at nominal clock)\n", t.name, ms, ms * 1e-3 * clk / instr);
+		fflush(stdout); printf("%-28s %8.3f ms  -> %.2f cycles per wave-instruction per SIMD (at nominal clock)\n", t.name, ms, ms * 1e-3 * clk / instr);
 	}
 	return 0;
 }
