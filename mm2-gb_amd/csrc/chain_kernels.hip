@@ -548,7 +548,9 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 	const int lane = lane_id(), wave = threadIdx.x / WAVE, n_waves = blockDim.x / WAVE;
 	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
 	auto wait_done = [&](int need) {
-		while (__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+		// a waiting wave must not steal issue slots from the waves it waits for: poll rarely (s_sleep 32 = 2048 cycles,
+		// a few percent of the shortest tile)
+		while (__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(32);
 	};
 	for (int t = wave; t < n_tiles; t += n_waves) {
 		const int i0 = cs + t * WAVE;
