@@ -48,6 +48,10 @@ struct DevBatch {
 	int32_t  *chunk_start, *chunk_end;
 	int64_t  *chunk_cost;
 	uint8_t  *chunk_track;     // needs the max_ii state machine
+	int64_t  *chunk_pp;        // planner scratch: pairs before the chunk's first block
+	int32_t  *chunk_kk, *chunk_blk; // planner scratch: clamped blocks before it; its first block
+	int64_t  *tile_sums, *tile_base; // planner scratch: 3 values per tile of 1024 planning blocks
+	int32_t  *bins;            // planner scratch: 2 x 256 cost bins
 	int32_t  *order;           // chunk ids, most expensive first
 	int32_t  *long_list;       // chunk ids routed to the cooperative kernel
 	// scalars

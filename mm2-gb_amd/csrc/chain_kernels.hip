@@ -5,7 +5,7 @@
 //   * k_split_soa   mm128_t AoS -> SoA on the device (the reference does this on one CPU thread, plmem.cu:154-198)
 //   * k_window      predecessor-window start per anchor by galloping + binary search (role of plrange.cu:38-76),
 //                   fused with the planner's per-block reductions (cuts, pair counts, max_iter clamps)
-//   * k_plan        turns cuts into independent, cost-ordered work items ("chunks") without host round trips
+//   * plan_*        turn cuts into independent, cost-ordered work items ("chunks") without host round trips
 //                   (role of the cut/long_seg/mid_seg bookkeeping, plscore.cu:314-385, and the host pairsort, plchain.cu:30-42)
 //   * k_score_wave  the DP: one wave64 per chunk, 64 anchors per tile held one-per-lane in registers; predecessors are
 //                   broadcast lane->SGPR (v_readlane) so every lane scores the same predecessor against its own anchor.
@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <algorithm>
 #include "chain_dev.h"
 
 namespace mm2gb {
@@ -60,8 +61,18 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	__shared__ int s_cut[PLAN_THREADS / WAVE];
 	__shared__ unsigned long long s_pairs[PLAN_THREADS / WAVE];
 	__shared__ int s_clamp[PLAN_THREADS / WAVE];
+	__shared__ int64_t s_read0;
 	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
+	if (threadIdx.x == 0) {
+		int64_t lo = 0, hi = b.n_reads;               // invariant: offsets[lo] <= base < offsets[hi]
+		while (hi - lo > 1) {
+			const int64_t mid = (lo + hi) >> 1;
+			if (b.offsets[mid] <= base) lo = mid; else hi = mid;
+		}
+		s_read0 = lo;
+	}
+	__syncthreads();
 	int my_cut = INT_MAX, my_clamp = 0;
 	unsigned long long my_pairs = 0;
 
@@ -69,8 +80,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		const int64_t i64 = base + it * PLAN_THREADS + threadIdx.x;
 		if (i64 >= b.n) break;
 		const int i = (int)i64;
-		// read that owns anchor i: last r with offsets[r] <= i
-		int64_t lo = 0, hi = b.n_reads;           // invariant: offsets[lo] <= i < offsets[hi]
+		// read that owns anchor i: last r with offsets[r] <= i.  The block's first anchor is looked up once (s_read0);
+		// most anchors of the block are in that read or the next few
+		int64_t lo = s_read0, hi = b.n_reads;
+		if (b.offsets[lo + 1] > i64) hi = lo + 1;
+		else {
+			int64_t step = 1;                          // gallop forward, then bisect: offsets[lo] <= i < offsets[hi]
+			while (lo + step < b.n_reads && b.offsets[lo + step] <= i64) { lo += step; step <<= 1; }
+			hi = min(lo + step, b.n_reads);
+		}
 		while (hi - lo > 1) {
 			const int64_t mid = (lo + hi) >> 1;
 			if (b.offsets[mid] <= i64) lo = mid; else hi = mid;
@@ -124,9 +142,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// Planner: one workgroup.  A chunk starts at the first cut of every planning block that has one and runs to the
-// next such cut, so chunks are independent DP problems of >= ~PLAN_BLOCK anchors (or one long segment).
-// Chunks are then bucket-sorted by estimated cost, most expensive first.
+// Planner.  A chunk starts at the first cut of every planning block that has one and runs to the next such cut, so
+// chunks are independent DP problems of >= ~PLAN_BLOCK anchors (or one long segment).  Chunks are bucket-sorted by
+// estimated cost, most expensive first, into the wave-mode list and the cooperative-mode list.  Six small launches, every
+// one parallel over planning blocks or chunks; nothing returns to the host.
+//   plan_tile_sums   per tile of 1024 planning blocks: #chunks, sum of pairs, #clamped blocks
+//   plan_tile_scan   one workgroup: exclusive scan of the tile sums, totals
+//   plan_emit        per tile: chunk start + prefix values at each chunk's first block
+//   plan_finish      per chunk: end, cost, flags; histogram of cost bins
+//   plan_bins        one workgroup: bin bases (descending cost), counters
+//   plan_scatter     per chunk: slot in its list
 // --------------------------------------------------------------------------------------------------------------
 constexpr int PLANNER_THREADS = 1024;
 constexpr int COST_BINS = 256;
@@ -140,9 +165,8 @@ __device__ __forceinline__ int cost_bin(int64_t c)
 }
 
 template <typename T>
-__device__ T block_exclusive_scan(T v, T *s_tmp /* PLANNER_THREADS/64 */, T *total)
+__device__ T block_exclusive_scan(T v, T *s_tmp /* blockDim/64 */, T *total)
 {
-	// inclusive scan inside the wave
 	T inc = v;
 	for (int off = 1; off < WAVE; off <<= 1) {
 		T o = __shfl_up(inc, off);
@@ -158,98 +182,111 @@ __device__ T block_exclusive_scan(T v, T *s_tmp /* PLANNER_THREADS/64 */, T *tot
 	return wave_base + inc - v;
 }
 
-__global__ __launch_bounds__(PLANNER_THREADS) void k_plan(DevBatch b, LaunchCfg cfg)
+__global__ __launch_bounds__(PLANNER_THREADS) void plan_tile_sums(DevBatch b)
 {
 	__shared__ long long s_tmp[PLANNER_THREADS / WAVE];
-	__shared__ int s_hist[2][COST_BINS];      // [0] wave-mode chunks, [1] cooperative-mode chunks
-	__shared__ int s_binbase[2][COST_BINS];
-	__shared__ int s_nlong;
-	const int64_t nb = b.n_blocks;
-	const int tid = threadIdx.x;
-	const int64_t per = (nb + PLANNER_THREADS - 1) / PLANNER_THREADS;
-	const int64_t b0 = min(nb, (int64_t)tid * per), b1 = min(nb, b0 + per);
+	const int64_t k = (int64_t)blockIdx.x * PLANNER_THREADS + threadIdx.x;
+	const bool in = k < b.n_blocks;
+	long long cnt = in && b.blk_firstcut[k] != INT_MAX, pairs = in ? b.blk_pairs[k] : 0, clamps = in ? b.blk_clamped[k] : 0;
+	long long t0, t1, t2;
+	block_exclusive_scan<long long>(cnt, s_tmp, &t0);
+	block_exclusive_scan<long long>(pairs, s_tmp, &t1);
+	block_exclusive_scan<long long>(clamps, s_tmp, &t2);
+	if (threadIdx.x == 0) { b.tile_sums[blockIdx.x * 3 + 0] = t0; b.tile_sums[blockIdx.x * 3 + 1] = t1; b.tile_sums[blockIdx.x * 3 + 2] = t2; }
+}
 
-	// pass 1: per-thread counts over its slice of planning blocks
-	long long cnt = 0, pairs = 0, clamps = 0;
-	for (int64_t k = b0; k < b1; ++k) {
-		cnt += b.blk_firstcut[k] != INT_MAX;
-		pairs += b.blk_pairs[k];
-		clamps += b.blk_clamped[k];
-	}
-	long long n_chunks, tot_pairs, tot_clamps;
-	long long c_base = block_exclusive_scan<long long>(cnt, s_tmp, &n_chunks);
-	long long p_base = block_exclusive_scan<long long>(pairs, s_tmp, &tot_pairs);
-	long long k_base = block_exclusive_scan<long long>(clamps, s_tmp, &tot_clamps);
-
-	// pass 2: chunk starts; stash the pair / clamp prefix at each chunk's first block in chunk_cost / chunk_end
-	{
-		long long c = c_base, pp = p_base, kk = k_base;
-		for (int64_t k = b0; k < b1; ++k) {
-			const int fc = b.blk_firstcut[k];
-			if (fc != INT_MAX) {
-				b.chunk_start[c] = fc;
-				b.chunk_cost[c] = pp;           // pairs in blocks before this one
-				b.chunk_end[c] = (int)kk;       // clamped blocks before this one (temporarily)
-				b.order[c] = (int)k;            // block id (temporarily)
-				++c;
-			}
-			pp += b.blk_pairs[k];
-			kk += b.blk_clamped[k];
+__global__ __launch_bounds__(PLANNER_THREADS) void plan_tile_scan(DevBatch b, int n_tiles)
+{
+	__shared__ long long s_tmp[PLANNER_THREADS / WAVE];
+	// n_tiles <= 2^31 / 2^20 = 2048: two per thread
+	long long carry[3] = { 0, 0, 0 };
+	for (int base = 0; base < n_tiles; base += PLANNER_THREADS) {
+		const int t = base + threadIdx.x;
+		for (int q = 0; q < 3; ++q) {
+			const long long v = t < n_tiles ? b.tile_sums[t * 3 + q] : 0;
+			long long tot;
+			const long long ex = block_exclusive_scan<long long>(v, s_tmp, &tot);
+			if (t < n_tiles) b.tile_base[t * 3 + q] = carry[q] + ex;
+			carry[q] += tot;
 		}
 	}
-	for (int k = tid; k < 2 * COST_BINS; k += PLANNER_THREADS) (&s_hist[0][0])[k] = 0;
-	__threadfence_block();
-	__syncthreads();
-
-	// pass 3: ends, costs, track flags, histogram.  Two sweeps because pass 3 overwrites what neighbours read.
-	const int64_t cper = (n_chunks + PLANNER_THREADS - 1) / PLANNER_THREADS;
-	const int64_t c0 = min((int64_t)n_chunks, (int64_t)tid * cper), c1 = min((int64_t)n_chunks, c0 + cper);
-	// values of the chunk after my last one, read before anyone overwrites them
-	long long nxt_pp = tot_pairs, nxt_kk = tot_clamps;
-	int nxt_start = (int)b.n, nxt_blk_clamped = 0;
-	if (c1 < n_chunks) {
-		nxt_pp = b.chunk_cost[c1]; nxt_kk = b.chunk_end[c1]; nxt_start = b.chunk_start[c1];
-		nxt_blk_clamped = b.blk_clamped[b.order[c1]];
+	if (threadIdx.x == 0) {
+		b.counters[CNT_NCHUNK] = (int)carry[0];
+		b.counters[CNT_NCLAMP] = (int)carry[2];
+		b.totals[0] = carry[1];
+		b.totals[1] = carry[2];
 	}
+}
+
+__global__ __launch_bounds__(PLANNER_THREADS) void plan_emit(DevBatch b)
+{
+	__shared__ long long s_tmp[PLANNER_THREADS / WAVE];
+	const int64_t k = (int64_t)blockIdx.x * PLANNER_THREADS + threadIdx.x;
+	const bool in = k < b.n_blocks;
+	const int fc = in ? b.blk_firstcut[k] : INT_MAX;
+	const long long cnt = fc != INT_MAX, pairs = in ? b.blk_pairs[k] : 0, clamps = in ? b.blk_clamped[k] : 0;
+	long long tot;
+	const long long c = b.tile_base[blockIdx.x * 3 + 0] + block_exclusive_scan<long long>(cnt, s_tmp, &tot);
+	const long long pp = b.tile_base[blockIdx.x * 3 + 1] + block_exclusive_scan<long long>(pairs, s_tmp, &tot);
+	const long long kk = b.tile_base[blockIdx.x * 3 + 2] + block_exclusive_scan<long long>(clamps, s_tmp, &tot);
+	if (cnt) {
+		b.chunk_start[c] = fc;
+		b.chunk_pp[c] = pp;                  // pairs in blocks before this chunk's first block
+		b.chunk_kk[c] = (int)kk;             // clamped blocks before it
+		b.chunk_blk[c] = (int)k;
+	}
+}
+
+__global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
+{
+	__shared__ int s_hist[2][COST_BINS];
+	for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) (&s_hist[0][0])[k] = 0;
 	__syncthreads();
+	const int n_chunks = b.counters[CNT_NCHUNK];
 	int n_track = 0;
-	for (int64_t c = c1 - 1; c >= c0; --c) {   // backwards so "next" values are still the stashed ones
-		const long long pp = b.chunk_cost[c], kk = b.chunk_end[c];
-		const int start = b.chunk_start[c], blk = b.order[c];
-		const int end = nxt_start;
-		// the chunk covers its own block .. part of the next chunk's block: count clamps inclusively (superset is safe)
-		const bool track = (nxt_kk + nxt_blk_clamped - kk) > 0;
-		const long long cost = (nxt_pp - pp) + (long long)(end - start) * COST_PER_ANCHOR;
-		// heavy chunks with wide windows go to the cooperative mode (bit 1 of chunk_track)
+	for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
+		const bool last = c + 1 >= n_chunks;
+		const int start = b.chunk_start[c], end = last ? (int)b.n : b.chunk_start[c + 1];
+		const long long pp_next = last ? b.totals[0] : b.chunk_pp[c + 1];
+		// the chunk covers its own block .. part of the next chunk's block: count clamps inclusively (a superset is safe)
+		const long long kk_next = last ? b.totals[1] : (long long)b.chunk_kk[c + 1] + b.blk_clamped[b.chunk_blk[c + 1]];
+		const bool track = kk_next - b.chunk_kk[c] > 0;
+		const long long cost = (pp_next - b.chunk_pp[c]) + (long long)(end - start) * COST_PER_ANCHOR;
+		// heavy chunks with wide enough windows go to the cooperative mode (bit 1)
 		const bool is_long = cfg.ring_mask >= 0 && cost >= cfg.long_min_cost && (long long)(end - start) * cfg.long_min_window <= cost;
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;
 		b.chunk_track[c] = (uint8_t)((track ? 1 : 0) | (is_long ? 2 : 0));
 		n_track += track;
 		atomicAdd(&s_hist[is_long][cost_bin(cost)], 1);
-		nxt_pp = pp; nxt_kk = kk; nxt_start = start; nxt_blk_clamped = b.blk_clamped[blk];
 	}
 	__syncthreads();
-	// descending bin order -> base offsets
-	if (tid < 2) {
+	for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) {
+		const int v = (&s_hist[0][0])[k];
+		if (v) atomicAdd(&b.bins[k], v);
+	}
+	for (int off = WAVE / 2; off > 0; off >>= 1) n_track += __shfl_xor(n_track, off);
+	if (lane_id() == 0 && n_track) atomicAdd(&b.counters[CNT_NTRACK], n_track);
+}
+
+__global__ __launch_bounds__(64) void plan_bins(DevBatch b)
+{
+	if (threadIdx.x < 2) {
 		int acc = 0;
-		for (int k = COST_BINS - 1; k >= 0; --k) { s_binbase[tid][k] = acc; acc += s_hist[tid][k]; }
-		if (tid == 1) s_nlong = acc;
+		int *bins = b.bins + threadIdx.x * COST_BINS;
+		for (int k = COST_BINS - 1; k >= 0; --k) { const int v = bins[k]; bins[k] = acc; acc += v; }   // count -> base
+		if (threadIdx.x == 1) b.counters[CNT_NLONG] = acc;
 	}
-	__syncthreads();
-	for (int64_t c = c0; c < c1; ++c) {
+	if (threadIdx.x == 0) { b.counters[CNT_CURSOR] = 0; b.counters[CNT_LCURSOR] = 0; }
+}
+
+__global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
+{
+	const int n_chunks = b.counters[CNT_NCHUNK];
+	for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
 		const int is_long = (b.chunk_track[c] >> 1) & 1;
-		const int slot = atomicAdd(&s_binbase[is_long][cost_bin(b.chunk_cost[c])], 1);
+		const int slot = atomicAdd(&b.bins[is_long * COST_BINS + cost_bin(b.chunk_cost[c])], 1);
 		(is_long ? b.long_list : b.order)[slot] = (int)c;
-	}
-	if (n_track) atomicAdd(&b.counters[CNT_NTRACK], n_track);
-	if (tid == 0) {
-		b.counters[CNT_NCHUNK] = (int)n_chunks;
-		b.counters[CNT_CURSOR] = 0;
-		b.counters[CNT_NLONG] = s_nlong;
-		b.counters[CNT_LCURSOR] = 0;
-		b.counters[CNT_NCLAMP] = (int)tot_clamps;
-		b.totals[0] = tot_pairs;
 	}
 }
 
@@ -656,7 +693,15 @@ void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s)
 
 void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLANNER_THREADS), 0, s, b, cfg);
+	const int n_tiles = (int)((b.n_blocks + PLANNER_THREADS - 1) / PLANNER_THREADS);
+	const int chunk_grid = (int)std::min<int64_t>(1024, (b.n_blocks + 255) / 256);
+	(void)hipMemsetAsync(b.bins, 0, 2 * COST_BINS * sizeof(int), s);
+	hipLaunchKernelGGL(plan_tile_sums, dim3(n_tiles), dim3(PLANNER_THREADS), 0, s, b);
+	hipLaunchKernelGGL(plan_tile_scan, dim3(1), dim3(PLANNER_THREADS), 0, s, b, n_tiles);
+	hipLaunchKernelGGL(plan_emit, dim3(n_tiles), dim3(PLANNER_THREADS), 0, s, b);
+	hipLaunchKernelGGL(plan_finish, dim3(chunk_grid), dim3(256), 0, s, b, cfg);
+	hipLaunchKernelGGL(plan_bins, dim3(1), dim3(64), 0, s, b);
+	hipLaunchKernelGGL(plan_scatter, dim3(chunk_grid), dim3(256), 0, s, b);
 }
 
 void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)

@@ -50,6 +50,7 @@ struct Engine {
 	DevBuf x, y, xhi, tag, st;
 	DevBuf blk_firstcut, blk_pairs, blk_clamped;
 	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list;
+	DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
 	DevBuf counters, totals, flags, lut;
 	// staging for the host-buffer API
 	DevBuf raw, offsets, f, p;

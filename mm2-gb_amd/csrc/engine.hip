@@ -129,7 +129,7 @@ void Engine::shutdown()
 	(void)hipSetDevice(device);
 	if (stream) (void)hipStreamSynchronize(stream);
 	for (DevBuf *b : { &x, &y, &xhi, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &chunk_start, &chunk_end, &chunk_cost,
-	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &raw, &offsets, &f, &p, &lut })
+	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &raw, &offsets, &f, &p, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
 		b->release();
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
@@ -150,7 +150,8 @@ int Engine::reserve(int64_t n, int64_t n_reads, bool host_staging)
 		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
 		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4)) return -1;
 		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
-		    order.ensure(nb * 4) || long_list.ensure(nb * 4)) return -1;
+		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
+		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(2 * 256 * 4)) return -1;
 		cap_n = nn; cap_blocks = nb; cap_reads = std::max(cap_reads, n_reads);
 	}
 	if (host_staging) {
@@ -172,6 +173,8 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	b.n_blocks = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
 	b.chunk_start = (int32_t*)chunk_start.ptr; b.chunk_end = (int32_t*)chunk_end.ptr; b.chunk_cost = (int64_t*)chunk_cost.ptr;
 	b.chunk_track = (uint8_t*)chunk_track.ptr; b.order = (int32_t*)order.ptr; b.long_list = (int32_t*)long_list.ptr;
+	b.chunk_pp = (int64_t*)chunk_pp.ptr; b.chunk_kk = (int32_t*)chunk_kk.ptr; b.chunk_blk = (int32_t*)chunk_blk.ptr;
+	b.tile_sums = (int64_t*)tile_sums.ptr; b.tile_base = (int64_t*)tile_base.ptr; b.bins = (int32_t*)bins.ptr;
 	b.counters = (int32_t*)counters.ptr; b.totals = (int64_t*)totals.ptr; b.flags = (unsigned*)flags.ptr;
 	b.lut = (const int32_t*)lut.ptr;
 
