@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 //   MODE_GENERAL  every branch of comput_sc (segment ids, cDNA, n_seg > 1).
 // --------------------------------------------------------------------------------------------------------------
 enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
+constexpr int SCORE_THREADS = 1024;
 constexpr int LUT_REJECT = 1 << 29;
 
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
@@ -406,6 +407,54 @@ __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; g.t[u] = st[j0 + u]; }
 	return g;
 }
+struct SrcXY { int x[4], y[4]; };
+__device__ __forceinline__ SrcXY load_xy(const DevBatch &b, int j0)
+{
+	const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y);
+	SrcXY g;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; }
+	return g;
+}
+
+// MODE_LUT sweep.  Per source step the vector ALU sees only: two subtractions against scalar x/y, |dr-dq|, the table
+// index, min3, two additions, the dq range test, the running-max test and two selects.  The source's score and q_span
+// arrive as one LDS broadcast read (stage[k], written by this wave just before), the penalty as one LDS gather.
+// CHECK adds "source inside this target's window" and "dr != 0" (lchain.c:120), which can only fail in the first and last
+// blocks of a sweep: sources of interior blocks lie inside every target's window and strictly left of every target's x.
+template <bool CHECK>
+__device__ __forceinline__ void sweep_block_lut(const DevBatch &b, const Target &T, int jb, int k_from, const int2 *stage,
+                                                const DevParams &P, const int *lut, int &best, int &arg)
+{
+	int kg = k_from & ~3;
+	SrcXY nxt = load_xy(b, jb + kg);
+	for (; kg < WAVE; kg += 4) {
+		const SrcXY g = nxt;
+		const int j0 = jb + kg;
+		int dq[4], dr[4], pen[4];
+		int2 fq[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) fq[u] = stage[kg + u];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			dq[u] = T.y - g.y[u]; dr[u] = T.x - g.x[u];
+			const unsigned dd = abs_diff_u32(dr[u], dq[u]);
+			pen[u] = lut[dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last];
+		}
+		nxt = load_xy(b, kg + 4 < WAVE ? j0 + 4 : j0);      // overlaps the arithmetic below
+		int jv;
+		asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j0));       // index arithmetic below stays VGPR + literal (full rate)
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int dg = dr[u] < dq[u] ? dr[u] : dq[u];
+			const int cand = (fq[u].y < dg ? fq[u].y : dg) - pen[u] + fq[u].x;
+			// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
+			bool take = ((unsigned)(dq[u] - 1) < (unsigned)P.dq_lim) & (cand >= best);
+			if (CHECK) take = take & (dr[u] != 0) & (j0 + u >= T.st);
+			best = take ? cand : best; arg = take ? jv + u : arg;
+		}
+	}
+}
 
 template <int MODE, bool CHECK>
 __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, int jb, int k_from, int sf,
@@ -416,44 +465,48 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 	for (; kg < WAVE; kg += 4) {
 		const SrcGroup g = nxt;
 		const int j0 = jb + kg;
-		if (MODE == MODE_LUT) {
-			// stage 1: geometry and the four table look-ups (issued together so one wait covers them)
-			int dq[4], dr[4], pen[4];
+		nxt = load_group(b, kg + 4 < WAVE ? j0 + 4 : j0);
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				dq[u] = T.y - g.y[u]; dr[u] = T.x - g.x[u];
-				const unsigned dd = abs_diff_u32(dr[u], dq[u]);
-				pen[u] = lut[dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last];
-			}
-			// the next group's scalar loads overlap the arithmetic below (clamped: the last group re-reads itself)
-			nxt = load_group(b, kg + 4 < WAVE ? j0 + 4 : j0);
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const int j = j0 + u;
-				const int uf = bcast(sf, kg + u);
-				const int span = g.t[u] & 0xff;
-				const int dg = dr[u] < dq[u] ? dr[u] : dq[u];
-				const int cand = (span < dg ? span : dg) - pen[u] + uf;
-				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
-				bool take = ((unsigned)(dq[u] - 1) < (unsigned)P.dq_lim) & (dr[u] != 0) & (cand >= best);
-				if (CHECK) take = take & (j >= T.st);
-				best = take ? cand : best; arg = take ? j : arg;
-			}
-		} else {
-			nxt = load_group(b, kg + 4 < WAVE ? j0 + 4 : j0);
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const int j = j0 + u;
-				const int uf = bcast(sf, kg + u);
-				int sc;
-				bool take = pair_score<MODE>(T.x, T.y, T.seg, g.x[u], g.y[u], g.t[u], P, lut, sc);
-				const int cand = sc + uf;
-				take = take && cand >= best;
-				if (CHECK) take = take && j >= T.st;
-				if (take) { best = cand; arg = j; }
-			}
+		for (int u = 0; u < 4; ++u) {
+			const int j = j0 + u;
+			const int uf = bcast(sf, kg + u);
+			int sc;
+			bool take = pair_score<MODE>(T.x, T.y, T.seg, g.x[u], g.y[u], g.t[u], P, lut, sc);
+			const int cand = sc + uf;
+			take = take && cand >= best;
+			if (CHECK) take = take && j >= T.st;
+			if (take) { best = cand; arg = j; }
 		}
 	}
+}
+
+// Sweep of one full source block for either build.  `stage` is this wave's 64-entry LDS scratch (MODE_LUT only).
+// no_check: every source of the block is inside every live target's window and left of every target's x.
+template <int MODE>
+__device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, int jb, int k_from, int sf, int sq, bool no_check,
+                                          int2 *stage, const DevParams &P, const int *lut, int &best, int &arg)
+{
+	if (MODE == MODE_LUT) {
+		stage[lane_id()] = make_int2(sf, sq);
+		__builtin_amdgcn_wave_barrier();                    // LDS is in-order per wave; keep the compiler from reordering
+		if (no_check) sweep_block_lut<false>(b, T, jb, k_from, stage, P, lut, best, arg);
+		else sweep_block_lut<true>(b, T, jb, k_from, stage, P, lut, best, arg);
+		__builtin_amdgcn_wave_barrier();
+	} else {
+		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
+		if (no_check) sweep_block<MODE, false>(b, T, jb, k_from, sf, P, lut, best, arg);
+		else sweep_block<MODE, true>(b, T, jb, k_from, sf, P, lut, best, arg);
+	}
+}
+
+// First anchor of the run of equal reference positions that ends at anchor i0 (scalar walk, bounded).
+__device__ __forceinline__ int equal_x_run_start(const DevBatch &b, int cs, int i0, int x0)
+{
+	const scalar_i32_ptr sx = as_scalar(b.x);
+	int e = i0;
+	for (int n = 0; n < 64 && e > cs && sx[e - 1] == x0; ++n) --e;
+	if (e > cs && sx[e - 1] == x0) e = cs;                  // longer than the bound: check everything
+	return e;
 }
 
 __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce, bool want_hi)
@@ -539,7 +592,7 @@ __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int 
 
 // ---- wave mode: one wave owns the chunk [cs, ce) --------------------------------------------------------------
 template <int MODE, bool TRACK>
-__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, const int cs, const int ce)
+__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, int2 *stage, const int cs, const int ce)
 {
 	const int lane = lane_id();
 	Keep keep; keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
@@ -551,14 +604,15 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 		const int st_hi = bcast(T.st, n_here - 1);            // the last live lane the largest
 		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
 		if (jb < i0) {
-			int sf = b.f[jb + lane];
+			const int eq_lo = MODE == MODE_LUT ? equal_x_run_start(b, cs, i0, first_lane(T.x)) : i0;
+			int sf = b.f[jb + lane], sq = MODE == MODE_LUT ? b.tag[jb + lane] & 0xff : 0;
 			for (; jb < i0; jb += WAVE) {
 				// next block's scores are requested before this block is consumed
-				const int nf = b.f[jb + WAVE < i0 ? jb + WAVE + lane : jb + lane];
+				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
+				const int nf = b.f[jn], nq = MODE == MODE_LUT ? b.tag[jn] & 0xff : 0;
 				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
-				if (jb >= st_hi) sweep_block<MODE, false>(b, T, jb, k_from, sf, P, lut, best, arg);
-				else sweep_block<MODE, true>(b, T, jb, k_from, sf, P, lut, best, arg);
-				sf = nf;
+				sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);
+				sf = nf; sq = nq;
 			}
 		}
 		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, best, arg, keep, [&](int jj) { return b.f[jj]; });
@@ -579,7 +633,7 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 struct CoopShared { int done; int keep[6]; int chunk; };
 
 template <int MODE, bool TRACK>
-__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int *ring, const int ring_mask, CoopShared *sh,
+__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int2 *stage, int *ring, const int ring_mask, CoopShared *sh,
                            const int cs, const int ce)
 {
 	const int lane = lane_id(), wave = threadIdx.x / WAVE, n_waves = blockDim.x / WAVE;
@@ -597,12 +651,13 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 		const int tile_lo = first_lane(T.st);
 		const int st_hi = bcast(T.st, n_here - 1);
 		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
+		const int eq_lo = MODE == MODE_LUT && jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(T.x)) : i0;
 		for (; jb < i0; jb += WAVE) {
+			const int sq = MODE == MODE_LUT ? b.tag[jb + lane] & 0xff : 0;
 			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring
 			const int sf = ring[(jb + lane) & ring_mask];
 			const int k_from = tile_lo > jb ? tile_lo - jb : 0;
-			if (jb >= st_hi) sweep_block<MODE, false>(b, T, jb, k_from, sf, P, lut, best, arg);
-			else sweep_block<MODE, true>(b, T, jb, k_from, sf, P, lut, best, arg);
+			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);
 		}
 		wait_done(t);                                                    // every earlier tile is final
 		Keep keep;
@@ -627,9 +682,8 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 // list and run them cooperatively.  Phase 2: every wave pulls ordinary chunks on its own, most expensive first.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_split_soa).
-// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ CoopShared ]
+// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ stage : 16 waves x 64 x int2 ][ CoopShared ]
 // --------------------------------------------------------------------------------------------------------------
-constexpr int SCORE_THREADS = 1024;
 
 template <int MODE>
 __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_mask)
@@ -641,7 +695,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	int *lut = smem;
 	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
 	int *ring = smem + lut_words;
-	CoopShared *sh = (CoopShared*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0));
+	int2 *stage = (int2*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
+	CoopShared *sh = (CoopShared*)((int2*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + SCORE_THREADS);
 	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];
 	__syncthreads();
 
@@ -655,8 +710,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			if (c >= n_long) break;
 			const int ci = b.long_list[c];
 			const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
-			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, ring, ring_mask, sh, cs, ce);
-			else coop_chunk<MODE, false>(b, P, lut, ring, ring_mask, sh, cs, ce);
+			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, ring, ring_mask, sh, cs, ce);
+			else coop_chunk<MODE, false>(b, P, lut, stage, ring, ring_mask, sh, cs, ce);
 			__syncthreads();
 		}
 	}
@@ -669,8 +724,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		if (c >= n_chunks) break;
 		const int ci = b.order[c];
 		const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
-		if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, cs, ce);
-		else run_chunk<MODE, false>(b, P, lut, cs, ce);
+		if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, stage, cs, ce);
+		else run_chunk<MODE, false>(b, P, lut, stage, cs, ce);
 	}
 }
 
@@ -712,7 +767,7 @@ void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
 size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask)
 {
 	const size_t lut_words = host_mode == MODE_LUT ? (size_t)((P.lut_last + 1 + 3) & ~3) : 0;
-	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + sizeof(CoopShared) + 16;
+	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + (size_t)SCORE_THREADS * sizeof(int2) + sizeof(CoopShared) + 16;
 }
 
 int score_set_lds_limit(size_t bytes)
