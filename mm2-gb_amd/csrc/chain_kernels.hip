@@ -417,31 +417,28 @@ __device__ __forceinline__ SrcXY load_xy(const DevBatch &b, int j0)
 	return g;
 }
 
-// MODE_LUT sweep.  Per source step the vector ALU sees only: two subtractions against scalar x/y, |dr-dq|, the table
-// index, min3, two additions, the dq range test, the running-max test and two selects.  The source's score and q_span
-// arrive as one LDS broadcast read (stage[k], written by this wave just before), the penalty as one LDS gather.
+// MODE_LUT sweep.  A block's 64 sources are first written to this wave's LDS scratch as {f, q_span, x, y}; each step then
+// takes ONE LDS broadcast read (ds_read_b128, same address in every lane) for the source and one LDS gather for the
+// penalty, so every vector-ALU operand is a VGPR (ops with an SGPR operand issue at half rate on gfx950, profiles/ubench):
+// two subtractions, |dr-dq|, the table index, min3, two additions, the dq range test, the running-max test, two selects.
 // CHECK adds "source inside this target's window" and "dr != 0" (lchain.c:120), which can only fail in the first and last
 // blocks of a sweep: sources of interior blocks lie inside every target's window and strictly left of every target's x.
 template <bool CHECK>
-__device__ __forceinline__ void sweep_block_lut(const DevBatch &b, const Target &T, int jb, int k_from, const int2 *stage,
+__device__ __forceinline__ void sweep_block_lut(const DevBatch &b, const Target &T, int jb, int k_from, const int4 *stage,
                                                 const DevParams &P, const int *lut, int &best, int &arg)
 {
-	int kg = k_from & ~3;
-	SrcXY nxt = load_xy(b, jb + kg);
-	for (; kg < WAVE; kg += 4) {
-		const SrcXY g = nxt;
+	for (int kg = k_from & ~3; kg < WAVE; kg += 4) {
 		const int j0 = jb + kg;
 		int dq[4], dr[4], pen[4];
-		int2 fq[4];
+		int4 fq[4];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) fq[u] = stage[kg + u];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
-			dq[u] = T.y - g.y[u]; dr[u] = T.x - g.x[u];
+			dq[u] = T.y - fq[u].w; dr[u] = T.x - fq[u].z;
 			const unsigned dd = abs_diff_u32(dr[u], dq[u]);
 			pen[u] = lut[dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last];
 		}
-		nxt = load_xy(b, kg + 4 < WAVE ? j0 + 4 : j0);      // overlaps the arithmetic below
 		int jv;
 		asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j0));       // index arithmetic below stays VGPR + literal (full rate)
 #pragma unroll
@@ -484,10 +481,10 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 // no_check: every source of the block is inside every live target's window and left of every target's x.
 template <int MODE>
 __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, int jb, int k_from, int sf, int sq, bool no_check,
-                                          int2 *stage, const DevParams &P, const int *lut, int &best, int &arg)
+                                          int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		stage[lane_id()] = make_int2(sf, sq);
+		stage[lane_id()] = make_int4(sf, sq, b.x[jb + lane_id()], b.y[jb + lane_id()]);
 		__builtin_amdgcn_wave_barrier();                    // LDS is in-order per wave; keep the compiler from reordering
 		if (no_check) sweep_block_lut<false>(b, T, jb, k_from, stage, P, lut, best, arg);
 		else sweep_block_lut<true>(b, T, jb, k_from, stage, P, lut, best, arg);
@@ -592,7 +589,7 @@ __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int 
 
 // ---- wave mode: one wave owns the chunk [cs, ce) --------------------------------------------------------------
 template <int MODE, bool TRACK>
-__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, int2 *stage, const int cs, const int ce)
+__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, const int cs, const int ce)
 {
 	const int lane = lane_id();
 	Keep keep; keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
@@ -633,7 +630,7 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 struct CoopShared { int done; int keep[6]; int chunk; };
 
 template <int MODE, bool TRACK>
-__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int2 *stage, int *ring, const int ring_mask, CoopShared *sh,
+__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_mask, CoopShared *sh,
                            const int cs, const int ce)
 {
 	const int lane = lane_id(), wave = threadIdx.x / WAVE, n_waves = blockDim.x / WAVE;
@@ -682,7 +679,7 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 // list and run them cooperatively.  Phase 2: every wave pulls ordinary chunks on its own, most expensive first.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_split_soa).
-// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ stage : 16 waves x 64 x int2 ][ CoopShared ]
+// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared ]
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE>
@@ -695,8 +692,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	int *lut = smem;
 	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
 	int *ring = smem + lut_words;
-	int2 *stage = (int2*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
-	CoopShared *sh = (CoopShared*)((int2*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + SCORE_THREADS);
+	int4 *stage = (int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
+	CoopShared *sh = (CoopShared*)((int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + SCORE_THREADS);
 	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];
 	__syncthreads();
 
@@ -767,7 +764,7 @@ void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
 size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask)
 {
 	const size_t lut_words = host_mode == MODE_LUT ? (size_t)((P.lut_last + 1 + 3) & ~3) : 0;
-	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + (size_t)SCORE_THREADS * sizeof(int2) + sizeof(CoopShared) + 16;
+	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + (size_t)SCORE_THREADS * sizeof(int4) + sizeof(CoopShared) + 16;
 }
 
 int score_set_lds_limit(size_t bytes)
