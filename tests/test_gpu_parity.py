@@ -121,6 +121,50 @@ def test_default_max_iter_repeat_block(engine):
     assert st["n_tracked_chunks"] >= 1
 
 
+def test_equal_reference_positions(engine):
+    """Runs of anchors sharing one reference position (dr == 0 is rejected, lchain.c:120): short runs, runs longer than a
+    tile, runs longer than the kernel's bounded scalar walk, inside windows that other anchors chain through."""
+    rng = np.random.default_rng(5)
+    parts = []
+    for run in (1, 2, 3, 70, 200):
+        base = sc.colinear(300, 100 + run, r0=500_000, q0=200, max_gap=12)
+        xs = int(base[150, 0] & np.uint64(0xffffffff))
+        dup = sc.pack(np.full(run, 3), np.zeros(run, np.int64), np.full(run, xs), np.sort(rng.integers(200, 6000, run)))
+        parts.append(sc.sort_by_x(np.concatenate([base, dup])))
+    # a dense block where most positions repeat (12k anchors on 4k positions), wide enough for cooperative mode
+    parts.append(sc.sort_by_x(sc.repeat_block(6000, 77, xwin=1500, ywin=5000)))
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    st = check_batch(engine, np.concatenate(parts), off, orc.default_param())
+    assert st["n_long_chunks"] >= 1
+
+
+def test_cooperative_and_wave_modes_agree(monkeypatch):
+    """Heavy chunks through the workgroup-cooperative mode and, with it switched off, through the wave mode."""
+    parts = [sc.sort_by_x(sc.repeat_block(4500, 51)), sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 52), sc.colinear(900, 53)])),
+             sc.read_like(9000, 54), sc.rescue_case(n_noise=6000, n_chain=50, seed=9)]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    prm = orc.default_param()
+    with mm.Engine() as e1:
+        st1 = check_batch(e1, a, off, prm)
+    assert st1["n_long_chunks"] >= 3 and st1["n_tracked_chunks"] >= 2
+    monkeypatch.setenv("MM2GB_NO_COOP", "1")
+    with mm.Engine() as e2:
+        st2 = check_batch(e2, a, off, prm)
+    assert st2["n_long_chunks"] == 0 and st2["n_tracked_chunks"] == st1["n_tracked_chunks"]
+
+
+@pytest.mark.parametrize("kw", [dict(bw=9000, max_dist_x=20000, max_dist_y=20000), dict(pen_skip=np.float32(0.02), max_iter=20000)])
+def test_modes_without_the_penalty_table(kw):
+    """bw too large for the LDS table, or chn_pen_skip != 0: per-pair float path (MODE_FAST), also in cooperative mode."""
+    a = sc.sort_by_x(np.concatenate([sc.repeat_block(5200, 61), sc.colinear(700, 62)]))
+    with mm.Engine() as e:
+        st = check_batch(e, a, np.array([0, len(a)], np.int64), orc.default_param(**kw))
+    assert st["n_pairs"] > 1_000_000
+
+
 def test_synthetic_ont_batch_full_chain(engine):
     """The bench workload at small scale: 24 reads of 10-100 kb; scores, then chains, against the oracle."""
     a, off = mm.synth_reads(7, 0, 24, 10_000, 100_000)
