@@ -35,40 +35,54 @@ struct PinnedBuf {
 	void release();
 };
 
+// Device-side staging of one host micro-batch: raw anchors + offsets in, f/p out.  Two sets alternate so that the H2D of
+// micro-batch k+1, the kernels of k and the D2H of k-1 run at the same time on three streams.
+struct IoSet {
+	DevBuf raw, offsets, f, p;
+	hipEvent_t in_start = nullptr, in_done = nullptr, comp_done = nullptr, out_start = nullptr, out_done = nullptr;
+	bool used = false;
+};
+
+// Timing + result counters of one enqueued micro-batch (a host call may enqueue several).
+struct BatchSlot { hipEvent_t prep0 = nullptr, prep1 = nullptr, score1 = nullptr; };
+constexpr int MAX_SLOTS = 256;
+
 struct Engine {
 	int device = 0;
 	mm2gb_config_t cfg;
 	mm2gb_misc_t   misc;
 	DevParams      params;
 	LaunchCfg      launch;
-	hipStream_t    stream = nullptr;       // compute (and, for now, copies)
-	hipEvent_t     ev[6] = {};             // start, h2d done, prep done, score done, d2h done, spare
+	hipStream_t    stream = nullptr;       // kernels
+	hipStream_t    s_in = nullptr, s_out = nullptr;   // H2D / D2H of the host-buffer paths
 	int            n_cu = 256;
 
-	// work arenas (sized by capacity_n / capacity_blocks)
+	// work arenas (sized by capacity_n / capacity_blocks); one set: kernels of consecutive micro-batches serialise anyway
 	int64_t cap_n = 0, cap_reads = 0, cap_blocks = 0;
 	DevBuf x, y, xhi, tag, st;
 	DevBuf blk_firstcut, blk_pairs, blk_clamped;
 	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list;
 	DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
 	DevBuf counters, totals, flags, lut;
-	// staging for the host-buffer API
-	DevBuf raw, offsets, f, p;
-	// pinned scalars for stats read-back
-	int32_t *h_counters = nullptr;
-	int64_t *h_totals = nullptr;
+	IoSet io[2];
+	uint64_t io_seq = 0;
+	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host
+	// per-slot read-back (pinned)
+	int32_t *h_counters = nullptr;         // MAX_SLOTS x CNT_WORDS
+	int64_t *h_totals = nullptr;           // MAX_SLOTS x 2
+	BatchSlot slots[MAX_SLOTS];
+	int n_slots = 0;
 
 	mm2gb_stats_t last = {};
-	bool stats_pending = false;
-	bool timed_h2d = false, timed_d2h = false;
 	bool misc_valid = false, coop_disabled = false;
 
 	int  init(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);
 	void shutdown();
 	int  set_misc(const mm2gb_misc_t *m);
 	int  configure_score();
-	int  reserve(int64_t n_anchors, int64_t n_reads, bool host_staging);
-	// host buffers (pinned for true asynchrony): H2D, kernels, D2H enqueued; returns without waiting
+	int  reserve(int64_t n_anchors, int64_t n_reads);
+	int  begin_call();                     // start of a host-level call: resets slots and `last`
+	// host buffers (pinned for true asynchrony): H2D, kernels, D2H enqueued on three streams; returns without waiting
 	int  enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p);
 	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p);
 	int  sync();

@@ -4,7 +4,10 @@
 // split -> window(+planner reductions) -> plan -> score are all enqueued back to back, no host sort, no hipMalloc per batch.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <string>
 #include "engine.h"
 
@@ -116,29 +119,39 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
 	MM2GB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-	if (set_misc(m)) return -1;
-	for (auto &e : ev) MM2GB_HIP(hipEventCreate(&e));
-	MM2GB_HIP(hipHostMalloc((void**)&h_counters, CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
-	MM2GB_HIP(hipHostMalloc((void**)&h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+	MM2GB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+	MM2GB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+	for (IoSet &s : io)
+		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) MM2GB_HIP(hipEventCreate(e));
+	MM2GB_HIP(hipHostMalloc((void**)&h_counters, (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
+	MM2GB_HIP(hipHostMalloc((void**)&h_totals, (size_t)MAX_SLOTS * 2 * sizeof(int64_t), hipHostMallocDefault));
 	if (counters.ensure(CNT_WORDS * sizeof(int32_t)) || totals.ensure(2 * sizeof(int64_t)) || flags.ensure(4 * sizeof(unsigned))) return -1;
+	if (set_misc(m)) return -1;
 	return 0;
 }
 
 void Engine::shutdown()
 {
 	(void)hipSetDevice(device);
-	if (stream) (void)hipStreamSynchronize(stream);
+	for (hipStream_t s : { s_in, stream, s_out }) if (s) (void)hipStreamSynchronize(s);
 	for (DevBuf *b : { &x, &y, &xhi, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &chunk_start, &chunk_end, &chunk_cost,
-	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &raw, &offsets, &f, &p, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
+	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
 		b->release();
+	for (IoSet &s : io) {
+		s.raw.release(); s.offsets.release(); s.f.release(); s.p.release();
+		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+		s.used = false;
+	}
+	for (BatchSlot &b : slots)
+		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+	h_slice_off.release();
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
-	for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-	if (stream) (void)hipStreamDestroy(stream);
-	stream = nullptr; h_counters = nullptr; h_totals = nullptr;
+	for (hipStream_t *s : { &s_in, &stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+	h_counters = nullptr; h_totals = nullptr;
 }
 
-int Engine::reserve(int64_t n, int64_t n_reads, bool host_staging)
+int Engine::reserve(int64_t n, int64_t n_reads)
 {
 	MM2GB_HIP(hipSetDevice(device));
 	if (n >= ((int64_t)1 << 31) - 2 * PLAN_BLOCK) return fail("mm2gb: a micro-batch is limited to 2^31 anchors (got " + std::to_string(n) + ")");
@@ -154,17 +167,25 @@ int Engine::reserve(int64_t n, int64_t n_reads, bool host_staging)
 		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(2 * 256 * 4)) return -1;
 		cap_n = nn; cap_blocks = nb; cap_reads = std::max(cap_reads, n_reads);
 	}
-	if (host_staging) {
-		if (raw.ensure((size_t)std::max<int64_t>(n, 1) * 16) || f.ensure((size_t)std::max<int64_t>(n, 1) * 4) || p.ensure((size_t)std::max<int64_t>(n, 1) * 4) ||
-		    offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
-	}
+	return 0;
+}
+
+int Engine::begin_call()
+{
+	if (n_slots > 0 && sync()) return -1;     // a previous call was never collected
+	n_slots = 0;
+	last = mm2gb_stats_t();
 	return 0;
 }
 
 int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p)
 {
 	if (n < 0 || n_reads < 0) return fail("mm2gb: negative batch size");
-	if (reserve(n, n_reads, false)) return -1;
+	if (n_slots >= MAX_SLOTS && sync()) return -1;      // fold what is done so far into `last`, keep counting
+	if (reserve(n, n_reads)) return -1;
+	const int slot = n_slots++;
+	BatchSlot &bs = slots[slot];
+	for (hipEvent_t *e : { &bs.prep0, &bs.prep1, &bs.score1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
 	DevBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
 	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
@@ -181,64 +202,76 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
 	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 2 * sizeof(int64_t), stream));
 	MM2GB_HIP(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(unsigned), stream));
-	MM2GB_HIP(hipEventRecord(ev[1], stream));
+	MM2GB_HIP(hipEventRecord(bs.prep0, stream));
 	if (n > 0) {
 		launch_split_soa(b, stream);
 		launch_window(b, params, stream);
 		launch_plan(b, launch, stream);
 	}
-	MM2GB_HIP(hipEventRecord(ev[2], stream));
+	MM2GB_HIP(hipEventRecord(bs.prep1, stream));
 	if (n > 0) launch_score(b, params, launch, stream);
-	MM2GB_HIP(hipEventRecord(ev[3], stream));
-	MM2GB_HIP(hipMemcpyAsync(h_counters, counters.ptr, CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-	MM2GB_HIP(hipMemcpyAsync(h_totals, totals.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipEventRecord(bs.score1, stream));
+	MM2GB_HIP(hipMemcpyAsync(h_counters + (size_t)slot * CNT_WORDS, counters.ptr, CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipMemcpyAsync(h_totals + (size_t)slot * 2, totals.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 	MM2GB_HIP(hipGetLastError());
-	last = mm2gb_stats_t();
-	last.n_anchors = n; last.n_reads = n_reads;
-	stats_pending = true;
+	last.n_anchors += n; last.n_reads += n_reads;
 	return 0;
 }
 
 int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p)
 {
 	MM2GB_HIP(hipSetDevice(device));
-	if (reserve(n, n_reads, true)) return -1;
-	MM2GB_HIP(hipEventRecord(ev[0], stream));
-	MM2GB_HIP(hipMemcpyAsync(offsets.ptr, h_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
-	if (n > 0) MM2GB_HIP(hipMemcpyAsync(raw.ptr, h_anchors, (size_t)n * 16, hipMemcpyHostToDevice, stream));
-	if (enqueue(n_reads, (const int64_t*)offsets.ptr, (const mm2gb_anchor_t*)raw.ptr, n, (int32_t*)f.ptr, (int32_t*)p.ptr)) return -1;
-	if (n > 0) {
-		MM2GB_HIP(hipMemcpyAsync(h_f, f.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-		MM2GB_HIP(hipMemcpyAsync(h_p, p.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+	IoSet &s = io[io_seq++ & 1];
+	const size_t nn = (size_t)std::max<int64_t>(n, 1);
+	if (s.raw.bytes < nn * 16 || s.f.bytes < nn * 4 || s.p.bytes < nn * 4 || s.offsets.bytes < (size_t)(n_reads + 1) * 8) {
+		// growing a set frees its old buffers: nothing may be in flight on it
+		for (hipStream_t q : { s_in, stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+		if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
 	}
-	MM2GB_HIP(hipEventRecord(ev[4], stream));
-	timed_h2d = timed_d2h = true;
+	// H2D may overwrite raw/offsets only after the kernels that last read this set are done
+	if (s.used) MM2GB_HIP(hipStreamWaitEvent(s_in, s.comp_done, 0));
+	MM2GB_HIP(hipEventRecord(s.in_start, s_in));
+	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, h_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s_in));
+	if (n > 0) MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, h_anchors, (size_t)n * 16, hipMemcpyHostToDevice, s_in));
+	MM2GB_HIP(hipEventRecord(s.in_done, s_in));
+	// kernels need the inputs, and may overwrite f/p only after the previous D2H from this set is done
+	MM2GB_HIP(hipStreamWaitEvent(stream, s.in_done, 0));
+	if (s.used) MM2GB_HIP(hipStreamWaitEvent(stream, s.out_done, 0));
+	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr)) return -1;
+	MM2GB_HIP(hipEventRecord(s.comp_done, stream));
+	MM2GB_HIP(hipStreamWaitEvent(s_out, s.comp_done, 0));
+	MM2GB_HIP(hipEventRecord(s.out_start, s_out));
+	if (n > 0) {
+		MM2GB_HIP(hipMemcpyAsync(h_f, s.f.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipMemcpyAsync(h_p, s.p.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, s_out));
+	}
+	MM2GB_HIP(hipEventRecord(s.out_done, s_out));
+	s.used = true;
 	return 0;
 }
 
 int Engine::sync()
 {
 	MM2GB_HIP(hipSetDevice(device));
-	MM2GB_HIP(hipStreamSynchronize(stream));
+	for (hipStream_t q : { s_in, stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
 	return collect_stats();
 }
 
 int Engine::collect_stats()
 {
-	if (!stats_pending) return 0;
-	stats_pending = false;
-	last.n_pairs = h_totals[0];
-	last.n_chunks = h_counters[CNT_NCHUNK];
-	last.n_long_chunks = h_counters[CNT_NLONG];
-	last.n_tracked_chunks = h_counters[CNT_NTRACK];
-	last.n_clamped_blocks = h_counters[CNT_NCLAMP];
-	float ms = 0;
-	if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) last.ms_prep = ms;
-	if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) last.ms_score = ms;
-	if (timed_h2d && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) last.ms_h2d = ms;
-	if (timed_d2h && hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) last.ms_d2h = ms;
-	if (hipEventElapsedTime(&ms, timed_h2d ? ev[0] : ev[1], timed_d2h ? ev[4] : ev[3]) == hipSuccess) last.ms_total = ms;
-	timed_h2d = timed_d2h = false;
+	for (int k = 0; k < n_slots; ++k) {
+		const int32_t *c = h_counters + (size_t)k * CNT_WORDS;
+		last.n_pairs += h_totals[(size_t)k * 2];
+		last.n_chunks += c[CNT_NCHUNK];
+		last.n_long_chunks += c[CNT_NLONG];
+		last.n_tracked_chunks += c[CNT_NTRACK];
+		last.n_clamped_blocks += c[CNT_NCLAMP];
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, slots[k].prep0, slots[k].prep1) == hipSuccess) last.ms_prep += ms;
+		if (hipEventElapsedTime(&ms, slots[k].prep1, slots[k].score1) == hipSuccess) last.ms_score += ms;
+	}
+	if (n_slots > 0) last.ms_total = last.ms_prep + last.ms_score;     // host-buffer calls overwrite this with wall time
+	n_slots = 0;
 	return 0;
 }
 
@@ -277,7 +310,7 @@ void mm2gb_engine_destroy(mm2gb_engine_t *eng)
 
 int mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc) { return eng ? eng->e.set_misc(misc) : fail("mm2gb: null engine"); }
 int mm2gb_engine_device(const mm2gb_engine_t *eng) { return eng ? eng->e.device : -1; }
-int mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads) { return eng ? eng->e.reserve(n_anchors, n_reads, true) : fail("mm2gb: null engine"); }
+int mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads) { return eng ? eng->e.reserve(n_anchors, n_reads) : fail("mm2gb: null engine"); }
 void *mm2gb_engine_stream(mm2gb_engine_t *eng) { return eng ? (void*)eng->e.stream : nullptr; }
 float mm2gb_engine_last_kernel_ms(mm2gb_engine_t *eng) { return eng ? eng->e.last.ms_prep + eng->e.last.ms_score : 0.f; }
 
@@ -287,6 +320,7 @@ int mm2gb_score_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_of
 	if (!eng) return fail("mm2gb: null engine");
 	Engine &e = eng->e;
 	MM2GB_HIP(hipSetDevice(e.device));
+	if (e.begin_call()) return -1;
 	return e.enqueue(n_reads, d_offsets, d_anchors, n_anchors, d_f, d_p);
 }
 
@@ -309,8 +343,42 @@ int mm2gb_score_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offset
 	if (offsets[0] != 0) return fail("mm2gb_score_host: offsets[0] must be 0");
 	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_score_host: offsets must be non-decreasing");
 	if (n > 0 && (!anchors || !f || !p)) return fail("mm2gb_score_host: null buffer");
-	if (e.enqueue_host(n_reads, offsets, anchors, n, f, p)) return -1;
+	MM2GB_HIP(hipSetDevice(e.device));
+	if (e.begin_call()) return -1;
+	const auto t0 = std::chrono::steady_clock::now();
+	// Large batches are cut at read boundaries into slices so that the H2D of slice k+1, the kernels of slice k and the
+	// D2H of slice k-1 overlap (three streams, two device staging sets).  MM2GB_SLICE_ANCHORS sets the slice size.
+	int64_t slice = 64 * 1000 * 1000;
+	if (const char *v = getenv("MM2GB_SLICE_ANCHORS")) slice = std::max<int64_t>(1, atoll(v));
+	if (n <= slice + slice / 2) {
+		if (e.enqueue_host(n_reads, offsets, anchors, n, f, p)) return -1;
+	} else {
+		std::vector<int64_t> first(1, 0);
+		int64_t acc = 0;
+		for (int64_t r = 0; r < n_reads; ++r) {
+			acc += offsets[r + 1] - offsets[r];
+			if (acc >= slice && r + 1 < n_reads) { first.push_back(r + 1); acc = 0; }
+		}
+		first.push_back(n_reads);
+		const size_t n_sl = first.size() - 1;
+		if (e.h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8)) return -1;
+		int64_t *lo = (int64_t*)e.h_slice_off.ptr;
+		size_t w = 0;
+		for (size_t k = 0; k < n_sl; ++k) {
+			const int64_t r0 = first[k], r1 = first[k + 1];
+			const size_t base = w;
+			for (int64_t r = r0; r <= r1; ++r) lo[w++] = offsets[r] - offsets[r0];
+			if (e.enqueue_host(r1 - r0, lo + base, anchors + offsets[r0], offsets[r1] - offsets[r0], f + offsets[r0], p + offsets[r0])) return -1;
+		}
+	}
 	if (e.sync()) return -1;
+	e.last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	{   // transfer times of the last slice (events on the copy streams)
+		const IoSet &s = e.io[(e.io_seq - 1) & 1];
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, s.in_start, s.in_done) == hipSuccess) e.last.ms_h2d = ms;
+		if (hipEventElapsedTime(&ms, s.out_start, s.out_done) == hipSuccess) e.last.ms_d2h = ms;
+	}
 	if (stats) *stats = e.last;
 	return 0;
 }

@@ -130,11 +130,12 @@ static int launch_slot(StreamSlot &slot, mm2gb_chain_read_t *reads, int n_read)
 	int64_t *off = slot.goff.data();
 	mm2gb_anchor_t *raw = (mm2gb_anchor_t*)slot.h_raw.ptr;
 	off[0] = 0;
-	for (int r = 0; r < n_read; ++r) {
-		const int64_t n = reads[r].n > 0 ? reads[r].n : 0;
+	for (int r = 0; r < n_read; ++r) off[r + 1] = off[r] + (reads[r].n > 0 ? reads[r].n : 0);
+	// pack the reads' anchor arrays into the pinned staging buffer (MM2GB_POST_THREADS host threads)
+	parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &) {
+		const int64_t n = off[r + 1] - off[r];
 		if (n) memcpy(raw + off[r], reads[r].a, (size_t)n * 16);
-		off[r + 1] = off[r] + n;
-	}
+	});
 	// micro-batches: greedy split so each holds at most max_total_n anchors (plchain.cu:356-366); unlike the reference
 	// nothing is ever sent back to the CPU -- a batch simply takes as many micro-batches as it needs
 	const int64_t cap = g_streams.cfg.max_total_n > 0 ? g_streams.cfg.max_total_n : total;
@@ -148,6 +149,7 @@ static int launch_slot(StreamSlot &slot, mm2gb_chain_read_t *reads, int n_read)
 	slot.mb_first.push_back(n_read);
 	// every micro-batch needs offsets that start at 0: build them after the global ones
 	const size_t n_mb = slot.mb_first.size() - 1;
+	if (slot.eng.begin_call()) return -1;
 	if (slot.h_off.ensure(((size_t)n_read + n_mb + 1) * 8)) return -1;
 	int64_t *local_off = (int64_t*)slot.h_off.ptr;
 	size_t w = 0;

@@ -202,6 +202,24 @@ def test_ultralong_reads_properties(engine):
         assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
 
 
+def test_sliced_host_call_overlapped_streams(monkeypatch):
+    """mm2gb_score_host cuts a large batch into slices (H2D / kernels / D2H on three streams, two staging sets):
+    same results as one piece, counters add up, staging sets are reused more than once."""
+    a, off = mm.synth_reads(21, 0, 40, 10_000, 60_000)
+    prm = orc.default_param()
+    with mm.Engine() as e:
+        f1, p1, st1 = e.score(a, off)
+    monkeypatch.setenv("MM2GB_SLICE_ANCHORS", "60000")
+    with mm.Engine() as e:
+        f2, p2, st2 = e.score(a, off)
+        f3, p3, st3 = e.score(a, off)          # second call on the same engine: slots and sets start over
+    assert np.array_equal(f1, f2) and np.array_equal(p1, p2) and np.array_equal(f1, f3) and np.array_equal(p1, p3)
+    assert st2["n_pairs"] == st1["n_pairs"] == st3["n_pairs"] and st2["n_anchors"] == len(a) and st2["n_reads"] == 40
+    assert st2["n_chunks"] >= st1["n_chunks"]
+    fo, po, pairs = orc.chain_fill_many(a, off, prm, threads=4)
+    assert np.array_equal(f2, fo) and st2["n_pairs"] == pairs
+
+
 def test_lchain_dp_signature_entry():
     """mm2gb_lchain_dp: same call shape as mg_lchain_dp (lchain.c:148), input consumed, outputs malloc'd."""
     import ctypes as C
