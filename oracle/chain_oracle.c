@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <assert.h>
+#include <pthread.h>
 #include "chain_oracle.h"
 
 #define ORC_REJECT INT32_MIN
@@ -65,12 +66,12 @@ int32_t orc_pair_score(const orc_anchor_t *cur, const orc_anchor_t *prev, const 
 }
 
 /* lchain.c:155-207 */
-void orc_chain_fill(const orc_param_t *prm_in, int64_t n, const orc_anchor_t *a,
-                    int32_t *f, int64_t *p, orc_stats_t *stats)
+static void chain_fill_ws(const orc_param_t *prm_in, int64_t n, const orc_anchor_t *a,
+                          int32_t *f, int64_t *p, orc_stats_t *stats, int32_t *mark_ws)
 {
 	orc_param_t prm = *prm_in;
 	orc_stats_t s;
-	int32_t *mark;            /* the reference's t[] (lchain.c:166) */
+	int32_t *mark;            /* the reference's t[] (lchain.c:166); caller-provided scratch of n ints, or NULL */
 	int64_t i, lo = 0, keep = -1; /* lo = "st" (lchain.c:152), keep = "max_ii" */
 
 	memset(&s, 0, sizeof(s));
@@ -78,7 +79,8 @@ void orc_chain_fill(const orc_param_t *prm_in, int64_t n, const orc_anchor_t *a,
 	if (n <= 0 || a == 0) return;
 	if (prm.max_dist_x < prm.bw) prm.max_dist_x = prm.bw;                   /* :160 */
 	if (prm.max_dist_y < prm.bw && !prm.is_cdna) prm.max_dist_y = prm.bw;   /* :161 */
-	mark = (int32_t*)calloc((size_t)n, sizeof(int32_t));
+	if (mark_ws) { mark = mark_ws; memset(mark, 0, (size_t)n * sizeof(int32_t)); }
+	else mark = (int32_t*)calloc((size_t)n, sizeof(int32_t));
 
 	for (i = 0; i < n; ++i) {
 		int32_t best = a_qspan(&a[i]), n_skip = 0;                          /* :171 */
@@ -123,8 +125,13 @@ void orc_chain_fill(const orc_param_t *prm_in, int64_t n, const orc_anchor_t *a,
 		if (keep < 0 || (a[i].x - a[keep].x <= (uint64_t)(int64_t)prm.max_dist_x && f[keep] < f[i]))
 			keep = i;
 	}
-	free(mark);
+	if (!mark_ws) free(mark);
 	if (stats) *stats = s;
+}
+
+void orc_chain_fill(const orc_param_t *prm, int64_t n, const orc_anchor_t *a, int32_t *f, int64_t *p, orc_stats_t *stats)
+{
+	chain_fill_ws(prm, n, a, f, p, stats, 0);
 }
 
 /* ---- ksort.h:98-151, key = .x, 8 key bytes, 8 bits per pass, <=64 -> insertion sort ---- */
@@ -308,3 +315,46 @@ orc_anchor_t *orc_lchain_dp(const orc_param_t *prm, int64_t n, const orc_anchor_
 }
 
 void orc_free(void *ptr) { free(ptr); }
+
+/* ---- many reads on several host threads: the CPU baseline of bench.py (reads dealt dynamically, one call of
+ *      orc_chain_fill per read, like kt_for over reads in map.c:1323) ---- */
+typedef struct {
+	const orc_param_t *prm; const int64_t *off; const orc_anchor_t *a; int32_t *f; int64_t *p;
+	int64_t n_reads; volatile int64_t next; int64_t pairs; pthread_mutex_t mu;
+} orc_mt_t;
+
+static void *orc_mt_worker(void *arg)
+{
+	orc_mt_t *w = (orc_mt_t*)arg;
+	int64_t mine = 0, cap = 0;
+	int32_t *ws = 0;          /* per-thread scratch, like the reference's per-thread kalloc arena (no allocator contention) */
+	for (;;) {
+		int64_t r = __sync_fetch_and_add(&w->next, 1), n;
+		orc_stats_t st;
+		if (r >= w->n_reads) break;
+		n = w->off[r + 1] - w->off[r];
+		if (n > cap) { free(ws); cap = n + n / 4 + 1024; ws = (int32_t*)malloc((size_t)cap * sizeof(int32_t)); }
+		chain_fill_ws(w->prm, n, w->a + w->off[r], w->f + w->off[r], w->p + w->off[r], &st, ws);
+		mine += st.n_pairs;
+	}
+	free(ws);
+	pthread_mutex_lock(&w->mu); w->pairs += mine; pthread_mutex_unlock(&w->mu);
+	return 0;
+}
+
+int64_t orc_chain_fill_reads_mt(const orc_param_t *prm, int64_t n_reads, const int64_t *offsets, const orc_anchor_t *a,
+                                int32_t *f, int64_t *p, int n_threads)
+{
+	orc_mt_t w;
+	pthread_t *tid;
+	int t;
+	if (n_threads < 1) n_threads = 1;
+	w.prm = prm; w.off = offsets; w.a = a; w.f = f; w.p = p; w.n_reads = n_reads; w.next = 0; w.pairs = 0;
+	pthread_mutex_init(&w.mu, 0);
+	tid = (pthread_t*)malloc((size_t)n_threads * sizeof(pthread_t));
+	for (t = 0; t < n_threads; ++t) pthread_create(&tid[t], 0, orc_mt_worker, &w);
+	for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+	free(tid);
+	pthread_mutex_destroy(&w.mu);
+	return w.pairs;
+}

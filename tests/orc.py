@@ -71,6 +71,8 @@ def lib():
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.orc_compact.restype = C.c_void_p
         L.orc_compact.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_chain_fill_reads_mt.restype = C.c_int64
+        L.orc_chain_fill_reads_mt.argtypes = [C.POINTER(Param), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_free.restype = None
         L.orc_free.argtypes = [C.c_void_p]
         _lib = L
@@ -159,27 +161,16 @@ def radix_sort_x(arr):
 
 
 def chain_fill_many(anchors, offsets, prm, threads=1):
-    """cpu_baseline helper: run chain_fill per read over `threads` host threads (ctypes drops the GIL).
+    """cpu_baseline helper: orc_chain_fill per read on `threads` pthreads inside the oracle library.
     Returns (f, p_local, total_pairs)."""
     anchors = as_anchors(anchors)
     offsets = np.asarray(offsets, dtype=np.int64)
     n = anchors.shape[0]
     f = np.empty(n, dtype=np.int32)
     p = np.empty(n, dtype=np.int64)
-    L = lib()
-
-    def work(r):
-        s, e = int(offsets[r]), int(offsets[r + 1])
-        st = Stats()
-        L.orc_chain_fill(C.byref(prm), e - s, anchors[s:e].ctypes.data, f[s:e].ctypes.data, p[s:e].ctypes.data, C.byref(st))
-        return st.n_pairs
-
-    R = len(offsets) - 1
-    if threads <= 1:
-        pairs = sum(work(r) for r in range(R))
-    else:
-        with ThreadPoolExecutor(threads) as ex:
-            pairs = sum(ex.map(work, range(R)))
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    pairs = lib().orc_chain_fill_reads_mt(C.byref(prm), len(off) - 1, off.ctypes.data, anchors.ctypes.data, f.ctypes.data, p.ctypes.data,
+                                          max(1, int(threads)))
     return f, p, pairs
 
 
