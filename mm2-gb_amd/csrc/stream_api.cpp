@@ -5,6 +5,7 @@
 //     same deferred hand-back protocol (launch batch k, return batch k-1 finished), one engine per stream/thread id.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,13 @@ extern "C" {
 mm2gb_Misc build_misc(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, const int64_t qlen_sum, const int n_seg) __attribute__((weak));
 void post_chaining_helper(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *read, mm2gb_Misc misc, void *km) __attribute__((weak));
 }
+
+// Layout of the records shared with the host, as a C compiler lays out gpu/plutils.h:19-73 on x86-64 (checked against the
+// reference header with offsetof in the dev container; tests/test_gpu_stream_api.py repeats the check from Python).
+static_assert(sizeof(mm2gb_Misc) == 44, "Misc layout");
+static_assert(sizeof(mm2gb_seq_meta_t) == 232 && offsetof(mm2gb_seq_meta_t, name) == 12 && offsetof(mm2gb_seq_meta_t, qlen_sum) == 224, "mm_seq_meta_t layout");
+static_assert(sizeof(mm2gb_chain_read_t) == 312 && offsetof(mm2gb_chain_read_t, a) == 280 && offsetof(mm2gb_chain_read_t, n) == 288 &&
+              offsetof(mm2gb_chain_read_t, u) == 296 && offsetof(mm2gb_chain_read_t, n_u) == 304, "chain_read_t layout");
 
 namespace mm2gb {
 

@@ -1,0 +1,119 @@
+"""The drop-in boundary (init/chain/finish/free_stream_gpu, gpu/plutils.h:98-104) driven the way map.c:924-1153 drives it,
+without a minimap2 host: batches of chain_read_t records, deferred hand-back, several micro-batches per batch."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+mm = pytest.importorskip("mm2gb_amd")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class SeqMeta(C.Structure):      # mm_seq_meta_t, gpu/plutils.h:19-31
+    _fields_ = [("i", C.c_long), ("seg_id", C.c_int), ("name", C.c_char * 200), ("len", C.c_uint32), ("n_alt", C.c_int),
+                ("is_alt", C.c_int), ("qlen_sum", C.c_int)]
+
+
+class ChainRead(C.Structure):    # chain_read_t, gpu/plutils.h:45-73
+    _fields_ = [("seq", SeqMeta), ("qseqs", C.c_void_p), ("qlens", C.c_void_p), ("n_seg", C.c_int), ("rep_len", C.c_int),
+                ("frag_gap", C.c_int), ("mini_pos", C.c_void_p), ("n_mini_pos", C.c_int), ("a", C.c_void_p), ("n", C.c_int64),
+                ("u", C.c_void_p), ("n_u", C.c_int)]
+
+
+libc = C.CDLL(None)
+libc.malloc.restype = C.c_void_p
+libc.malloc.argtypes = [C.c_size_t]
+libc.free.argtypes = [C.c_void_p]
+
+
+def test_struct_layout_matches_reference_header():
+    # offsets a C compiler gives gpu/plutils.h on x86-64 (checked against the reference header in the dev container)
+    assert C.sizeof(SeqMeta) == 232 and SeqMeta.name.offset == 12 and SeqMeta.len.offset == 212 and SeqMeta.qlen_sum.offset == 224
+    assert ChainRead.a.offset == 280 and ChainRead.n.offset == 288 and ChainRead.u.offset == 296 and ChainRead.n_u.offset == 304
+    assert C.sizeof(ChainRead) == 312
+
+
+def make_batch(reads):
+    arr = (ChainRead * len(reads))()
+    for k, a in enumerate(reads):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        buf = libc.malloc(max(a.nbytes, 16))
+        C.memmove(buf, a.ctypes.data, a.nbytes)
+        arr[k].a, arr[k].n, arr[k].n_seg = buf, len(a), 1
+        arr[k].seq.i = k
+    return arr
+
+
+def collect(ptr, n):
+    out = []
+    arr = C.cast(ptr, C.POINTER(ChainRead))
+    for k in range(n):
+        r = arr[k]
+        if r.n_u > 0:
+            u = np.ctypeslib.as_array(C.cast(r.u, C.POINTER(C.c_uint64)), shape=(r.n_u,)).copy()
+            na = int((u & 0xffffffff).sum())
+            a = np.ctypeslib.as_array(C.cast(r.a, C.POINTER(C.c_uint64)), shape=(na, 2)).copy()
+            libc.free(r.u)
+            libc.free(r.a)
+        else:
+            assert not r.a, "a must be 0 when nothing chains (plchain.cu:134-137)"
+            u, a = np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+        out.append((r.seq.i, u, a))
+    return out
+
+
+@pytest.mark.parametrize("max_total_n,micro_batch", [(500_000_000, 4), (40_000, 2)])
+def test_batched_deferred_protocol(tmp_path, max_total_n, micro_batch):
+    L = mm.lib()
+    cfg = json.load(open(os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json")))
+    cfg["max_total_n"], cfg["score_kernel"]["micro_batch"], cfg["max_read"] = max_total_n, micro_batch, 1000
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    misc = mm.default_misc()
+    prm = orc.default_param()
+    mt, mr, mn = C.c_size_t(0), C.c_int(0), C.c_int(0)
+    L.init_stream_gpu.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, mm.Misc]
+    L.chain_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    L.finish_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    L.free_stream_gpu.argtypes = [C.c_int]
+    L.init_stream_gpu(C.byref(mt), C.byref(mr), C.byref(mn), str(path).encode(), misc)
+    assert mt.value == max_total_n * micro_batch and mr.value == 1000 * micro_batch and mn.value == cfg["min_n"]
+
+    anchors, off = mm.synth_reads(31, 0, 30, 5_000, 40_000)
+    reads = [anchors[off[r]:off[r + 1]] for r in range(30)] + [np.zeros((0, 2), np.uint64)]    # and one read without anchors
+    batches = [reads[0:9], reads[9:10], reads[10:24], reads[24:31]]
+    expect = {}
+    done = []
+    keep_alive = []
+    base = 0
+    for b in batches:
+        arr = make_batch(b)
+        for k in range(len(b)):
+            arr[k].seq.i = base + k
+            expect[base + k] = orc.lchain_dp(b[k], prm, want_fp=False) if len(b[k]) else dict(u=np.zeros(0, np.uint64), a_out=np.zeros((0, 2), np.uint64))
+        base += len(b)
+        keep_alive.append(arr)
+        ptr, n = C.c_void_p(C.addressof(arr)), C.c_int(len(b))
+        L.chain_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+        # first call hands back nothing; later calls hand back the previous batch, complete
+        if len(keep_alive) == 1:
+            assert not ptr.value and n.value == 0
+        else:
+            assert ptr.value == C.addressof(keep_alive[-2]) and n.value == len(keep_alive[-2])
+            done += collect(ptr.value, n.value)
+    ptr, n = C.c_void_p(0), C.c_int(0)
+    L.finish_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+    assert ptr.value == C.addressof(keep_alive[-1]) and n.value == len(batches[-1])
+    done += collect(ptr.value, n.value)
+    L.finish_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)          # nothing in flight any more
+    assert not ptr.value and n.value == 0
+    L.free_stream_gpu(1)
+    assert sorted(i for i, _, _ in done) == list(range(31))
+    for i, u, a in done:
+        assert np.array_equal(u, expect[i]["u"]) and np.array_equal(a, expect[i]["a_out"]), f"read {i}"
