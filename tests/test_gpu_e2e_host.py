@@ -54,3 +54,26 @@ def test_small_micro_batches_and_multiple_batches(tmp_path):
     r = subprocess.run(cmd, capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout.decode() == open(os.path.join(GOLD, "real_inv_inf.paf")).read()
+
+
+@needs_host
+def test_simulated_long_reads_paf_diff_empty(tmp_path):
+    """160 simulated 5-60 kb reads (8 % error) on a 3 Mbp genome with interspersed and tandem repeats: real seeding, several
+    host batches through chain_stream_gpu/finish_stream_gpu with the host's kalloc, post_chaining_helper's RMQ re-chain,
+    then alignment-free PAF.  Expected PAF was printed by the reference CPU path (tests/golden/sim160.json)."""
+    import hashlib
+    import json
+    import sim_reads
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    assert hashlib.md5(open(ref, "rb").read()).hexdigest() == meta["ref_md5"], "simulator drifted: regenerate the golden"
+    assert hashlib.md5(open(reads, "rb").read()).hexdigest() == meta["reads_md5"]
+    r = subprocess.run([HOST, "-t", "1", "--gpu-chain", "--gpu-cfg", CFG, ref, reads], capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
+    got = r.stdout.decode()
+    if got != want:
+        w, g = want.splitlines(), got.splitlines()
+        bad = [k for k in range(min(len(w), len(g))) if w[k] != g[k]]
+        raise AssertionError(f"{len(bad)} of {len(w)} PAF lines differ (got {len(g)} lines); first: {g[bad[0]] if bad else None} vs {w[bad[0]] if bad else None}")
