@@ -14,7 +14,8 @@ struct DevParams {
 };
 
 // bits of DevBatch::flags[0]
-enum : unsigned { FLAG_ANY_SEGID = 1u };
+enum : unsigned { FLAG_ANY_SEGID = 1u,     // some anchor carries a segment id -> MODE_GENERAL
+                  FLAG_NO_LUT = 2u };      // a query position >= 2^27 or a zero q_span -> the x4 table sweep is not exact, use MODE_FAST
 
 // Planner granularity: anchors per planning block (one k_window workgroup).
 constexpr int PLAN_BLOCK = 1024;

@@ -31,7 +31,7 @@ __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readf
 __global__ __launch_bounds__(256) void k_split_soa(DevBatch b)
 {
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	bool any_seg = false;
+	bool any_seg = false, big_y = false;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
 		const uint4 v = b.raw[i];                 // x.lo x.hi y.lo y.hi
 		b.x[i] = (int32_t)v.x;
@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void k_split_soa(DevBatch b)
 		const unsigned seg = (v.w >> 16) & 0xffu; // (y & MM_SEED_SEG_MASK) >> 48 (lchain.c:116)
 		b.tag[i] = (int32_t)(seg << 8 | span);
 		any_seg |= seg != 0;
+		big_y |= v.z >= (1u << 27) || span == 0;
 	}
 	if (__ballot(any_seg) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_ANY_SEGID);
+	if (__ballot(big_y) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_NO_LUT);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 // --------------------------------------------------------------------------------------------------------------
 enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
 constexpr int SCORE_THREADS = 1024;
-constexpr int LUT_REJECT = 1 << 29;
+constexpr int LUT_REJECT = 1 << 30;     // in the x4 domain of the LUT sweep: 4*f < 2^29 is guaranteed there (FLAG_NO_LUT)
 
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
 {
@@ -325,7 +327,7 @@ __global__ void k_build_lut(int *lut, DevParams P)
 {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k > P.lut_last) return;
-	lut[k] = k == P.lut_last ? LUT_REJECT : gap_penalty(k, 0, P);   // skip == 0 here: the dg term is +0.0f
+	lut[k] = k == P.lut_last ? LUT_REJECT : 4 * gap_penalty(k, 0, P);   // skip == 0 here: the dg term is +0.0f
 }
 
 __device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
@@ -347,7 +349,7 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 		// accepted pairs have dr >= 0 (same strand|rid, sorted by x) and dq >= 1, so the unsigned |dr-dq| is dd
 		const unsigned dd = abs_diff_u32(dr, dq);
 		const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-		sc_out = sc - lut[idx];
+		sc_out = sc - (lut[idx] >> 2);          // the table stores 4*penalty for the block sweep
 		return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0;
 	}
 	const int ddiff = (int)((unsigned)dr - (unsigned)dq);
@@ -423,32 +425,38 @@ __device__ __forceinline__ SrcXY load_xy(const DevBatch &b, int j0)
 // two subtractions, |dr-dq|, the table index, min3, two additions, the dq range test, the running-max test, two selects.
 // CHECK adds "source inside this target's window" and "dr != 0" (lchain.c:120), which can only fail in the first and last
 // blocks of a sweep: sources of interior blocks lie inside every target's window and strictly left of every target's x.
+// Everything in the sweep is kept multiplied by 4 and shifted by one: the scratch holds {4(f+1), 4(q_span-1), 4x, 4y}, the
+// target registers 4(x-1), 4(y-1), the table 4*penalty.  Then 4(dr-1) - 4(dq-1) = 4(dr-dq), so |.| is directly the BYTE offset
+// into the table (no shift), "(dq-1) <u lim" needs no decrement, and min3 + the two additions give 4*cand.  Exact while
+// 4*f < 2^29 and differences fit 30 bits: k_split_soa raises FLAG_NO_LUT for query positions >= 2^27 (f <= y always) and
+// the batch then runs the MODE_FAST build.
 template <bool CHECK>
-__device__ __forceinline__ void sweep_block_lut(const DevBatch &b, const Target &T, int jb, int k_from, const int4 *stage,
-                                                const DevParams &P, const int *lut, int &best, int &arg)
+__device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty4, int jb, int k_from, const int4 *stage,
+                                                const DevParams &P, const int *lut, int &best4, int &arg)
 {
+	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
 	for (int kg = k_from & ~3; kg < WAVE; kg += 4) {
 		const int j0 = jb + kg;
-		int dq[4], dr[4], pen[4];
-		int4 fq[4];
+		int dqm[4], drm[4], pen4[4];
+		int4 s4[4];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) fq[u] = stage[kg + u];
+		for (int u = 0; u < 4; ++u) s4[u] = stage[kg + u];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
-			dq[u] = T.y - fq[u].w; dr[u] = T.x - fq[u].z;
-			const unsigned dd = abs_diff_u32(dr[u], dq[u]);
-			pen[u] = lut[dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last];
+			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
+			const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]);
+			pen4[u] = *(const int*)((const char*)lut + (dd4 < last4 ? dd4 : last4));
 		}
 		int jv;
 		asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j0));       // index arithmetic below stays VGPR + literal (full rate)
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
-			const int dg = dr[u] < dq[u] ? dr[u] : dq[u];
-			const int cand = (fq[u].y < dg ? fq[u].y : dg) - pen[u] + fq[u].x;
+			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
+			const int cand4 = (s4[u].y < dg ? s4[u].y : dg) - pen4[u] + s4[u].x;
 			// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
-			bool take = ((unsigned)(dq[u] - 1) < (unsigned)P.dq_lim) & (cand >= best);
-			if (CHECK) take = take & (dr[u] != 0) & (j0 + u >= T.st);
-			best = take ? cand : best; arg = take ? jv + u : arg;
+			bool take = ((unsigned)dqm[u] < lim4) & (cand4 >= best4);
+			if (CHECK) take = take & (drm[u] != -4) & (j0 + u >= T.st);
+			best4 = take ? cand4 : best4; arg = take ? jv + u : arg;
 		}
 	}
 }
@@ -484,10 +492,14 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		stage[lane_id()] = make_int4(sf, sq, b.x[jb + lane_id()], b.y[jb + lane_id()]);
+		const int js = jb + lane_id();
+		stage[lane_id()] = make_int4((sf + 1) * 4, (sq - 1) * 4, (int)((unsigned)b.x[js] << 2), (int)((unsigned)b.y[js] << 2));
 		__builtin_amdgcn_wave_barrier();                    // LDS is in-order per wave; keep the compiler from reordering
-		if (no_check) sweep_block_lut<false>(b, T, jb, k_from, stage, P, lut, best, arg);
-		else sweep_block_lut<true>(b, T, jb, k_from, stage, P, lut, best, arg);
+		const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
+		int best4 = best * 4;
+		if (no_check) sweep_block_lut<false>(T, tx4, ty4, jb, k_from, stage, P, lut, best4, arg);
+		else sweep_block_lut<true>(T, tx4, ty4, jb, k_from, stage, P, lut, best4, arg);
+		best = best4 >> 2;
 		__builtin_amdgcn_wave_barrier();
 	} else {
 		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
@@ -686,8 +698,8 @@ template <int MODE>
 __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_mask)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	const bool any_seg = (b.flags[0] & FLAG_ANY_SEGID) != 0;
-	const int mode = any_seg ? MODE_GENERAL : host_mode;
+	const unsigned fl = b.flags[0];
+	const int mode = (fl & FLAG_ANY_SEGID) ? MODE_GENERAL : (host_mode == MODE_LUT && (fl & FLAG_NO_LUT)) ? MODE_FAST : host_mode;
 	if (mode != MODE) return;
 	int *lut = smem;
 	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
@@ -781,7 +793,7 @@ void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, h
 	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_mask);
 	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_mask);
 	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
-	if (cfg.host_mode == MODE_FAST) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
+	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
 	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_mask);
 }
 

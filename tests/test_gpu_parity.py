@@ -165,6 +165,20 @@ def test_modes_without_the_penalty_table(kw):
     assert st["n_pairs"] > 1_000_000
 
 
+def test_inputs_outside_the_table_sweep_domain(engine):
+    """The table sweep works on coordinates x4 and needs query positions < 2^27 and q_span > 0; anything else must be
+    detected on the device and scored by the per-pair build, with identical results."""
+    base = sc.sort_by_x(np.concatenate([sc.repeat_block(5200, 71), sc.colinear(900, 72)]))
+    far = base.copy()
+    far[:, 1] += np.uint64((1 << 27) + 12345)                      # query positions beyond 2^27
+    zero = base.copy()
+    zero[::7, 1] &= ~(np.uint64(0xff) << np.uint64(32))            # some anchors with q_span == 0
+    huge_x = base.copy()
+    huge_x[:, 0] += np.uint64(0x7ff00000)                          # reference positions near 2^31 (x4 wraps; differences do not)
+    for a in (far, zero, huge_x):
+        check_batch(engine, a, np.array([0, len(a)], np.int64), orc.default_param())
+
+
 def test_synthetic_ont_batch_full_chain(engine):
     """The bench workload at small scale: 24 reads of 10-100 kb; scores, then chains, against the oracle."""
     a, off = mm.synth_reads(7, 0, 24, 10_000, 100_000)
