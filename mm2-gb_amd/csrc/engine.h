@@ -83,8 +83,11 @@ struct Engine {
 	int  reserve(int64_t n_anchors, int64_t n_reads);
 	int  begin_call();                     // start of a host-level call: resets slots and `last`
 	// host buffers (pinned for true asynchrony): H2D, kernels, D2H enqueued on three streams; returns without waiting
-	int  enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p);
-	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p);
+	// want_stats = false: no timing events / counter read-back for this micro-batch (the drop-in boundary keeps two host
+	// batches in flight and never asks for statistics)
+	int  enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p, bool want_stats = true);
+	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats = true);
+	int  record_outputs_done(hipEvent_t ev);   // fires when every D2H enqueued so far has landed
 	int  sync();
 	int  collect_stats();
 };

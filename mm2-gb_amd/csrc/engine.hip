@@ -178,14 +178,14 @@ int Engine::begin_call()
 	return 0;
 }
 
-int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p)
+int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats)
 {
 	if (n < 0 || n_reads < 0) return fail("mm2gb: negative batch size");
-	if (n_slots >= MAX_SLOTS && sync()) return -1;      // fold what is done so far into `last`, keep counting
+	if (want_stats && n_slots >= MAX_SLOTS && sync()) return -1;      // fold what is done so far into `last`, keep counting
 	if (reserve(n, n_reads)) return -1;
-	const int slot = n_slots++;
+	const int slot = want_stats ? n_slots++ : 0;
 	BatchSlot &bs = slots[slot];
-	for (hipEvent_t *e : { &bs.prep0, &bs.prep1, &bs.score1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
+	if (want_stats) for (hipEvent_t *e : { &bs.prep0, &bs.prep1, &bs.score1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
 	DevBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
 	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
@@ -202,23 +202,32 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
 	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 2 * sizeof(int64_t), stream));
 	MM2GB_HIP(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(unsigned), stream));
-	MM2GB_HIP(hipEventRecord(bs.prep0, stream));
+	if (want_stats) MM2GB_HIP(hipEventRecord(bs.prep0, stream));
 	if (n > 0) {
 		launch_split_soa(b, stream);
 		launch_window(b, params, stream);
 		launch_plan(b, launch, stream);
 	}
-	MM2GB_HIP(hipEventRecord(bs.prep1, stream));
+	if (want_stats) MM2GB_HIP(hipEventRecord(bs.prep1, stream));
 	if (n > 0) launch_score(b, params, launch, stream);
-	MM2GB_HIP(hipEventRecord(bs.score1, stream));
-	MM2GB_HIP(hipMemcpyAsync(h_counters + (size_t)slot * CNT_WORDS, counters.ptr, CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-	MM2GB_HIP(hipMemcpyAsync(h_totals + (size_t)slot * 2, totals.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	if (want_stats) {
+		MM2GB_HIP(hipEventRecord(bs.score1, stream));
+		MM2GB_HIP(hipMemcpyAsync(h_counters + (size_t)slot * CNT_WORDS, counters.ptr, CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+		MM2GB_HIP(hipMemcpyAsync(h_totals + (size_t)slot * 2, totals.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+		last.n_anchors += n; last.n_reads += n_reads;
+	}
 	MM2GB_HIP(hipGetLastError());
-	last.n_anchors += n; last.n_reads += n_reads;
 	return 0;
 }
 
-int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p)
+int Engine::record_outputs_done(hipEvent_t ev)
+{
+	MM2GB_HIP(hipSetDevice(device));
+	MM2GB_HIP(hipEventRecord(ev, s_out));
+	return 0;
+}
+
+int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p, bool want_stats)
 {
 	MM2GB_HIP(hipSetDevice(device));
 	IoSet &s = io[io_seq++ & 1];
@@ -237,7 +246,7 @@ int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_
 	// kernels need the inputs, and may overwrite f/p only after the previous D2H from this set is done
 	MM2GB_HIP(hipStreamWaitEvent(stream, s.in_done, 0));
 	if (s.used) MM2GB_HIP(hipStreamWaitEvent(stream, s.out_done, 0));
-	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr)) return -1;
+	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, want_stats)) return -1;
 	MM2GB_HIP(hipEventRecord(s.comp_done, stream));
 	MM2GB_HIP(hipStreamWaitEvent(s_out, s.comp_done, 0));
 	MM2GB_HIP(hipEventRecord(s.out_start, s_out));

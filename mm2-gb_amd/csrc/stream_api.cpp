@@ -58,14 +58,23 @@ static void parallel_reads(int64_t n, int n_threads, F fn)
 // ---------------------------------------------------------------------------------------------------------------
 // drop-in boundary state: one slot per stream / host thread id
 // ---------------------------------------------------------------------------------------------------------------
+// Host side of one batch in flight: page-locked staging and the reads it belongs to.
+struct HostStage {
+	PinnedBuf h_raw, h_f, h_p, h_off;      // h_off: per-micro-batch offsets, each from 0
+	std::vector<int64_t> goff;             // offsets of every read in h_raw / h_f / h_p, size n_read + 1
+	mm2gb_chain_read_t *reads = nullptr;   // owned by the host
+	int  n_read = 0;
+	bool busy = false;
+	hipEvent_t done = nullptr;             // all f/p of this batch are back in h_f / h_p
+};
+
+// One stream / host thread id.  Two stages alternate: batch k is packed and launched while batch k-1's scores are still
+// being turned into chains on the host, so the GPU never waits for the host post-pass.
 struct StreamSlot {
 	Engine eng;
-	bool   live = false, busy = false;
-	mm2gb_chain_read_t *reads = nullptr;   // batch in flight (owned by the host)
-	int    n_read = 0;
-	PinnedBuf h_raw, h_f, h_p, h_off;      // staging for the batch in flight (h_off: per-micro-batch offsets, each from 0)
-	std::vector<int64_t> goff;             // offsets of every read in h_raw / h_f / h_p, size n_read + 1
-	std::vector<int64_t> mb_first;         // micro-batch boundaries (read indices), size n_mb + 1
+	HostStage stage[2];
+	int  cur = 0;                          // stage of the batch in flight
+	bool live = false;
 };
 
 static struct {
@@ -102,41 +111,58 @@ static int devices_for_streams(std::vector<int> &out)
 	return 0;
 }
 
-// Finish the batch in flight on `slot`: wait, extract chains per read, hand the reads back.
-static int finish_slot(StreamSlot &slot, void *km, mm2gb_chain_read_t **reads_out, int *n_out)
+// Finish the batch held by `st`: wait for its scores, extract chains per read, hand the reads back.
+static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_read_t **reads_out, int *n_out)
 {
 	*reads_out = nullptr; *n_out = 0;
-	if (!slot.busy) return 0;
-	if (slot.eng.sync()) return -1;
-	mm2gb_chain_read_t *reads = slot.reads;
-	const int n_read = slot.n_read;
-	const int64_t *off = slot.goff.data();
-	const int32_t *f = (const int32_t*)slot.h_f.ptr, *p = (const int32_t*)slot.h_p.ptr;
-	HostAlloc mem; mem.km = km; mem.use_kalloc = host_kalloc_present();
+	if (!st.busy) return 0;
+	MM2GB_HIP(hipSetDevice(slot.eng.device));
+	MM2GB_HIP(hipEventSynchronize(st.done));
+	mm2gb_chain_read_t *reads = st.reads;
+	const int n_read = st.n_read;
+	const int64_t *off = st.goff.data();
+	const int32_t *f = (const int32_t*)st.h_f.ptr, *p = (const int32_t*)st.h_p.ptr;
 	const mm2gb_misc_t misc = slot.eng.misc;
-	// kalloc arenas are not thread-safe: with the host's allocator, allocation happens on this thread only
-	const int threads = mem.use_kalloc ? 1 : g_streams.post_threads;
-	parallel_reads(n_read, threads, [&](int64_t r, BacktrackScratch &ws) {
-		mm2gb_chain_read_t &rd = reads[r];
-		uint64_t *u = nullptr; mm2gb_anchor_t *a_new = nullptr;
-		const int n_u = backtrack_compact(misc, rd.n, rd.a, f + off[r], p + off[r], mem, ws, &u, &a_new);
-		mem.release(rd.a);                      // compact_a frees the oversized input (lchain.c:108-109, plchain.cu:135)
-		rd.a = a_new; rd.u = u; rd.n_u = n_u;   // a = 0 when nothing chained (plchain.cu:134-137)
+	HostAlloc libc_mem;                                   // worker threads allocate from libc only
+	HostAlloc host_mem; host_mem.km = km; host_mem.use_kalloc = host_kalloc_present();
+	std::vector<uint64_t*> u_of((size_t)n_read, nullptr);
+	std::vector<mm2gb_anchor_t*> a_of((size_t)n_read, nullptr);
+	std::vector<int> nu_of((size_t)n_read, 0);
+	parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &ws) {
+		nu_of[r] = backtrack_compact(misc, reads[r].n, reads[r].a, f + off[r], p + off[r], libc_mem, ws, &u_of[r], &a_of[r]);
 	});
-	slot.busy = false; slot.reads = nullptr; slot.n_read = 0;
+	// hand-over on the calling thread: kalloc arenas are not thread-safe, so results move into the host's arena here
+	for (int r = 0; r < n_read; ++r) {
+		mm2gb_chain_read_t &rd = reads[r];
+		uint64_t *u = u_of[r]; mm2gb_anchor_t *a_new = a_of[r];
+		if (host_mem.use_kalloc && nu_of[r] > 0) {
+			size_t na = 0;
+			for (int k = 0; k < nu_of[r]; ++k) na += (uint32_t)u[k];
+			uint64_t *ku = (uint64_t*)host_mem.alloc((size_t)nu_of[r] * 8);
+			mm2gb_anchor_t *ka = (mm2gb_anchor_t*)host_mem.alloc(na * 16);
+			memcpy(ku, u, (size_t)nu_of[r] * 8); memcpy(ka, a_new, na * 16);
+			free(u); free(a_new);
+			u = ku; a_new = ka;
+		}
+		host_mem.release(rd.a);                 // compact_a frees the oversized input (lchain.c:108-109, plchain.cu:135)
+		rd.a = a_new; rd.u = u; rd.n_u = nu_of[r];   // a = 0 when nothing chained (plchain.cu:134-137)
+	}
+	st.busy = false; st.reads = nullptr; st.n_read = 0;
 	*reads_out = reads; *n_out = n_read;
 	return 0;
 }
 
-// Launch `reads` on `slot`: pack anchors into pinned memory, enqueue one or more micro-batches, return at once.
-static int launch_slot(StreamSlot &slot, mm2gb_chain_read_t *reads, int n_read)
+// Launch `reads` through `st`: pack anchors into pinned memory, enqueue one or more micro-batches, return at once.
+static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *reads, int n_read)
 {
 	int64_t total = 0;
 	for (int r = 0; r < n_read; ++r) total += reads[r].n > 0 ? reads[r].n : 0;
-	if (slot.h_raw.ensure((size_t)(total + 1) * 16) || slot.h_f.ensure((size_t)(total + 1) * 4) || slot.h_p.ensure((size_t)(total + 1) * 4)) return -1;
-	slot.goff.resize((size_t)n_read + 1);
-	int64_t *off = slot.goff.data();
-	mm2gb_anchor_t *raw = (mm2gb_anchor_t*)slot.h_raw.ptr;
+	MM2GB_HIP(hipSetDevice(slot.eng.device));
+	if (!st.done) MM2GB_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+	if (st.h_raw.ensure((size_t)(total + 1) * 16) || st.h_f.ensure((size_t)(total + 1) * 4) || st.h_p.ensure((size_t)(total + 1) * 4)) return -1;
+	st.goff.resize((size_t)n_read + 1);
+	int64_t *off = st.goff.data();
+	mm2gb_anchor_t *raw = (mm2gb_anchor_t*)st.h_raw.ptr;
 	off[0] = 0;
 	for (int r = 0; r < n_read; ++r) off[r + 1] = off[r] + (reads[r].n > 0 ? reads[r].n : 0);
 	// pack the reads' anchor arrays into the pinned staging buffer (MM2GB_POST_THREADS host threads)
@@ -147,28 +173,28 @@ static int launch_slot(StreamSlot &slot, mm2gb_chain_read_t *reads, int n_read)
 	// micro-batches: greedy split so each holds at most max_total_n anchors (plchain.cu:356-366); unlike the reference
 	// nothing is ever sent back to the CPU -- a batch simply takes as many micro-batches as it needs
 	const int64_t cap = g_streams.cfg.max_total_n > 0 ? g_streams.cfg.max_total_n : total;
-	slot.mb_first.assign(1, 0);
+	std::vector<int64_t> mb_first(1, 0);
 	int64_t acc = 0;
 	for (int r = 0; r < n_read; ++r) {
 		const int64_t n = off[r + 1] - off[r];
-		if (acc > 0 && acc + n > cap) { slot.mb_first.push_back(r); acc = 0; }
+		if (acc > 0 && acc + n > cap) { mb_first.push_back(r); acc = 0; }
 		acc += n;
 	}
-	slot.mb_first.push_back(n_read);
+	mb_first.push_back(n_read);
 	// every micro-batch needs offsets that start at 0: build them after the global ones
-	const size_t n_mb = slot.mb_first.size() - 1;
-	if (slot.eng.begin_call()) return -1;
-	if (slot.h_off.ensure(((size_t)n_read + n_mb + 1) * 8)) return -1;
-	int64_t *local_off = (int64_t*)slot.h_off.ptr;
+	const size_t n_mb = mb_first.size() - 1;
+	if (st.h_off.ensure(((size_t)n_read + n_mb + 1) * 8)) return -1;
+	int64_t *local_off = (int64_t*)st.h_off.ptr;
 	size_t w = 0;
 	for (size_t m = 0; m < n_mb; ++m) {
-		const int64_t r0 = slot.mb_first[m], r1 = slot.mb_first[m + 1];
+		const int64_t r0 = mb_first[m], r1 = mb_first[m + 1];
 		const size_t base = w;
 		for (int64_t r = r0; r <= r1; ++r) local_off[w++] = off[r] - off[r0];
 		const int64_t n = off[r1] - off[r0];
-		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)slot.h_f.ptr + off[r0], (int32_t*)slot.h_p.ptr + off[r0])) return -1;
+		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)st.h_f.ptr + off[r0], (int32_t*)st.h_p.ptr + off[r0], false)) return -1;
 	}
-	slot.reads = reads; slot.n_read = n_read; slot.busy = true;
+	if (slot.eng.record_outputs_done(st.done)) return -1;
+	st.reads = reads; st.n_read = n_read; st.busy = true;
 	return 0;
 }
 
@@ -293,7 +319,9 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	}
 	g_streams.misc = misc;
 	const char *pt = getenv("MM2GB_POST_THREADS");
-	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : 1;
+	// host threads for packing anchors and for backtrack + compaction; results enter the host's kalloc arena on the calling
+	// thread only, so this is safe with the single-threaded reference host
+	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 2));
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
 	for (int s = 0; s < cfg.num_streams; ++s) {
@@ -316,10 +344,15 @@ void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, 
 	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;   // plchain.cu:500
 	mm2gb_chain_read_t *new_reads = *in_arr_ptr;
 	const int n_new = *n_read_ptr;
-	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
-	if (finish_slot(slot, km, &done, &n_done)) die(mm2gb_last_error());          // plchain.cu:300-305
+	HostStage &prev = slot.stage[slot.cur], &next = slot.stage[slot.cur ^ 1];
+	// launch first, then finish the previous batch on the host while the GPU works (the reference does it the other way
+	// round, plchain.cu:300-305, and leaves the GPU idle during its post-pass)
 	if (slot.eng.set_misc(&misc)) die(mm2gb_last_error());
-	if (new_reads && n_new > 0) { if (launch_slot(slot, new_reads, n_new)) die(mm2gb_last_error()); }
+	const bool launched = new_reads && n_new > 0;
+	if (launched && launch_stage(slot, next, new_reads, n_new)) die(mm2gb_last_error());
+	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
+	if (finish_stage(slot, prev, km, &done, &n_done)) die(mm2gb_last_error());
+	if (launched) slot.cur ^= 1;
 	*in_arr_ptr = done; *n_read_ptr = n_done;
 	if (done && post_chaining_helper)
 		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:502-507
@@ -331,7 +364,7 @@ void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt,
 	StreamSlot &slot = slot_for(num_batch);
 	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
-	if (finish_slot(slot, km, &done, &n_done)) die(mm2gb_last_error());
+	if (finish_stage(slot, slot.stage[slot.cur], km, &done, &n_done)) die(mm2gb_last_error());
 	if (done && post_chaining_helper)
 		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:539-541
 	*batches = done; *num_reads = n_done;
@@ -341,8 +374,11 @@ void free_stream_gpu(int n_threads)
 {
 	(void)n_threads;
 	for (StreamSlot *slot : g_streams.slots) {
-		if (slot->busy) (void)slot->eng.sync();
-		slot->h_raw.release(); slot->h_f.release(); slot->h_p.release(); slot->h_off.release();
+		(void)slot->eng.sync();
+		for (HostStage &st : slot->stage) {
+			st.h_raw.release(); st.h_f.release(); st.h_p.release(); st.h_off.release();
+			if (st.done) (void)hipEventDestroy(st.done);
+		}
 		slot->eng.shutdown();
 		delete slot;
 	}
