@@ -78,51 +78,80 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	int my_cut = INT_MAX, my_clamp = 0;
 	unsigned long long my_pairs = 0;
 
-	for (int it = 0; it < PLAN_BLOCK / PLAN_THREADS; ++it) {
-		const int64_t i64 = base + it * PLAN_THREADS + threadIdx.x;
+	// Each thread owns PLAN_BLOCK / PLAN_THREADS consecutive anchors.  The first gets a full backward search; window
+	// starts are monotone (st[i+1] >= st[i]), so the others continue forward from their predecessor's start.
+	constexpr int PER = PLAN_BLOCK / PLAN_THREADS;
+	const int64_t i_first = base + (int64_t)threadIdx.x * PER;
+	int64_t rd = s_read0;                             // read of the current anchor
+	int rs = 0, re = 0, st_prev = 0;
+	for (int k = 0; k < PER; ++k) {
+		const int64_t i64 = i_first + k;
 		if (i64 >= b.n) break;
 		const int i = (int)i64;
-		// read that owns anchor i: last r with offsets[r] <= i.  The block's first anchor is looked up once (s_read0);
-		// most anchors of the block are in that read or the next few
-		int64_t lo = s_read0, hi = b.n_reads;
-		if (b.offsets[lo + 1] > i64) hi = lo + 1;
-		else {
-			int64_t step = 1;                          // gallop forward, then bisect: offsets[lo] <= i < offsets[hi]
-			while (lo + step < b.n_reads && b.offsets[lo + step] <= i64) { lo += step; step <<= 1; }
-			hi = min(lo + step, b.n_reads);
+		bool fresh = k == 0;
+		if (k == 0 || i >= re) {
+			// read that owns anchor i: last r with offsets[r] <= i (gallop forward from the last known read, then bisect)
+			int64_t lo = rd, hi = b.n_reads;
+			if (b.offsets[lo + 1] > i64) hi = lo + 1;
+			else {
+				int64_t step = 1;
+				while (lo + step < b.n_reads && b.offsets[lo + step] <= i64) { lo += step; step <<= 1; }
+				hi = min(lo + step, b.n_reads);
+			}
+			while (hi - lo > 1) {
+				const int64_t mid = (lo + hi) >> 1;
+				if (b.offsets[mid] <= i64) lo = mid; else hi = mid;
+			}
+			rd = lo; rs = (int)b.offsets[lo]; re = (int)b.offsets[lo + 1];
+			fresh = true;
 		}
-		while (hi - lo > 1) {
-			const int64_t mid = (lo + hi) >> 1;
-			if (b.offsets[mid] <= i64) lo = mid; else hi = mid;
-		}
-		const int rs = (int)b.offsets[lo];
-		int lb = i - P.max_iter;                  // may be negative
+		int lb = i - P.max_iter;                      // may be negative
 		if (lb < rs) lb = rs;
 		const int hi_i = b.xhi[i];
 		const unsigned x_i = (unsigned)b.x[i];
 		int st = i;
 		if (i > lb && in_reach(b, i - 1, hi_i, x_i, dist)) {
-			// gallop back from i until out of reach or at lb, then bisect
-			int good = i - 1, step = 2, bad = -1;
-			while (true) {
-				int probe = i - step;
-				if (probe <= lb) { probe = lb; if (in_reach(b, probe, hi_i, x_i, dist)) good = lb; else bad = lb; break; }
-				if (in_reach(b, probe, hi_i, x_i, dist)) { good = probe; step <<= 1; }
-				else { bad = probe; break; }
-			}
-			if (bad >= 0) {
-				int l = bad, h = good;            // l out of reach, h in reach
-				while (h - l > 1) {
-					const int mid = (l + h) >> 1;
-					if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
+			if (fresh) {
+				// gallop back from i until out of reach or at lb, then bisect
+				int good = i - 1, step = 2, bad = -1;
+				while (true) {
+					int probe = i - step;
+					if (probe <= lb) { probe = lb; if (in_reach(b, probe, hi_i, x_i, dist)) good = lb; else bad = lb; break; }
+					if (in_reach(b, probe, hi_i, x_i, dist)) { good = probe; step <<= 1; }
+					else { bad = probe; break; }
 				}
-				good = h;
+				if (bad >= 0) {
+					int l = bad, h = good;            // l out of reach, h in reach
+					while (h - l > 1) {
+						const int mid = (l + h) >> 1;
+						if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
+					}
+					good = h;
+				}
+				st = good;
+			} else {
+				// first in-reach index >= max(previous start, lb); i - 1 is known to be in reach
+				int from = st_prev > lb ? st_prev : lb;
+				if (in_reach(b, from, hi_i, x_i, dist)) st = from;
+				else {
+					int l = from, step = 1;           // l out of reach; gallop forward to an in-reach h <= i - 1, then bisect
+					int h = i - 1;
+					while (l + step < i - 1) {
+						if (in_reach(b, l + step, hi_i, x_i, dist)) { h = l + step; break; }
+						l += step; step <<= 1;
+					}
+					while (h - l > 1) {
+						const int mid = (l + h) >> 1;
+						if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
+					}
+					st = h;
+				}
 			}
-			st = good;
 			// the max_iter clamp bit (lchain.c:173): window would have reached further back
 			if (st == lb && lb > rs && lb == i - P.max_iter && in_reach(b, lb - 1, hi_i, x_i, dist)) my_clamp = 1;
 		}
 		b.st[i] = st;
+		st_prev = st;
 		my_pairs += (unsigned)(i - st);
 		if (st == i && i < my_cut) my_cut = i;
 	}
@@ -303,6 +332,10 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 // --------------------------------------------------------------------------------------------------------------
 enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
 constexpr int SCORE_THREADS = 1024;
+#ifndef MM2GB_SWEEP_GROUP
+#define MM2GB_SWEEP_GROUP 4
+#endif
+constexpr int SWEEP_GROUP = MM2GB_SWEEP_GROUP;
 constexpr int LUT_REJECT = 1 << 30;     // in the x4 domain of the LUT sweep: 4*f < 2^29 is guaranteed there (FLAG_NO_LUT)
 
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
@@ -435,14 +468,15 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
                                                 const DevParams &P, const int *lut, int &best4, int &arg)
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
-	for (int kg = k_from & ~3; kg < WAVE; kg += 4) {
+	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
+	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
 		const int j0 = jb + kg;
-		int dqm[4], drm[4], pen4[4];
-		int4 s4[4];
+		int dqm[G], drm[G], pen4[G];
+		int4 s4[G];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) s4[u] = stage[kg + u];
+		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
+		for (int u = 0; u < G; ++u) {
 			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
 			const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]);
 			pen4[u] = *(const int*)((const char*)lut + (dd4 < last4 ? dd4 : last4));
@@ -450,7 +484,7 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
 		int jv;
 		asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j0));       // index arithmetic below stays VGPR + literal (full rate)
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
+		for (int u = 0; u < G; ++u) {
 			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
 			const int cand4 = (s4[u].y < dg ? s4[u].y : dg) - pen4[u] + s4[u].x;
 			// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
