@@ -313,11 +313,24 @@ __global__ __launch_bounds__(64) void plan_bins(DevBatch b)
 
 __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 {
+	// most chunks fall into a handful of bins: rank them inside the workgroup first (LDS), then reserve one range per bin
+	// per workgroup in global memory
+	__shared__ int s_cnt[2 * COST_BINS], s_base[2 * COST_BINS];
 	const int n_chunks = b.counters[CNT_NCHUNK];
-	for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
-		const int is_long = (b.chunk_track[c] >> 1) & 1;
-		const int slot = atomicAdd(&b.bins[is_long * COST_BINS + cost_bin(b.chunk_cost[c])], 1);
-		(is_long ? b.long_list : b.order)[slot] = (int)c;
+	for (int64_t c0 = (int64_t)blockIdx.x * blockDim.x; c0 < n_chunks; c0 += (int64_t)gridDim.x * blockDim.x) {
+		for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) s_cnt[k] = 0;
+		__syncthreads();
+		const int64_t c = c0 + threadIdx.x;
+		int key = -1, rank = 0;
+		if (c < n_chunks) {
+			key = ((b.chunk_track[c] >> 1) & 1) * COST_BINS + cost_bin(b.chunk_cost[c]);
+			rank = atomicAdd(&s_cnt[key], 1);
+		}
+		__syncthreads();
+		for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) if (s_cnt[k]) s_base[k] = atomicAdd(&b.bins[k], s_cnt[k]);
+		__syncthreads();
+		if (key >= 0) (key >= COST_BINS ? b.long_list : b.order)[s_base[key] + rank] = (int)c;
+		__syncthreads();
 	}
 }
 
