@@ -81,8 +81,17 @@ void flag_pass(mm2gb_anchor_t *v, size_t lo, size_t hi, int shift)
 void sort_by_x_like_host(mm2gb_anchor_t *beg, mm2gb_anchor_t *end)
 {
 	const size_t n = (size_t)(end - beg);
-	if (n <= SMALL_RUN) insertion_run(beg, 0, n);   // ksort.h:149
-	else flag_pass(beg, 0, n, 56);                   // 8 key bytes, top byte first
+	if (n <= SMALL_RUN) { insertion_run(beg, 0, n); return; }   // ksort.h:149
+	// The host starts at the top key byte (shift 56).  A pass in which every key has the same byte moves nothing (one
+	// non-empty bucket: every element is already "in place") and recurses on the whole range with the next byte, so the
+	// outcome is the same as starting at the highest byte in which the keys actually differ.
+	uint64_t all_or = 0, all_and = ~(uint64_t)0;
+	for (size_t i = 0; i < n; ++i) { all_or |= beg[i].x; all_and &= beg[i].x; }
+	const uint64_t diff = all_or ^ all_and;
+	if (diff == 0) return;                                       // all keys equal: no pass moves anything
+	int shift = 56;
+	while (shift > 0 && ((diff >> shift) & 255) == 0) shift -= 8;
+	flag_pass(beg, 0, n, shift);
 }
 
 // ---- backtrack ----------------------------------------------------------------------------------------------
@@ -92,7 +101,7 @@ inline int64_t pred_of(const int32_t *p_rel, int64_t i) { return p_rel[i] ? i - 
 
 // lchain.c:9-25: walk back from the chain end k until an anchor that is taken, the start of the path, or an X-drop of
 // more than max_drop below the best prefix; returns where the kept part stops.
-int64_t kept_until(int32_t max_drop, int32_t top_score, int64_t start, const int32_t *f, const int32_t *p_rel, int32_t *mark)
+int64_t kept_until(int32_t max_drop, int32_t top_score, int64_t start, const int32_t *f, const int32_t *p_rel, uint8_t *mark)
 {
 	int64_t i = start, last = -1, best_i = start;
 	int32_t best = 0;
@@ -119,10 +128,13 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 	const int32_t max_drop = misc.is_cdna ? INT_MAX : misc.bw;                 // lchain.c:151,162
 
 	// candidates: anchors scoring at least min_sc, ordered by score the way the host orders them (lchain.c:35-41)
-	ws.keyed.clear();
+	size_t n_z = 0;
+	for (int64_t i = 0; i < n; ++i) n_z += f[i] >= min_sc;
+	if (n_z == 0) return 0;
+	ws.keyed.resize(n_z);
+	n_z = 0;
 	for (int64_t i = 0; i < n; ++i)
-		if (f[i] >= min_sc) ws.keyed.push_back(mm2gb_anchor_t{ (uint64_t)(int64_t)f[i], (uint64_t)i });
-	if (ws.keyed.empty()) return 0;
+		if (f[i] >= min_sc) ws.keyed[n_z++] = mm2gb_anchor_t{ (uint64_t)(int64_t)f[i], (uint64_t)i };
 	sort_by_x_like_host(ws.keyed.data(), ws.keyed.data() + ws.keyed.size());
 
 	ws.mark.assign((size_t)n, 0);
@@ -145,16 +157,16 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 	const int n_u = (int)ws.chains.size();
 	if (n_u == 0) return 0;
 
-	// compaction (lchain.c:84-110): each chain start->end, chains ordered by the x of their first anchor
+	// compaction (lchain.c:84-110): each chain start->end, chains ordered by the x of their first anchor.  The host packs
+	// into a temporary and copies again after sorting; here the order is decided first and every anchor is copied once.
 	const size_t n_v = ws.picked.size();
-	ws.packed.resize(n_v);
 	ws.heads.resize((size_t)n_u);
 	size_t k = 0;
 	for (int c = 0; c < n_u; ++c) {
-		const size_t cnt = (size_t)(uint32_t)ws.chains[c], k0 = k;
-		for (size_t j = 0; j < cnt; ++j) ws.packed[k++] = a[ws.picked[k0 + (cnt - j - 1)]];
-		ws.heads[c].x = ws.packed[k0].x;
-		ws.heads[c].y = (uint64_t)k0 << 32 | (uint64_t)c;
+		const size_t cnt = (size_t)(uint32_t)ws.chains[c];
+		ws.heads[c].x = a[ws.picked[k + cnt - 1]].x;            // first anchor of the chain = last one picked
+		ws.heads[c].y = (uint64_t)k << 32 | (uint64_t)c;
+		k += cnt;
 	}
 	sort_by_x_like_host(ws.heads.data(), ws.heads.data() + n_u);
 	uint64_t *u = (uint64_t*)mem.alloc((size_t)n_u * sizeof(uint64_t));
@@ -162,9 +174,9 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 	k = 0;
 	for (int c = 0; c < n_u; ++c) {
 		const int src = (int)(uint32_t)ws.heads[c].y;
-		const size_t cnt = (size_t)(uint32_t)ws.chains[src];
+		const size_t cnt = (size_t)(uint32_t)ws.chains[src], k0 = (size_t)(ws.heads[c].y >> 32);
 		u[c] = ws.chains[src];
-		memcpy(out + k, ws.packed.data() + (ws.heads[c].y >> 32), cnt * sizeof(mm2gb_anchor_t));
+		for (size_t j = 0; j < cnt; ++j) out[k + j] = a[ws.picked[k0 + (cnt - j - 1)]];
 		k += cnt;
 	}
 	*u_out = u; *a_out = out;

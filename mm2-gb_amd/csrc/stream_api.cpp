@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -226,15 +227,16 @@ int mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offset
 	if (!eng || !out || !offsets) return fail("mm2gb_chain_host: null argument");
 	memset(out, 0, sizeof(*out));
 	const int64_t n = offsets[n_reads];
-	std::vector<int32_t> f((size_t)(n > 0 ? n : 1)), p((size_t)(n > 0 ? n : 1));
-	if (mm2gb_score_host(eng, n_reads, offsets, anchors, f.data(), p.data(), stats)) return -1;
+	// scores land here; no need to clear 8 bytes per anchor first
+	std::unique_ptr<int32_t[]> f(new int32_t[(size_t)(n > 0 ? n : 1)]), p(new int32_t[(size_t)(n > 0 ? n : 1)]);
+	if (mm2gb_score_host(eng, n_reads, offsets, anchors, f.get(), p.get(), stats)) return -1;
 	std::vector<uint64_t*> u_of((size_t)n_reads, nullptr);
 	std::vector<mm2gb_anchor_t*> a_of((size_t)n_reads, nullptr);
 	std::vector<int> nu_of((size_t)n_reads, 0);
 	const mm2gb_misc_t misc = eng->e.misc;
 	HostAlloc mem;
 	parallel_reads(n_reads, n_threads, [&](int64_t r, BacktrackScratch &ws) {
-		nu_of[r] = backtrack_compact(misc, offsets[r + 1] - offsets[r], anchors + offsets[r], f.data() + offsets[r], p.data() + offsets[r],
+		nu_of[r] = backtrack_compact(misc, offsets[r + 1] - offsets[r], anchors + offsets[r], f.get() + offsets[r], p.get() + offsets[r],
 		                             mem, ws, &u_of[r], &a_of[r]);
 	});
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
@@ -248,13 +250,13 @@ int mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offset
 	}
 	out->u = (uint64_t*)malloc((size_t)(out->u_off[n_reads] + 1) * 8);
 	out->a = (mm2gb_anchor_t*)malloc((size_t)(out->a_off[n_reads] + 1) * 16);
-	for (int64_t r = 0; r < n_reads; ++r) {
+	parallel_reads(n_reads, n_threads, [&](int64_t r, BacktrackScratch &) {
 		if (nu_of[r]) {
 			memcpy(out->u + out->u_off[r], u_of[r], (size_t)nu_of[r] * 8);
 			memcpy(out->a + out->a_off[r], a_of[r], (size_t)(out->a_off[r + 1] - out->a_off[r]) * 16);
 		}
 		free(u_of[r]); free(a_of[r]);
-	}
+	});
 	return 0;
 }
 
