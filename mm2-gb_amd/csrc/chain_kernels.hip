@@ -7,9 +7,11 @@
 //                   fused with the planner's per-block reductions (cuts, pair counts, max_iter clamps)
 //   * plan_*        turn cuts into independent, cost-ordered work items ("chunks") without host round trips
 //                   (role of the cut/long_seg/mid_seg bookkeeping, plscore.cu:314-385, and the host pairsort, plchain.cu:30-42)
-//   * k_score_wave  the DP: one wave64 per chunk, 64 anchors per tile held one-per-lane in registers; predecessors are
-//                   broadcast lane->SGPR (v_readlane) so every lane scores the same predecessor against its own anchor.
-//                   No block barriers, no global read-modify-write (role of plscore.cu:109-187, 290-451).
+//   * k_score<MODE> the DP: persistent workgroups; 64 anchors per tile held one-per-lane in registers; predecessors are staged
+//                   64 at a time in per-wave LDS and broadcast-read, so every step scores ONE predecessor against the
+//                   wave's 64 anchors.  Heavy chunks are pipelined over the 16 waves of a workgroup through an LDS ring of
+//                   scores (the sliding predecessor window).  No block barrier per anchor, no global read-modify-write
+//                   (role of plscore.cu:109-187, 290-451).
 // Arithmetic follows lchain.c:113-138 + mmpriv.h:118-126 bit for bit: compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -431,8 +433,9 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 //   best / arg : running maximum in "threshold" form: best starts at q_span+1 with arg=-1, so "cand >= best" is the
 //                CPU's strict '>' against q_span first and "latest j wins ties" afterwards (predecessors are visited in
 //                ascending j here; descending with strict '>' on the CPU, lchain.c:174-181).
-// Predecessors ("sources") come 64 at a time, one per lane, and are broadcast lane -> SGPR with v_readlane, so each
-// step scores ONE source against the wave's 64 targets: 64x register reuse of every source, no LDS or memory in the loop.
+// Predecessors ("sources") come 64 at a time and are broadcast to all lanes, so each step scores ONE source against the
+// wave's 64 targets: 64x reuse of every source.  MODE_LUT broadcasts through LDS (sweep_block_lut); the other builds take
+// x/y/tag from the scalar path and the score with v_readlane (sweep_block).
 // --------------------------------------------------------------------------------------------------------------
 struct Target { int x, y, tag, seg, q, st, hi; bool live; };
 struct Keep { int idx, x, hi, y, tag, f; };   // the remembered best anchor ("max_ii", lchain.c:189-205), wave-uniform
@@ -444,8 +447,8 @@ typedef const int __attribute__((address_space(4))) *scalar_i32_ptr;
 __device__ __forceinline__ scalar_i32_ptr as_scalar(const void *p) { return (scalar_i32_ptr)(uintptr_t)p; }
 
 // Sources jb+k, k in [k_from, 64), all final.  CHECK: some target windows start inside this block.
-// x, y and the span/segment tag of each source come through the scalar path; its score f (written by this very kernel)
-// sits in lane k of `sf` and is broadcast with v_readlane.
+// MODE_FAST / MODE_GENERAL sweep: x, y and the span/segment tag of each source come through the scalar path; its score f
+// (written by this very kernel, so not readable that way) sits in lane k of `sf` and is broadcast with v_readlane.
 struct SrcGroup { int x[4], y[4], t[4]; };
 __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 {
