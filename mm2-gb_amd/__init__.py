@@ -42,7 +42,7 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_anchors", C.c_int64), ("n_reads", C.c_int64), ("n_pairs", C.c_int64), ("n_chunks", C.c_int64),
-                ("n_long_chunks", C.c_int64), ("n_tracked_chunks", C.c_int64), ("n_clamped_blocks", C.c_int64),
+                ("n_long_chunks", C.c_int64), ("n_mid_chunks", C.c_int64), ("n_tracked_chunks", C.c_int64), ("n_clamped_blocks", C.c_int64),
                 ("ms_h2d", C.c_float), ("ms_prep", C.c_float), ("ms_score", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float)]
 
     def as_dict(self):

@@ -44,6 +44,7 @@ struct DevBatch {
 	int32_t  *blk_firstcut;    // smallest i in block with st[i] == i, INT32_MAX if none
 	int64_t  *blk_pairs;       // sum of window sizes in block
 	int32_t  *blk_clamped;     // 1 if any window in block was cut by max_iter
+	int32_t  *blk_wmax;        // widest window in block
 	int64_t   n_blocks;
 	// chunks (independent runs of anchors between cuts), at most n_blocks of them
 	int32_t  *chunk_start, *chunk_end;
@@ -52,23 +53,25 @@ struct DevBatch {
 	int64_t  *chunk_pp;        // planner scratch: pairs before the chunk's first block
 	int32_t  *chunk_kk, *chunk_blk; // planner scratch: clamped blocks before it; its first block
 	int64_t  *tile_sums, *tile_base; // planner scratch: 3 values per tile of 1024 planning blocks
-	int32_t  *bins;            // planner scratch: 2 x 256 cost bins
+	int32_t  *bins;            // planner scratch: 3 x 256 cost bins
 	int32_t  *order;           // chunk ids, most expensive first
-	int32_t  *long_list;       // chunk ids routed to the cooperative kernel
+	int32_t  *long_list;       // chunk ids scored by a whole workgroup
+	int32_t  *mid_list;        // chunk ids scored by a 4-wave team
 	// scalars
 	int32_t  *counters;        // [0] n_chunks [1] work cursor (wave kernel) [2] n_long [3] work cursor (long kernel) [4] n_tracked [5] n_clamped_blocks
 	int64_t  *totals;          // [0] total pairs
 	unsigned *flags;           // FLAG_*
 	const int32_t *lut;        // penalty by dd, lut_last + 1 entries (MODE_LUT only)
 };
-enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_WORDS = 8 };
+enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_NMID = 6, CNT_MCURSOR = 7, CNT_WORDS = 8 };
 
 struct LaunchCfg {
 	int score_grid;          // persistent 1024-thread workgroups of k_score
 	int host_mode;           // MODE_* the host's parameters allow (the device may still fall back to MODE_GENERAL)
 	int ring_mask;           // LDS ring of the cooperative mode holds ring_mask+1 scores; -1 = cooperative mode off
 	int64_t long_min_cost;   // chunks at least this expensive ...
-	int     long_min_window; // ... whose mean window is at least this are scored cooperatively
+	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode
+	int     wide_window;     // mean window from which a 16-wave team is mostly busy; narrower heavy chunks get 4-wave teams
 };
 
 void launch_split_soa(const DevBatch &b, hipStream_t s);

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	__shared__ int s_cut[PLAN_THREADS / WAVE];
 	__shared__ unsigned long long s_pairs[PLAN_THREADS / WAVE];
 	__shared__ int s_clamp[PLAN_THREADS / WAVE];
+	__shared__ int s_wmax[PLAN_THREADS / WAVE];
 	__shared__ int64_t s_read0;
 	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		s_read0 = lo;
 	}
 	__syncthreads();
-	int my_cut = INT_MAX, my_clamp = 0;
+	int my_cut = INT_MAX, my_clamp = 0, my_wmax = 0;
 	unsigned long long my_pairs = 0;
 
 	// Each thread owns PLAN_BLOCK / PLAN_THREADS consecutive anchors.  The first gets a full backward search; window
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		b.st[i] = st;
 		st_prev = st;
 		my_pairs += (unsigned)(i - st);
+		my_wmax = max(my_wmax, i - st);
 		if (st == i && i < my_cut) my_cut = i;
 	}
 	// wave then block reductions
@@ -162,12 +164,14 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		my_cut = min(my_cut, __shfl_xor(my_cut, off));
 		my_pairs += __shfl_xor(my_pairs, off);
 		my_clamp |= __shfl_xor(my_clamp, off);
+		my_wmax = max(my_wmax, __shfl_xor(my_wmax, off));
 	}
 	const int w = threadIdx.x / WAVE;
-	if (lane_id() == 0) { s_cut[w] = my_cut; s_pairs[w] = my_pairs; s_clamp[w] = my_clamp; }
+	if (lane_id() == 0) { s_cut[w] = my_cut; s_pairs[w] = my_pairs; s_clamp[w] = my_clamp; s_wmax[w] = my_wmax; }
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		for (int k = 1; k < PLAN_THREADS / WAVE; ++k) { my_cut = min(my_cut, s_cut[k]); my_pairs += s_pairs[k]; my_clamp |= s_clamp[k]; }
+		for (int k = 1; k < PLAN_THREADS / WAVE; ++k) { my_cut = min(my_cut, s_cut[k]); my_pairs += s_pairs[k]; my_clamp |= s_clamp[k]; my_wmax = max(my_wmax, s_wmax[k]); }
+		b.blk_wmax[blockIdx.x] = my_wmax;
 		b.blk_firstcut[blockIdx.x] = my_cut;
 		b.blk_pairs[blockIdx.x] = (int64_t)my_pairs;
 		b.blk_clamped[blockIdx.x] = my_clamp;
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 // --------------------------------------------------------------------------------------------------------------
 constexpr int PLANNER_THREADS = 1024;
 constexpr int COST_BINS = 256;
+enum { LIST_WAVE = 0, LIST_TEAM16 = 1, LIST_TEAM4 = 2, N_LISTS = 3 };
 
 __device__ __forceinline__ int cost_bin(int64_t c)
 {
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(PLANNER_THREADS) void plan_emit(DevBatch b)
 
 __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 {
-	__shared__ int s_hist[2][COST_BINS];
-	for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) (&s_hist[0][0])[k] = 0;
+	__shared__ int s_hist[N_LISTS][COST_BINS];
+	for (int k = threadIdx.x; k < N_LISTS * COST_BINS; k += blockDim.x) (&s_hist[0][0])[k] = 0;
 	__syncthreads();
 	const int n_chunks = b.counters[CNT_NCHUNK];
 	int n_track = 0;
@@ -285,16 +290,30 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 		const long long kk_next = last ? b.totals[1] : (long long)b.chunk_kk[c + 1] + b.blk_clamped[b.chunk_blk[c + 1]];
 		const bool track = kk_next - b.chunk_kk[c] > 0;
 		const long long cost = (pp_next - b.chunk_pp[c]) + (long long)(end - start) * COST_PER_ANCHOR;
-		// heavy chunks with wide enough windows go to the cooperative mode (bit 1)
-		const bool is_long = cfg.ring_mask >= 0 && cost >= cfg.long_min_cost && (long long)(end - start) * cfg.long_min_window <= cost;
+		// How the chunk will be scored (bits 1-2 of chunk_track): LIST_WAVE one wave; LIST_TEAM16 the 16 waves of a workgroup;
+		// LIST_TEAM4 a 4-wave team (four chunks per workgroup at a time).  A chunk with mean window W keeps about
+		// (W + 128) / 128 waves busy, so wide windows get the big team and a few blocks of window the small one, which also
+		// needs the chunk's widest window to fit its quarter of the LDS ring.
+		const long long len = end - start;
+		const bool heavy = cfg.ring_mask >= 0 && cost >= cfg.long_min_cost && len * cfg.long_min_window <= cost;
+		int list = LIST_WAVE;
+		if (heavy) {
+			if (len * cfg.wide_window <= cost) list = LIST_TEAM16;
+			else {
+				int wmax = 0;
+				const int blk_last = last ? (int)b.n_blocks - 1 : b.chunk_blk[c + 1];
+				for (int k = b.chunk_blk[c]; k <= blk_last; ++k) wmax = max(wmax, b.blk_wmax[k]);
+				list = wmax + WAVE <= (cfg.ring_mask + 1) / 4 ? LIST_TEAM4 : LIST_TEAM16;
+			}
+		}
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;
-		b.chunk_track[c] = (uint8_t)((track ? 1 : 0) | (is_long ? 2 : 0));
+		b.chunk_track[c] = (uint8_t)((track ? 1 : 0) | (list << 1));
 		n_track += track;
-		atomicAdd(&s_hist[is_long][cost_bin(cost)], 1);
+		atomicAdd(&s_hist[list][cost_bin(cost)], 1);
 	}
 	__syncthreads();
-	for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) {
+	for (int k = threadIdx.x; k < N_LISTS * COST_BINS; k += blockDim.x) {
 		const int v = (&s_hist[0][0])[k];
 		if (v) atomicAdd(&b.bins[k], v);
 	}
@@ -304,34 +323,38 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 
 __global__ __launch_bounds__(64) void plan_bins(DevBatch b)
 {
-	if (threadIdx.x < 2) {
+	if (threadIdx.x < N_LISTS) {
 		int acc = 0;
 		int *bins = b.bins + threadIdx.x * COST_BINS;
 		for (int k = COST_BINS - 1; k >= 0; --k) { const int v = bins[k]; bins[k] = acc; acc += v; }   // count -> base
-		if (threadIdx.x == 1) b.counters[CNT_NLONG] = acc;
+		if (threadIdx.x == LIST_TEAM16) b.counters[CNT_NLONG] = acc;
+		if (threadIdx.x == LIST_TEAM4) b.counters[CNT_NMID] = acc;
 	}
-	if (threadIdx.x == 0) { b.counters[CNT_CURSOR] = 0; b.counters[CNT_LCURSOR] = 0; }
+	if (threadIdx.x == 0) { b.counters[CNT_CURSOR] = 0; b.counters[CNT_LCURSOR] = 0; b.counters[CNT_MCURSOR] = 0; }
 }
 
 __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 {
 	// most chunks fall into a handful of bins: rank them inside the workgroup first (LDS), then reserve one range per bin
 	// per workgroup in global memory
-	__shared__ int s_cnt[2 * COST_BINS], s_base[2 * COST_BINS];
+	__shared__ int s_cnt[N_LISTS * COST_BINS], s_base[N_LISTS * COST_BINS];
 	const int n_chunks = b.counters[CNT_NCHUNK];
 	for (int64_t c0 = (int64_t)blockIdx.x * blockDim.x; c0 < n_chunks; c0 += (int64_t)gridDim.x * blockDim.x) {
-		for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) s_cnt[k] = 0;
+		for (int k = threadIdx.x; k < N_LISTS * COST_BINS; k += blockDim.x) s_cnt[k] = 0;
 		__syncthreads();
 		const int64_t c = c0 + threadIdx.x;
 		int key = -1, rank = 0;
 		if (c < n_chunks) {
-			key = ((b.chunk_track[c] >> 1) & 1) * COST_BINS + cost_bin(b.chunk_cost[c]);
+			key = ((b.chunk_track[c] >> 1) & 3) * COST_BINS + cost_bin(b.chunk_cost[c]);
 			rank = atomicAdd(&s_cnt[key], 1);
 		}
 		__syncthreads();
-		for (int k = threadIdx.x; k < 2 * COST_BINS; k += blockDim.x) if (s_cnt[k]) s_base[k] = atomicAdd(&b.bins[k], s_cnt[k]);
+		for (int k = threadIdx.x; k < N_LISTS * COST_BINS; k += blockDim.x) if (s_cnt[k]) s_base[k] = atomicAdd(&b.bins[k], s_cnt[k]);
 		__syncthreads();
-		if (key >= 0) (key >= COST_BINS ? b.long_list : b.order)[s_base[key] + rank] = (int)c;
+		if (key >= 0) {
+			int *dst = key >= LIST_TEAM4 * COST_BINS ? b.mid_list : key >= LIST_TEAM16 * COST_BINS ? b.long_list : b.order;
+			dst[s_base[key] + rank] = (int)c;
+		}
 		__syncthreads();
 	}
 }
@@ -689,13 +712,31 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 // (a tile needs ~(window/64 + 2) block sweeps, its critical dependency is 2 of them).  Final scores travel between
 // waves through an LDS ring indexed by anchor number (the sliding predecessor window, max_iter + slack entries);
 // "tiles done" is a release/acquire counter in LDS.  No block barrier inside a chunk.
-struct CoopShared { int done; int keep[6]; int chunk; };
+struct CoopShared { int done; int keep[6]; int chunk; int bar_count; int bar_gen; };   // one per team
+constexpr int SMALL_TEAM = 4, N_SMALL_TEAMS = SCORE_THREADS / WAVE / SMALL_TEAM;
+
+// Barrier among the waves of one small team (a workgroup barrier would stall the other teams): sense-reversing counter
+// in LDS, one lane per wave takes part.
+__device__ __forceinline__ void team_barrier(CoopShared *sh, int team_size)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	if (lane_id() == 0) {
+		const int gen = __hip_atomic_load(&sh->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (__hip_atomic_fetch_add(&sh->bar_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == team_size - 1) {
+			__hip_atomic_store(&sh->bar_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_add(&sh->bar_gen, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		} else {
+			while (__hip_atomic_load(&sh->bar_gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == gen) __builtin_amdgcn_s_sleep(2);
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 template <int MODE, bool TRACK>
 __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_mask, CoopShared *sh,
-                           const int cs, const int ce)
+                           const int cs, const int ce, const int wave, const int n_waves)
 {
-	const int lane = lane_id(), wave = threadIdx.x / WAVE, n_waves = blockDim.x / WAVE;
+	const int lane = lane_id();
 	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
 	auto wait_done = [&](int need) {
 		// a waiting wave must not steal issue slots from the waves it waits for: poll rarely (s_sleep 32 = 2048 cycles,
@@ -737,11 +778,12 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// The score kernel: persistent 1024-thread workgroups (16 waves).  Phase 1: workgroups pull heavy chunks from the long
-// list and run them cooperatively.  Phase 2: every wave pulls ordinary chunks on its own, most expensive first.
+// The score kernel: persistent 1024-thread workgroups (16 waves).  Phase 1a: workgroups pull wide-window heavy chunks and run
+// them with all 16 waves.  Phase 1b: each workgroup splits into four 4-wave teams that pull narrower heavy chunks.
+// Phase 2: every wave pulls ordinary chunks on its own.  All lists most expensive first.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_split_soa).
-// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared ]
+// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 4 ]
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE>
@@ -755,13 +797,16 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
 	int *ring = smem + lut_words;
 	int4 *stage = (int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
-	CoopShared *sh = (CoopShared*)((int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + SCORE_THREADS);
+	CoopShared *teams = (CoopShared*)((int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + SCORE_THREADS);   // N_SMALL_TEAMS of them
 	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];
+	if (threadIdx.x < N_SMALL_TEAMS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
 	__syncthreads();
 
-	// phase 1: cooperative
-	const int n_long = b.counters[CNT_NLONG];
+	const int n_long = b.counters[CNT_NLONG], n_mid = b.counters[CNT_NMID];
+	const int wave = threadIdx.x / WAVE;
 	if (ring_mask >= 0) {
+		// phase 1a: the whole workgroup on one chunk at a time (wide windows)
+		CoopShared *sh = &teams[0];
 		while (true) {
 			if (threadIdx.x == 0) { sh->chunk = atomicAdd(&b.counters[CNT_LCURSOR], 1); sh->done = 0; sh->keep[0] = -1; }
 			__syncthreads();
@@ -769,13 +814,29 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			if (c >= n_long) break;
 			const int ci = b.long_list[c];
 			const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
-			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, ring, ring_mask, sh, cs, ce);
-			else coop_chunk<MODE, false>(b, P, lut, stage, ring, ring_mask, sh, cs, ce);
+			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, ring, ring_mask, sh, cs, ce, wave, SCORE_THREADS / WAVE);
+			else coop_chunk<MODE, false>(b, P, lut, stage, ring, ring_mask, sh, cs, ce, wave, SCORE_THREADS / WAVE);
 			__syncthreads();
+		}
+		// phase 1b: four 4-wave teams, each on its own chunk with a quarter of the ring (narrower windows)
+		const int team = wave / SMALL_TEAM, team_wave = wave % SMALL_TEAM;
+		const int q_mask = (ring_mask + 1) / N_SMALL_TEAMS - 1;
+		int *q_ring = ring + team * (q_mask + 1);
+		sh = &teams[team];
+		while (true) {
+			if (team_wave == 0 && lane_id() == 0) { sh->chunk = atomicAdd(&b.counters[CNT_MCURSOR], 1); sh->done = 0; sh->keep[0] = -1; }
+			team_barrier(sh, SMALL_TEAM);
+			const int c = sh->chunk;
+			if (c >= n_mid) break;
+			const int ci = b.mid_list[c];
+			const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
+			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, q_ring, q_mask, sh, cs, ce, team_wave, SMALL_TEAM);
+			else coop_chunk<MODE, false>(b, P, lut, stage, q_ring, q_mask, sh, cs, ce, team_wave, SMALL_TEAM);
+			team_barrier(sh, SMALL_TEAM);
 		}
 	}
 	// phase 2: one wave per chunk
-	const int n_chunks = b.counters[CNT_NCHUNK] - n_long;
+	const int n_chunks = b.counters[CNT_NCHUNK] - n_long - n_mid;
 	while (true) {
 		int c = 0;
 		if (lane_id() == 0) c = atomicAdd(&b.counters[CNT_CURSOR], 1);
@@ -809,7 +870,7 @@ void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s)
 {
 	const int n_tiles = (int)((b.n_blocks + PLANNER_THREADS - 1) / PLANNER_THREADS);
 	const int chunk_grid = (int)std::min<int64_t>(1024, (b.n_blocks + 255) / 256);
-	(void)hipMemsetAsync(b.bins, 0, 2 * COST_BINS * sizeof(int), s);
+	(void)hipMemsetAsync(b.bins, 0, N_LISTS * COST_BINS * sizeof(int), s);
 	hipLaunchKernelGGL(plan_tile_sums, dim3(n_tiles), dim3(PLANNER_THREADS), 0, s, b);
 	hipLaunchKernelGGL(plan_tile_scan, dim3(1), dim3(PLANNER_THREADS), 0, s, b, n_tiles);
 	hipLaunchKernelGGL(plan_emit, dim3(n_tiles), dim3(PLANNER_THREADS), 0, s, b);
@@ -826,7 +887,7 @@ void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
 size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask)
 {
 	const size_t lut_words = host_mode == MODE_LUT ? (size_t)((P.lut_last + 1 + 3) & ~3) : 0;
-	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + (size_t)SCORE_THREADS * sizeof(int4) + sizeof(CoopShared) + 16;
+	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_SMALL_TEAMS * sizeof(CoopShared) + 16;
 }
 
 int score_set_lds_limit(size_t bytes)

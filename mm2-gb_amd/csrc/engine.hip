@@ -114,7 +114,9 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	// plscore.cu:330,378): cost threshold = mid_seg_cutoff units of anchors at the minimum window.
 	launch.long_min_window = 128;
 	launch.long_min_cost = (int64_t)std::max(1, cfg.score_kernel.mid_seg_cutoff) * std::max(64, cfg.range_kernel.blockdim) * 1024;
+	launch.wide_window = 1024;
 	if (const char *v = getenv("MM2GB_LONG_MIN_WINDOW")) launch.long_min_window = std::max(1, atoi(v));
+	if (const char *v = getenv("MM2GB_WIDE_WINDOW")) launch.wide_window = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_LONG_MIN_COST")) launch.long_min_cost = std::max<int64_t>(1, atoll(v));
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
@@ -135,7 +137,7 @@ void Engine::shutdown()
 	(void)hipSetDevice(device);
 	for (hipStream_t s : { s_in, stream, s_out }) if (s) (void)hipStreamSynchronize(s);
 	for (DevBuf *b : { &x, &y, &xhi, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &chunk_start, &chunk_end, &chunk_cost,
-	                   &chunk_track, &order, &long_list, &counters, &totals, &flags, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
+	                   &chunk_track, &order, &long_list, &mid_list, &blk_wmax, &counters, &totals, &flags, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
 		b->release();
 	for (IoSet &s : io) {
 		s.raw.release(); s.offsets.release(); s.f.release(); s.p.release();
@@ -161,10 +163,10 @@ int Engine::reserve(int64_t n, int64_t n_reads)
 		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
 		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
 		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
-		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4)) return -1;
+		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4) || blk_wmax.ensure(nb * 4)) return -1;
 		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
-		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
-		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(2 * 256 * 4)) return -1;
+		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || mid_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
+		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(3 * 256 * 4)) return -1;
 		cap_n = nn; cap_blocks = nb; cap_reads = std::max(cap_reads, n_reads);
 	}
 	return 0;
@@ -190,10 +192,10 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
 	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
 	b.f = d_f; b.p = d_p;
-	b.blk_firstcut = (int32_t*)blk_firstcut.ptr; b.blk_pairs = (int64_t*)blk_pairs.ptr; b.blk_clamped = (int32_t*)blk_clamped.ptr;
+	b.blk_firstcut = (int32_t*)blk_firstcut.ptr; b.blk_pairs = (int64_t*)blk_pairs.ptr; b.blk_clamped = (int32_t*)blk_clamped.ptr; b.blk_wmax = (int32_t*)blk_wmax.ptr;
 	b.n_blocks = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
 	b.chunk_start = (int32_t*)chunk_start.ptr; b.chunk_end = (int32_t*)chunk_end.ptr; b.chunk_cost = (int64_t*)chunk_cost.ptr;
-	b.chunk_track = (uint8_t*)chunk_track.ptr; b.order = (int32_t*)order.ptr; b.long_list = (int32_t*)long_list.ptr;
+	b.chunk_track = (uint8_t*)chunk_track.ptr; b.order = (int32_t*)order.ptr; b.long_list = (int32_t*)long_list.ptr; b.mid_list = (int32_t*)mid_list.ptr;
 	b.chunk_pp = (int64_t*)chunk_pp.ptr; b.chunk_kk = (int32_t*)chunk_kk.ptr; b.chunk_blk = (int32_t*)chunk_blk.ptr;
 	b.tile_sums = (int64_t*)tile_sums.ptr; b.tile_base = (int64_t*)tile_base.ptr; b.bins = (int32_t*)bins.ptr;
 	b.counters = (int32_t*)counters.ptr; b.totals = (int64_t*)totals.ptr; b.flags = (unsigned*)flags.ptr;
@@ -273,6 +275,7 @@ int Engine::collect_stats()
 		last.n_pairs += h_totals[(size_t)k * 2];
 		last.n_chunks += c[CNT_NCHUNK];
 		last.n_long_chunks += c[CNT_NLONG];
+		last.n_mid_chunks += c[CNT_NMID];
 		last.n_tracked_chunks += c[CNT_NTRACK];
 		last.n_clamped_blocks += c[CNT_NCLAMP];
 		float ms = 0;

@@ -8,6 +8,7 @@
 //   q_span = 15, seg_id = 0, sorted by x.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -31,6 +32,14 @@ struct ReadPlan {
 	int64_t total() const { int64_t t = 4 * n_true; for (int b : block_sizes) t += b; return t; }
 };
 
+// Repeat-block probability per 50 kb of read: 0.3 in the SURVEY 8(d) recipe.  MM2GB_SYNTH_REPEAT_P overrides it for
+// experiments (e.g. 0 = chains and noise only, windows of a few hundred anchors); read once.
+double repeat_probability()
+{
+	static const double p = [] { const char *v = getenv("MM2GB_SYNTH_REPEAT_P"); return v && *v ? atof(v) : 0.3; }();
+	return p;
+}
+
 // The header draws: everything that decides the anchor count.  The body continues from the same stream.
 ReadPlan plan_read(Rng &rng, int len_lo, int len_hi)
 {
@@ -41,7 +50,7 @@ ReadPlan plan_read(Rng &rng, int len_lo, int len_hi)
 	for (int w = 0; w < n_win; ++w) {
 		const double u = rng.unit();
 		const int sz = (int)rng.range(2000, 12001);
-		if (u < 0.3) pl.block_sizes.push_back(sz);
+		if (u < repeat_probability()) pl.block_sizes.push_back(sz);
 	}
 	return pl;
 }

@@ -165,6 +165,23 @@ def test_modes_without_the_penalty_table(kw):
     assert st["n_pairs"] > 1_000_000
 
 
+def test_four_wave_teams(engine):
+    """Heavy chunks with narrow windows are pipelined over 4-wave teams with a quarter of the LDS ring each: plain chains,
+    and max_iter-clamped windows (rescue state handed from wave to wave inside a team)."""
+    prm = orc.default_param()
+    chains = [sc.sort_by_x(np.concatenate([sc.colinear(9000, 300 + k, r0=1_000_000 + 7 * k), sc.noise(3000, 400 + k)])) for k in range(6)]
+    off = np.zeros(len(chains) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in chains])
+    st = check_batch(engine, np.concatenate(chains), off, prm)
+    assert st["n_mid_chunks"] >= 4 and st["n_long_chunks"] == 0
+    clamped = [sc.sort_by_x(np.concatenate([sc.repeat_block(6000, 500 + k), sc.colinear(500, 600 + k)])) for k in range(3)]
+    clamped.append(sc.rescue_case(n_noise=5000, n_chain=60, seed=12))
+    off = np.zeros(len(clamped) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in clamped])
+    st = check_batch(engine, np.concatenate(clamped), off, orc.default_param(max_iter=160))
+    assert st["n_mid_chunks"] >= 3 and st["n_tracked_chunks"] >= 3
+
+
 def test_inputs_outside_the_table_sweep_domain(engine):
     """The table sweep works on coordinates x4 and needs query positions < 2^27 and q_span > 0; anything else must be
     detected on the device and scored by the per-pair build, with identical results."""
