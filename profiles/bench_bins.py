@@ -88,7 +88,7 @@ def main():
         st = eng.stats()
         row = {"read_len": [lo, hi], "reads": n_reads, "anchors": n, "pairs": st["n_pairs"], "pairs_per_anchor": round(st["n_pairs"] / n, 1),
                "gpu_pairs_per_s": st["n_pairs"] / wall, "gpu_ms_per_step": wall * 1e3, "gpu_score_kernel_ms": st["ms_score"], "gpu_prep_ms": st["ms_prep"],
-               "long_chunks": st["n_long_chunks"], "tracked_chunks": st["n_tracked_chunks"], "cpu": {}}
+               "long_chunks": st["n_long_chunks"], "mid_chunks": st["n_mid_chunks"], "tracked_chunks": st["n_tracked_chunks"], "cpu": {}}
         for tag, L in (("O3", L_ref), ("O3_native", L_nat)):
             for th in (1, cores):
                 rate, reads_used, pairs, dt = cpu_rate(L, a, off, th, args.cpu_seconds)
