@@ -44,7 +44,7 @@ struct DevBatch {
 	int32_t  *blk_firstcut;    // smallest i in block with st[i] == i, INT32_MAX if none
 	int64_t  *blk_pairs;       // sum of window sizes in block
 	int32_t  *blk_clamped;     // 1 if any window in block was cut by max_iter
-	int32_t  *blk_wmax;        // widest window in block
+	int32_t  *blk_wmax;        // two per block: widest window before the block's first cut, and from it on
 	int64_t   n_blocks;
 	// chunks (independent runs of anchors between cuts), at most n_blocks of them
 	int32_t  *chunk_start, *chunk_end;

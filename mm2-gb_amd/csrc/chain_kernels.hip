@@ -65,7 +65,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	__shared__ int s_cut[PLAN_THREADS / WAVE];
 	__shared__ unsigned long long s_pairs[PLAN_THREADS / WAVE];
 	__shared__ int s_clamp[PLAN_THREADS / WAVE];
-	__shared__ int s_wmax[PLAN_THREADS / WAVE];
+	__shared__ int s_wmax[2 * PLAN_THREADS / WAVE];
 	__shared__ int64_t s_read0;
 	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		s_read0 = lo;
 	}
 	__syncthreads();
-	int my_cut = INT_MAX, my_clamp = 0, my_wmax = 0;
+	int my_cut = INT_MAX, my_clamp = 0;
 	unsigned long long my_pairs = 0;
 
 	// Each thread owns PLAN_BLOCK / PLAN_THREADS consecutive anchors.  The first gets a full backward search; window
@@ -87,6 +87,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	const int64_t i_first = base + (int64_t)threadIdx.x * PER;
 	int64_t rd = s_read0;                             // read of the current anchor
 	int rs = 0, re = 0, st_prev = 0;
+	int win[PER];
+#pragma unroll
+	for (int k = 0; k < PER; ++k) win[k] = -1;
+#pragma unroll
 	for (int k = 0; k < PER; ++k) {
 		const int64_t i64 = i_first + k;
 		if (i64 >= b.n) break;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		b.st[i] = st;
 		st_prev = st;
 		my_pairs += (unsigned)(i - st);
-		my_wmax = max(my_wmax, i - st);
+		win[k] = i - st;
 		if (st == i && i < my_cut) my_cut = i;
 	}
 	// wave then block reductions
@@ -164,15 +168,30 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		my_cut = min(my_cut, __shfl_xor(my_cut, off));
 		my_pairs += __shfl_xor(my_pairs, off);
 		my_clamp |= __shfl_xor(my_clamp, off);
-		my_wmax = max(my_wmax, __shfl_xor(my_wmax, off));
 	}
 	const int w = threadIdx.x / WAVE;
-	if (lane_id() == 0) { s_cut[w] = my_cut; s_pairs[w] = my_pairs; s_clamp[w] = my_clamp; s_wmax[w] = my_wmax; }
+	if (lane_id() == 0) { s_cut[w] = my_cut; s_pairs[w] = my_pairs; s_clamp[w] = my_clamp; }
+	__syncthreads();
+	int blk_cut = s_cut[0];
+	for (int k = 1; k < PLAN_THREADS / WAVE; ++k) blk_cut = min(blk_cut, s_cut[k]);
+	// widest window before the block's first cut (belongs to the chunk that started earlier) and from it on (belongs to
+	// the chunk that starts here)
+	int head = 0, tail = 0;
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		if (win[k] < 0) continue;
+		if (i_first + k < blk_cut) head = max(head, win[k]); else tail = max(tail, win[k]);
+	}
+	for (int off = WAVE / 2; off > 0; off >>= 1) { head = max(head, __shfl_xor(head, off)); tail = max(tail, __shfl_xor(tail, off)); }
+	if (lane_id() == 0) { s_wmax[w] = head; s_wmax[PLAN_THREADS / WAVE + w] = tail; }
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		for (int k = 1; k < PLAN_THREADS / WAVE; ++k) { my_cut = min(my_cut, s_cut[k]); my_pairs += s_pairs[k]; my_clamp |= s_clamp[k]; my_wmax = max(my_wmax, s_wmax[k]); }
-		b.blk_wmax[blockIdx.x] = my_wmax;
-		b.blk_firstcut[blockIdx.x] = my_cut;
+		for (int k = 1; k < PLAN_THREADS / WAVE; ++k) { my_pairs += s_pairs[k]; my_clamp |= s_clamp[k]; }
+		head = tail = 0;
+		for (int k = 0; k < PLAN_THREADS / WAVE; ++k) { head = max(head, s_wmax[k]); tail = max(tail, s_wmax[PLAN_THREADS / WAVE + k]); }
+		b.blk_wmax[2 * blockIdx.x] = head;
+		b.blk_wmax[2 * blockIdx.x + 1] = tail;
+		b.blk_firstcut[blockIdx.x] = blk_cut;
 		b.blk_pairs[blockIdx.x] = (int64_t)my_pairs;
 		b.blk_clamped[blockIdx.x] = my_clamp;
 	}
@@ -298,13 +317,15 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 		const bool heavy = cfg.ring_mask >= 0 && cost >= cfg.long_min_cost && len * cfg.long_min_window <= cost;
 		int list = LIST_WAVE;
 		if (heavy) {
-			if (len * cfg.wide_window <= cost) list = LIST_TEAM16;
-			else {
-				int wmax = 0;
-				const int blk_last = last ? (int)b.n_blocks - 1 : b.chunk_blk[c + 1];
-				for (int k = b.chunk_blk[c]; k <= blk_last; ++k) wmax = max(wmax, b.blk_wmax[k]);
-				list = wmax + WAVE <= (cfg.ring_mask + 1) / 4 ? LIST_TEAM4 : LIST_TEAM16;
-			}
+			// widest window of the chunk: the part of its first block from the first cut on, then whole (cut-free) blocks,
+			// then the part of the next chunk's block before that block's first cut
+			const int blk0 = b.chunk_blk[c], blk_end = last ? (int)b.n_blocks : b.chunk_blk[c + 1];
+			int wmax = b.blk_wmax[2 * blk0 + 1];
+			for (int k = blk0 + 1; k < blk_end; ++k) wmax = max(wmax, b.blk_wmax[2 * k]);
+			if (!last) wmax = max(wmax, b.blk_wmax[2 * blk_end]);
+			const int ring = cfg.ring_mask + 1;
+			if (len * cfg.wide_window > cost && wmax + WAVE <= ring / 4) list = LIST_TEAM4;
+			else if (wmax + WAVE <= ring) list = LIST_TEAM16;      // else: window wider than the ring can hold -> one wave
 		}
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;

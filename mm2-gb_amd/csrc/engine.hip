@@ -79,11 +79,14 @@ int Engine::configure_score()
 	if (!single) launch.host_mode = SCORE_MODE_GENERAL;
 	else if (params.skip == 0.0f && params.lut_last + 1 <= LUT_MAX) launch.host_mode = SCORE_MODE_LUT;
 	else launch.host_mode = SCORE_MODE_FAST;
-	// cooperative mode: ring must cover max_iter predecessors plus the tile being written
-	int ring = 1024;
-	while (ring < params.max_iter + 2 * 64 && ring < (1 << 20)) ring <<= 1;
-	launch.ring_mask = ring - 1;
+	// Team modes: the LDS ring holds the scores of the most recent anchors of a chunk and must cover the widest predecessor
+	// window of any chunk it is used for (+ the tile being written).  Sized for max_iter when that fits the LDS budget of
+	// two workgroups per CU, otherwise as large as fits; the planner sends a chunk to a team only if its widest window fits.
 	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS)
+	int64_t ring = 1024;
+	while (ring < (int64_t)params.max_iter + 2 * 64 && ring < (1 << 16)) ring <<= 1;
+	while (ring > 1024 && score_lds_bytes(params, launch.host_mode, (int)ring - 1) > LDS_BUDGET) ring >>= 1;
+	launch.ring_mask = (int)ring - 1;
 	if (coop_disabled || score_lds_bytes(params, launch.host_mode, launch.ring_mask) > LDS_BUDGET) launch.ring_mask = -1;
 	const size_t need = std::max(score_lds_bytes(params, launch.host_mode, launch.ring_mask), score_lds_bytes(params, SCORE_MODE_GENERAL, launch.ring_mask));
 	if (score_set_lds_limit(need)) return fail("mm2gb: cannot raise the dynamic LDS limit of the score kernel");
@@ -163,7 +166,7 @@ int Engine::reserve(int64_t n, int64_t n_reads)
 		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
 		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
 		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
-		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4) || blk_wmax.ensure(nb * 4)) return -1;
+		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4) || blk_wmax.ensure(nb * 8)) return -1;
 		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
 		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || mid_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
 		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(3 * 256 * 4)) return -1;

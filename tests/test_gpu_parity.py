@@ -182,6 +182,18 @@ def test_four_wave_teams(engine):
     assert st["n_mid_chunks"] >= 3 and st["n_tracked_chunks"] >= 3
 
 
+@pytest.mark.parametrize("max_iter", [9000, 40000, orc.INT32_MAX])
+def test_max_iter_beyond_the_lds_ring(engine, max_iter):
+    """max_iter larger than the LDS score ring can hold: chunks whose widest window still fits go to teams, the others to
+    single waves; results unchanged (this is also the `-x sr`-style max_iter = INT32_MAX)."""
+    parts = [sc.sort_by_x(np.concatenate([sc.repeat_block(12000, 81, xwin=4500), sc.colinear(600, 82)])),   # windows up to ~12000
+             sc.sort_by_x(np.concatenate([sc.repeat_block(5000, 83), sc.colinear(600, 84)]))]                # windows up to ~5000
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    st = check_batch(engine, np.concatenate(parts), off, orc.default_param(max_iter=max_iter))
+    assert st["n_long_chunks"] + st["n_mid_chunks"] >= 1
+
+
 def test_inputs_outside_the_table_sweep_domain(engine):
     """The table sweep works on coordinates x4 and needs query positions < 2^27 and q_span > 0; anything else must be
     detected on the device and scored by the per-pair build, with identical results."""
