@@ -77,3 +77,25 @@ def test_simulated_long_reads_paf_diff_empty(tmp_path):
         w, g = want.splitlines(), got.splitlines()
         bad = [k for k in range(min(len(w), len(g))) if w[k] != g[k]]
         raise AssertionError(f"{len(bad)} of {len(w)} PAF lines differ (got {len(g)} lines); first: {g[bad[0]] if bad else None} vs {w[bad[0]] if bad else None}")
+
+
+@needs_host
+def test_multithreaded_host_one_stream_per_thread(tmp_path):
+    """-t 3 with num_streams = 3: every host thread drives its own engine/stream through the boundary at the same time
+    (the reference supports -t 1 only, README.md:46-47).  Same PAF as the single-threaded CPU path."""
+    import json
+    import sim_reads
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    cfg = json.load(open(CFG))
+    cfg["num_streams"] = 3
+    cfg["max_total_n"] = 300_000           # small batches so that every thread launches several
+    cfg["max_read"] = 8
+    p = tmp_path / "mt.json"
+    p.write_text(json.dumps(cfg))
+    r = subprocess.run([HOST, "-t", "3", "--gpu-chain", "--gpu-cfg", str(p), ref, reads], capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = sorted(open(os.path.join(GOLD, "sim160_inf.paf")).read().splitlines())
+    got = sorted(r.stdout.decode().splitlines())
+    assert got == want

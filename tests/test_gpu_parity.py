@@ -263,6 +263,44 @@ def test_sliced_host_call_overlapped_streams(monkeypatch):
     assert np.array_equal(f2, fo) and st2["n_pairs"] == pairs
 
 
+def test_fuzz_random_batches_and_parameters(engine):
+    """Seeded fuzz: random mixtures of chains, noise, repeat blocks, duplicated positions, empty reads, and random chaining
+    parameters (window limits around tile and ring sizes, both score builds)."""
+    rng = np.random.default_rng(20241002)
+    for it in range(40):
+        reads = []
+        for _ in range(int(rng.integers(1, 7))):
+            kind = int(rng.integers(0, 6))
+            seed = int(rng.integers(1, 1 << 30))
+            if kind == 0:
+                reads.append(np.zeros((0, 2), np.uint64))
+            elif kind == 1:
+                reads.append(sc.noise(int(rng.integers(1, 400)), seed, n_rid=int(rng.integers(1, 4)), span=int(rng.integers(2_000, 200_000)), qlen=20_000))
+            elif kind == 2:
+                reads.append(sc.read_like(int(rng.integers(1_000, 25_000)), seed))
+            elif kind == 3:
+                reads.append(sc.sort_by_x(np.concatenate([sc.repeat_block(int(rng.integers(100, 3000)), seed, xwin=int(rng.integers(50, 5000)), ywin=int(rng.integers(50, 7000))),
+                                                          sc.colinear(int(rng.integers(10, 800)), seed + 1, max_gap=int(rng.integers(2, 60)))])))
+            elif kind == 4:
+                reads.append(sc.variable_span(int(rng.integers(50, 900)), seed))
+            else:
+                reads.append(sc.grid_ties(nx=int(rng.integers(3, 50)), ny=int(rng.integers(2, 14)), step=int(rng.integers(1, 40))))
+        off = np.zeros(len(reads) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(r) for r in reads])
+        a = np.concatenate(reads) if off[-1] else np.zeros((0, 2), np.uint64)
+        kw = dict(max_iter=int(rng.choice([1, 7, 63, 64, 65, 200, 1000, 5000])), bw=int(rng.choice([0, 1, 50, 500, 3000])),
+                  max_dist_x=int(rng.choice([10, 500, 5000, 20000])), max_dist_y=int(rng.choice([10, 500, 5000, 20000])),
+                  pen_gap=np.float32(rng.choice([0.0, 0.12, 0.19, 1.5])), pen_skip=np.float32(rng.choice([0.0, 0.0, 0.01, 0.3])),
+                  min_cnt=int(rng.integers(1, 5)), min_sc=int(rng.choice([1, 20, 40, 100])))
+        prm = orc.default_param(**kw)
+        check_batch(engine, a, off, prm, threads=2)
+        if it % 8 == 0 and off[-1]:
+            res, _ = engine.chain(a, off, threads=2)
+            for r in range(len(off) - 1):
+                o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
+                assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (it, r, kw)
+
+
 def test_lchain_dp_signature_entry():
     """mm2gb_lchain_dp: same call shape as mg_lchain_dp (lchain.c:148), input consumed, outputs malloc'd."""
     import ctypes as C
