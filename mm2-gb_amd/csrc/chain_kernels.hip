@@ -502,16 +502,6 @@ __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; g.t[u] = st[j0 + u]; }
 	return g;
 }
-struct SrcXY { int x[4], y[4]; };
-__device__ __forceinline__ SrcXY load_xy(const DevBatch &b, int j0)
-{
-	const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y);
-	SrcXY g;
-#pragma unroll
-	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; }
-	return g;
-}
-
 // MODE_LUT sweep.  A block's 64 sources are first written to this wave's LDS scratch as {f, q_span, x, y}; each step then
 // takes ONE LDS broadcast read (ds_read_b128, same address in every lane) for the source and one LDS gather for the
 // penalty, so every vector-ALU operand is a VGPR (ops with an SGPR operand issue at half rate on gfx950, profiles/ubench):
