@@ -99,21 +99,24 @@ namespace {
 
 inline int64_t pred_of(const int32_t *p_rel, int64_t i) { return p_rel[i] ? i - p_rel[i] : -1; }
 
-// lchain.c:9-25: walk back from the chain end k until an anchor that is taken, the start of the path, or an X-drop of
-// more than max_drop below the best prefix; returns where the kept part stops.
-int64_t kept_until(int32_t max_drop, int32_t top_score, int64_t start, const int32_t *f, const int32_t *p_rel, uint8_t *mark)
+// lchain.c:9-25: walk back from the chain end until an anchor that is taken, the start of the path, or an X-drop of more
+// than max_drop below the best prefix; returns where the kept part stops.  The host marks the nodes it visits (t = 2) and
+// walks the same links again to clear the marks, and its caller walks them a third time to collect the chain; here the
+// visited nodes are remembered in `path` (in walk order), so the links are chased once.
+int64_t kept_until(int32_t max_drop, int32_t top_score, int64_t start, const int32_t *f, const int32_t *p_rel, const uint8_t *mark,
+                   std::vector<int32_t> &path)
 {
-	int64_t i = start, last = -1, best_i = start;
+	int64_t i = start, best_i = start;
 	int32_t best = 0;
+	path.clear();
 	if (i < 0 || mark[i] != 0) return i;
 	do {
-		mark[i] = 2;
-		last = i = pred_of(p_rel, i);
+		path.push_back((int32_t)i);                 // the host's t[i] = 2: a node is never reached twice within one walk
+		i = pred_of(p_rel, i);
 		const int32_t s = i < 0 ? top_score : top_score - f[i];
 		if (s > best) { best = s; best_i = i; }
 		else if (best - s > max_drop) break;
 	} while (i >= 0 && mark[i] == 0);
-	for (i = start; i >= 0 && i != last; i = pred_of(p_rel, i)) mark[i] = 0;   // undo the provisional marks
 	return best_i;
 }
 
@@ -146,9 +149,14 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 		if (ws.mark[start] != 0) continue;
 		const int32_t top = (int32_t)ws.keyed[k].x;
 		const size_t n_before = ws.picked.size();
-		const int64_t stop = kept_until(max_drop, top, start, f, p_rel, ws.mark.data());
-		int64_t i;
-		for (i = start; i != stop; i = pred_of(p_rel, i)) { ws.picked.push_back((int32_t)i); ws.mark[i] = 1; }
+		const int64_t stop = kept_until(max_drop, top, start, f, p_rel, ws.mark.data(), ws.path);
+		// the chain: visited nodes from the end up to (not including) `stop`; `stop` is a visited node, or the node the
+		// walk ended on (taken / none), in which case every visited node belongs to the chain
+		int64_t i = stop;
+		for (size_t q = 0; q < ws.path.size(); ++q) {
+			if (ws.path[q] == stop) break;
+			ws.picked.push_back(ws.path[q]); ws.mark[ws.path[q]] = 1;
+		}
 		const int32_t sc = i < 0 ? top : top - f[i];
 		const size_t cnt = ws.picked.size() - n_before;
 		if (sc >= min_sc && cnt > 0 && (int64_t)cnt >= min_cnt) ws.chains.push_back((uint64_t)sc << 32 | (uint64_t)cnt);

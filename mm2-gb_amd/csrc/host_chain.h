@@ -22,6 +22,7 @@ struct BacktrackScratch {
 	std::vector<mm2gb_anchor_t> keyed;     // (score, index) pairs to sort -- the reference's z[] (lchain.c:38-41)
 	std::vector<uint8_t> mark;             // the reference's t[] (lchain.c:43), a byte per anchor is enough (values 0,1,2)
 	std::vector<int32_t> picked;           // the reference's v[] (lchain.c:65)
+	std::vector<int32_t> path;             // nodes visited by the current walk
 	std::vector<uint64_t> chains;          // u[] before it is copied out
 	std::vector<mm2gb_anchor_t> heads;     // (first x, offset<<32|chain) to order chains (lchain.c:94-99)
 };
