@@ -62,6 +62,7 @@ struct DevBatch {
 	int64_t  *totals;          // [0] total pairs
 	unsigned *flags;           // FLAG_*
 	const int32_t *lut;        // penalty by dd, lut_last + 1 entries (MODE_LUT only)
+	int64_t  *dbg;             // optional: 4 time stamps per score workgroup (MM2GB_DEBUG_PHASES), else null
 };
 enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_NMID = 6, CNT_MCURSOR = 7, CNT_WORDS = 8 };
 

@@ -815,6 +815,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 
 	const int n_long = b.counters[CNT_NLONG], n_mid = b.counters[CNT_NMID];
 	const int wave = threadIdx.x / WAVE;
+	// optional phase stamps (MM2GB_DEBUG_PHASES): 100 MHz wall clock at start / end of 1a / end of 1b / end, per workgroup
+	if (b.dbg && threadIdx.x == 0) b.dbg[blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
 	if (ring_mask >= 0) {
 		// phase 1a: the whole workgroup on one chunk at a time (wide windows)
 		CoopShared *sh = &teams[0];
@@ -829,6 +831,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			else coop_chunk<MODE, false>(b, P, lut, stage, ring, ring_mask, sh, cs, ce, wave, SCORE_THREADS / WAVE);
 			__syncthreads();
 		}
+		if (b.dbg && threadIdx.x == 0) b.dbg[blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
 		// phase 1b: four 4-wave teams, each on its own chunk with a quarter of the ring (narrower windows)
 		const int team = wave / SMALL_TEAM, team_wave = wave % SMALL_TEAM;
 		const int q_mask = (ring_mask + 1) / N_SMALL_TEAMS - 1;
@@ -846,6 +849,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			team_barrier(sh, SMALL_TEAM);
 		}
 	}
+	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 	// phase 2: one wave per chunk
 	const int n_chunks = b.counters[CNT_NCHUNK] - n_long - n_mid;
 	while (true) {
@@ -858,6 +862,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, stage, cs, ce);
 		else run_chunk<MODE, false>(b, P, lut, stage, cs, ce);
 	}
+	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // --------------------------------------------------------------------------------------------------------------

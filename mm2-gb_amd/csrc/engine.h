@@ -63,7 +63,7 @@ struct Engine {
 	DevBuf blk_firstcut, blk_pairs, blk_clamped, blk_wmax;
 	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
 	DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
-	DevBuf counters, totals, flags, lut;
+	DevBuf counters, totals, flags, lut, dbg;
 	IoSet io[2];
 	uint64_t io_seq = 0;
 	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host
@@ -74,7 +74,7 @@ struct Engine {
 	int n_slots = 0;
 
 	mm2gb_stats_t last = {};
-	bool misc_valid = false, coop_disabled = false;
+	bool misc_valid = false, coop_disabled = false, debug_phases = false;
 
 	int  init(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);
 	void shutdown();

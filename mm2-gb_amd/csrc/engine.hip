@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -121,6 +122,8 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_LONG_MIN_WINDOW")) launch.long_min_window = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_WIDE_WINDOW")) launch.wide_window = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_LONG_MIN_COST")) launch.long_min_cost = std::max<int64_t>(1, atoll(v));
+	if (const char *v = getenv("MM2GB_DEBUG_PHASES")) debug_phases = *v && *v != '0';
+	if (debug_phases && dbg.ensure((size_t)launch.score_grid * 32)) return -1;
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
 	MM2GB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -203,6 +206,8 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	b.tile_sums = (int64_t*)tile_sums.ptr; b.tile_base = (int64_t*)tile_base.ptr; b.bins = (int32_t*)bins.ptr;
 	b.counters = (int32_t*)counters.ptr; b.totals = (int64_t*)totals.ptr; b.flags = (unsigned*)flags.ptr;
 	b.lut = (const int32_t*)lut.ptr;
+	b.dbg = debug_phases ? (int64_t*)dbg.ptr : nullptr;
+	if (debug_phases) MM2GB_HIP(hipMemsetAsync(dbg.ptr, 0, (size_t)launch.score_grid * 32, stream));
 
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
 	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 2 * sizeof(int64_t), stream));
@@ -273,6 +278,20 @@ int Engine::sync()
 
 int Engine::collect_stats()
 {
+	if (debug_phases && n_slots > 0) {
+		std::vector<int64_t> h((size_t)launch.score_grid * 4);
+		if (hipMemcpy(h.data(), dbg.ptr, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			int64_t t0 = INT64_MAX, e1 = 0, e2 = 0, e3 = 0, s1 = 0, s2 = 0, s3 = 0; int n = 0;
+			for (int w = 0; w < launch.score_grid; ++w) if (h[4 * w]) t0 = std::min(t0, h[4 * w]);
+			for (int w = 0; w < launch.score_grid; ++w) {
+				if (!h[4 * w]) continue;
+				const int64_t a = h[4 * w + 1] ? h[4 * w + 1] - t0 : 0, b2 = h[4 * w + 2] - t0, c = h[4 * w + 3] - t0;
+				e1 = std::max(e1, a); e2 = std::max(e2, b2); e3 = std::max(e3, c); s1 += a; s2 += b2; s3 += c; ++n;
+			}
+			if (n) fprintf(stderr, "[mm2gb phases] workgroups %d | end of 16-wave phase: mean %.2f max %.2f ms | end of 4-wave phase: mean %.2f max %.2f ms | end: mean %.2f max %.2f ms\n",
+			               n, s1 / 1e5 / n, e1 / 1e5, s2 / 1e5 / n, e2 / 1e5, s3 / 1e5 / n, e3 / 1e5);
+		}
+	}
 	for (int k = 0; k < n_slots; ++k) {
 		const int32_t *c = h_counters + (size_t)k * CNT_WORDS;
 		last.n_pairs += h_totals[(size_t)k * 2];
