@@ -117,3 +117,22 @@ def test_batched_deferred_protocol(tmp_path, max_total_n, micro_batch):
     assert sorted(i for i, _, _ in done) == list(range(31))
     for i, u, a in done:
         assert np.array_equal(u, expect[i]["u"]) and np.array_equal(a, expect[i]["a_out"]), f"read {i}"
+
+
+def test_auto_sized_batch_limits(tmp_path):
+    """A config without max_total_n / max_read (only avg_read_n, plmem.cu:497-539): limits are derived from the device's
+    memory and this engine's per-anchor footprint."""
+    L = mm.lib()
+    cfg = json.load(open(os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json")))
+    del cfg["max_total_n"], cfg["max_read"]
+    cfg["avg_read_n"] = 20000
+    path = tmp_path / "auto.json"
+    path.write_text(json.dumps(cfg))
+    mt, mr, mn = C.c_size_t(0), C.c_int(0), C.c_int(0)
+    L.init_stream_gpu.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, mm.Misc]
+    L.free_stream_gpu.argtypes = [C.c_int]
+    L.init_stream_gpu(C.byref(mt), C.byref(mr), C.byref(mn), str(path).encode(), mm.default_misc())
+    per_mb = mt.value // cfg["score_kernel"]["micro_batch"]
+    assert 100_000_000 <= per_mb <= 2_000_000_000          # 288 GB device: capped at 2 G anchors per micro-batch
+    assert mr.value >= per_mb // 20000
+    L.free_stream_gpu(1)
