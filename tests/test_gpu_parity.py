@@ -301,6 +301,60 @@ def test_fuzz_random_batches_and_parameters(engine):
                 assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (it, r, kw)
 
 
+def test_large_batch_properties_and_mode_agreement(monkeypatch):
+    """Bench-shaped batch at scale (40 M anchors, ~2.4e10 pairs; the oracle would need minutes): size-independent
+    properties, idempotence, and agreement of independent code paths -- team modes vs one-wave-per-chunk, table sweep vs
+    per-pair arithmetic -- through checksums of f and p."""
+    a, off = mm.synth_reads(2024, 0, 720, 100_000, 300_000, threads=32)
+    n = len(a)
+    assert n > 30_000_000
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with mm.Engine() as e:
+            f, p, st = e.score(a, off)
+        for k in env:
+            monkeypatch.delenv(k)
+        return f, p, st
+
+    f, p, st = run({})
+    assert st["n_long_chunks"] > 100 and st["n_pairs"] > 10_000_000_000
+    span = ((a[:, 1] >> np.uint64(32)) & np.uint64(0xff)).astype(np.int32)
+    has = p > 0
+    assert np.all(f >= span) and np.all(f[~has] == span[~has]) and np.all(f[has] > span[has])
+    idx = np.arange(n, dtype=np.int64)
+    j = idx - p
+    read_of = np.searchsorted(off, idx, side="right") - 1
+    assert np.all(j[has] >= off[read_of[has]])
+    assert np.all((a[idx[has], 0] >> np.uint64(32)) == (a[j[has], 0] >> np.uint64(32)))
+    assert np.all(a[idx[has], 0] - a[j[has], 0] <= 5000)
+    # a predecessor's score plus at most q_span reaches the successor's score: f[i] <= f[j] + span[j]
+    assert np.all(f[has] <= f[j[has]] + span[j[has]])
+    ck = (int(f.astype(np.int64).sum()), int(p.astype(np.int64).sum()), int((f.astype(np.int64) * (idx % 1009)).sum()))
+    for env in ({"MM2GB_NO_COOP": "1"}, {"MM2GB_WIDE_WINDOW": "100000000"}, {"MM2GB_LONG_MIN_COST": "50000000"}):
+        f2, p2, st2 = run(env)
+        assert st2["n_pairs"] == st["n_pairs"]
+        ck2 = (int(f2.astype(np.int64).sum()), int(p2.astype(np.int64).sum()), int((f2.astype(np.int64) * (idx % 1009)).sum()))
+        assert ck2 == ck, env
+        assert np.array_equal(f2, f) and np.array_equal(p2, p), env
+    # per-pair float build (chn_pen_skip tiny but non-zero disables the table): scores may differ only where the skip term
+    # changes a truncation, so compare against the same build without teams instead
+    misc = mm.default_misc(chn_pen_skip=np.float32(1e-9))
+    with mm.Engine(misc=misc) as e:
+        f3, p3, _ = e.score(a, off)
+    monkeypatch.setenv("MM2GB_NO_COOP", "1")
+    with mm.Engine(misc=misc) as e:
+        f4, p4, _ = e.score(a, off)
+    monkeypatch.delenv("MM2GB_NO_COOP")
+    assert np.array_equal(f3, f4) and np.array_equal(p3, p4)
+    # oracle on a few reads of this batch
+    prm = orc.default_param()
+    for r in (0, 359, 719):
+        fo, po, _ = orc.chain_fill(a[off[r]:off[r + 1]], prm)
+        assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po))
+
+
 def test_lchain_dp_signature_entry():
     """mm2gb_lchain_dp: same call shape as mg_lchain_dp (lchain.c:148), input consumed, outputs malloc'd."""
     import ctypes as C
