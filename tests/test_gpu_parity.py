@@ -165,6 +165,27 @@ def test_modes_without_the_penalty_table(kw):
     assert st["n_pairs"] > 1_000_000
 
 
+def test_many_tiny_reads(engine):
+    """50 000 reads of 0-40 anchors packed into one micro-batch: read boundaries every few anchors (several per planning block
+    and per tile), reads without anchors in between."""
+    rng = np.random.default_rng(99)
+    sizes = rng.integers(0, 41, 50_000)
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(sizes)
+    n = int(off[-1])
+    # every read: a short colinear run on one of two reference sequences + a few stray anchors, sorted by x within the read
+    rid = rng.integers(0, 2, n)
+    read_of = np.repeat(np.arange(len(sizes)), sizes)
+    pos_in_read = np.arange(n) - off[read_of]
+    x = 10_000 + pos_in_read * rng.integers(5, 30, n) + rng.integers(0, 3, n)
+    y = 100 + pos_in_read * 17 + rng.integers(0, 9, n)
+    a = sc.pack(rid, np.zeros(n, np.int64), x, y)
+    order = np.lexsort((a[:, 0], read_of))
+    a = a[order]
+    st = check_batch(engine, a, off, orc.default_param(min_cnt=2, min_sc=20), threads=8)
+    assert st["n_reads"] == 50_000
+
+
 def test_four_wave_teams(engine):
     """Heavy chunks with narrow windows are pipelined over 4-wave teams with a quarter of the LDS ring each: plain chains,
     and max_iter-clamped windows (rescue state handed from wave to wave inside a team)."""
