@@ -643,8 +643,10 @@ __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int 
 		const int j = i0 + t;
 		const int xt = bcast(T.x, t), yt = bcast(T.y, t), tgt = bcast(T.tag, t), ht = bcast(T.hi, t), stt = bcast(T.st, t);
 		// lchain.c:190-195: the remembered anchor fell out of reach (or none yet): arg-max of f over the window,
-		// largest index among equals
-		if (keep.idx < 0 || ht != keep.hi || (unsigned)(xt - keep.x) > (unsigned)P.max_dist_x) {
+		// largest index among equals.  An empty window (stt == j) is a natural cut, where the host's scan finds nothing
+		// too, or the first anchor of a read, where the host starts over with max_ii = -1 (lchain.c:156) even if the
+		// previous read's remembered anchor lies within max_dist_x on the same strand and reference.
+		if (keep.idx < 0 || stt == j || ht != keep.hi || (unsigned)(xt - keep.x) > (unsigned)P.max_dist_x) {
 			int bf = INT_MIN, bi = -1;
 			for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)
 				const int v = f_old(jj);

@@ -107,3 +107,40 @@ def multi_read_batch(n_reads, seed, min_len=2_000, max_len=30_000):
     off = np.zeros(n_reads + 1, dtype=np.int64)
     off[1:] = np.cumsum([len(r) for r in reads])
     return np.concatenate(reads), off
+
+
+def fuzz_case(rng):
+    """One random batch and one random set of chaining parameters for the seeded fuzz test and tests/fuzz_soak.py:
+    mixtures of chains, noise, repeat blocks, duplicated positions, empty reads, reads repeated or overlapping an earlier
+    read of the batch; window limits around the tile (64) and ring sizes.  Returns (anchors, read offsets, parameter dict)."""
+    reads = []
+    for _ in range(int(rng.integers(1, 7))):
+        kind = int(rng.integers(0, 7))
+        seed = int(rng.integers(1, 1 << 30))
+        if kind == 0:
+            reads.append(np.zeros((0, 2), np.uint64))
+        elif kind == 1:
+            reads.append(noise(int(rng.integers(1, 400)), seed, n_rid=int(rng.integers(1, 4)), span=int(rng.integers(2_000, 200_000)), qlen=20_000))
+        elif kind == 2:
+            reads.append(read_like(int(rng.integers(1_000, 25_000)), seed))
+        elif kind == 3:
+            reads.append(sort_by_x(np.concatenate([repeat_block(int(rng.integers(100, 3000)), seed, xwin=int(rng.integers(50, 5000)), ywin=int(rng.integers(50, 7000))),
+                                                   colinear(int(rng.integers(10, 800)), seed + 1, max_gap=int(rng.integers(2, 60)))])))
+        elif kind == 4:
+            reads.append(variable_span(int(rng.integers(50, 900)), seed))
+        elif kind == 5:
+            reads.append(grid_ties(nx=int(rng.integers(3, 50)), ny=int(rng.integers(2, 14)), step=int(rng.integers(1, 40))))
+        elif reads and len(reads[-1]):
+            prev = reads[-1]                       # a read over the same region: a slice of the previous one
+            lo = int(rng.integers(0, len(prev)))
+            reads.append(prev[lo:lo + int(rng.integers(1, len(prev) - lo + 1))].copy())
+        else:
+            reads.append(colinear(int(rng.integers(1, 300)), seed))
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    a = np.concatenate(reads) if off[-1] else np.zeros((0, 2), np.uint64)
+    kw = dict(max_iter=int(rng.choice([1, 7, 63, 64, 65, 200, 1000, 5000])), bw=int(rng.choice([0, 1, 50, 500, 3000])),
+              max_dist_x=int(rng.choice([10, 500, 5000, 20000])), max_dist_y=int(rng.choice([10, 500, 5000, 20000])),
+              pen_gap=np.float32(rng.choice([0.0, 0.12, 0.19, 1.5])), pen_skip=np.float32(rng.choice([0.0, 0.0, 0.01, 0.3])),
+              min_cnt=int(rng.integers(1, 5)), min_sc=int(rng.choice([1, 20, 40, 100])))
+    return a, off, kw

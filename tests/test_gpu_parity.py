@@ -115,6 +115,26 @@ def test_saturated_windows_and_rescue(engine):
     assert st["n_tracked_chunks"] >= 1 and st["n_clamped_blocks"] >= 1
 
 
+def test_rescue_state_restarts_at_every_read(engine):
+    """The remembered best anchor (max_ii, lchain.c:156,189-205) belongs to one read.  Reads that map to the same region
+    put the next read's first anchors within max_dist_x of the previous read's remembered anchor, on the same strand and
+    reference; the state must not carry over.  First case: the batch a seeded fuzz run found (730 anchors, two reads,
+    max_iter 7); second: several copies of one repeat-rich read back to back."""
+    import json, os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "fuzz_keep_across_reads.npz"))
+    kw = json.loads(str(z["kw"]))
+    prm = orc.default_param(**{k: (np.float32(v) if k.startswith("pen") else int(v)) for k, v in kw.items()})
+    st = check_batch(engine, z["a"], z["off"], prm)
+    assert st["n_reads"] == 2 and st["n_chunks"] == 1 and st["n_tracked_chunks"] == 1
+    one = sc.sort_by_x(np.concatenate([sc.repeat_block(500, 61, xwin=300, ywin=400), sc.colinear(120, 62, max_gap=20)]))
+    for max_iter in (7, 63, 200):
+        reads = [one, one[: len(one) // 2], one, one[len(one) // 3:]]
+        off = np.zeros(len(reads) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(r) for r in reads])
+        st = check_batch(engine, np.concatenate(reads), off, orc.default_param(max_iter=max_iter, max_dist_x=500, bw=100))
+        assert st["n_tracked_chunks"] >= 1
+
+
 def test_default_max_iter_repeat_block(engine):
     a = sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 41), sc.colinear(800, 42), sc.noise(3000, 43)]))
     st = check_batch(engine, a, np.array([0, len(a)], np.int64), orc.default_param())
@@ -287,32 +307,10 @@ def test_sliced_host_call_overlapped_streams(monkeypatch):
 def test_fuzz_random_batches_and_parameters(engine):
     """Seeded fuzz: random mixtures of chains, noise, repeat blocks, duplicated positions, empty reads, and random chaining
     parameters (window limits around tile and ring sizes, both score builds)."""
-    rng = np.random.default_rng(20241002)
-    for it in range(40):
-        reads = []
-        for _ in range(int(rng.integers(1, 7))):
-            kind = int(rng.integers(0, 6))
-            seed = int(rng.integers(1, 1 << 30))
-            if kind == 0:
-                reads.append(np.zeros((0, 2), np.uint64))
-            elif kind == 1:
-                reads.append(sc.noise(int(rng.integers(1, 400)), seed, n_rid=int(rng.integers(1, 4)), span=int(rng.integers(2_000, 200_000)), qlen=20_000))
-            elif kind == 2:
-                reads.append(sc.read_like(int(rng.integers(1_000, 25_000)), seed))
-            elif kind == 3:
-                reads.append(sc.sort_by_x(np.concatenate([sc.repeat_block(int(rng.integers(100, 3000)), seed, xwin=int(rng.integers(50, 5000)), ywin=int(rng.integers(50, 7000))),
-                                                          sc.colinear(int(rng.integers(10, 800)), seed + 1, max_gap=int(rng.integers(2, 60)))])))
-            elif kind == 4:
-                reads.append(sc.variable_span(int(rng.integers(50, 900)), seed))
-            else:
-                reads.append(sc.grid_ties(nx=int(rng.integers(3, 50)), ny=int(rng.integers(2, 14)), step=int(rng.integers(1, 40))))
-        off = np.zeros(len(reads) + 1, dtype=np.int64)
-        off[1:] = np.cumsum([len(r) for r in reads])
-        a = np.concatenate(reads) if off[-1] else np.zeros((0, 2), np.uint64)
-        kw = dict(max_iter=int(rng.choice([1, 7, 63, 64, 65, 200, 1000, 5000])), bw=int(rng.choice([0, 1, 50, 500, 3000])),
-                  max_dist_x=int(rng.choice([10, 500, 5000, 20000])), max_dist_y=int(rng.choice([10, 500, 5000, 20000])),
-                  pen_gap=np.float32(rng.choice([0.0, 0.12, 0.19, 1.5])), pen_skip=np.float32(rng.choice([0.0, 0.0, 0.01, 0.3])),
-                  min_cnt=int(rng.integers(1, 5)), min_sc=int(rng.choice([1, 20, 40, 100])))
+    import os
+    rng = np.random.default_rng(int(os.environ.get("MM2GB_FUZZ_SEED", 20241002)))
+    for it in range(int(os.environ.get("MM2GB_FUZZ_ITERS", 40))):
+        a, off, kw = sc.fuzz_case(rng)
         prm = orc.default_param(**kw)
         check_batch(engine, a, off, prm, threads=2)
         if it % 8 == 0 and off[-1]:
