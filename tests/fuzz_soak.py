@@ -1,6 +1,8 @@
-"""Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N]
+"""Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N] [--teams]
 Runs tests/synth_cases.fuzz_case batches through the HIP path and the oracle; the first batch that differs is written
-to gpurun_out/fuzz_fail_<seed>_<iteration>.npz (anchors, offsets, GPU f/p, parameters) and the exit code is 1."""
+to gpurun_out/fuzz_fail_<seed>_<iteration>.npz (anchors, offsets, GPU f/p, parameters) and the exit code is 1.
+--teams adds two engines whose planner thresholds send every chunk that fits the LDS ring to the 16-wave teams and to
+the 4-wave teams (normally reserved for long chunks), so the cooperative paths see the same odd shapes."""
 import argparse, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
@@ -11,27 +13,52 @@ from test_gpu_parity import misc_from, rel
 ap = argparse.ArgumentParser()
 ap.add_argument("seeds", type=int, nargs="+")
 ap.add_argument("--iters", type=int, default=200)
+ap.add_argument("--teams", action="store_true")
 args = ap.parse_args()
 out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
 failed = False
-with mm.Engine() as eng:
-    for seed in args.seeds:
-        rng = np.random.default_rng(seed)
-        for it in range(args.iters):
-            a, off, kw = sc.fuzz_case(rng)
-            prm = orc.default_param(**kw)
+
+
+def make_engine(env):
+    for k, v in env.items():
+        os.environ[k] = v
+    e = mm.Engine()                        # the planner thresholds are read when the engine is created
+    for k in env:
+        del os.environ[k]
+    return e
+
+
+engines = [("default", make_engine({}))]
+if args.teams:
+    engines.append(("team16", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1"})))
+    engines.append(("team4", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "100000000"})))
+seen = {name: [0, 0] for name, _ in engines}
+for seed in args.seeds:
+    rng = np.random.default_rng(seed)
+    for it in range(args.iters):
+        a, off, kw = sc.fuzz_case(rng)
+        prm = orc.default_param(**kw)
+        fo, po, pairs = orc.chain_fill_many(a, off, prm, threads=4)
+        po_rel = np.concatenate([rel(po[off[r]:off[r + 1]]) for r in range(len(off) - 1)]) if len(a) else np.zeros(0, np.int32)
+        for name, eng in engines:
             eng.set_misc(misc_from(prm))
             f, p, st = eng.score(a, off)
-            fo, po, pairs = orc.chain_fill_many(a, off, prm, threads=4)
-            po_rel = np.concatenate([rel(po[off[r]:off[r + 1]]) for r in range(len(off) - 1)]) if len(a) else np.zeros(0, np.int32)
+            seen[name][0] += st["n_long_chunks"]; seen[name][1] += st["n_mid_chunks"]
             bad = np.flatnonzero((f != fo) | (p != po_rel))
             if bad.size or st["n_pairs"] != pairs:
                 plain = {k: float(v) for k, v in kw.items()}
-                print("seed", seed, "iteration", it, "differs at", bad[:10], "pairs", st["n_pairs"], pairs, "parameters", plain, "stats", st, flush=True)
-                np.savez(os.path.join(out_dir, f"fuzz_fail_{seed}_{it}.npz"), a=a, off=off, f=f, p=p, kw=json.dumps(plain))
+                print("engine", name, "seed", seed, "iteration", it, "differs at", bad[:10], "pairs", st["n_pairs"], pairs, "parameters", plain, "stats", st, flush=True)
+                np.savez(os.path.join(out_dir, f"fuzz_fail_{name}_{seed}_{it}.npz"), a=a, off=off, f=f, p=p, kw=json.dumps(plain))
                 failed = True
                 break
-        else:
-            print("seed", seed, "clean over", args.iters, "batches", flush=True)
+        if failed:
+            break
+    else:
+        print("seed", seed, "clean over", args.iters, "batches", flush=True)
+    if failed:
+        break
+print("chunks sent to 16-wave / 4-wave teams per engine:", seen)
+for _, e in engines:
+    e.close()
 sys.exit(1 if failed else 0)
