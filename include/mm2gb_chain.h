@@ -98,8 +98,9 @@ float mm2gb_engine_last_kernel_ms(mm2gb_engine_t *eng);
 
 /* ---- full chaining of a batch on host buffers: scores on the GPU, then backtrack + compaction
  *      (replaces plchain_cal_score_async + plchain_post_gpu_helper, plchain.cu:201-464).
- *      Outputs are malloc'd by the library: u_off[n_reads+1] indexes u[], a_off[n_reads+1] indexes a_out[].
- *      Free with mm2gb_free(). ---- */
+ *      The post-pass starts on each slice of reads as soon as its scores are back, while later slices are on the device.
+ *      Outputs are malloc'd by the library: u_off[n_reads+1] indexes u[], a_off[n_reads+1] indexes a[].
+ *      Free with mm2gb_chains_free().  Stats of a multi-device call: counts are summed, times are the slowest device's. ---- */
 typedef struct {
 	int64_t *u_off;   uint64_t *u;            /* chains per read: score<<32 | n_anchors (lchain.c:145) */
 	int64_t *a_off;   mm2gb_anchor_t *a;      /* compacted anchors per read, chain by chain (lchain.c:78-111) */
@@ -107,6 +108,23 @@ typedef struct {
 int  mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                       int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats);
 void mm2gb_chains_free(mm2gb_chains_t *out);
+
+/* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
+ *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
+ *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;
+ *      n_devices <= 0: every visible device.  A device id may repeat (two engines sharing one GPU).
+ *      mm2gb_pool_score_host: first_read_of_device (optional, n_devices+1 entries) reports how the reads were dealt.
+ *      Replaces the reference's one-GPU stream_setup (plmem.cu:370, plchain.cu:299) for hosts that own whole batches. ---- */
+typedef struct mm2gb_pool mm2gb_pool_t;
+mm2gb_pool_t *mm2gb_pool_create(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int n_devices, const int *devices);
+void mm2gb_pool_destroy(mm2gb_pool_t *pool);
+int  mm2gb_pool_size(const mm2gb_pool_t *pool);
+int  mm2gb_pool_device(const mm2gb_pool_t *pool, int k);              /* HIP device of engine k, -1 if out of range */
+int  mm2gb_pool_set_misc(mm2gb_pool_t *pool, const mm2gb_misc_t *misc);
+int  mm2gb_pool_score_host(mm2gb_pool_t *pool, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                           int32_t *f, int32_t *p, mm2gb_stats_t *stats, int64_t *first_read_of_device);
+int  mm2gb_pool_chain_host(mm2gb_pool_t *pool, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                           int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats);
 
 /* ---- host post-pass on given f / relative p for ONE read (restates mg_chain_backtrack + compact_a,
  *      lchain.c:27-111, including the radix_sort_128x order, ksort.h:98-151).  Returns number of chains;

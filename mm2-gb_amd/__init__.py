@@ -64,7 +64,9 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_device_count", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device",
                 "mm2gb_engine_reserve", "mm2gb_score_host", "mm2gb_score_device", "mm2gb_engine_sync", "mm2gb_engine_stats",
                 "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chains_free", "mm2gb_backtrack_host",
-                "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill"]
+                "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
+                "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
+                "mm2gb_pool_score_host", "mm2gb_pool_chain_host"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -110,6 +112,15 @@ def lib():
         L.mm2gb_synth_count.restype = C.c_int64
         L.mm2gb_synth_count.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.mm2gb_synth_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.mm2gb_pool_create.restype = C.c_void_p
+        L.mm2gb_pool_create.argtypes = [C.POINTER(Config), C.POINTER(Misc), C.c_int, C.c_void_p]
+        L.mm2gb_pool_destroy.argtypes = [C.c_void_p]
+        L.mm2gb_pool_destroy.restype = None
+        L.mm2gb_pool_size.argtypes = [C.c_void_p]
+        L.mm2gb_pool_device.argtypes = [C.c_void_p, C.c_int]
+        L.mm2gb_pool_set_misc.argtypes = [C.c_void_p, C.POINTER(Misc)]
+        L.mm2gb_pool_score_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]
+        L.mm2gb_pool_chain_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Chains), C.POINTER(Stats)]
         _lib = L
     return _lib
 
@@ -213,16 +224,81 @@ class Engine:
         out = Chains()
         st = Stats()
         _check(lib().mm2gb_chain_host(self._h, R, off.ctypes.data, a.ctypes.data, threads, C.byref(out), C.byref(st)))
-        try:
-            u_off = np.ctypeslib.as_array(out.u_off, shape=(R + 1,)).copy()
-            a_off = np.ctypeslib.as_array(out.a_off, shape=(R + 1,)).copy()
-            u_all = np.ctypeslib.as_array(out.u, shape=(int(u_off[-1]),)).copy() if u_off[-1] else np.zeros(0, np.uint64)
-            a_all = (np.ctypeslib.as_array(C.cast(out.a, C.POINTER(C.c_uint64)), shape=(int(a_off[-1]), 2)).copy()
-                     if a_off[-1] else np.zeros((0, 2), np.uint64))
-        finally:
-            lib().mm2gb_chains_free(C.byref(out))
-        res = [(u_all[u_off[r]:u_off[r + 1]], a_all[a_off[r]:a_off[r + 1]]) for r in range(R)]
-        return res, st.as_dict()
+        return _take_chains(out, R), st.as_dict()
+
+
+def _take_chains(out, R):
+    """Copy a mm2gb_chains_t into per-read (u, a_out) arrays and release it."""
+    try:
+        u_off = np.ctypeslib.as_array(out.u_off, shape=(R + 1,)).copy()
+        a_off = np.ctypeslib.as_array(out.a_off, shape=(R + 1,)).copy()
+        u_all = np.ctypeslib.as_array(out.u, shape=(int(u_off[-1]),)).copy() if u_off[-1] else np.zeros(0, np.uint64)
+        a_all = (np.ctypeslib.as_array(C.cast(out.a, C.POINTER(C.c_uint64)), shape=(int(a_off[-1]), 2)).copy()
+                 if a_off[-1] else np.zeros((0, 2), np.uint64))
+    finally:
+        lib().mm2gb_chains_free(C.byref(out))
+    return [(u_all[u_off[r]:u_off[r + 1]], a_all[a_off[r]:a_off[r + 1]]) for r in range(R)]
+
+
+class Pool:
+    """Several engines in one process (mm2gb_pool_t): reads are dealt to the devices as contiguous runs with about the same
+    number of anchors, nothing is exchanged between devices.  devices=None: every visible GPU; ids may repeat."""
+
+    def __init__(self, devices=None, misc=None, config=None):
+        L = lib()
+        self.misc = misc if misc is not None else default_misc()
+        self.config = config if config is not None else default_config()
+        ids = np.ascontiguousarray(devices, dtype=np.int32) if devices is not None else None
+        self._h = L.mm2gb_pool_create(C.byref(self.config), C.byref(self.misc), 0 if ids is None else len(ids),
+                                      None if ids is None else ids.ctypes.data)
+        if not self._h:
+            raise Mm2gbError(L.mm2gb_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm2gb_pool_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self):
+        return lib().mm2gb_pool_size(self._h)
+
+    def devices(self):
+        return [lib().mm2gb_pool_device(self._h, k) for k in range(len(self))]
+
+    def set_misc(self, misc):
+        _check(lib().mm2gb_pool_set_misc(self._h, C.byref(misc)))
+        self.misc = misc
+
+    def score(self, anchors, offsets):
+        """Like Engine.score; also returns first_read_of_device (len(pool)+1,) = how the reads were dealt."""
+        a = np.ascontiguousarray(anchors, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = int(off[-1])
+        assert a.shape == (n, 2)
+        f = np.empty(n, dtype=np.int32)
+        p = np.empty(n, dtype=np.int32)
+        first = np.zeros(len(self) + 1, dtype=np.int64)
+        st = Stats()
+        _check(lib().mm2gb_pool_score_host(self._h, len(off) - 1, off.ctypes.data, a.ctypes.data, f.ctypes.data, p.ctypes.data,
+                                           C.byref(st), first.ctypes.data))
+        return f, p, st.as_dict(), first
+
+    def chain(self, anchors, offsets, threads=1):
+        a = np.ascontiguousarray(anchors, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        R = len(off) - 1
+        out = Chains()
+        st = Stats()
+        _check(lib().mm2gb_pool_chain_host(self._h, R, off.ctypes.data, a.ctypes.data, threads, C.byref(out), C.byref(st)))
+        return _take_chains(out, R), st.as_dict()
 
 
 def backtrack_host(misc, anchors, f, p_rel):

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/mm2gb_chain.h"
@@ -87,6 +88,8 @@ struct Engine {
 	// batches in flight and never asks for statistics)
 	int  enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p, bool want_stats = true);
 	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats = true);
+	int  score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int32_t *f, int32_t *p,
+	                const std::function<void(int64_t, int64_t)> *slice_done);   // sliced + overlapped, waits for the end
 	int  record_outputs_done(hipEvent_t ev);   // fires when every D2H enqueued so far has landed
 	int  sync();
 	int  collect_stats();

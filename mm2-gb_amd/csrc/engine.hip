@@ -309,6 +309,58 @@ int Engine::collect_stats()
 	return 0;
 }
 
+// Scores for reads [0, n_reads) whose anchors are anchors[offsets[0] .. offsets[n_reads]) (offsets[0] need not be 0: a
+// device of a pool gets a run of reads out of a larger batch); f/p are indexed like anchors.
+// Large batches are cut at read boundaries into slices so that the H2D of slice k+1, the kernels of slice k and the D2H of
+// slice k-1 overlap (three streams, two device staging sets).  MM2GB_SLICE_ANCHORS sets the slice size.
+// slice_done(r0, r1), if given, is called on this thread as soon as the scores of reads [r0, r1) are in host memory, in
+// read order, while later slices are still in flight: the caller's post-pass can start on them.
+int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int32_t *f, int32_t *p,
+                       const std::function<void(int64_t, int64_t)> *slice_done)
+{
+	const int64_t base = offsets[0], n = offsets[n_reads] - base;
+	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_score_host: offsets must be non-decreasing");
+	if (n > 0 && (!anchors || !f || !p)) return fail("mm2gb_score_host: null buffer");
+	MM2GB_HIP(hipSetDevice(device));
+	if (begin_call()) return -1;
+	const auto t0 = std::chrono::steady_clock::now();
+	int64_t slice = 64 * 1000 * 1000;
+	if (const char *v = getenv("MM2GB_SLICE_ANCHORS")) slice = std::max<int64_t>(1, atoll(v));
+	std::vector<int64_t> first(1, 0);
+	if (n > slice + slice / 2) {
+		int64_t acc = 0;
+		for (int64_t r = 0; r < n_reads; ++r) {
+			acc += offsets[r + 1] - offsets[r];
+			if (acc >= slice && r + 1 < n_reads) { first.push_back(r + 1); acc = 0; }
+		}
+	}
+	first.push_back(n_reads);
+	const size_t n_sl = first.size() - 1;
+	if (h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8)) return -1;
+	int64_t *lo = (int64_t*)h_slice_off.ptr;
+	size_t w = 0;
+	for (size_t k = 0; k < n_sl; ++k) {
+		const int64_t r0 = first[k], r1 = first[k + 1];
+		const size_t at = w;
+		for (int64_t r = r0; r <= r1; ++r) lo[w++] = offsets[r] - offsets[r0];
+		if (enqueue_host(r1 - r0, lo + at, anchors + offsets[r0], offsets[r1] - offsets[r0], f + offsets[r0], p + offsets[r0])) return -1;
+		if (slice_done && k > 0) {           // slice k is queued behind it: hand slice k-1 over once its D2H has landed
+			MM2GB_HIP(hipEventSynchronize(io[(io_seq - 2) & 1].out_done));
+			(*slice_done)(first[k - 1], first[k]);
+		}
+	}
+	if (sync()) return -1;
+	if (slice_done) (*slice_done)(first[n_sl - 1], first[n_sl]);
+	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	{   // transfer times of the last slice (events on the copy streams)
+		const IoSet &s = io[(io_seq - 1) & 1];
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, s.in_start, s.in_done) == hipSuccess) last.ms_h2d = ms;
+		if (hipEventElapsedTime(&ms, s.out_start, s.out_done) == hipSuccess) last.ms_d2h = ms;
+	}
+	return 0;
+}
+
 } // namespace mm2gb
 
 using namespace mm2gb;
@@ -370,50 +422,10 @@ int mm2gb_engine_stats(mm2gb_engine_t *eng, mm2gb_stats_t *stats)
 int mm2gb_score_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                      int32_t *f, int32_t *p, mm2gb_stats_t *stats)
 {
-	if (!eng) return fail("mm2gb: null engine");
-	if (n_reads < 0 || !offsets) return fail("mm2gb_score_host: bad offsets");
-	Engine &e = eng->e;
-	const int64_t n = offsets[n_reads];
+	if (!eng || !offsets || n_reads < 0) return fail("mm2gb_score_host: null argument");
 	if (offsets[0] != 0) return fail("mm2gb_score_host: offsets[0] must be 0");
-	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_score_host: offsets must be non-decreasing");
-	if (n > 0 && (!anchors || !f || !p)) return fail("mm2gb_score_host: null buffer");
-	MM2GB_HIP(hipSetDevice(e.device));
-	if (e.begin_call()) return -1;
-	const auto t0 = std::chrono::steady_clock::now();
-	// Large batches are cut at read boundaries into slices so that the H2D of slice k+1, the kernels of slice k and the
-	// D2H of slice k-1 overlap (three streams, two device staging sets).  MM2GB_SLICE_ANCHORS sets the slice size.
-	int64_t slice = 64 * 1000 * 1000;
-	if (const char *v = getenv("MM2GB_SLICE_ANCHORS")) slice = std::max<int64_t>(1, atoll(v));
-	if (n <= slice + slice / 2) {
-		if (e.enqueue_host(n_reads, offsets, anchors, n, f, p)) return -1;
-	} else {
-		std::vector<int64_t> first(1, 0);
-		int64_t acc = 0;
-		for (int64_t r = 0; r < n_reads; ++r) {
-			acc += offsets[r + 1] - offsets[r];
-			if (acc >= slice && r + 1 < n_reads) { first.push_back(r + 1); acc = 0; }
-		}
-		first.push_back(n_reads);
-		const size_t n_sl = first.size() - 1;
-		if (e.h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8)) return -1;
-		int64_t *lo = (int64_t*)e.h_slice_off.ptr;
-		size_t w = 0;
-		for (size_t k = 0; k < n_sl; ++k) {
-			const int64_t r0 = first[k], r1 = first[k + 1];
-			const size_t base = w;
-			for (int64_t r = r0; r <= r1; ++r) lo[w++] = offsets[r] - offsets[r0];
-			if (e.enqueue_host(r1 - r0, lo + base, anchors + offsets[r0], offsets[r1] - offsets[r0], f + offsets[r0], p + offsets[r0])) return -1;
-		}
-	}
-	if (e.sync()) return -1;
-	e.last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	{   // transfer times of the last slice (events on the copy streams)
-		const IoSet &s = e.io[(e.io_seq - 1) & 1];
-		float ms = 0;
-		if (hipEventElapsedTime(&ms, s.in_start, s.in_done) == hipSuccess) e.last.ms_h2d = ms;
-		if (hipEventElapsedTime(&ms, s.out_start, s.out_done) == hipSuccess) e.last.ms_d2h = ms;
-	}
-	if (stats) *stats = e.last;
+	if (eng->e.score_host(n_reads, offsets, anchors, f, p, nullptr)) return -1;
+	if (stats) *stats = eng->e.last;
 	return 0;
 }
 

@@ -1,5 +1,4 @@
 // stream_api.cpp -- batch-level host logic above the engine:
-//   * mm2gb_chain_host     : scores on the GPU, then backtrack + compaction on a pool of host threads
 //   * mm2gb_lchain_dp      : single-read entry with the mg_lchain_dp signature (mmpriv.h:84-85)
 //   * init/chain/finish/free_stream_gpu : the reference's drop-in boundary (gpu/plutils.h:98-104; plchain.cu:466-561),
 //     same deferred hand-back protocol (launch batch k, return batch k-1 finished), one engine per stream/thread id.
@@ -221,52 +220,6 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------------------------
 // core: whole batch, host buffers
 // ---------------------------------------------------------------------------------------------------------------
-int mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
-                     int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats)
-{
-	if (!eng || !out || !offsets) return fail("mm2gb_chain_host: null argument");
-	memset(out, 0, sizeof(*out));
-	const int64_t n = offsets[n_reads];
-	// scores land here; no need to clear 8 bytes per anchor first
-	std::unique_ptr<int32_t[]> f(new int32_t[(size_t)(n > 0 ? n : 1)]), p(new int32_t[(size_t)(n > 0 ? n : 1)]);
-	if (mm2gb_score_host(eng, n_reads, offsets, anchors, f.get(), p.get(), stats)) return -1;
-	std::vector<uint64_t*> u_of((size_t)n_reads, nullptr);
-	std::vector<mm2gb_anchor_t*> a_of((size_t)n_reads, nullptr);
-	std::vector<int> nu_of((size_t)n_reads, 0);
-	const mm2gb_misc_t misc = eng->e.misc;
-	HostAlloc mem;
-	parallel_reads(n_reads, n_threads, [&](int64_t r, BacktrackScratch &ws) {
-		nu_of[r] = backtrack_compact(misc, offsets[r + 1] - offsets[r], anchors + offsets[r], f.get() + offsets[r], p.get() + offsets[r],
-		                             mem, ws, &u_of[r], &a_of[r]);
-	});
-	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
-	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
-	out->u_off[0] = out->a_off[0] = 0;
-	for (int64_t r = 0; r < n_reads; ++r) {
-		int64_t na = 0;
-		for (int k = 0; k < nu_of[r]; ++k) na += (uint32_t)u_of[r][k];
-		out->u_off[r + 1] = out->u_off[r] + nu_of[r];
-		out->a_off[r + 1] = out->a_off[r] + na;
-	}
-	out->u = (uint64_t*)malloc((size_t)(out->u_off[n_reads] + 1) * 8);
-	out->a = (mm2gb_anchor_t*)malloc((size_t)(out->a_off[n_reads] + 1) * 16);
-	parallel_reads(n_reads, n_threads, [&](int64_t r, BacktrackScratch &) {
-		if (nu_of[r]) {
-			memcpy(out->u + out->u_off[r], u_of[r], (size_t)nu_of[r] * 8);
-			memcpy(out->a + out->a_off[r], a_of[r], (size_t)(out->a_off[r + 1] - out->a_off[r]) * 16);
-		}
-		free(u_of[r]); free(a_of[r]);
-	});
-	return 0;
-}
-
-void mm2gb_chains_free(mm2gb_chains_t *out)
-{
-	if (!out) return;
-	free(out->u_off); free(out->u); free(out->a_off); free(out->a);
-	memset(out, 0, sizeof(*out));
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // core: one read, mg_lchain_dp's signature (lchain.c:148-217)
 // ---------------------------------------------------------------------------------------------------------------
