@@ -68,6 +68,7 @@ struct Engine {
 	IoSet io[2];
 	uint64_t io_seq = 0;
 	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host
+	PinnedBuf h_res_f, h_res_p;            // scores of whole-batch chaining calls (pool.cpp): page-locked, reused, grow-only
 	// per-slot read-back (pinned)
 	int32_t *h_counters = nullptr;         // MAX_SLOTS x CNT_WORDS
 	int64_t *h_totals = nullptr;           // MAX_SLOTS x 2

@@ -152,7 +152,7 @@ void Engine::shutdown()
 	}
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-	h_slice_off.release();
+	h_slice_off.release(); h_res_f.release(); h_res_p.release();
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
 	for (hipStream_t *s : { &s_in, &stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
@@ -310,7 +310,7 @@ int Engine::collect_stats()
 }
 
 // Scores for reads [0, n_reads) whose anchors are anchors[offsets[0] .. offsets[n_reads]) (offsets[0] need not be 0: a
-// device of a pool gets a run of reads out of a larger batch); f/p are indexed like anchors.
+// device of a pool gets a run of reads out of a larger batch); f[0] / p[0] belong to anchor offsets[0].
 // Large batches are cut at read boundaries into slices so that the H2D of slice k+1, the kernels of slice k and the D2H of
 // slice k-1 overlap (three streams, two device staging sets).  MM2GB_SLICE_ANCHORS sets the slice size.
 // slice_done(r0, r1), if given, is called on this thread as soon as the scores of reads [r0, r1) are in host memory, in
@@ -343,7 +343,7 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 		const int64_t r0 = first[k], r1 = first[k + 1];
 		const size_t at = w;
 		for (int64_t r = r0; r <= r1; ++r) lo[w++] = offsets[r] - offsets[r0];
-		if (enqueue_host(r1 - r0, lo + at, anchors + offsets[r0], offsets[r1] - offsets[r0], f + offsets[r0], p + offsets[r0])) return -1;
+		if (enqueue_host(r1 - r0, lo + at, anchors + offsets[r0], offsets[r1] - offsets[r0], f + (offsets[r0] - base), p + (offsets[r0] - base))) return -1;
 		if (slice_done && k > 0) {           // slice k is queued behind it: hand slice k-1 over once its D2H has landed
 			MM2GB_HIP(hipEventSynchronize(io[(io_seq - 2) & 1].out_done));
 			(*slice_done)(first[k - 1], first[k]);

@@ -122,10 +122,10 @@ int64_t kept_until(int32_t max_drop, int32_t top_score, int64_t start, const int
 
 } // namespace
 
-int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
-                      const HostAlloc &mem, BacktrackScratch &ws, uint64_t **u_out, mm2gb_anchor_t **a_out)
+int backtrack_order(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                    BacktrackScratch &ws, int64_t *n_kept)
 {
-	*u_out = nullptr; *a_out = nullptr;
+	*n_kept = 0;
 	if (n <= 0) return 0;
 	const int32_t min_sc = misc.min_score, min_cnt = misc.min_cnt;
 	const int32_t max_drop = misc.is_cdna ? INT_MAX : misc.bw;                 // lchain.c:151,162
@@ -165,9 +165,8 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 	const int n_u = (int)ws.chains.size();
 	if (n_u == 0) return 0;
 
-	// compaction (lchain.c:84-110): each chain start->end, chains ordered by the x of their first anchor.  The host packs
-	// into a temporary and copies again after sorting; here the order is decided first and every anchor is copied once.
-	const size_t n_v = ws.picked.size();
+	// order of compaction (lchain.c:84-110): chains by the x of their first anchor.  The host packs the anchors into a
+	// temporary and copies again after sorting; here the order is decided first and every anchor is copied once.
 	ws.heads.resize((size_t)n_u);
 	size_t k = 0;
 	for (int c = 0; c < n_u; ++c) {
@@ -177,13 +176,38 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 		k += cnt;
 	}
 	sort_by_x_like_host(ws.heads.data(), ws.heads.data() + n_u);
+	*n_kept = (int64_t)ws.picked.size();
+	return n_u;
+}
+
+void emit_chain_list(const BacktrackScratch &ws, uint64_t *u)
+{
+	for (size_t c = 0; c < ws.heads.size(); ++c) u[c] = ws.chains[(size_t)(uint32_t)ws.heads[c].y];
+}
+
+void emit_anchor_order(const BacktrackScratch &ws, int32_t *idx)
+{
+	size_t k = 0;
+	for (size_t c = 0; c < ws.heads.size(); ++c) {
+		const size_t cnt = (size_t)(uint32_t)ws.chains[(size_t)(uint32_t)ws.heads[c].y], k0 = (size_t)(ws.heads[c].y >> 32);
+		for (size_t j = 0; j < cnt; ++j) idx[k + j] = ws.picked[k0 + (cnt - j - 1)];          // each chain start -> end
+		k += cnt;
+	}
+}
+
+int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                      const HostAlloc &mem, BacktrackScratch &ws, uint64_t **u_out, mm2gb_anchor_t **a_out)
+{
+	*u_out = nullptr; *a_out = nullptr;
+	int64_t n_v = 0;
+	const int n_u = backtrack_order(misc, n, a, f, p_rel, ws, &n_v);
+	if (n_u == 0) return 0;
 	uint64_t *u = (uint64_t*)mem.alloc((size_t)n_u * sizeof(uint64_t));
-	mm2gb_anchor_t *out = (mm2gb_anchor_t*)mem.alloc(n_v * sizeof(mm2gb_anchor_t));
-	k = 0;
+	mm2gb_anchor_t *out = (mm2gb_anchor_t*)mem.alloc((size_t)n_v * sizeof(mm2gb_anchor_t));
+	emit_chain_list(ws, u);
+	size_t k = 0;
 	for (int c = 0; c < n_u; ++c) {
-		const int src = (int)(uint32_t)ws.heads[c].y;
-		const size_t cnt = (size_t)(uint32_t)ws.chains[src], k0 = (size_t)(ws.heads[c].y >> 32);
-		u[c] = ws.chains[src];
+		const size_t cnt = (size_t)(uint32_t)u[c], k0 = (size_t)(ws.heads[c].y >> 32);
 		for (size_t j = 0; j < cnt; ++j) out[k + j] = a[ws.picked[k0 + (cnt - j - 1)]];
 		k += cnt;
 	}

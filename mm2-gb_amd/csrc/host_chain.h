@@ -31,7 +31,15 @@ struct BacktrackScratch {
 // that implementation's order, which decides chain priority.
 void sort_by_x_like_host(mm2gb_anchor_t *beg, mm2gb_anchor_t *end);
 
-// Backtrack (lchain.c:27-76) + compaction (lchain.c:78-111) for one read.
+// Backtrack (lchain.c:27-76) and the order of compaction (lchain.c:78-111) for one read, left in `ws`: returns the number of
+// chains, *n_kept = anchors in them.  emit_chain_list writes u[] (score<<32 | count) in output order; emit_anchor_order writes,
+// for every output position, the index of the input anchor that goes there.  `a` is only read.
+int  backtrack_order(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
+                     BacktrackScratch &ws, int64_t *n_kept);
+void emit_chain_list(const BacktrackScratch &ws, uint64_t *u);
+void emit_anchor_order(const BacktrackScratch &ws, int32_t *idx);
+
+// Both steps and the copy, results allocated from `mem`.
 // p_rel[i] = i - predecessor, 0 = none.  Returns the number of chains; *u_out / *a_out come from `mem`
 // (both NULL when there is no chain).  `a` is only read.
 int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,

@@ -6,7 +6,9 @@
 // later slices are still being copied and scored, so the devices and the host threads work at the same time.
 // Replaces plchain_cal_score_async + plchain_post_gpu_helper for callers that own whole batches (plchain.cu:201-464).
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -14,6 +16,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
 #include "engine.h"
 #include "host_chain.h"
 
@@ -24,14 +27,21 @@ struct mm2gb_pool {
 namespace mm2gb {
 namespace {
 
-// Runs of reads whose scores are in host memory, consumed a few reads at a time by the post-pass threads.
+// A run of reads whose scores are in host memory: f[0] / p[0] belong to the first anchor of read `shift_read`.
+struct ScoredRun {
+	int64_t r0, r1;
+	const int32_t *f, *p;
+	int64_t shift;          // offsets[shift_read]
+};
+
+// Scored runs, consumed a few reads at a time by the post-pass threads.
 class ReadyReads {
 public:
 	explicit ReadyReads(const int64_t *offsets) : off_(offsets) {}
-	void push(int64_t r0, int64_t r1)
+	void push(const ScoredRun &run)
 	{
-		if (r1 <= r0) return;
-		{ std::lock_guard<std::mutex> g(mu_); runs_.emplace_back(r0, r1); }
+		if (run.r1 <= run.r0) return;
+		{ std::lock_guard<std::mutex> g(mu_); runs_.push_back(run); }
 		cv_.notify_all();
 	}
 	void close()
@@ -39,18 +49,18 @@ public:
 		{ std::lock_guard<std::mutex> g(mu_); closed_ = true; }
 		cv_.notify_all();
 	}
-	// next group of reads [r0, r1): about GRAIN anchors, so that tiny reads do not pay one lock each
-	bool pop(int64_t &r0, int64_t &r1)
+	// next group of reads: about GRAIN anchors, so that tiny reads do not pay one lock each
+	bool pop(ScoredRun &part)
 	{
 		std::unique_lock<std::mutex> g(mu_);
 		cv_.wait(g, [&] { return closed_ || !runs_.empty(); });
 		if (runs_.empty()) return false;
-		auto &run = runs_.front();
-		r0 = run.first;
-		r1 = r0 + 1;
-		while (r1 < run.second && off_[r1] - off_[r0] < GRAIN) ++r1;
-		run.first = r1;
-		if (run.first >= run.second) runs_.pop_front();
+		ScoredRun &run = runs_.front();
+		part = run;
+		part.r1 = part.r0 + 1;
+		while (part.r1 < run.r1 && off_[part.r1] - off_[part.r0] < GRAIN) ++part.r1;
+		run.r0 = part.r1;
+		if (run.r0 >= run.r1) runs_.pop_front();
 		return true;
 	}
 private:
@@ -58,7 +68,7 @@ private:
 	const int64_t *off_;
 	std::mutex mu_;
 	std::condition_variable cv_;
-	std::deque<std::pair<int64_t, int64_t>> runs_;
+	std::deque<ScoredRun> runs_;
 	bool closed_ = false;
 };
 
@@ -89,7 +99,9 @@ std::vector<int64_t> deal_reads(int64_t n_reads, const int64_t *offsets, int n_d
 	return first;
 }
 
-// Scores on every engine (one host thread each when there are several), slice_done forwarded with batch-level read ids.
+// Scores on every engine (one host thread each when there are several).  f / p given: results go there, indexed like
+// anchors.  f == NULL: results stay in each engine's page-locked result buffers (true asynchronous D2H, no page faults on
+// fresh memory, reused by the next call) and are only announced through `ready`.
 int score_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                      int32_t *f, int32_t *p, mm2gb_stats_t *stats, int64_t *first_read_of_device, ReadyReads *ready)
 {
@@ -99,9 +111,17 @@ int score_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_read
 	std::vector<int> rc((size_t)n_dev, 0);
 	std::vector<std::string> err((size_t)n_dev);
 	auto run = [&](int d) {
-		const int64_t r0 = first[d], r1 = first[d + 1];
-		std::function<void(int64_t, int64_t)> forward = [&, r0](int64_t a, int64_t b) { ready->push(r0 + a, r0 + b); };
-		rc[d] = engines[d]->e.score_host(r1 - r0, offsets + r0, anchors, f, p, ready ? &forward : nullptr);
+		Engine &e = engines[d]->e;
+		const int64_t r0 = first[d], r1 = first[d + 1], shift = offsets[r0], share = offsets[r1] - shift;
+		int32_t *fd = f ? f + shift : nullptr, *pd = p ? p + shift : nullptr;
+		if (!f) {
+			if (hipSetDevice(e.device) != hipSuccess || e.h_res_f.ensure((size_t)std::max<int64_t>(share, 1) * 4) || e.h_res_p.ensure((size_t)std::max<int64_t>(share, 1) * 4)) {
+				rc[d] = -1; err[d] = mm2gb_last_error(); return;
+			}
+			fd = (int32_t*)e.h_res_f.ptr; pd = (int32_t*)e.h_res_p.ptr;
+		}
+		std::function<void(int64_t, int64_t)> forward = [&, r0, fd, pd, shift](int64_t a, int64_t b) { ready->push(ScoredRun{ r0 + a, r0 + b, fd, pd, shift }); };
+		rc[d] = e.score_host(r1 - r0, offsets + r0, anchors, fd, pd, ready ? &forward : nullptr);
 		if (rc[d]) err[d] = mm2gb_last_error();          // the error text is per thread: carry it to the caller's
 	};
 	if (n_dev == 1) run(0);
@@ -119,6 +139,22 @@ int score_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_read
 	return 0;
 }
 
+// What a post-pass thread keeps of the reads it handled: chain lists and, for every anchor kept, its index in the read.
+struct PostSlab {
+	std::vector<uint64_t> u;
+	std::vector<int32_t> idx;
+};
+struct ReadChains { int32_t slab = 0, n_u = 0; int64_t n_kept = 0; size_t u_at = 0, idx_at = 0; };
+
+template <typename F>
+void on_threads(int n_threads, F fn)
+{
+	if (n_threads <= 1) { fn(0); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t) th.emplace_back(fn, t);
+	for (auto &t : th) t.join();
+}
+
 int chain_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                      int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats)
 {
@@ -126,63 +162,75 @@ int chain_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_read
 	memset(out, 0, sizeof(*out));
 	if (offsets[0] != 0) return fail("mm2gb_chain_host: offsets[0] must be 0");
 	if (n_threads < 1) n_threads = 1;
-	const int64_t n = offsets[n_reads];
-	// scores land here; no need to clear 8 bytes per anchor first
-	std::unique_ptr<int32_t[]> f(new int32_t[(size_t)(n > 0 ? n : 1)]), p(new int32_t[(size_t)(n > 0 ? n : 1)]);
-	std::vector<uint64_t*> u_of((size_t)n_reads, nullptr);
-	std::vector<mm2gb_anchor_t*> a_of((size_t)n_reads, nullptr);
-	std::vector<int> nu_of((size_t)n_reads, 0);
 	const mm2gb_misc_t misc = engines[0]->e.misc;
-	const HostAlloc mem;
 	ReadyReads ready(offsets);
+	const char *dbg_env = getenv("MM2GB_DEBUG_PHASES");
+	const bool dbg = dbg_env && *dbg_env && *dbg_env != '0';
+	const auto t0 = std::chrono::steady_clock::now();
+	auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+	// Post-pass: chains of each read as soon as its slice is back.  Only the order is kept (4 bytes per anchor kept); the
+	// anchors themselves are copied once, from the caller's array straight to their final place, when every size is known.
+	std::vector<PostSlab> slabs((size_t)n_threads);
+	std::vector<ReadChains> of((size_t)n_reads);
 	std::vector<std::thread> post;
 	for (int t = 0; t < n_threads; ++t)
-		post.emplace_back([&]() {
+		post.emplace_back([&, t]() {
 			BacktrackScratch ws;
-			int64_t r0, r1;
-			while (ready.pop(r0, r1))
-				for (int64_t r = r0; r < r1; ++r)
-					nu_of[r] = backtrack_compact(misc, offsets[r + 1] - offsets[r], anchors + offsets[r], f.get() + offsets[r], p.get() + offsets[r],
-					                             mem, ws, &u_of[r], &a_of[r]);
+			PostSlab &slab = slabs[(size_t)t];
+			ScoredRun part;
+			while (ready.pop(part))
+				for (int64_t r = part.r0; r < part.r1; ++r) {
+					ReadChains &rc = of[(size_t)r];
+					const int64_t at = offsets[r] - part.shift;
+					rc.n_u = backtrack_order(misc, offsets[r + 1] - offsets[r], anchors + offsets[r], part.f + at, part.p + at, ws, &rc.n_kept);
+					if (rc.n_u == 0) continue;
+					rc.slab = t; rc.u_at = slab.u.size(); rc.idx_at = slab.idx.size();
+					slab.u.resize(rc.u_at + (size_t)rc.n_u);
+					slab.idx.resize(rc.idx_at + (size_t)rc.n_kept);
+					emit_chain_list(ws, slab.u.data() + rc.u_at);
+					emit_anchor_order(ws, slab.idx.data() + rc.idx_at);
+				}
 		});
-	const int rc = score_on_engines(engines, n_reads, offsets, anchors, f.get(), p.get(), stats, nullptr, &ready);
+	const int rc = score_on_engines(engines, n_reads, offsets, anchors, nullptr, nullptr, stats, nullptr, &ready);
+	const double t_scored = since();
 	ready.close();
 	for (auto &t : post) t.join();
-	if (rc) {
-		for (int64_t r = 0; r < n_reads; ++r) { free(u_of[r]); free(a_of[r]); }
-		return -1;
-	}
+	const double t_post = since();
+	if (rc) return -1;
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->u_off[0] = out->a_off[0] = 0;
 	for (int64_t r = 0; r < n_reads; ++r) {
-		int64_t na = 0;
-		for (int k = 0; k < nu_of[r]; ++k) na += (uint32_t)u_of[r][k];
-		out->u_off[r + 1] = out->u_off[r] + nu_of[r];
-		out->a_off[r + 1] = out->a_off[r] + na;
+		out->u_off[r + 1] = out->u_off[r] + of[(size_t)r].n_u;
+		out->a_off[r + 1] = out->a_off[r] + of[(size_t)r].n_kept;
 	}
 	out->u = (uint64_t*)malloc((size_t)(out->u_off[n_reads] + 1) * 8);
-	out->a = (mm2gb_anchor_t*)malloc((size_t)(out->a_off[n_reads] + 1) * 16);
+	{   // large result: ask for huge pages where the system offers them (first touch is most of the copy's cost); free() still applies
+		const size_t bytes = (size_t)(out->a_off[n_reads] + 1) * 16;
+		void *mem = nullptr;
+		if (bytes >= ((size_t)64 << 20) && posix_memalign(&mem, (size_t)2 << 20, bytes) == 0) (void)madvise(mem, bytes, MADV_HUGEPAGE);
+		else mem = malloc(bytes);
+		out->a = (mm2gb_anchor_t*)mem;
+	}
 	std::atomic<int64_t> next(0);
-	auto gather = [&]() {
+	on_threads(n_reads < 128 ? 1 : n_threads, [&](int) {
 		for (;;) {
-			const int64_t r0 = next.fetch_add(64), r1 = std::min(n_reads, r0 + 64);
+			const int64_t r0 = next.fetch_add(16), r1 = std::min(n_reads, r0 + 16);
 			if (r0 >= n_reads) break;
 			for (int64_t r = r0; r < r1; ++r) {
-				if (nu_of[r]) {
-					memcpy(out->u + out->u_off[r], u_of[r], (size_t)nu_of[r] * 8);
-					memcpy(out->a + out->a_off[r], a_of[r], (size_t)(out->a_off[r + 1] - out->a_off[r]) * 16);
-				}
-				free(u_of[r]); free(a_of[r]);
+				const ReadChains &rc = of[(size_t)r];
+				if (rc.n_u == 0) continue;
+				const PostSlab &slab = slabs[(size_t)rc.slab];
+				memcpy(out->u + out->u_off[r], slab.u.data() + rc.u_at, (size_t)rc.n_u * 8);
+				const mm2gb_anchor_t *src = anchors + offsets[r];
+				const int32_t *idx = slab.idx.data() + rc.idx_at;
+				mm2gb_anchor_t *dst = out->a + out->a_off[r];
+				for (int64_t j = 0; j < rc.n_kept; ++j) dst[j] = src[idx[j]];
 			}
 		}
-	};
-	if (n_threads == 1 || n_reads < 128) gather();
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < n_threads; ++t) th.emplace_back(gather);
-		for (auto &t : th) t.join();
-	}
+	});
+	if (dbg) fprintf(stderr, "[mm2gb chain_host] scores back %.1f ms | post-pass done %.1f ms | chains gathered %.1f ms (%lld chains, %lld anchors kept)\n",
+	                 t_scored, t_post, since(), (long long)out->u_off[n_reads], (long long)out->a_off[n_reads]);
 	return 0;
 }
 
