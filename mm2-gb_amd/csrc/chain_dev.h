@@ -9,13 +9,14 @@ namespace mm2gb {
 struct DevParams {
 	int   max_dist_x, max_dist_y, bw, max_iter, n_seg, is_cdna;
 	int   dq_lim;            // min(max_dist_x, max_dist_y): the single-segment fast path's dq bound
-	int   lut_last;          // bw + 1: index of the "reject" entry of the penalty table
+	int   lut_last;          // last index of the penalty table: bw + 1 (the "reject" entry) when lut_clamp, else max_dist_x
+	int   lut_clamp;         // 1: the sweep clamps the table index to lut_last; 0: the table covers every index that can matter
 	float gap, skip;
 };
 
 // bits of DevBatch::flags[0]
 enum : unsigned { FLAG_ANY_SEGID = 1u,     // some anchor carries a segment id -> MODE_GENERAL
-                  FLAG_NO_LUT = 2u };      // a query position >= 2^27 or a zero q_span -> the x4 table sweep is not exact, use MODE_FAST
+                  FLAG_NO_LUT = 2u };      // a query position >= 2^22 or a zero q_span -> the table sweep is not exact, use MODE_FAST
 
 // Planner granularity: anchors per planning block (one k_window workgroup).
 constexpr int PLAN_BLOCK = 1024;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_split_soa(DevBatch b)
 		const unsigned seg = (v.w >> 16) & 0xffu; // (y & MM_SEED_SEG_MASK) >> 48 (lchain.c:116)
 		b.tag[i] = (int32_t)(seg << 8 | span);
 		any_seg |= seg != 0;
-		big_y |= v.z >= (1u << 27) || span == 0;
+		big_y |= v.z >= (1u << 22) || span == 0;
 	}
 	if (__ballot(any_seg) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_ANY_SEGID);
 	if (__ballot(big_y) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_NO_LUT);
@@ -395,7 +395,7 @@ constexpr int SCORE_THREADS = 1024;
 #define MM2GB_SWEEP_GROUP 4
 #endif
 constexpr int SWEEP_GROUP = MM2GB_SWEEP_GROUP;
-constexpr int LUT_REJECT = 1 << 30;     // in the x4 domain of the LUT sweep: 4*f < 2^29 is guaranteed there (FLAG_NO_LUT)
+constexpr int LUT_REJECT = 1 << 30;     // in the x128 score domain of the LUT sweep: 128*(f+16) < 2^30 is guaranteed there (FLAG_NO_LUT)
 
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
 {
@@ -419,7 +419,7 @@ __global__ void k_build_lut(int *lut, DevParams P)
 {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k > P.lut_last) return;
-	lut[k] = k == P.lut_last ? LUT_REJECT : 4 * gap_penalty(k, 0, P);   // skip == 0 here: the dg term is +0.0f
+	lut[k] = k > P.bw ? LUT_REJECT : 128 * gap_penalty(k, 0, P);        // skip == 0 here: the dg term is +0.0f
 }
 
 __device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
@@ -441,7 +441,7 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 		// accepted pairs have dr >= 0 (same strand|rid, sorted by x) and dq >= 1, so the unsigned |dr-dq| is dd
 		const unsigned dd = abs_diff_u32(dr, dq);
 		const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-		sc_out = sc - (lut[idx] >> 2);          // the table stores 4*penalty for the block sweep
+		sc_out = sc - (lut[idx] >> 7);          // the table stores 128*penalty for the block sweep
 		return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0;
 	}
 	const int ddiff = (int)((unsigned)dr - (unsigned)dq);
@@ -488,6 +488,7 @@ struct Keep { int idx, x, hi, y, tag, f; };   // the remembered best anchor ("ma
 // compiler emit s_load_dword* (scalar cache -> SGPRs), which costs no vector-ALU issue slot at all.  Only arrays that no
 // kernel in flight writes may be read this way (x, y, tag: written by k_split_soa in an earlier launch).
 typedef const int __attribute__((address_space(4))) *scalar_i32_ptr;
+typedef const int __attribute__((address_space(3))) *lds_i32_ptr;
 __device__ __forceinline__ scalar_i32_ptr as_scalar(const void *p) { return (scalar_i32_ptr)(uintptr_t)p; }
 
 // Sources jb+k, k in [k_from, 64), all final.  CHECK: some target windows start inside this block.
@@ -502,26 +503,36 @@ __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; g.t[u] = st[j0 + u]; }
 	return g;
 }
-// MODE_LUT sweep.  A block's 64 sources are first written to this wave's LDS scratch as {f, q_span, x, y}; each step then
-// takes ONE LDS broadcast read (ds_read_b128, same address in every lane) for the source and one LDS gather for the
-// penalty, so every vector-ALU operand is a VGPR (ops with an SGPR operand issue at half rate on gfx950, profiles/ubench):
-// two subtractions, |dr-dq|, the table index, min3, two additions, the dq range test, the running-max test, two selects.
+// MODE_LUT sweep.  A block's 64 sources are first written to this wave's LDS scratch; each step then takes ONE LDS
+// broadcast read (ds_read_b128, same address in every lane) for the source and one LDS gather for the penalty, so every
+// vector-ALU operand is a VGPR (ops with an SGPR operand issue at half rate on gfx950, profiles/ubench).
+// Coordinates are kept multiplied by 4 and shifted by one: the scratch holds 4x, 4y and 4(q_span-1), the target registers
+// 4(x-1), 4(y-1).  Then 4(dr-1) - 4(dq-1) = 4(dr-dq), so |.| is directly the BYTE offset into the penalty table (no shift)
+// and "(dq-1) <u lim" needs no decrement.
+// Scores are kept multiplied by 128 with the source's position in the block, k+1 in 1..64, in the low 7 bits:
+//   V = 128*(f_j + min(q_span, dr, dq) - penalty) + (k+1) = (min3 << 5) + scratch.x - table[|dr-dq|]
+// with scratch.x = 128(f+1) + (k+1) and the table in units of 128.  The running best enters a block as 128*best (low bits
+// clear), so "V > best" is exactly "cand >= best" for the first acceptance and "cand > or (cand == and later source)" after
+// it -- the same choices as comparing (cand, j) pairs -- and the arg-max needs no instruction per source: whoever won left
+// its k+1 in the low bits.  Per source: two subtractions, |dr-dq|, min3, shift-add, subtraction, the dq range test, the
+// running-max test, one select.
+// CLAMP: the table has bw+2 entries and the index is clamped to the last ("reject") one.  Without it the table covers every
+// distance a pair that passes the range tests can have (|dr-dq| <= max(dr, dq) <= max_dist_x inside a window) and the clamp
+// instruction goes; the index of a pair that fails them may point anywhere -- reads beyond the LDS allocation return 0 on
+// gfx950 (profiles/ubench) and whatever is read is discarded by the range test.
 // CHECK adds "source inside this target's window" and "dr != 0" (lchain.c:120), which can only fail in the first and last
 // blocks of a sweep: sources of interior blocks lie inside every target's window and strictly left of every target's x.
-// Everything in the sweep is kept multiplied by 4 and shifted by one: the scratch holds {4(f+1), 4(q_span-1), 4x, 4y}, the
-// target registers 4(x-1), 4(y-1), the table 4*penalty.  Then 4(dr-1) - 4(dq-1) = 4(dr-dq), so |.| is directly the BYTE offset
-// into the table (no shift), "(dq-1) <u lim" needs no decrement, and min3 + the two additions give 4*cand.  Exact while
-// 4*f < 2^29 and differences fit 30 bits: k_split_soa raises FLAG_NO_LUT for query positions >= 2^27 (f <= y always) and
-// the batch then runs the MODE_FAST build.
-template <bool CHECK>
+// Exact while 128*(f+16) < 2^30 and coordinate differences fit 30 bits: k_split_soa raises FLAG_NO_LUT for query positions
+// >= 2^22 (f <= y + q_span always) and the batch then runs the MODE_FAST build.
+template <bool CHECK, bool CLAMP>
 __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty4, int jb, int k_from, const int4 *stage,
-                                                const DevParams &P, const int *lut, int &best4, int &arg)
+                                                const DevParams &P, const int *lut, int &bestv)
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
 	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
 		const int j0 = jb + kg;
-		int dqm[G], drm[G], pen4[G];
+		int dqm[G], drm[G], pen[G];
 		int4 s4[G];
 #pragma unroll
 		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
@@ -529,18 +540,17 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
 		for (int u = 0; u < G; ++u) {
 			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
 			const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]);
-			pen4[u] = *(const int*)((const char*)lut + (dd4 < last4 ? dd4 : last4));
+			// the table sits at LDS address 0 (k_score checks): the byte offset IS the address, no base to add
+			pen[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (dd4 < last4 ? dd4 : last4) : dd4);
 		}
-		int jv;
-		asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j0));       // index arithmetic below stays VGPR + literal (full rate)
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
 			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
-			const int cand4 = (s4[u].y < dg ? s4[u].y : dg) - pen4[u] + s4[u].x;
+			const int v = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x - pen[u];
 			// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
-			bool take = ((unsigned)dqm[u] < lim4) & (cand4 >= best4);
+			bool take = ((unsigned)dqm[u] < lim4) & (v > bestv);
 			if (CHECK) take = take & (drm[u] != -4) & (j0 + u >= T.st);
-			best4 = take ? cand4 : best4; arg = take ? jv + u : arg;
+			bestv = take ? v : bestv;
 		}
 	}
 }
@@ -576,14 +586,21 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		const int js = jb + lane_id();
-		stage[lane_id()] = make_int4((sf + 1) * 4, (sq - 1) * 4, (int)((unsigned)b.x[js] << 2), (int)((unsigned)b.y[js] << 2));
+		const int k = lane_id(), js = jb + k;
+		stage[k] = make_int4(((sf + 1) << 7) + k + 1, (sq - 1) * 4, (int)((unsigned)b.x[js] << 2), (int)((unsigned)b.y[js] << 2));
 		__builtin_amdgcn_wave_barrier();                    // LDS is in-order per wave; keep the compiler from reordering
 		const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
-		int best4 = best * 4;
-		if (no_check) sweep_block_lut<false>(T, tx4, ty4, jb, k_from, stage, P, lut, best4, arg);
-		else sweep_block_lut<true>(T, tx4, ty4, jb, k_from, stage, P, lut, best4, arg);
-		best = best4 >> 2;
+		int bestv = best << 7;
+		if (P.lut_clamp) {
+			if (no_check) sweep_block_lut<false, true>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
+			else sweep_block_lut<true, true>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
+		} else {
+			if (no_check) sweep_block_lut<false, false>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
+			else sweep_block_lut<true, false>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
+		}
+		const int won = bestv & 127;                        // k+1 of the source that holds the best, 0 = none of this block
+		arg = won ? jb + won - 1 : arg;
+		best = bestv >> 7;
 		__builtin_amdgcn_wave_barrier();
 	} else {
 		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
@@ -807,6 +824,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	const int mode = (fl & FLAG_ANY_SEGID) ? MODE_GENERAL : (host_mode == MODE_LUT && (fl & FLAG_NO_LUT)) ? MODE_FAST : host_mode;
 	if (mode != MODE) return;
 	int *lut = smem;
+	// the table sweep addresses the penalty table by raw LDS offset: it must be the first thing in LDS
+	if (MODE == MODE_LUT && (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)smem != 0u) __builtin_trap();
 	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
 	int *ring = smem + lut_words;
 	int4 *stage = (int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch

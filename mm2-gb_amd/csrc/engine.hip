@@ -55,7 +55,7 @@ static DevParams make_params(const mm2gb_misc_t &m)
 	if (P.max_dist_y < P.bw && !m.is_cdna) P.max_dist_y = P.bw;        // lchain.c:161
 	P.max_iter = m.max_iter; P.n_seg = m.n_seg; P.is_cdna = m.is_cdna;
 	P.dq_lim = std::min(P.max_dist_x, P.max_dist_y);
-	P.lut_last = P.bw + 1;
+	P.lut_last = P.bw + 1; P.lut_clamp = 1;
 	P.gap = m.chn_pen_gap; P.skip = m.chn_pen_skip;
 	return P;
 }
@@ -64,11 +64,11 @@ int Engine::set_misc(const mm2gb_misc_t *m)
 {
 	if (!m) return fail("mm2gb: null misc");
 	if (m->max_iter < 0 || m->bw < 0 || m->max_dist_x < 0 || m->max_dist_y < 0) return fail("mm2gb: negative chaining parameter");
-	const bool changed = !misc_valid || memcmp(&misc, m, sizeof(misc)) != 0;
+	if (misc_valid && memcmp(&misc, m, sizeof(misc)) == 0) return 0;      // params / table / LDS split stay as configured
 	misc = *m;
 	misc_valid = true;
 	params = make_params(misc);
-	if (!changed || !stream) return 0;
+	if (!stream) return 0;
 	return configure_score();
 }
 
@@ -86,6 +86,14 @@ int Engine::configure_score()
 	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS)
 	int64_t ring = 1024;
 	while (ring < (int64_t)params.max_iter + 2 * 64 && ring < (1 << 16)) ring <<= 1;
+	// Penalty table: bw+2 entries with a clamped index, or -- one instruction less per pair -- max_dist_x+1 entries and no
+	// clamp, if that still leaves room for the ring this max_iter asks for.
+	params.lut_last = params.bw + 1; params.lut_clamp = 1;
+	if (launch.host_mode == SCORE_MODE_LUT && !getenv("MM2GB_LUT_CLAMP")) {
+		DevParams wide = params;
+		wide.lut_last = std::max(params.max_dist_x, params.bw + 1); wide.lut_clamp = 0;
+		if (score_lds_bytes(wide, launch.host_mode, (int)ring - 1) <= LDS_BUDGET) params = wide;
+	}
 	while (ring > 1024 && score_lds_bytes(params, launch.host_mode, (int)ring - 1) > LDS_BUDGET) ring >>= 1;
 	launch.ring_mask = (int)ring - 1;
 	if (coop_disabled || score_lds_bytes(params, launch.host_mode, launch.ring_mask) > LDS_BUDGET) launch.ring_mask = -1;

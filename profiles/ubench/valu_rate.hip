@@ -45,8 +45,27 @@ KERNEL(k_min3_sgpr, asm volatile("v_min3_i32 %0, s20, %1, %0\n v_min3_i32 %2, s2
 KERNEL(k_cmp_cnd, asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "vcc");)
 KERNEL(k_cnd_only, asm volatile("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %3, %2, %1, vcc" : "=v"(v0), "+v"(v1), "+v"(v2), "=v"(v3));)
 KERNEL(k_readlane_use, asm volatile("v_readlane_b32 s20, %0, 3\n v_add_u32 %1, s20, %1" : "+v"(v0), "+v"(v1) :: "s20");)
+KERNEL(k_mad_u24,  asm volatile("v_mad_u32_u24 %0, %1, 32, %0\n v_mad_u32_u24 %2, %3, 32, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_mad_i24,  asm volatile("v_mad_i32_i24 %0, %1, 32, %0\n v_mad_i32_i24 %2, %3, 32, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_mad_i24v, asm volatile("v_mad_i32_i24 %0, %1, %2, %0\n v_mad_i32_i24 %2, %3, %1, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_sub_co,   asm volatile("v_sub_co_u32 %0, vcc, %1, %0\n v_sub_co_u32 %2, vcc, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "vcc");)
+KERNEL(k_max3_i32, asm volatile("v_max3_i32 %0, %1, %0, %2\n v_max3_i32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
 KERNEL(k_ds_read,  { int t; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v0 & 0xff) << 2)); v1 ^= t; })
 KERNEL(k_ds_read_nw, { int t; int u; asm volatile("ds_read_b32 %0, %2\n ds_read_b32 %1, %2 offset:4" : "=v"(t), "=v"(u) : "v"((v0 & 0xff) << 2)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v1 ^= t + u; })
+
+// What does a ds_read beyond the workgroup's LDS allocation return?  (The score kernel may index its penalty table with a
+// distance that a later test rejects.)  1 KB allocated and filled with 0x5a5a5a5a; byte offsets given by the host.
+__global__ void k_lds_oob(const unsigned *offsets, int n, unsigned *out)
+{
+	extern __shared__ unsigned dyn[];
+	for (int i = threadIdx.x; i < 256; i += blockDim.x) dyn[i] = 0x5a5a5a5au;
+	__syncthreads();
+	if (threadIdx.x < (unsigned)n) {
+		unsigned v;
+		asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(offsets[threadIdx.x]) : "memory");
+		out[threadIdx.x] = v;
+	}
+}
 
 typedef void (*kfn)(int*, int, int, int);
 
@@ -58,9 +77,21 @@ int main()
 		{"v_cmp_gt_u32 vcc", k_cmp_u32}, {"v_cmp_gt_u32 sgpr", k_cmp_e64}, {"v_readlane_b32", k_readlane}, {"v_mov_b32", k_mov},
 		{"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_min_f32", k_min_f32}, {"v_cmp_gt_f32", k_cmp_f32}, {"v_cvt_f32_i32", k_cvt_i2f},
 		{"v_pk_add_f32", k_pk_add_f32}, 
-		{"v_sub_u32 sgpr src", k_sub_sgpr}, {"v_subrev_u32 sgpr src", k_subrev_sgpr}, {"v_cmp vcc, sgpr, v", k_cmp_sgpr}, {"v_min3_i32 sgpr src", k_min3_sgpr}, {"v_cmp + v_cndmask (2 instr)", k_cmp_cnd}, {"v_cndmask indep", k_cnd_only}, {"v_readlane + v_add using it", k_readlane_use}, {"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
+		{"v_sub_u32 sgpr src", k_sub_sgpr}, {"v_subrev_u32 sgpr src", k_subrev_sgpr}, {"v_cmp vcc, sgpr, v", k_cmp_sgpr}, {"v_min3_i32 sgpr src", k_min3_sgpr}, {"v_cmp + v_cndmask (2 instr)", k_cmp_cnd}, {"v_cndmask indep", k_cnd_only}, {"v_readlane + v_add using it", k_readlane_use}, {"v_mad_u32_u24 (x32 literal)", k_mad_u24}, {"v_mad_i32_i24 (x32 literal)", k_mad_i24}, {"v_mad_i32_i24 (vgpr)", k_mad_i24v}, {"v_sub_co_u32", k_sub_co}, {"v_max3_i32", k_max3_i32}, {"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
 	};
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+	{
+		const unsigned offs[] = { 0u, 1020u, 1024u, 4096u, 65532u, 65536u, 163836u, 163840u, 1u << 20, 1u << 24, 0x7ffffffcu, 0xfffffffcu };
+		const int n = (int)(sizeof(offs) / 4);
+		unsigned *d_off, *d_out, h_out[16];
+		hipMalloc(&d_off, sizeof(offs)); hipMalloc(&d_out, sizeof(offs));
+		hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice);
+		hipLaunchKernelGGL(k_lds_oob, dim3(1), dim3(64), 1024, 0, d_off, n, d_out);
+		hipMemcpy(h_out, d_out, sizeof(offs), hipMemcpyDeviceToHost);
+		printf("ds_read_b32 with 1 KB of LDS allocated (filled 0x5a5a5a5a): ");
+		for (int i = 0; i < n; ++i) printf("[%u]=0x%x ", offs[i], h_out[i]);
+		printf("\n"); fflush(stdout);
+	}
 	const int cus = prop.multiProcessorCount;
 	int *out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
