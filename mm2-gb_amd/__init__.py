@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmm2gb_chain.so")
+LIB_PATH = os.environ.get("MM2GB_LIB_PATH") or os.path.join(_HERE, "libmm2gb_chain.so")   # override: A/B runs of kernel builds
 INT32_MAX = 2**31 - 1
 
 

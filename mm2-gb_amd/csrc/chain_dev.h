@@ -70,7 +70,8 @@ enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRAC
 struct LaunchCfg {
 	int score_grid;          // persistent 1024-thread workgroups of k_score
 	int host_mode;           // MODE_* the host's parameters allow (the device may still fall back to MODE_GENERAL)
-	int ring_mask;           // LDS ring of the cooperative mode holds ring_mask+1 scores; -1 = cooperative mode off
+	int ring_slots;          // LDS ring of the team modes: slots of 64 scores, shared out among the teams of a phase; 0 = team modes off
+	int big_team;            // waves per team in the first phase: 16 (one team per workgroup) or 8 (two)
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode
 	int     wide_window;     // mean window from which a 16-wave team is mostly busy; narrower heavy chunks get 4-wave teams
@@ -81,7 +82,7 @@ void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s);
 void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s);
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s);
 void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s);
-size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask);
+size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots);
 int  score_set_lds_limit(size_t bytes);     // hipFuncSetAttribute on every k_score instance
 enum { SCORE_MODE_LUT = 0, SCORE_MODE_FAST = 1, SCORE_MODE_GENERAL = 2 };
 

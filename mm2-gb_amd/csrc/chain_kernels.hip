@@ -27,6 +27,7 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+
 // --------------------------------------------------------------------------------------------------------------
 // AoS -> SoA
 // --------------------------------------------------------------------------------------------------------------
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 		// (W + 128) / 128 waves busy, so wide windows get the big team and a few blocks of window the small one, which also
 		// needs the chunk's widest window to fit its quarter of the LDS ring.
 		const long long len = end - start;
-		const bool heavy = cfg.ring_mask >= 0 && cost >= cfg.long_min_cost && len * cfg.long_min_window <= cost;
+		const bool heavy = cfg.ring_slots > 0 && cost >= cfg.long_min_cost && len * cfg.long_min_window <= cost;
 		int list = LIST_WAVE;
 		if (heavy) {
 			// widest window of the chunk: the part of its first block from the first cut on, then whole (cut-free) blocks,
@@ -323,9 +324,11 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 			int wmax = b.blk_wmax[2 * blk0 + 1];
 			for (int k = blk0 + 1; k < blk_end; ++k) wmax = max(wmax, b.blk_wmax[2 * k]);
 			if (!last) wmax = max(wmax, b.blk_wmax[2 * blk_end]);
-			const int ring = cfg.ring_mask + 1;
-			if (len * cfg.wide_window > cost && wmax + WAVE <= ring / 4) list = LIST_TEAM4;
-			else if (wmax + WAVE <= ring) list = LIST_TEAM16;      // else: window wider than the ring can hold -> one wave
+			// a team's share of the LDS ring must hold the tiles its widest window reaches back to, plus the one being written
+			const int need_slots = (wmax + WAVE - 1) / WAVE + 1;
+			const int big_slots = cfg.ring_slots / (16 / cfg.big_team), small_slots = cfg.ring_slots / 4;   // k_score: 16 waves, four small teams
+			if (len * cfg.wide_window > cost && need_slots <= small_slots) list = LIST_TEAM4;
+			else if (need_slots <= big_slots) list = LIST_TEAM16;   // else: window wider than the ring can hold -> one wave
 		}
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;
@@ -632,13 +635,164 @@ __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce,
 	return T;
 }
 
+// ---- inside the tile, table build -----------------------------------------------------------------------------
+// Same packed arithmetic as sweep_block_lut with the tile's own anchors as sources: scratch entry t = {-, 4(q_span-1), 4x, 4y}
+// of lane t; its score is not known until step t, so 128(f_t+1) + (t+1) is formed on the scalar side from one v_readlane of
+// lane t's running value.  Lane state: V = 128*cand + (k+1) as in the sweep; a lane without predecessor so far enters as
+// 128*q_span + 127 (one below the acceptance threshold 128(q_span+1)), so that f = V >> 7 holds for every lane at any time.
+// The four acceptance tests are ballots combined on the scalar side with "lane > t", and one v_cndmask takes the mask.
+__device__ __forceinline__ int select_lanes(unsigned long long mask, int yes, int no)
+{
+	int r;
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(mask));
+	return r;
+}
+
+struct TileLut {
+	int tx4, ty4, lo;
+	unsigned lim4, last4;
+	const int4 *stage;
+};
+
+// Source t against the lanes above it, in two parts.  tile_pre: everything that does not depend on scores -- LDS broadcast of
+// the source, distances, penalty gather, the three tests that only involve coordinates -- issued one step AHEAD, so that its
+// two LDS round trips overlap the previous step.  tile_fin: the dependent chain, one v_readlane of lane t's final value ->
+// scalar or/add -> v_add -> v_cmp -> select.  The chain is what bounds a team: tile t+1 cannot finish before tile t has.
+struct StepPre { int basev; unsigned long long ok; };
+
+template <bool CLAMP>
+__device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
+{
+	const int4 s4 = tl.stage[t];
+	const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
+	const unsigned dd4 = abs_diff_u32(drm, dqm);
+	const int pen = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (dd4 < tl.last4 ? dd4 : tl.last4) : dd4);
+	const int dg = drm < dqm ? drm : dqm;
+	StepPre pre;
+	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) - pen;
+	const unsigned long long above = t < WAVE - 1 ? ~0ull << (t + 1) : 0ull;
+	pre.ok = __ballot((unsigned)dqm < tl.lim4) & __ballot(drm != -4) & __ballot(tl.lo <= t) & above;
+	return pre;
+}
+
+__device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, int &bestv)
+{
+	const int fx = (s_bv | 127) + t + 2;                    // 128(f_t + 1) + (t + 1), scalar
+	const int v = pre.basev + fx;
+	bestv = select_lanes(pre.ok & __ballot(v > bestv), v, bestv);
+}
+
+// lchain.c:113-138 for one pair with every input wave-uniform (single segment, no cDNA, chn_pen_skip == 0: the MODE_LUT
+// conditions).  The penalty is computed (same function that filled the table) rather than read: an LDS read would put a
+// memory round trip into the serial chain of the tile.
+__device__ __forceinline__ bool pair_score_uniform(const DevParams &P, int xi, int yi, int xj, int yj, int tagj, int &sc_out)
+{
+	const int dq = yi - yj, dr = xi - xj, span = tagj & 0xff;
+	const int dg = dr < dq ? dr : dq;
+	const int diff = dr - dq;
+	const int dd = diff < 0 ? -diff : diff;
+	sc_out = (span < dg ? span : dg) - gap_penalty(dd, 0, P);
+	return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && dd <= P.bw;
+}
+
+template <bool TRACK, bool CLAMP, typename FOld>
+__device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, int4 *stage,
+                                            int &best, int &arg, Keep &keep, FOld f_old)
+{
+	const int lane = lane_id(), i = i0 + lane;
+	stage[lane] = make_int4(0, (T.q - 1) * 4, (int)((unsigned)T.x << 2), (int)((unsigned)T.y << 2));
+	__builtin_amdgcn_wave_barrier();
+	TileLut tl;
+	tl.tx4 = (int)(((unsigned)T.x - 1u) << 2); tl.ty4 = (int)(((unsigned)T.y - 1u) << 2);
+	tl.lo = T.live ? (T.st > i0 ? T.st - i0 : 0) : WAVE;    // first in-tile source inside this lane's window
+	tl.lim4 = (unsigned)P.dq_lim << 2; tl.last4 = (unsigned)P.lut_last << 2;
+	tl.stage = stage;
+	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
+	if (!TRACK) {
+		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
+		unsigned long long need = __ballot(T.live && T.st < i) >> 1;
+		if (need) {
+			int t = __builtin_ctzll(need);
+			StepPre cur = tile_pre<CLAMP>(tl, t);
+			for (;;) {
+				need &= need - 1;
+				const int tn = need ? __builtin_ctzll(need) : t;
+				const StepPre nxt = tile_pre<CLAMP>(tl, tn);
+				tile_fin(cur, t, bcast(bestv, t), bestv);
+				if (!need) break;
+				cur = nxt; t = tn;
+			}
+		}
+	} else {
+		// the state machine of lchain.c:189-205 runs on the scalar side.  Anchor t's fields come by v_readlane: scalar loads
+		// would share the wave's lgkm counter with the LDS reads of every step and expose their latency
+		const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y), stg = as_scalar(b.tag);
+		StepPre cur = tile_pre<CLAMP>(tl, 0);
+		for (int t = 0; t < n_here; ++t) {
+			const int j = i0 + t;
+			const StepPre nxt = tile_pre<CLAMP>(tl, t + 1 < n_here ? t + 1 : t);
+			const int xt = bcast(T.x, t), yt = bcast(T.y, t), tgt = bcast(T.tag, t), ht = bcast(T.hi, t), stt = bcast(T.st, t);
+			// lchain.c:190-195: the remembered anchor fell out of reach (or none yet): arg-max of f over the window,
+			// largest index among equals.  An empty window (stt == j) is a natural cut, where the host's scan finds nothing
+			// too, or the first anchor of a read, where the host starts over with max_ii = -1 (lchain.c:156) even if the
+			// previous read's remembered anchor lies within max_dist_x on the same strand and reference.
+			if (keep.idx < 0 || stt == j || ht != keep.hi || (unsigned)(xt - keep.x) > (unsigned)P.max_dist_x) {
+				int bf = INT_MIN, bi = -1;
+				for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)
+					const int v = f_old(jj);
+					if (v >= bf) { bf = v; bi = jj; }
+				}
+				if (lane < t && i >= stt) {                                      // finished lanes of this tile
+					const int v = bestv >> 7;
+					if (v >= bf) { bf = v; bi = i; }
+				}
+				for (int off = WAVE / 2; off > 0; off >>= 1) {
+					const int of = __shfl_xor(bf, off), oi = __shfl_xor(bi, off);
+					if (of > bf || (of == bf && oi > bi)) { bf = of; bi = oi; }
+				}
+				keep.idx = first_lane(bi);
+				if (keep.idx >= 0) {
+					keep.f = first_lane(bf);
+					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;
+				}
+			}
+			// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf);
+			// strict: it replaces lane t's score only if larger, (V | 127) < 128*cand  <=>  V >> 7 < cand
+			if (keep.idx >= 0 && keep.idx < stt - 1) {
+				int sc;
+				if (pair_score_uniform(P, xt, yt, keep.x, keep.y, keep.tag, sc)) {
+					const int candv = (sc + keep.f) << 7;
+					const bool take = (lane == t) & ((bestv | 127) < candv);
+					bestv = take ? candv : bestv;
+					arg = take ? keep.idx : arg;
+				}
+			}
+			const int s_bv = bcast(bestv, t);
+			const int ft = s_bv >> 7;                                            // lchain.c:202
+			// lchain.c:204-205 (in reach is guaranteed after the refresh above)
+			if (keep.idx < 0 || keep.f < ft) { keep.idx = j; keep.x = xt; keep.hi = ht; keep.y = yt; keep.tag = tgt; keep.f = ft; }
+			tile_fin(cur, t, s_bv, bestv);
+			cur = nxt;
+		}
+	}
+	const int won = bestv & 127;                            // 1..64: source won-1 of this tile; 0: an earlier anchor; 127: none
+	arg = (unsigned)(won - 1) < (unsigned)WAVE ? i0 + won - 1 : arg;
+	best = (bestv + 1) >> 7;
+	__builtin_amdgcn_wave_barrier();
+}
+
 // Predecessors inside the tile: lane t becomes final at step t and is pushed to the lanes above it.
 // F(j) returns the final score of an anchor of an EARLIER tile (global memory for the wave kernel, LDS ring for the
 // cooperative one); only the rescue state machine needs it.
 template <int MODE, bool TRACK, typename FOld>
-__device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, const int *lut,
+__device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, const int *lut, int4 *stage,
                                         int &best, int &arg, Keep &keep, FOld f_old)
 {
+	if (MODE == MODE_LUT) {
+		if (P.lut_clamp) in_tile_lut<TRACK, true>(b, T, i0, n_here, P, stage, best, arg, keep, f_old);
+		else in_tile_lut<TRACK, false>(b, T, i0, n_here, P, stage, best, arg, keep, f_old);
+		return;
+	}
 	const int lane = lane_id(), i = i0 + lane;
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
@@ -727,7 +881,7 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 				sf = nf; sq = nq;
 			}
 		}
-		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, best, arg, keep, [&](int jj) { return b.f[jj]; });
+		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, stage, best, arg, keep, [&](int jj) { return b.f[jj]; });
 		if (T.live) {
 			const int i = i0 + lane;
 			b.f[i] = arg < 0 ? T.q : best;
@@ -744,6 +898,7 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 // "tiles done" is a release/acquire counter in LDS.  No block barrier inside a chunk.
 struct CoopShared { int done; int keep[6]; int chunk; int bar_count; int bar_gen; };   // one per team
 constexpr int SMALL_TEAM = 4, N_SMALL_TEAMS = SCORE_THREADS / WAVE / SMALL_TEAM;
+constexpr int N_TEAM_RECORDS = N_SMALL_TEAMS + 2;      // four small teams, then up to two big ones
 
 // Barrier among the waves of one small team (a workgroup barrier would stall the other teams): sense-reversing counter
 // in LDS, one lane per wave takes part.
@@ -763,7 +918,7 @@ __device__ __forceinline__ void team_barrier(CoopShared *sh, int team_size)
 }
 
 template <int MODE, bool TRACK>
-__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_mask, CoopShared *sh,
+__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int n_slots, CoopShared *sh,
                            const int cs, const int ce, const int wave, const int n_waves)
 {
 	const int lane = lane_id();
@@ -771,7 +926,7 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 	auto wait_done = [&](int need) {
 		// a waiting wave must not steal issue slots from the waves it waits for: poll rarely (s_sleep 32 = 2048 cycles,
 		// a few percent of the shortest tile)
-		while (__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(32);
+		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(32);
 	};
 	for (int t = wave; t < n_tiles; t += n_waves) {
 		const int i0 = cs + t * WAVE;
@@ -782,22 +937,28 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 		const int st_hi = bcast(T.st, n_here - 1);
 		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
 		const int eq_lo = MODE == MODE_LUT && jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(T.x)) : i0;
+		// tile k of the chunk lives in ring slot k mod n_slots (64 scores per slot; the planner made sure the slots cover
+		// this chunk's widest window plus the tile being written)
+		int slot = (int)((unsigned)((jb - cs) / WAVE) % (unsigned)n_slots);
 		for (; jb < i0; jb += WAVE) {
 			const int sq = MODE == MODE_LUT ? b.tag[jb + lane] & 0xff : 0;
 			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring
-			const int sf = ring[(jb + lane) & ring_mask];
+			const int sf = ring[slot * WAVE + lane];
+			slot = slot + 1 == n_slots ? 0 : slot + 1;
 			const int k_from = tile_lo > jb ? tile_lo - jb : 0;
 			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);
 		}
+		const int my_slot = (int)((unsigned)t % (unsigned)n_slots);
 		wait_done(t);                                                    // every earlier tile is final
 		Keep keep;
-		if (TRACK) { keep.idx = sh->keep[0]; keep.x = sh->keep[1]; keep.hi = sh->keep[2]; keep.y = sh->keep[3]; keep.tag = sh->keep[4]; keep.f = sh->keep[5]; }
+		if (TRACK) { keep.idx = first_lane(sh->keep[0]); keep.x = first_lane(sh->keep[1]); keep.hi = first_lane(sh->keep[2]); keep.y = first_lane(sh->keep[3]); keep.tag = first_lane(sh->keep[4]); keep.f = first_lane(sh->keep[5]); }
 		else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
-		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, best, arg, keep, [&](int jj) { return ring[jj & ring_mask]; });
+		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, stage, best, arg, keep,
+		                     [&](int jj) { const unsigned d = (unsigned)(jj - cs); return ring[(d / WAVE) % (unsigned)n_slots * WAVE + d % WAVE]; });
 		const int i = i0 + lane;
 		const int fi = arg < 0 ? T.q : best;
 		if (T.live) {
-			ring[i & ring_mask] = fi;
+			ring[my_slot * WAVE + lane] = fi;
 			b.f[i] = fi;
 			b.p[i] = arg < 0 ? 0 : i - arg;
 		}
@@ -807,17 +968,40 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 	}
 }
 
+// One phase of team work: the workgroup's waves form teams of team_size (4, 8 or 16) that pull chunks from `list`.
+template <int MODE>
+__device__ void team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
+                           const int32_t *list, const int n_list, const int cursor, const int wave, const int team_size)
+{
+	const int n_teams = SCORE_THREADS / WAVE / team_size;
+	const int team = wave / team_size, team_wave = wave - team * team_size;
+	const int slots = ring_slots / n_teams;
+	int *my_ring = ring + team * slots * WAVE;
+	CoopShared *sh = &teams[team];
+	while (true) {
+		if (team_wave == 0 && lane_id() == 0) { sh->chunk = atomicAdd(&b.counters[cursor], 1); sh->done = 0; sh->keep[0] = -1; }
+		team_barrier(sh, team_size);
+		const int c = first_lane(sh->chunk);
+		if (c >= n_list) break;
+		const int ci = first_lane(list[c]);
+		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
+		if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+		else coop_chunk<MODE, false>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+		team_barrier(sh, team_size);
+	}
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // The score kernel: persistent 1024-thread workgroups (16 waves).  Phase 1a: workgroups pull wide-window heavy chunks and run
 // them with all 16 waves.  Phase 1b: each workgroup splits into four 4-wave teams that pull narrower heavy chunks.
 // Phase 2: every wave pulls ordinary chunks on its own.  All lists most expensive first.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_split_soa).
-// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_mask+1 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 4 ]
+// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 4 ]
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE>
-__global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_mask)
+__global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_slots, int big_team)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	const unsigned fl = b.flags[0];
@@ -828,47 +1012,25 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	if (MODE == MODE_LUT && (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)smem != 0u) __builtin_trap();
 	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
 	int *ring = smem + lut_words;
-	int4 *stage = (int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
-	CoopShared *teams = (CoopShared*)((int4*)(ring + (ring_mask >= 0 ? ring_mask + 1 : 0)) + SCORE_THREADS);   // N_SMALL_TEAMS of them
+	int4 *stage = (int4*)(ring + ring_slots * WAVE) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
+	CoopShared *teams = (CoopShared*)((int4*)(ring + ring_slots * WAVE) + SCORE_THREADS);   // N_SMALL_TEAMS of them
 	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];
-	if (threadIdx.x < N_SMALL_TEAMS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
+	if (threadIdx.x < N_TEAM_RECORDS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
 	__syncthreads();
 
-	const int n_long = b.counters[CNT_NLONG], n_mid = b.counters[CNT_NMID];
-	const int wave = threadIdx.x / WAVE;
+	const int n_long = first_lane(b.counters[CNT_NLONG]), n_mid = first_lane(b.counters[CNT_NMID]);
+	// wave-uniform values are told to the compiler as such (v_readfirstlane): tile loops, window bounds and the rescue state
+	// machine then run on the scalar unit and read-only inputs can come through the scalar cache
+	const int wave = first_lane(threadIdx.x / WAVE);
 	// optional phase stamps (MM2GB_DEBUG_PHASES): 100 MHz wall clock at start / end of 1a / end of 1b / end, per workgroup
 	if (b.dbg && threadIdx.x == 0) b.dbg[blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
-	if (ring_mask >= 0) {
-		// phase 1a: the whole workgroup on one chunk at a time (wide windows)
-		CoopShared *sh = &teams[0];
-		while (true) {
-			if (threadIdx.x == 0) { sh->chunk = atomicAdd(&b.counters[CNT_LCURSOR], 1); sh->done = 0; sh->keep[0] = -1; }
-			__syncthreads();
-			const int c = sh->chunk;
-			if (c >= n_long) break;
-			const int ci = b.long_list[c];
-			const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
-			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, ring, ring_mask, sh, cs, ce, wave, SCORE_THREADS / WAVE);
-			else coop_chunk<MODE, false>(b, P, lut, stage, ring, ring_mask, sh, cs, ce, wave, SCORE_THREADS / WAVE);
-			__syncthreads();
-		}
-		if (b.dbg && threadIdx.x == 0) b.dbg[blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-		// phase 1b: four 4-wave teams, each on its own chunk with a quarter of the ring (narrower windows)
-		const int team = wave / SMALL_TEAM, team_wave = wave % SMALL_TEAM;
-		const int q_mask = (ring_mask + 1) / N_SMALL_TEAMS - 1;
-		int *q_ring = ring + team * (q_mask + 1);
-		sh = &teams[team];
-		while (true) {
-			if (team_wave == 0 && lane_id() == 0) { sh->chunk = atomicAdd(&b.counters[CNT_MCURSOR], 1); sh->done = 0; sh->keep[0] = -1; }
-			team_barrier(sh, SMALL_TEAM);
-			const int c = sh->chunk;
-			if (c >= n_mid) break;
-			const int ci = b.mid_list[c];
-			const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
-			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, q_ring, q_mask, sh, cs, ce, team_wave, SMALL_TEAM);
-			else coop_chunk<MODE, false>(b, P, lut, stage, q_ring, q_mask, sh, cs, ce, team_wave, SMALL_TEAM);
-			team_barrier(sh, SMALL_TEAM);
-		}
+	if (ring_slots > 0) {
+		// phase 1a: big teams (the whole workgroup, or two 8-wave teams) on wide-window heavy chunks; phase 1b: four 4-wave
+		// teams on narrower ones.  The ring is split hierarchically (a big team's share is made of its small teams' shares)
+		// and every phase has its own team records, so a team moves on without waiting for the rest of the workgroup.
+		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams + N_SMALL_TEAMS, b.long_list, n_long, CNT_LCURSOR, wave, big_team);
+		if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams, b.mid_list, n_mid, CNT_MCURSOR, wave, SMALL_TEAM);
 	}
 	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 	// phase 2: one wave per chunk
@@ -878,8 +1040,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		if (lane_id() == 0) c = atomicAdd(&b.counters[CNT_CURSOR], 1);
 		c = first_lane(c);
 		if (c >= n_chunks) break;
-		const int ci = b.order[c];
-		const int cs = b.chunk_start[ci], ce = b.chunk_end[ci];
+		const int ci = first_lane(b.order[c]);
+		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
 		if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, stage, cs, ce);
 		else run_chunk<MODE, false>(b, P, lut, stage, cs, ce);
 	}
@@ -921,10 +1083,10 @@ void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
 	hipLaunchKernelGGL(k_build_lut, dim3((P.lut_last + 256) / 256), dim3(256), 0, s, d_lut, P);
 }
 
-size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_mask)
+size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots)
 {
 	const size_t lut_words = host_mode == MODE_LUT ? (size_t)((P.lut_last + 1 + 3) & ~3) : 0;
-	return (lut_words + (ring_mask >= 0 ? (size_t)ring_mask + 1 : 0)) * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_SMALL_TEAMS * sizeof(CoopShared) + 16;
+	return (lut_words + (size_t)ring_slots * WAVE) * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) + 16;
 }
 
 int score_set_lds_limit(size_t bytes)
@@ -938,11 +1100,11 @@ int score_set_lds_limit(size_t bytes)
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s)
 {
 	if (b.n <= 0) return;
-	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_mask);
-	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_mask);
-	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
-	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_mask);
-	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_mask);
+	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_slots);
+	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_slots);
+	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team);
+	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team);
+	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team);
 }
 
 } // namespace mm2gb

@@ -80,24 +80,32 @@ int Engine::configure_score()
 	if (!single) launch.host_mode = SCORE_MODE_GENERAL;
 	else if (params.skip == 0.0f && params.lut_last + 1 <= LUT_MAX) launch.host_mode = SCORE_MODE_LUT;
 	else launch.host_mode = SCORE_MODE_FAST;
-	// Team modes: the LDS ring holds the scores of the most recent anchors of a chunk and must cover the widest predecessor
-	// window of any chunk it is used for (+ the tile being written).  Sized for max_iter when that fits the LDS budget of
-	// two workgroups per CU, otherwise as large as fits; the planner sends a chunk to a team only if its widest window fits.
 	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS)
-	int64_t ring = 1024;
-	while (ring < (int64_t)params.max_iter + 2 * 64 && ring < (1 << 16)) ring <<= 1;
+	// Team modes: a team's share of the LDS ring holds the scores of the most recent tiles of its chunk and must cover the
+	// chunk's widest predecessor window plus the tile being written (64 scores per slot).  The ring takes whatever the
+	// LDS budget of two workgroups per CU leaves; the planner sends a chunk to a team only if its widest window fits
+	// that team's share.
+	launch.big_team = 8;
+	if (const char *v = getenv("MM2GB_BIG_TEAM")) launch.big_team = atoi(v) == 16 ? 16 : 8;
+	const int n_big = 16 / launch.big_team;
+	auto fit_slots = [&](const DevParams &prm) {
+		int64_t slots = 1024;                                          // 64 K scores: more than any budget
+		while (slots > 0 && score_lds_bytes(prm, launch.host_mode, (int)slots) > LDS_BUDGET) slots -= 4;   // four small teams share it evenly
+		return slots;
+	};
 	// Penalty table: bw+2 entries with a clamped index, or -- one instruction less per pair -- max_dist_x+1 entries and no
-	// clamp, if that still leaves room for the ring this max_iter asks for.
+	// clamp, if that still leaves a big team room for windows of max_iter.
 	params.lut_last = params.bw + 1; params.lut_clamp = 1;
 	if (launch.host_mode == SCORE_MODE_LUT && !getenv("MM2GB_LUT_CLAMP")) {
 		DevParams wide = params;
 		wide.lut_last = std::max(params.max_dist_x, params.bw + 1); wide.lut_clamp = 0;
-		if (score_lds_bytes(wide, launch.host_mode, (int)ring - 1) <= LDS_BUDGET) params = wide;
+		const int64_t want_big = ((int64_t)std::min(params.max_iter, 1 << 20) + 63) / 64 + 1;
+		if (fit_slots(wide) / n_big >= std::min<int64_t>(want_big, fit_slots(params) / n_big)) params = wide;
 	}
-	while (ring > 1024 && score_lds_bytes(params, launch.host_mode, (int)ring - 1) > LDS_BUDGET) ring >>= 1;
-	launch.ring_mask = (int)ring - 1;
-	if (coop_disabled || score_lds_bytes(params, launch.host_mode, launch.ring_mask) > LDS_BUDGET) launch.ring_mask = -1;
-	const size_t need = std::max(score_lds_bytes(params, launch.host_mode, launch.ring_mask), score_lds_bytes(params, SCORE_MODE_GENERAL, launch.ring_mask));
+	int64_t slots = fit_slots(params);
+	if (slots < 8) slots = 0;                                        // less than two tiles of window per small team: not worth it
+	launch.ring_slots = coop_disabled ? 0 : (int)slots;
+	const size_t need = std::max(score_lds_bytes(params, launch.host_mode, launch.ring_slots), score_lds_bytes(params, SCORE_MODE_GENERAL, launch.ring_slots));
 	if (score_set_lds_limit(need)) return fail("mm2gb: cannot raise the dynamic LDS limit of the score kernel");
 	if (launch.host_mode == SCORE_MODE_LUT) {
 		if (lut.ensure((size_t)(params.lut_last + 1) * 4)) return -1;
