@@ -550,10 +550,17 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
 		for (int u = 0; u < G; ++u) {
 			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
 			const int v = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x - pen[u];
-			// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
-			bool take = ((unsigned)dqm[u] < lim4) & (v > bestv);
-			if (CHECK) take = take & (drm[u] != -4) & (j0 + u >= T.st);
-			bestv = take ? v : bestv;
+			if (!CHECK) {
+				// "bestv = max(bestv, v) in the lanes whose dq is in range": the range test goes straight into the execution
+				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement
+				unsigned long long saved;
+				asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
+				             : [b] "+v"(bestv), [sv] "=&s"(saved) : [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
+			} else {
+				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
+				const bool take = ((unsigned)dqm[u] < lim4) & (v > bestv) & (drm[u] != -4) & (j0 + u >= T.st);
+				bestv = take ? v : bestv;
+			}
 		}
 	}
 }
