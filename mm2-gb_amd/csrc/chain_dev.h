@@ -60,7 +60,7 @@ struct DevBatch {
 	int32_t  *mid_list;        // chunk ids scored by a 4-wave team
 	// scalars
 	int32_t  *counters;        // [0] n_chunks [1] work cursor (wave kernel) [2] n_long [3] work cursor (long kernel) [4] n_tracked [5] n_clamped_blocks
-	int64_t  *totals;          // [0] total pairs
+	int64_t  *totals;          // [0] total pairs [1] clamped windows [2] summed cost of the chunks on the big-team list
 	unsigned *flags;           // FLAG_*
 	const int32_t *lut;        // penalty by dd, lut_last + 1 entries (MODE_LUT only)
 	int64_t  *dbg;             // optional: 4 time stamps per score workgroup (MM2GB_DEBUG_PHASES), else null
@@ -72,6 +72,7 @@ struct LaunchCfg {
 	int host_mode;           // MODE_* the host's parameters allow (the device may still fall back to MODE_GENERAL)
 	int ring_slots;          // LDS ring of the team modes: slots of 64 scores, shared out among the teams of a phase; 0 = team modes off
 	int big_team;            // waves per team in the first phase: 16 (one team per workgroup) or 8 (two)
+	int whole_wg_pct;        // a big-team chunk costing more than this % of a workgroup's fair share of that list gets all 16 waves; 0 = never
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode
 	int     wide_window;     // mean window from which a 16-wave team is mostly busy; narrower heavy chunks get 4-wave teams

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 	__syncthreads();
 	const int n_chunks = b.counters[CNT_NCHUNK];
 	int n_track = 0;
+	long long big_cost = 0;
 	for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
 		const bool last = c + 1 >= n_chunks;
 		const int start = b.chunk_start[c], end = last ? (int)b.n : b.chunk_start[c + 1];
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 		b.chunk_cost[c] = cost;
 		b.chunk_track[c] = (uint8_t)((track ? 1 : 0) | (list << 1));
 		n_track += track;
+		if (list == LIST_TEAM16) big_cost += cost;
 		atomicAdd(&s_hist[list][cost_bin(cost)], 1);
 	}
 	__syncthreads();
@@ -341,8 +343,9 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 		const int v = (&s_hist[0][0])[k];
 		if (v) atomicAdd(&b.bins[k], v);
 	}
-	for (int off = WAVE / 2; off > 0; off >>= 1) n_track += __shfl_xor(n_track, off);
+	for (int off = WAVE / 2; off > 0; off >>= 1) { n_track += __shfl_xor(n_track, off); big_cost += __shfl_xor(big_cost, off); }
 	if (lane_id() == 0 && n_track) atomicAdd(&b.counters[CNT_NTRACK], n_track);
+	if (lane_id() == 0 && big_cost) atomicAdd((unsigned long long*)&b.totals[2], (unsigned long long)big_cost);
 }
 
 __global__ __launch_bounds__(64) void plan_bins(DevBatch b)
@@ -905,7 +908,7 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 // "tiles done" is a release/acquire counter in LDS.  No block barrier inside a chunk.
 struct CoopShared { int done; int keep[6]; int chunk; int bar_count; int bar_gen; };   // one per team
 constexpr int SMALL_TEAM = 4, N_SMALL_TEAMS = SCORE_THREADS / WAVE / SMALL_TEAM;
-constexpr int N_TEAM_RECORDS = N_SMALL_TEAMS + 2;      // four small teams, then up to two big ones
+constexpr int N_TEAM_RECORDS = N_SMALL_TEAMS + 3;      // four small teams, two big ones, the whole workgroup
 
 // Barrier among the waves of one small team (a workgroup barrier would stall the other teams): sense-reversing counter
 // in LDS, one lane per wave takes part.
@@ -976,9 +979,13 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 }
 
 // One phase of team work: the workgroup's waves form teams of team_size (4, 8 or 16) that pull chunks from `list`.
+// first: a chunk (position in the list) already pulled for team 0 by the previous phase, or -1.
+// min_cost: a chunk cheaper than this ends the phase for the team that pulled it; its position is returned (else -1) so
+// that the next phase can start with it.  Only meaningful for a one-team phase (whole workgroup).
 template <int MODE>
-__device__ void team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
-                           const int32_t *list, const int n_list, const int cursor, const int wave, const int team_size)
+__device__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
+                          const int32_t *list, const int n_list, const int cursor, const int wave, const int team_size,
+                          int first = -1, const long long min_cost = 0)
 {
 	const int n_teams = SCORE_THREADS / WAVE / team_size;
 	const int team = wave / team_size, team_wave = wave - team * team_size;
@@ -986,11 +993,14 @@ __device__ void team_phase(const DevBatch &b, const DevParams &P, const int *lut
 	int *my_ring = ring + team * slots * WAVE;
 	CoopShared *sh = &teams[team];
 	while (true) {
-		if (team_wave == 0 && lane_id() == 0) { sh->chunk = atomicAdd(&b.counters[cursor], 1); sh->done = 0; sh->keep[0] = -1; }
+		const bool given = first >= 0 && team == 0;
+		if (team_wave == 0 && lane_id() == 0) { sh->chunk = given ? first : atomicAdd(&b.counters[cursor], 1); sh->done = 0; sh->keep[0] = -1; }
+		first = -1;
 		team_barrier(sh, team_size);
 		const int c = first_lane(sh->chunk);
-		if (c >= n_list) break;
+		if (c >= n_list) return -1;
 		const int ci = first_lane(list[c]);
+		if (min_cost > 0 && b.chunk_cost[ci] < min_cost) return c;
 		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
 		if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
 		else coop_chunk<MODE, false>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
@@ -1008,7 +1018,7 @@ __device__ void team_phase(const DevBatch &b, const DevParams &P, const int *lut
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE>
-__global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_slots, int big_team)
+__global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_slots, int big_team, int whole_wg_pct)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	const unsigned fl = b.flags[0];
@@ -1035,7 +1045,16 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		// phase 1a: big teams (the whole workgroup, or two 8-wave teams) on wide-window heavy chunks; phase 1b: four 4-wave
 		// teams on narrower ones.  The ring is split hierarchically (a big team's share is made of its small teams' shares)
 		// and every phase has its own team records, so a team moves on without waiting for the rest of the workgroup.
-		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams + N_SMALL_TEAMS, b.long_list, n_long, CNT_LCURSOR, wave, big_team);
+		// The big-team list is served most expensive first.  A chunk that alone is more than whole_wg_pct % of a workgroup's fair
+		// share of that list gets the whole workgroup (the largest chunks decide when a small batch ends, and a team's speed
+		// is bounded by what one CU's LDS pipe and issue slots give it); the rest go to teams of big_team waves, two at a time.
+		int first = -1;
+		if (big_team < SCORE_THREADS / WAVE && whole_wg_pct > 0) {
+			const long long share = b.totals[2] / gridDim.x * whole_wg_pct / 100;
+			first = team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams + N_SMALL_TEAMS + 2, b.long_list, n_long, CNT_LCURSOR, wave,
+			                         SCORE_THREADS / WAVE, -1, share > 0 ? share : 1);
+		}
+		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams + N_SMALL_TEAMS, b.long_list, n_long, CNT_LCURSOR, wave, big_team, first);
 		if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams, b.mid_list, n_mid, CNT_MCURSOR, wave, SMALL_TEAM);
 	}
@@ -1109,9 +1128,9 @@ void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, h
 	if (b.n <= 0) return;
 	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_slots);
 	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_slots);
-	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team);
-	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team);
-	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team);
+	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
 }
 
 } // namespace mm2gb

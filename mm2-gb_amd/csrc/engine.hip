@@ -87,6 +87,8 @@ int Engine::configure_score()
 	// that team's share.
 	launch.big_team = 8;
 	if (const char *v = getenv("MM2GB_BIG_TEAM")) launch.big_team = atoi(v) == 16 ? 16 : 8;
+	launch.whole_wg_pct = 100;
+	if (const char *v = getenv("MM2GB_WHOLE_WG_PCT")) launch.whole_wg_pct = std::max(0, atoi(v));
 	const int n_big = 16 / launch.big_team;
 	auto fit_slots = [&](const DevParams &prm) {
 		int64_t slots = 1024;                                          // 64 K scores: more than any budget
@@ -149,7 +151,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) MM2GB_HIP(hipEventCreate(e));
 	MM2GB_HIP(hipHostMalloc((void**)&h_counters, (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
 	MM2GB_HIP(hipHostMalloc((void**)&h_totals, (size_t)MAX_SLOTS * 2 * sizeof(int64_t), hipHostMallocDefault));
-	if (counters.ensure(CNT_WORDS * sizeof(int32_t)) || totals.ensure(2 * sizeof(int64_t)) || flags.ensure(4 * sizeof(unsigned))) return -1;
+	if (counters.ensure(CNT_WORDS * sizeof(int32_t)) || totals.ensure(4 * sizeof(int64_t)) || flags.ensure(4 * sizeof(unsigned))) return -1;
 	if (set_misc(m)) return -1;
 	return 0;
 }
@@ -226,7 +228,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	if (debug_phases) MM2GB_HIP(hipMemsetAsync(dbg.ptr, 0, (size_t)launch.score_grid * 32, stream));
 
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
-	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 2 * sizeof(int64_t), stream));
+	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 4 * sizeof(int64_t), stream));
 	MM2GB_HIP(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(unsigned), stream));
 	if (want_stats) MM2GB_HIP(hipEventRecord(bs.prep0, stream));
 	if (n > 0) {
