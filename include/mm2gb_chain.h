@@ -50,7 +50,7 @@ typedef struct {
 	int64_t n_anchors, n_reads;
 	int64_t n_pairs;            /* sum of predecessor-window sizes == the reference's "anchor pairs" (planalyze.cu:69-83) */
 	int64_t n_chunks;           /* independent DP work items found by the planner */
-	int64_t n_long_chunks;      /* of those, pipelined over the 16 waves of a workgroup (LDS score ring) */
+	int64_t n_long_chunks;      /* of those, pipelined over a big team: 8 waves, or a whole workgroup (LDS score ring) */
 	int64_t n_mid_chunks;       /* of those, pipelined over a 4-wave team */
 	int64_t n_tracked_chunks;   /* of those, run with the max_ii rescue state machine (lchain.c:190-205) */
 	int64_t n_clamped_blocks;   /* planner blocks containing a window cut by max_iter (lchain.c:173) */

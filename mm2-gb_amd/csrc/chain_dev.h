@@ -75,7 +75,7 @@ struct LaunchCfg {
 	int whole_wg_pct;        // a big-team chunk costing more than this % of a workgroup's fair share of that list gets all 16 waves; 0 = never
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode
-	int     wide_window;     // mean window from which a 16-wave team is mostly busy; narrower heavy chunks get 4-wave teams
+	int     wide_window;     // mean window from which a big team pays; narrower heavy chunks get 4-wave teams
 };
 
 void launch_split_soa(const DevBatch &b, hipStream_t s);

@@ -9,7 +9,7 @@
 //                   (role of the cut/long_seg/mid_seg bookkeeping, plscore.cu:314-385, and the host pairsort, plchain.cu:30-42)
 //   * k_score<MODE> the DP: persistent workgroups; 64 anchors per tile held one-per-lane in registers; predecessors are staged
 //                   64 at a time in per-wave LDS and broadcast-read, so every step scores ONE predecessor against the
-//                   wave's 64 anchors.  Heavy chunks are pipelined over the 16 waves of a workgroup through an LDS ring of
+//                   wave's 64 anchors.  Heavy chunks are pipelined over teams of 4, 8 or 16 waves through an LDS ring of
 //                   scores (the sliding predecessor window).  No block barrier per anchor, no global read-modify-write
 //                   (role of plscore.cu:109-187, 290-451).
 // Arithmetic follows lchain.c:113-138 + mmpriv.h:118-126 bit for bit: compile with -ffp-contract=off.
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 // --------------------------------------------------------------------------------------------------------------
 constexpr int PLANNER_THREADS = 1024;
 constexpr int COST_BINS = 256;
-enum { LIST_WAVE = 0, LIST_TEAM16 = 1, LIST_TEAM4 = 2, N_LISTS = 3 };
+enum { LIST_WAVE = 0, LIST_BIG = 1, LIST_TEAM4 = 2, N_LISTS = 3 };
 
 __device__ __forceinline__ int cost_bin(int64_t c)
 {
@@ -311,10 +311,10 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 		const long long kk_next = last ? b.totals[1] : (long long)b.chunk_kk[c + 1] + b.blk_clamped[b.chunk_blk[c + 1]];
 		const bool track = kk_next - b.chunk_kk[c] > 0;
 		const long long cost = (pp_next - b.chunk_pp[c]) + (long long)(end - start) * COST_PER_ANCHOR;
-		// How the chunk will be scored (bits 1-2 of chunk_track): LIST_WAVE one wave; LIST_TEAM16 the 16 waves of a workgroup;
+		// How the chunk will be scored (bits 1-2 of chunk_track): LIST_WAVE one wave; LIST_BIG a big team (8 waves, or the whole workgroup for the largest);
 		// LIST_TEAM4 a 4-wave team (four chunks per workgroup at a time).  A chunk with mean window W keeps about
 		// (W + 128) / 128 waves busy, so wide windows get the big team and a few blocks of window the small one, which also
-		// needs the chunk's widest window to fit its quarter of the LDS ring.
+		// needs the chunk's widest window to fit its share of the LDS ring.
 		const long long len = end - start;
 		const bool heavy = cfg.ring_slots > 0 && cost >= cfg.long_min_cost && len * cfg.long_min_window <= cost;
 		int list = LIST_WAVE;
@@ -329,13 +329,13 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 			const int need_slots = (wmax + WAVE - 1) / WAVE + 1;
 			const int big_slots = cfg.ring_slots / (16 / cfg.big_team), small_slots = cfg.ring_slots / 4;   // k_score: 16 waves, four small teams
 			if (len * cfg.wide_window > cost && need_slots <= small_slots) list = LIST_TEAM4;
-			else if (need_slots <= big_slots) list = LIST_TEAM16;   // else: window wider than the ring can hold -> one wave
+			else if (need_slots <= big_slots) list = LIST_BIG;   // else: window wider than the ring can hold -> one wave
 		}
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;
 		b.chunk_track[c] = (uint8_t)((track ? 1 : 0) | (list << 1));
 		n_track += track;
-		if (list == LIST_TEAM16) big_cost += cost;
+		if (list == LIST_BIG) big_cost += cost;
 		atomicAdd(&s_hist[list][cost_bin(cost)], 1);
 	}
 	__syncthreads();
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void plan_bins(DevBatch b)
 		int acc = 0;
 		int *bins = b.bins + threadIdx.x * COST_BINS;
 		for (int k = COST_BINS - 1; k >= 0; --k) { const int v = bins[k]; bins[k] = acc; acc += v; }   // count -> base
-		if (threadIdx.x == LIST_TEAM16) b.counters[CNT_NLONG] = acc;
+		if (threadIdx.x == LIST_BIG) b.counters[CNT_NLONG] = acc;
 		if (threadIdx.x == LIST_TEAM4) b.counters[CNT_NMID] = acc;
 	}
 	if (threadIdx.x == 0) { b.counters[CNT_CURSOR] = 0; b.counters[CNT_LCURSOR] = 0; b.counters[CNT_MCURSOR] = 0; }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 		for (int k = threadIdx.x; k < N_LISTS * COST_BINS; k += blockDim.x) if (s_cnt[k]) s_base[k] = atomicAdd(&b.bins[k], s_cnt[k]);
 		__syncthreads();
 		if (key >= 0) {
-			int *dst = key >= LIST_TEAM4 * COST_BINS ? b.mid_list : key >= LIST_TEAM16 * COST_BINS ? b.long_list : b.order;
+			int *dst = key >= LIST_TEAM4 * COST_BINS ? b.mid_list : key >= LIST_BIG * COST_BINS ? b.long_list : b.order;
 			dst[s_base[key] + rank] = (int)c;
 		}
 		__syncthreads();
@@ -900,7 +900,7 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 	}
 }
 
-// ---- cooperative mode: the 16 waves of a workgroup pipeline the tiles of ONE heavy chunk ---------------------
+// ---- team mode: the waves of a team (4, 8 or 16) pipeline the tiles of ONE heavy chunk ------------------------
 // Wave w takes tiles w, w+16, ...  A tile's sources are swept oldest first, so the only sources that may not be final
 // yet are the most recent tiles': the sweep reaches them last, and by then the waves ahead have normally finished
 // (a tile needs ~(window/64 + 2) block sweeps, its critical dependency is 2 of them).  Final scores travel between
@@ -1009,12 +1009,13 @@ __device__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut,
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// The score kernel: persistent 1024-thread workgroups (16 waves).  Phase 1a: workgroups pull wide-window heavy chunks and run
-// them with all 16 waves.  Phase 1b: each workgroup splits into four 4-wave teams that pull narrower heavy chunks.
-// Phase 2: every wave pulls ordinary chunks on its own.  All lists most expensive first.
+// The score kernel: persistent 1024-thread workgroups (16 waves).  Phase 1a: the big-team list (wide-window heavy chunks) --
+// first the chunks that are larger than a workgroup's fair share of it with all 16 waves, then two 8-wave teams per
+// workgroup.  Phase 1b: four 4-wave teams per workgroup pull narrower heavy chunks.  Phase 2: every wave pulls ordinary
+// chunks on its own.  All lists most expensive first; a team enters the next phase as soon as its list is empty.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_split_soa).
-// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 4 ]
+// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 7 ]
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE>

@@ -306,7 +306,7 @@ int Engine::collect_stats()
 				const int64_t a = h[4 * w + 1] ? h[4 * w + 1] - t0 : 0, b2 = h[4 * w + 2] - t0, c = h[4 * w + 3] - t0;
 				e1 = std::max(e1, a); e2 = std::max(e2, b2); e3 = std::max(e3, c); s1 += a; s2 += b2; s3 += c; ++n;
 			}
-			if (n) fprintf(stderr, "[mm2gb phases] workgroups %d | end of 16-wave phase: mean %.2f max %.2f ms | end of 4-wave phase: mean %.2f max %.2f ms | end: mean %.2f max %.2f ms\n",
+			if (n) fprintf(stderr, "[mm2gb phases] workgroups %d | end of big-team phase: mean %.2f max %.2f ms | end of 4-wave phase: mean %.2f max %.2f ms | end: mean %.2f max %.2f ms\n",
 			               n, s1 / 1e5 / n, e1 / 1e5, s2 / 1e5 / n, e2 / 1e5, s3 / 1e5 / n, e3 / 1e5);
 		}
 	}

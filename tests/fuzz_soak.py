@@ -1,7 +1,7 @@
 """Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N] [--teams]
 Runs tests/synth_cases.fuzz_case batches through the HIP path and the oracle; the first batch that differs is written
 to gpurun_out/fuzz_fail_<seed>_<iteration>.npz (anchors, offsets, GPU f/p, parameters) and the exit code is 1.
---teams adds two engines whose planner thresholds send every chunk that fits the LDS ring to the 16-wave teams and to
+--teams adds three engines whose planner thresholds send every chunk that fits the LDS ring to the big (8/16-wave) teams and to
 the 4-wave teams (normally reserved for long chunks), so the cooperative paths see the same odd shapes."""
 import argparse, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,7 +31,8 @@ def make_engine(env):
 
 engines = [("default", make_engine({}))]
 if args.teams:
-    engines.append(("team16", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1"})))
+    engines.append(("team8", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "0"})))
+    engines.append(("team16", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "1"})))
     engines.append(("team4", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "100000000"})))
 seen = {name: [0, 0] for name, _ in engines}
 for seed in args.seeds:
@@ -58,7 +59,7 @@ for seed in args.seeds:
         print("seed", seed, "clean over", args.iters, "batches", flush=True)
     if failed:
         break
-print("chunks sent to 16-wave / 4-wave teams per engine:", seen)
+print("chunks sent to big / 4-wave teams per engine:", seen)
 for _, e in engines:
     e.close()
 sys.exit(1 if failed else 0)

@@ -160,7 +160,7 @@ def test_equal_reference_positions(engine):
 
 
 def test_cooperative_and_wave_modes_agree(monkeypatch):
-    """Heavy chunks through the workgroup-cooperative mode and, with it switched off, through the wave mode."""
+    """Heavy chunks through the team modes (every team size) and, with them switched off, through the wave mode."""
     parts = [sc.sort_by_x(sc.repeat_block(4500, 51)), sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 52), sc.colinear(900, 53)])),
              sc.read_like(9000, 54), sc.rescue_case(n_noise=6000, n_chain=50, seed=9)]
     off = np.zeros(len(parts) + 1, dtype=np.int64)
@@ -170,6 +170,15 @@ def test_cooperative_and_wave_modes_agree(monkeypatch):
     with mm.Engine() as e1:
         st1 = check_batch(e1, a, off, prm)
     assert st1["n_long_chunks"] >= 3 and st1["n_tracked_chunks"] >= 2
+    # every way of running the big-team list: all chunks by whole workgroups, none (8-wave teams only), 16-wave teams only
+    for env in ({"MM2GB_WHOLE_WG_PCT": "1"}, {"MM2GB_WHOLE_WG_PCT": "0"}, {"MM2GB_BIG_TEAM": "16"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with mm.Engine() as e:
+            st = check_batch(e, a, off, prm)
+        assert st["n_long_chunks"] == st1["n_long_chunks"]
+        for k in env:
+            monkeypatch.delenv(k)
     monkeypatch.setenv("MM2GB_NO_COOP", "1")
     with mm.Engine() as e2:
         st2 = check_batch(e2, a, off, prm)
@@ -207,7 +216,7 @@ def test_many_tiny_reads(engine):
 
 
 def test_four_wave_teams(engine):
-    """Heavy chunks with narrow windows are pipelined over 4-wave teams with a quarter of the LDS ring each: plain chains,
+    """Heavy chunks with narrow windows are pipelined over 4-wave teams with their share of the LDS ring each: plain chains,
     and max_iter-clamped windows (rescue state handed from wave to wave inside a team)."""
     prm = orc.default_param()
     chains = [sc.sort_by_x(np.concatenate([sc.colinear(9000, 300 + k, r0=1_000_000 + 7 * k), sc.noise(3000, 400 + k)])) for k in range(6)]
