@@ -20,7 +20,10 @@ enum : unsigned { FLAG_ANY_SEGID = 1u,     // some anchor carries a segment id -
 
 // Planner granularity: anchors per planning block (one k_window workgroup).
 constexpr int PLAN_BLOCK = 1024;
-constexpr int PLAN_THREADS = 256;
+#ifndef MM2GB_PLAN_THREADS
+#define MM2GB_PLAN_THREADS 256
+#endif
+constexpr int PLAN_THREADS = MM2GB_PLAN_THREADS;   // k_window: each thread owns PLAN_BLOCK / PLAN_THREADS consecutive anchors
 // cost charged per anchor on top of its pairs when ordering chunks (tile bookkeeping is not free)
 constexpr int COST_PER_ANCHOR = 16;
 
@@ -45,6 +48,7 @@ struct DevBatch {
 	int32_t  *blk_firstcut;    // smallest i in block with st[i] == i, INT32_MAX if none
 	int64_t  *blk_pairs;       // sum of window sizes in block
 	int32_t  *blk_clamped;     // 1 if any window in block was cut by max_iter
+	int32_t  *blk_read;        // read that owns the block's first anchor (k_block_reads)
 	int32_t  *blk_wmax;        // two per block: widest window before the block's first cut, and from it on
 	int64_t   n_blocks;
 	// chunks (independent runs of anchors between cuts), at most n_blocks of them

@@ -61,42 +61,65 @@ __device__ __forceinline__ bool in_reach(const DevBatch &b, int j, int hi_i, uns
 	return b.xhi[j] == hi_i && x_i <= (unsigned)b.x[j] + dist;   // positions < 2^31, dist < 2^31: no wrap
 }
 
+// Read that owns the first anchor of every planning block: one bisection of the read offsets per block, all blocks at once
+// (done by the first thread of each k_window workgroup it put ~13 dependent loads in front of every workgroup).
+__global__ __launch_bounds__(256) void k_block_reads(DevBatch b)
+{
+	const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (blk >= b.n_blocks) return;
+	const int64_t base = blk * PLAN_BLOCK;
+	int64_t lo = 0, hi = b.n_reads;                   // invariant: offsets[lo] <= base < offsets[hi]
+	while (hi - lo > 1) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (b.offsets[mid] <= base) lo = mid; else hi = mid;
+	}
+	b.blk_read[blk] = (int32_t)lo;
+}
+
+// A block of PLAN_BLOCK anchors first puts into LDS (a) its own anchors' x / xhi and (b) one sample per 32 anchors (one per
+// 128-byte line of x) of the max_iter anchors before it.  A window start is then found with LDS probes only -- bisection
+// over the block's own anchors, or over the samples followed by at most five probes inside the one line the answer lies in,
+// a line the block has just touched -- instead of ~25 dependent trips to L2/HBM per search.
+constexpr int WIN_SAMPLE = 32;                         // anchors per sample = ints per 128-byte line
+constexpr int WIN_MAX_SAMPLES = 512;                   // look-back of 16 K anchors; a larger max_iter probes memory beyond it
+
 __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P)
 {
 	__shared__ int s_cut[PLAN_THREADS / WAVE];
 	__shared__ unsigned long long s_pairs[PLAN_THREADS / WAVE];
 	__shared__ int s_clamp[PLAN_THREADS / WAVE];
 	__shared__ int s_wmax[2 * PLAN_THREADS / WAVE];
-	__shared__ int64_t s_read0;
+	__shared__ int own_x[PLAN_BLOCK], own_hi[PLAN_BLOCK];
+	__shared__ int smp_x[WIN_MAX_SAMPLES], smp_hi[WIN_MAX_SAMPLES];      // sample k-1 = anchor base - 32 k
 	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
-	if (threadIdx.x == 0) {
-		int64_t lo = 0, hi = b.n_reads;               // invariant: offsets[lo] <= base < offsets[hi]
-		while (hi - lo > 1) {
-			const int64_t mid = (lo + hi) >> 1;
-			if (b.offsets[mid] <= base) lo = mid; else hi = mid;
-		}
-		s_read0 = lo;
+	const int n_samples = (int)min((int64_t)WIN_MAX_SAMPLES, min(base, (int64_t)P.max_iter + WIN_SAMPLE - 1) / WIN_SAMPLE);
+	for (int k = threadIdx.x; k < PLAN_BLOCK; k += PLAN_THREADS) {
+		const int64_t g = base + k;
+		own_x[k] = g < b.n ? b.x[g] : 0; own_hi[k] = g < b.n ? b.xhi[g] : 0;
+	}
+	for (int k = threadIdx.x; k < n_samples; k += PLAN_THREADS) {
+		const int64_t g = base - (int64_t)(k + 1) * WIN_SAMPLE;
+		smp_x[k] = b.x[g]; smp_hi[k] = b.xhi[g];
 	}
 	__syncthreads();
 	int my_cut = INT_MAX, my_clamp = 0;
 	unsigned long long my_pairs = 0;
 
-	// Each thread owns PLAN_BLOCK / PLAN_THREADS consecutive anchors.  The first gets a full backward search; window
-	// starts are monotone (st[i+1] >= st[i]), so the others continue forward from their predecessor's start.
+	// Each thread owns PLAN_BLOCK / PLAN_THREADS anchors, PLAN_THREADS apart: consecutive lanes, consecutive anchors (coalesced st).
 	constexpr int PER = PLAN_BLOCK / PLAN_THREADS;
-	const int64_t i_first = base + (int64_t)threadIdx.x * PER;
-	int64_t rd = s_read0;                             // read of the current anchor
-	int rs = 0, re = 0, st_prev = 0;
+	const int64_t i_first = base + threadIdx.x;
+	const int base32 = (int)base;
+	int64_t rd = b.blk_read[blockIdx.x];              // read of the current anchor
+	int rs = 0, re = 0;
 	int win[PER];
 #pragma unroll
 	for (int k = 0; k < PER; ++k) win[k] = -1;
 #pragma unroll
 	for (int k = 0; k < PER; ++k) {
-		const int64_t i64 = i_first + k;
+		const int64_t i64 = i_first + (int64_t)k * PLAN_THREADS;
 		if (i64 >= b.n) break;
 		const int i = (int)i64;
-		bool fresh = k == 0;
 		if (k == 0 || i >= re) {
 			// read that owns anchor i: last r with offsets[r] <= i (gallop forward from the last known read, then bisect)
 			int64_t lo = rd, hi = b.n_reads;
@@ -111,55 +134,49 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 				if (b.offsets[mid] <= i64) lo = mid; else hi = mid;
 			}
 			rd = lo; rs = (int)b.offsets[lo]; re = (int)b.offsets[lo + 1];
-			fresh = true;
 		}
 		int lb = i - P.max_iter;                      // may be negative
 		if (lb < rs) lb = rs;
-		const int hi_i = b.xhi[i];
-		const unsigned x_i = (unsigned)b.x[i];
+		const int hi_i = own_hi[i - base32];
+		const unsigned x_i = (unsigned)own_x[i - base32];
+		auto reach_own = [&](int j) { return own_hi[j - base32] == hi_i && x_i <= (unsigned)own_x[j - base32] + dist; };
+		auto reach_smp = [&](int s) { return smp_hi[s] == hi_i && x_i <= (unsigned)smp_x[s] + dist; };   // anchor base - 32 (s + 1)
+		// validity is monotone over [lb, i): false ... false true ... true.  st = first valid index, i if none.
 		int st = i;
-		if (i > lb && in_reach(b, i - 1, hi_i, x_i, dist)) {
-			if (fresh) {
-				// gallop back from i until out of reach or at lb, then bisect
-				int good = i - 1, step = 2, bad = -1;
-				while (true) {
-					int probe = i - step;
-					if (probe <= lb) { probe = lb; if (in_reach(b, probe, hi_i, x_i, dist)) good = lb; else bad = lb; break; }
-					if (in_reach(b, probe, hi_i, x_i, dist)) { good = probe; step <<= 1; }
-					else { bad = probe; break; }
+		if (i > lb) {
+			int l, h;                                   // invariant: l is out of reach (or lb - 1), h is in reach (or i)
+			bool in_block = true;
+			if (lb >= base32) { l = lb - 1; h = i; }
+			else if (i > base32 && !reach_own(base32)) { l = base32; h = i; }
+			else {
+				// the window starts at or before the block's first anchor: bisect the samples (closest first: in reach ...
+				// in reach, out of reach ...), then the <= 32 anchors between two samples, which share one line of x
+				in_block = false;
+				const int s_cnt = min(n_samples, (base32 - lb) / WIN_SAMPLE);          // samples at positions >= lb
+				int sl = -1, sh = s_cnt;
+				while (sh - sl > 1) {
+					const int mid = (sl + sh) >> 1;
+					if (reach_smp(mid)) sl = mid; else sh = mid;
 				}
-				if (bad >= 0) {
-					int l = bad, h = good;            // l out of reach, h in reach
-					while (h - l > 1) {
-						const int mid = (l + h) >> 1;
-						if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
-					}
-					good = h;
+				h = sl >= 0 ? base32 - (sl + 1) * WIN_SAMPLE : (i > base32 ? base32 : i);
+				l = sh < s_cnt ? base32 - (sh + 1) * WIN_SAMPLE : lb - 1;
+			}
+			if (in_block) {
+				while (h - l > 1) {
+					const int mid = (l + h) >> 1;
+					if (reach_own(mid)) h = mid; else l = mid;
 				}
-				st = good;
 			} else {
-				// first in-reach index >= max(previous start, lb); i - 1 is known to be in reach
-				int from = st_prev > lb ? st_prev : lb;
-				if (in_reach(b, from, hi_i, x_i, dist)) st = from;
-				else {
-					int l = from, step = 1;           // l out of reach; gallop forward to an in-reach h <= i - 1, then bisect
-					int h = i - 1;
-					while (l + step < i - 1) {
-						if (in_reach(b, l + step, hi_i, x_i, dist)) { h = l + step; break; }
-						l += step; step <<= 1;
-					}
-					while (h - l > 1) {
-						const int mid = (l + h) >> 1;
-						if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
-					}
-					st = h;
+				while (h - l > 1) {
+					const int mid = (l + h) >> 1;
+					if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
 				}
 			}
+			st = h;
 			// the max_iter clamp bit (lchain.c:173): window would have reached further back
 			if (st == lb && lb > rs && lb == i - P.max_iter && in_reach(b, lb - 1, hi_i, x_i, dist)) my_clamp = 1;
 		}
 		b.st[i] = st;
-		st_prev = st;
 		my_pairs += (unsigned)(i - st);
 		win[k] = i - st;
 		if (st == i && i < my_cut) my_cut = i;
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 #pragma unroll
 	for (int k = 0; k < PER; ++k) {
 		if (win[k] < 0) continue;
-		if (i_first + k < blk_cut) head = max(head, win[k]); else tail = max(tail, win[k]);
+		if (i_first + (int64_t)k * PLAN_THREADS < blk_cut) head = max(head, win[k]); else tail = max(tail, win[k]);
 	}
 	for (int off = WAVE / 2; off > 0; off >>= 1) { head = max(head, __shfl_xor(head, off)); tail = max(tail, __shfl_xor(tail, off)); }
 	if (lane_id() == 0) { s_wmax[w] = head; s_wmax[PLAN_THREADS / WAVE + w] = tail; }
@@ -1089,6 +1106,7 @@ void launch_split_soa(const DevBatch &b, hipStream_t s)
 void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s)
 {
 	if (b.n <= 0) return;
+	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((b.n_blocks + 255) / 256)), dim3(256), 0, s, b);
 	hipLaunchKernelGGL(k_window, dim3((unsigned)b.n_blocks), dim3(PLAN_THREADS), 0, s, b, P);
 }
 
