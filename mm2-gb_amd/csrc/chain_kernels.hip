@@ -553,6 +553,7 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
+	const unsigned long long all_lanes = __builtin_amdgcn_read_exec();   // the execution mask the v_cmpx statements put back
 	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
 		const int j0 = jb + kg;
 		int dqm[G], drm[G], pen[G];
@@ -572,10 +573,9 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
 			const int v = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x - pen[u];
 			if (!CHECK) {
 				// "bestv = max(bestv, v) in the lanes whose dq is in range": the range test goes straight into the execution
-				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement
-				unsigned long long saved;
-				asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
-				             : [b] "+v"(bestv), [sv] "=&s"(saved) : [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
+				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement (from all_lanes, read once)
+				asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
+				             : [b] "+v"(bestv) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
 			} else {
 				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
 				const bool take = ((unsigned)dqm[u] < lim4) & (v > bestv) & (drm[u] != -4) & (j0 + u >= T.st);
