@@ -34,10 +34,9 @@ struct DevBatch {
 	const int64_t *offsets;    // n_reads + 1
 	int64_t        n;          // anchors
 	int64_t        n_reads;
-	// SoA (written by k_split_soa)
+	// SoA (written by k_window)
 	int32_t  *x;               // ref_pos  = (int32)a.x                                4 B
 	int32_t  *y;               // qry_pos  = (int32)a.y                                4 B
-	int32_t  *xhi;             // a.x >> 32 = rev<<31 | rid                            4 B
 	int32_t  *tag;             // seg_id<<8 | q_span (a dword so the scalar path can fetch it) 4 B
 	// range selection
 	int32_t  *st;              // first predecessor index of each anchor (lchain.c:172-173)   4 B
@@ -82,7 +81,6 @@ struct LaunchCfg {
 	int     wide_window;     // mean window from which a big team pays; narrower heavy chunks get 4-wave teams
 };
 
-void launch_split_soa(const DevBatch &b, hipStream_t s);
 void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s);
 void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s);
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s);

@@ -2,9 +2,9 @@
 //
 // What the path computes is fixed by the reference's CPU code (lchain.c:113-207); how it is computed here is not
 // taken from the reference's gpu/*.cu:
-//   * k_split_soa   mm128_t AoS -> SoA on the device (the reference does this on one CPU thread, plmem.cu:154-198)
-//   * k_window      predecessor-window start per anchor by galloping + binary search (role of plrange.cu:38-76),
-//                   fused with the planner's per-block reductions (cuts, pair counts, max_iter clamps)
+//   * k_window      mm128_t AoS -> SoA on the device (the reference does this on one CPU thread, plmem.cu:154-198) and, in the
+//                   same pass, the predecessor-window start of every anchor by bisection in LDS (role of plrange.cu:38-76)
+//                   and the planner's per-block reductions (cuts, pair counts, widest windows, max_iter clamps)
 //   * plan_*        turn cuts into independent, cost-ordered work items ("chunks") without host round trips
 //                   (role of the cut/long_seg/mid_seg bookkeeping, plscore.cu:314-385, and the host pairsort, plchain.cu:30-42)
 //   * k_score<MODE> the DP: persistent workgroups; 64 anchors per tile held one-per-lane in registers; predecessors are staged
@@ -29,36 +29,17 @@ __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readf
 
 
 // --------------------------------------------------------------------------------------------------------------
-// AoS -> SoA
-// --------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_split_soa(DevBatch b)
-{
-	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	bool any_seg = false, big_y = false;
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
-		const uint4 v = b.raw[i];                 // x.lo x.hi y.lo y.hi
-		b.x[i] = (int32_t)v.x;
-		b.xhi[i] = (int32_t)v.y;
-		b.y[i] = (int32_t)v.z;
-		const unsigned span = v.w & 0xffu;        // y>>32 & 0xff      (lchain.c:125)
-		const unsigned seg = (v.w >> 16) & 0xffu; // (y & MM_SEED_SEG_MASK) >> 48 (lchain.c:116)
-		b.tag[i] = (int32_t)(seg << 8 | span);
-		any_seg |= seg != 0;
-		big_y |= v.z >= (1u << 22) || span == 0;
-	}
-	if (__ballot(any_seg) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_ANY_SEGID);
-	if (__ballot(big_y) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_NO_LUT);
-}
-
-// --------------------------------------------------------------------------------------------------------------
-// Predecessor window start (lchain.c:172-173) + planner reductions
+// AoS -> SoA, predecessor window start (lchain.c:172-173), planner reductions
+//   the block's own anchors are read once as mm128_t (16 B, coalesced) and leave as x / y / tag for the score kernel
+//   (role of the CPU loop plmem.cu:154-198) together with the input flags; look-back probes read the raw anchors too
 //   st[i] = max( first j <= i in the same read with xhi[j]==xhi[i] and x[i] <= x[j]+max_dist_x ,  i - max_iter )
 // The CPU carries st across iterations; because validity is monotone in both i and j (anchors sorted by x) the
 // carried value equals this closed form ("window start").
 // --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool in_reach(const DevBatch &b, int j, int hi_i, unsigned x_i, unsigned dist)
 {
-	return b.xhi[j] == hi_i && x_i <= (unsigned)b.x[j] + dist;   // positions < 2^31, dist < 2^31: no wrap
+	const uint2 v = *(const uint2*)&b.raw[j];                    // x.lo = reference position, x.hi = strand | rid
+	return (int)v.y == hi_i && x_i <= v.x + dist;                // positions < 2^31, dist < 2^31: no wrap
 }
 
 // Read that owns the first anchor of every planning block: one bisection of the read offsets per block, all blocks at once
@@ -76,7 +57,7 @@ __global__ __launch_bounds__(256) void k_block_reads(DevBatch b)
 	b.blk_read[blk] = (int32_t)lo;
 }
 
-// A block of PLAN_BLOCK anchors first puts into LDS (a) its own anchors' x / xhi and (b) one sample per 32 anchors (one per
+// A block of PLAN_BLOCK anchors first puts into LDS (a) its own anchors' reference position and strand|rid (a.x) and (b) one sample per 32 anchors (one per
 // 128-byte line of x) of the max_iter anchors before it.  A window start is then found with LDS probes only -- bisection
 // over the block's own anchors, or over the samples followed by at most five probes inside the one line the answer lies in,
 // a line the block has just touched -- instead of ~25 dependent trips to L2/HBM per search.
@@ -94,14 +75,26 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
 	const int n_samples = (int)min((int64_t)WIN_MAX_SAMPLES, min(base, (int64_t)P.max_iter + WIN_SAMPLE - 1) / WIN_SAMPLE);
+	bool any_seg = false, big_y = false;
 	for (int k = threadIdx.x; k < PLAN_BLOCK; k += PLAN_THREADS) {
 		const int64_t g = base + k;
-		own_x[k] = g < b.n ? b.x[g] : 0; own_hi[k] = g < b.n ? b.xhi[g] : 0;
+		uint4 v = make_uint4(0, 0, 0, 0);                 // x.lo x.hi y.lo y.hi
+		if (g < b.n) {
+			v = b.raw[g];
+			const unsigned span = v.w & 0xffu;            // y>>32 & 0xff      (lchain.c:125)
+			const unsigned seg = (v.w >> 16) & 0xffu;     // (y & MM_SEED_SEG_MASK) >> 48 (lchain.c:116)
+			b.x[g] = (int32_t)v.x; b.y[g] = (int32_t)v.z; b.tag[g] = (int32_t)(seg << 8 | span);
+			any_seg |= seg != 0;
+			big_y |= v.z >= (1u << 22) || span == 0;
+		}
+		own_x[k] = (int)v.x; own_hi[k] = (int)v.y;
 	}
 	for (int k = threadIdx.x; k < n_samples; k += PLAN_THREADS) {
-		const int64_t g = base - (int64_t)(k + 1) * WIN_SAMPLE;
-		smp_x[k] = b.x[g]; smp_hi[k] = b.xhi[g];
+		const uint2 v = *(const uint2*)&b.raw[base - (int64_t)(k + 1) * WIN_SAMPLE];
+		smp_x[k] = (int)v.x; smp_hi[k] = (int)v.y;
 	}
+	if (__ballot(any_seg) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_ANY_SEGID);
+	if (__ballot(big_y) != 0 && lane_id() == 0) atomicOr(b.flags, FLAG_NO_LUT);
 	__syncthreads();
 	int my_cut = INT_MAX, my_clamp = 0;
 	unsigned long long my_pairs = 0;
@@ -509,7 +502,7 @@ struct Keep { int idx, x, hi, y, tag, f; };   // the remembered best anchor ("ma
 
 // Read-only inputs fetched through the scalar path: a wave-uniform index into constant address space makes the
 // compiler emit s_load_dword* (scalar cache -> SGPRs), which costs no vector-ALU issue slot at all.  Only arrays that no
-// kernel in flight writes may be read this way (x, y, tag: written by k_split_soa in an earlier launch).
+// kernel in flight writes may be read this way (x, y, tag: written by k_window in an earlier launch).
 typedef const int __attribute__((address_space(4))) *scalar_i32_ptr;
 typedef const int __attribute__((address_space(3))) *lds_i32_ptr;
 __device__ __forceinline__ scalar_i32_ptr as_scalar(const void *p) { return (scalar_i32_ptr)(uintptr_t)p; }
@@ -545,7 +538,7 @@ __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 // gfx950 (profiles/ubench) and whatever is read is discarded by the range test.
 // CHECK adds "source inside this target's window" and "dr != 0" (lchain.c:120), which can only fail in the first and last
 // blocks of a sweep: sources of interior blocks lie inside every target's window and strictly left of every target's x.
-// Exact while 128*(f+16) < 2^30 and coordinate differences fit 30 bits: k_split_soa raises FLAG_NO_LUT for query positions
+// Exact while 128*(f+16) < 2^30 and coordinate differences fit 30 bits: k_window raises FLAG_NO_LUT for query positions
 // >= 2^22 (f <= y + q_span always) and the batch then runs the MODE_FAST build.
 template <bool CHECK, bool CLAMP>
 __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty4, int jb, int k_from, const int4 *stage,
@@ -656,7 +649,7 @@ __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce,
 	T.live = i < ce;
 	const int il = T.live ? i : ce - 1;
 	T.x = b.x[il]; T.y = b.y[il]; T.tag = b.tag[il];
-	T.hi = want_hi ? b.xhi[il] : 0;
+	T.hi = want_hi ? (int)((const uint2*)&b.raw[il])->y : 0;   // strand | rid, only the rescue state machine looks at it
 	T.st = T.live ? b.st[il] : INT_MAX;          // dead lanes never activate
 	T.q = T.tag & 0xff; T.seg = T.tag >> 8;
 	return T;
@@ -1031,7 +1024,7 @@ __device__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut,
 // workgroup.  Phase 1b: four 4-wave teams per workgroup pull narrower heavy chunks.  Phase 2: every wave pulls ordinary
 // chunks on its own.  All lists most expensive first; a team enters the next phase as soon as its list is empty.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
-// "some anchor carries a segment id" flag found on the device by k_split_soa).
+// "some anchor carries a segment id" flag found on the device by k_window).
 // LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 7 ]
 // --------------------------------------------------------------------------------------------------------------
 
@@ -1095,14 +1088,6 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 // --------------------------------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------------------------------
-void launch_split_soa(const DevBatch &b, hipStream_t s)
-{
-	if (b.n <= 0) return;
-	int64_t blocks = (b.n + 255) / 256;
-	if (blocks > 256 * 16) blocks = 256 * 16;
-	hipLaunchKernelGGL(k_split_soa, dim3((unsigned)blocks), dim3(256), 0, s, b);
-}
-
 void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s)
 {
 	if (b.n <= 0) return;

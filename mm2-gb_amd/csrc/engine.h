@@ -60,7 +60,7 @@ struct Engine {
 
 	// work arenas (sized by capacity_n / capacity_blocks); one set: kernels of consecutive micro-batches serialise anyway
 	int64_t cap_n = 0, cap_reads = 0, cap_blocks = 0;
-	DevBuf x, y, xhi, tag, st;
+	DevBuf x, y, tag, st;
 	DevBuf blk_firstcut, blk_pairs, blk_clamped, blk_wmax, blk_read;
 	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
 	DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;

@@ -160,7 +160,7 @@ void Engine::shutdown()
 {
 	(void)hipSetDevice(device);
 	for (hipStream_t s : { s_in, stream, s_out }) if (s) (void)hipStreamSynchronize(s);
-	for (DevBuf *b : { &x, &y, &xhi, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
+	for (DevBuf *b : { &x, &y, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
 	                   &chunk_track, &order, &long_list, &mid_list, &blk_wmax, &counters, &totals, &flags, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
 		b->release();
 	for (IoSet &s : io) {
@@ -186,7 +186,7 @@ int Engine::reserve(int64_t n, int64_t n_reads)
 		MM2GB_HIP(hipStreamSynchronize(stream));
 		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
 		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
-		if (x.ensure(nn * 4) || y.ensure(nn * 4) || xhi.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
+		if (x.ensure(nn * 4) || y.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
 		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4) || blk_wmax.ensure(nb * 8) || blk_read.ensure(nb * 4)) return -1;
 		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
 		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || mid_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
@@ -214,7 +214,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	if (want_stats) for (hipEvent_t *e : { &bs.prep0, &bs.prep1, &bs.score1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
 	DevBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
-	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.xhi = (int32_t*)xhi.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
+	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
 	b.f = d_f; b.p = d_p;
 	b.blk_firstcut = (int32_t*)blk_firstcut.ptr; b.blk_pairs = (int64_t*)blk_pairs.ptr; b.blk_clamped = (int32_t*)blk_clamped.ptr; b.blk_wmax = (int32_t*)blk_wmax.ptr; b.blk_read = (int32_t*)blk_read.ptr;
 	b.n_blocks = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
@@ -232,7 +232,6 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	MM2GB_HIP(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(unsigned), stream));
 	if (want_stats) MM2GB_HIP(hipEventRecord(bs.prep0, stream));
 	if (n > 0) {
-		launch_split_soa(b, stream);
 		launch_window(b, params, stream);
 		launch_plan(b, launch, stream);
 	}

@@ -23,7 +23,7 @@ def counters(path, kernel=KERNEL):
     acc, n = collections.defaultdict(float), collections.defaultdict(int)
     rows = []
     for r in csv.DictReader(open(path)):
-        if kernel in r["Kernel_Name"] or "k_split_soa" in r["Kernel_Name"]:
+        if kernel in r["Kernel_Name"] or "k_window" in r["Kernel_Name"]:
             rows.append(r)
         if kernel in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
@@ -40,8 +40,8 @@ for kind in ("fetch", "write"):
     out[kind] = vals
     with open(os.path.join(P, f"{tag}_{kind}_pmc.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-    # calibration: k_split_soa reads 16 B and writes 16 B per anchor
-    split = [r for r in rows if "k_split_soa" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
+    # calibration: k_window reads 16 B per anchor (+ look-back samples and probes) and writes 16 B per anchor
+    split = [r for r in rows if "k_window" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
     out[kind + "_split_kb"] = sum(float(r["Counter_Value"]) for r in split) / max(1, len(split))
 sq = {}
 for grp in ("sq1", "sq2", "lds", "l2"):
@@ -67,12 +67,12 @@ json.dump(sq, open(os.path.join(P, f"{tag}_sq_counters.json"), "w"), indent=1)
 fetch_kb, write_kb = out["fetch"]["FETCH_SIZE"], out["write"]["WRITE_SIZE"]
 traffic = {
     "anchors": anchors, "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-    "k_split_soa_fetch_kb": out["fetch_split_kb"], "k_split_soa_write_kb": out["write_split_kb"],
+    "k_window_fetch_kb": out["fetch_split_kb"], "k_window_write_kb": out["write_split_kb"],
     "source": f"profiles/{tag}_fetch_pmc.csv + {tag}_write_pmc.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {KERNEL} = MODE_LUT, "
-              "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (the x2 is calibrated on k_split_soa in the same run: its 16 B/anchor read shows as 8)",
+              "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (the x2 is calibrated on k_window in the same run: its 16 B/anchor read of the raw anchors shows as ~8)",
     "valu_busy_fraction": round(sq["derived"]["valu_busy"], 3),
     "valu_source": f"profiles/{tag}_sq_counters.json",
 }
 json.dump(traffic, open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps({"kernel_ms": kernel_ms, **sq["derived"], "hbm_GB": traffic["hbm_bytes_per_launch"] / 1e9,
-                  "split_fetch_B_per_anchor": out["fetch_split_kb"] * 1024 / anchors, "split_write_B_per_anchor": out["write_split_kb"] * 1024 / anchors}, indent=1))
+                  "k_window_fetch_B_per_anchor": out["fetch_split_kb"] * 1024 / anchors, "k_window_write_B_per_anchor": out["write_split_kb"] * 1024 / anchors}, indent=1))
