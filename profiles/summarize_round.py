@@ -69,7 +69,7 @@ traffic = {
     "anchors": anchors, "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
     "k_window_fetch_kb": out["fetch_split_kb"], "k_window_write_kb": out["write_split_kb"],
     "source": f"profiles/{tag}_fetch_pmc.csv + {tag}_write_pmc.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {KERNEL} = MODE_LUT, "
-              "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (the x2 is calibrated on k_window in the same run: its 16 B/anchor read of the raw anchors shows as ~8)",
+              "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (the x2 was calibrated on k_split_soa, the pure 16 B-in / 16 B-out kernel of earlier builds, whose read showed as 8 B/anchor: profiles/earlier/r01c_fetch_pmc.csv)",
     "valu_busy_fraction": round(sq["derived"]["valu_busy"], 3),
     "valu_source": f"profiles/{tag}_sq_counters.json",
 }
