@@ -747,10 +747,49 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 		// the state machine of lchain.c:189-205 runs on the scalar side.  Anchor t's fields come by v_readlane: scalar loads
 		// would share the wave's lgkm counter with the LDS reads of every step and expose their latency
 		const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y), stg = as_scalar(b.tag);
+		// In a tile whose windows all start before the tile (the usual case where windows are cut by max_iter) only the anchor
+		// remembered at the tile's START can ever be out of reach or an extra candidate: one remembered later is an anchor of
+		// this tile, hence inside every later window.  What the state machine needs about the entry anchor is computed for all
+		// 64 anchors at once -- which find it out of reach, which have it as extra candidate, that candidate's score -- and a
+		// step costs a few bit tests; after the first update there is nothing to test at all.  The full state machine below
+		// takes over from the first step that needs a rescan (or a cut) until the end of the tile, and runs narrow tiles.
+		enum { ENTRY = 0, IN_TILE = 1, FULL = 2 };
+		unsigned long long slow = 0ull, extra = 0ull;
+		int extra_v = 0;
+		const int keep0 = keep.idx;
+		int mode = FULL;
+		if (keep0 >= 0 && bcast(T.st, n_here - 1) <= i0) {
+			mode = ENTRY;
+			slow = __ballot(!T.live || T.st == i || T.hi != keep.hi || (unsigned)(T.x - keep.x) > (unsigned)P.max_dist_x);
+			// lchain.c:113-138 for (entry anchor -> every anchor of the tile); a distance beyond bw reads the table's "reject"
+			// entry, which keeps the candidate far below any score
+			const int dq = T.y - keep.y, dr = T.x - keep.x, span = keep.tag & 0xff;
+			const int dg = dr < dq ? dr : dq;
+			const unsigned dd = abs_diff_u32(dr, dq);
+			const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
+			const int sc = (span < dg ? span : dg) - (*(lds_i32_ptr)(uintptr_t)(idx << 2) >> 7);
+			extra = __ballot((unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && keep0 < T.st - 1);
+			extra_v = (sc + keep.f) << 7;
+		}
 		StepPre cur = tile_pre<CLAMP>(tl, 0);
 		for (int t = 0; t < n_here; ++t) {
 			const int j = i0 + t;
 			const StepPre nxt = tile_pre<CLAMP>(tl, t + 1 < n_here ? t + 1 : t);
+			if (mode == IN_TILE || (mode == ENTRY && !(slow >> t & 1))) {
+				// lchain.c:196-201 with the precomputed candidate; strict: (V | 127) < 128*cand  <=>  V >> 7 < cand
+				if (mode == ENTRY && (extra >> t & 1)) {
+					const bool take = (lane == t) & ((bestv | 127) < extra_v);
+					bestv = take ? extra_v : bestv;
+					arg = take ? keep0 : arg;
+				}
+				const int s_bv = bcast(bestv, t);
+				const int ft = s_bv >> 7;                                        // lchain.c:202
+				if (keep.f < ft) { keep.idx = j; keep.f = ft; mode = IN_TILE; }  // lchain.c:204-205; its other fields when the tile ends
+				tile_fin(cur, t, s_bv, bestv);
+				cur = nxt;
+				continue;
+			}
+			mode = FULL;                                                         // (only ever from ENTRY: IN_TILE stays in the branch above)
 			const int xt = bcast(T.x, t), yt = bcast(T.y, t), tgt = bcast(T.tag, t), ht = bcast(T.hi, t), stt = bcast(T.st, t);
 			// lchain.c:190-195: the remembered anchor fell out of reach (or none yet): arg-max of f over the window,
 			// largest index among equals.  An empty window (stt == j) is a natural cut, where the host's scan finds nothing
@@ -776,8 +815,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;
 				}
 			}
-			// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf);
-			// strict: it replaces lane t's score only if larger, (V | 127) < 128*cand  <=>  V >> 7 < cand
+			// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf)
 			if (keep.idx >= 0 && keep.idx < stt - 1) {
 				int sc;
 				if (pair_score_uniform(P, xt, yt, keep.x, keep.y, keep.tag, sc)) {
@@ -793,6 +831,10 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			if (keep.idx < 0 || keep.f < ft) { keep.idx = j; keep.x = xt; keep.hi = ht; keep.y = yt; keep.tag = tgt; keep.f = ft; }
 			tile_fin(cur, t, s_bv, bestv);
 			cur = nxt;
+		}
+		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile
+			const int k = keep.idx - i0;
+			keep.x = bcast(T.x, k); keep.y = bcast(T.y, k); keep.tag = bcast(T.tag, k); keep.hi = bcast(T.hi, k);
 		}
 	}
 	const int won = bestv & 127;                            // 1..64: source won-1 of this tile; 0: an earlier anchor; 127: none
