@@ -672,6 +672,7 @@ struct TileLut {
 	int tx4, ty4, lo;
 	unsigned lim4, last4;
 	const int4 *stage;
+	bool edges;              // some window starts inside the tile, or two of its anchors share a reference position
 };
 
 // Source t against the lanes above it, in two parts.  tile_pre: everything that does not depend on scores -- LDS broadcast of
@@ -691,7 +692,8 @@ __device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
 	StepPre pre;
 	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) - pen;
 	const unsigned long long above = t < WAVE - 1 ? ~0ull << (t + 1) : 0ull;
-	pre.ok = __ballot((unsigned)dqm < tl.lim4) & __ballot(drm != -4) & __ballot(tl.lo <= t) & above;
+	pre.ok = __ballot((unsigned)dqm < tl.lim4) & above;
+	if (tl.edges) pre.ok &= __ballot(drm != -4) & __ballot(tl.lo <= t);   // wave-uniform: most tiles of wide-window chunks skip both
 	return pre;
 }
 
@@ -727,6 +729,11 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	tl.lo = T.live ? (T.st > i0 ? T.st - i0 : 0) : WAVE;    // first in-tile source inside this lane's window
 	tl.lim4 = (unsigned)P.dq_lim << 2; tl.last4 = (unsigned)P.lut_last << 2;
 	tl.stage = stage;
+	// "source inside this lane's window" and "dr != 0" (lchain.c:120) cannot fail when every window starts before the tile
+	// (then all its anchors share strand|rid and are sorted by position, so equal positions are neighbours) and no two
+	// neighbours are equal.  Lanes past the end of the chunk may then accept anything: they are never stored nor broadcast.
+	const int x_prev = __shfl_up(T.x, 1);
+	tl.edges = __ballot(T.live && (T.st > i0 || (lane > 0 && T.x == x_prev))) != 0;
 	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
