@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("seeds", type=int, nargs="+")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--teams", action="store_true")
+ap.add_argument("--big", type=int, default=0, help="per seed, also this many batches of bench-like reads (10-100 kb, ~1-2 M anchors) with random parameters")
 args = ap.parse_args()
 out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
@@ -57,6 +58,32 @@ for seed in args.seeds:
             break
     else:
         print("seed", seed, "clean over", args.iters, "batches", flush=True)
+    if failed:
+        break
+    # many planning blocks per read, look-back across blocks, every list of the planner in one batch
+    for it in range(args.big):
+        a, off = mm.synth_reads(seed * 1000 + it, 0, int(rng.integers(8, 40)), 10_000, 100_000, threads=8)
+        kw = dict(max_iter=int(rng.choice([100, 1000, 5000, 20000])), bw=int(rng.choice([100, 500, 2000])),
+                  max_dist_x=int(rng.choice([1000, 5000, 10000])), max_dist_y=int(rng.choice([1000, 5000, 10000])),
+                  pen_gap=np.float32(rng.choice([0.12, 0.19])), pen_skip=np.float32(0.0))
+        prm = orc.default_param(**kw)
+        fo, po, pairs = orc.chain_fill_many(a, off, prm, threads=16)
+        po_rel = np.concatenate([rel(po[off[r]:off[r + 1]]) for r in range(len(off) - 1)])
+        for name, eng in engines:
+            eng.set_misc(misc_from(prm))
+            f, p, st = eng.score(a, off)
+            bad = np.flatnonzero((f != fo) | (p != po_rel))
+            if bad.size or st["n_pairs"] != pairs:
+                plain = {k: float(v) for k, v in kw.items()}
+                print("BIG engine", name, "seed", seed, "iteration", it, "differs at", bad[:10], "pairs", st["n_pairs"], pairs, "parameters", plain, "stats", st, flush=True)
+                np.savez(os.path.join(out_dir, f"fuzz_fail_big_{name}_{seed}_{it}.npz"), a=a, off=off, f=f, p=p, kw=json.dumps(plain))
+                failed = True
+                break
+        if failed:
+            break
+    else:
+        if args.big:
+            print("seed", seed, "clean over", args.big, "large batches", flush=True)
     if failed:
         break
 print("chunks sent to big / 4-wave teams per engine:", seen)
