@@ -19,12 +19,25 @@ void set_error(const std::string &msg) { g_err = msg; }
 int fail(const std::string &msg) { g_err = msg; return -1; }
 const char *last_error_cstr() { return g_err.c_str(); }
 
+// Buffers only grow.  A buffer that has to grow again takes a quarter more than asked for: batches of slowly increasing size
+// (reads differ) would otherwise reallocate -- and, for page-locked memory, re-pin at ~0.4 s per GB -- at every new maximum.
+static size_t grown(size_t need, size_t have)
+{
+	return have == 0 ? need : std::max(need, have + have / 4);
+}
+
 int DevBuf::ensure(size_t need)
 {
 	if (need <= bytes) return 0;
+	const size_t want = grown(need, bytes);
 	release();
-	MM2GB_HIP(hipMalloc(&ptr, need));
-	bytes = need;
+	if (hipMalloc(&ptr, want) != hipSuccess) {        // no room for the slack: take exactly what is needed
+		(void)hipGetLastError();
+		MM2GB_HIP(hipMalloc(&ptr, need));
+		bytes = need;
+		return 0;
+	}
+	bytes = want;
 	return 0;
 }
 void DevBuf::release()
@@ -36,9 +49,15 @@ void DevBuf::release()
 int PinnedBuf::ensure(size_t need)
 {
 	if (need <= bytes) return 0;
+	const size_t want = grown(need, bytes);
 	release();
-	MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
-	bytes = need;
+	if (hipHostMalloc(&ptr, want, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
+		bytes = need;
+		return 0;
+	}
+	bytes = want;
 	return 0;
 }
 void PinnedBuf::release()

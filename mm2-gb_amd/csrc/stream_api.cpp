@@ -4,6 +4,7 @@
 //     same deferred hand-back protocol (launch batch k, return batch k-1 finished), one engine per stream/thread id.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <chrono>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -83,7 +84,13 @@ static struct {
 	mm2gb_misc_t   misc;
 	int  post_threads = 1;
 	bool ready = false;
+	bool debug = false;                    // MM2GB_DEBUG_PHASES: where a batch's host time goes, on stderr
 } g_streams;
+
+static double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 [[noreturn]] static void die(const std::string &msg)
 {
@@ -117,7 +124,9 @@ static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_r
 	*reads_out = nullptr; *n_out = 0;
 	if (!st.busy) return 0;
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
+	const double t0 = now_ms();
 	MM2GB_HIP(hipEventSynchronize(st.done));
+	const double t_wait = now_ms();
 	mm2gb_chain_read_t *reads = st.reads;
 	const int n_read = st.n_read;
 	const int64_t *off = st.goff.data();
@@ -131,6 +140,7 @@ static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_r
 	parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &ws) {
 		nu_of[r] = backtrack_compact(misc, reads[r].n, reads[r].a, f + off[r], p + off[r], libc_mem, ws, &u_of[r], &a_of[r]);
 	});
+	const double t_post = now_ms();
 	// hand-over on the calling thread: kalloc arenas are not thread-safe, so results move into the host's arena here
 	for (int r = 0; r < n_read; ++r) {
 		mm2gb_chain_read_t &rd = reads[r];
@@ -149,6 +159,9 @@ static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_r
 	}
 	st.busy = false; st.reads = nullptr; st.n_read = 0;
 	*reads_out = reads; *n_out = n_read;
+	if (g_streams.debug)
+		fprintf(stderr, "[mm2gb stream] finish: %d reads, %lld anchors | wait for scores %.2f ms | post-pass %.2f ms | hand-over %.2f ms\n",
+		        n_read, (long long)off[n_read], t_wait - t0, t_post - t_wait, now_ms() - t_post);
 	return 0;
 }
 
@@ -157,6 +170,7 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 {
 	int64_t total = 0;
 	for (int r = 0; r < n_read; ++r) total += reads[r].n > 0 ? reads[r].n : 0;
+	const double t0 = now_ms();
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
 	if (!st.done) MM2GB_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
 	if (st.h_raw.ensure((size_t)(total + 1) * 16) || st.h_f.ensure((size_t)(total + 1) * 4) || st.h_p.ensure((size_t)(total + 1) * 4)) return -1;
@@ -170,6 +184,7 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 		const int64_t n = off[r + 1] - off[r];
 		if (n) memcpy(raw + off[r], reads[r].a, (size_t)n * 16);
 	});
+	const double t_pack = now_ms();
 	// micro-batches: greedy split so each holds at most max_total_n anchors (plchain.cu:356-366); unlike the reference
 	// nothing is ever sent back to the CPU -- a batch simply takes as many micro-batches as it needs
 	const int64_t cap = g_streams.cfg.max_total_n > 0 ? g_streams.cfg.max_total_n : total;
@@ -195,6 +210,9 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 	}
 	if (slot.eng.record_outputs_done(st.done)) return -1;
 	st.reads = reads; st.n_read = n_read; st.busy = true;
+	if (g_streams.debug)
+		fprintf(stderr, "[mm2gb stream] launch: %d reads, %lld anchors, %zu micro-batch(es) | pack %.2f ms | enqueue %.2f ms\n",
+		        n_read, (long long)total, n_mb, t_pack - t0, now_ms() - t_pack);
 	return 0;
 }
 
@@ -277,6 +295,7 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	// host threads for packing anchors and for backtrack + compaction; results enter the host's kalloc arena on the calling
 	// thread only, so this is safe with the single-threaded reference host
 	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 2));
+	{ const char *dbg = getenv("MM2GB_DEBUG_PHASES"); g_streams.debug = dbg && *dbg && *dbg != '0'; }
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
 	for (int s = 0; s < cfg.num_streams; ++s) {

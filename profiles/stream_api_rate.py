@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Throughput of the drop-in boundary (chain_stream_gpu, deferred hand-back) driven without a minimap2 host: batches of
+chain_read_t records of a given size, one stream.  What a batch costs end to end (pack, H2D, kernels, D2H, host post-pass,
+results into malloc'd arrays) and where the time goes.   python profiles/stream_api_rate.py [--reads-per-batch 64 ...]"""
+import argparse, ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import mm2gb_amd as mm
+from test_gpu_stream_api import ChainRead, libc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stream_api_rate.json"))
+args = ap.parse_args()
+L = mm.lib()
+L.init_stream_gpu.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, mm.Misc]
+L.chain_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+L.finish_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+L.free_stream_gpu.argtypes = [C.c_int]
+mt, mr, mn = C.c_size_t(0), C.c_int(0), C.c_int(0)
+L.init_stream_gpu(C.byref(mt), C.byref(mr), C.byref(mn), os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json").encode(), mm.default_misc())
+
+
+def release(ptr, n):
+    arr = C.cast(ptr, C.POINTER(ChainRead))
+    chains = 0
+    for k in range(n):
+        r = arr[k]
+        chains += r.n_u
+        if r.n_u > 0:
+            libc.free(r.u); libc.free(r.a)
+    return chains
+
+
+rows = []
+for reads_per_batch, lo, hi, n_batches in ((64, 10_000, 100_000, 24), (512, 10_000, 100_000, 8), (4096, 10_000, 100_000, 3), (64, 100_000, 300_000, 12)):
+    anchors, off = mm.synth_reads(77, 0, reads_per_batch * n_batches, lo, hi, threads=16)
+    batches = []
+    for bi in range(n_batches):
+        arr = (ChainRead * reads_per_batch)()
+        for k in range(reads_per_batch):
+            r = bi * reads_per_batch + k
+            a = anchors[off[r]:off[r + 1]]
+            buf = libc.malloc(max(a.nbytes, 16))
+            C.memmove(buf, a.ctypes.data, a.nbytes)
+            arr[k].a, arr[k].n, arr[k].n_seg = buf, len(a), 1
+        batches.append(arr)
+    n_anch = int(off[-1])
+
+    def fresh_batches():
+        out = []
+        for bi in range(n_batches):
+            arr = (ChainRead * reads_per_batch)()
+            for k in range(reads_per_batch):
+                r = bi * reads_per_batch + k
+                a = anchors[off[r]:off[r + 1]]
+                buf = libc.malloc(max(a.nbytes, 16))
+                C.memmove(buf, a.ctypes.data, a.nbytes)
+                arr[k].a, arr[k].n, arr[k].n_seg = buf, len(a), 1
+            out.append(arr)
+        return out
+
+    # warm-up pass: staging buffers get their size (page-locking is a one-time cost); then the timed pass on fresh copies
+    for arr in batches:
+        ptr, n = C.c_void_p(C.addressof(arr)), C.c_int(reads_per_batch)
+        L.chain_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+        if ptr.value:
+            release(ptr.value, n.value)
+    ptr, n = C.c_void_p(0), C.c_int(0)
+    L.finish_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+    release(ptr.value, n.value)
+    batches = fresh_batches()
+    t0 = time.perf_counter()
+    chains = 0
+    for arr in batches:
+        ptr, n = C.c_void_p(C.addressof(arr)), C.c_int(reads_per_batch)
+        L.chain_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+        if ptr.value:
+            chains += release(ptr.value, n.value)
+    ptr, n = C.c_void_p(0), C.c_int(0)
+    L.finish_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+    chains += release(ptr.value, n.value)
+    dt = time.perf_counter() - t0
+    rows.append({"reads_per_batch": reads_per_batch, "read_len": [lo, hi], "batches": n_batches, "anchors": n_anch, "anchors_per_batch": n_anch // n_batches,
+                 "seconds": round(dt, 4), "ms_per_batch": round(dt * 1e3 / n_batches, 2), "anchors_per_s": n_anch / dt, "chains": chains})
+    print(rows[-1], flush=True)
+L.free_stream_gpu(1)
+json.dump({"post_threads": os.environ.get("MM2GB_POST_THREADS", "default"), "rows": rows}, open(args.out, "w"), indent=1)
