@@ -50,6 +50,11 @@ KERNEL(k_mad_i24,  asm volatile("v_mad_i32_i24 %0, %1, 32, %0\n v_mad_i32_i24 %2
 KERNEL(k_mad_i24v, asm volatile("v_mad_i32_i24 %0, %1, %2, %0\n v_mad_i32_i24 %2, %3, %1, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
 KERNEL(k_sub_co,   asm volatile("v_sub_co_u32 %0, vcc, %1, %0\n v_sub_co_u32 %2, vcc, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "vcc");)
 KERNEL(k_max3_i32, asm volatile("v_max3_i32 %0, %1, %0, %2\n v_max3_i32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+// same-address (broadcast) LDS reads of growing width: what one source broadcast of the score sweep costs the LDS pipe
+KERNEL(k_ds_b32_bc,  { int t; asm volatile("ds_read_b32 %0, %1\n ds_read_b32 %0, %1 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v4 & 0x3f) << 4)); v1 ^= t; })
+KERNEL(k_ds_b64_bc,  { long long t; asm volatile("ds_read_b64 %0, %1\n ds_read_b64 %0, %1 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v4 & 0x3f) << 4)); v1 ^= (int)t; })
+KERNEL(k_ds_b96_bc,  { int t0; int t1; int t2; asm volatile("ds_read_b96 v[40:42], %3\n ds_read_b96 v[40:42], %3 offset:16\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n v_mov_b32 %2, v42" : "=v"(t0), "=v"(t1), "=v"(t2) : "v"((v4 & 0x3f) << 4) : "v40", "v41", "v42"); v1 ^= t0 + t1 + t2; })
+KERNEL(k_ds_b128_bc, { int t0; int t1; asm volatile("ds_read_b128 v[40:43], %2\n ds_read_b128 v[40:43], %2 offset:16\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v40\n v_mov_b32 %1, v43" : "=v"(t0), "=v"(t1) : "v"((v4 & 0x3f) << 4) : "v40", "v41", "v42", "v43"); v1 ^= t0 + t1; })
 KERNEL(k_ds_read,  { int t; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v0 & 0xff) << 2)); v1 ^= t; })
 KERNEL(k_ds_read_nw, { int t; int u; asm volatile("ds_read_b32 %0, %2\n ds_read_b32 %1, %2 offset:4" : "=v"(t), "=v"(u) : "v"((v0 & 0xff) << 2)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v1 ^= t + u; })
 
@@ -77,7 +82,7 @@ int main()
 		{"v_cmp_gt_u32 vcc", k_cmp_u32}, {"v_cmp_gt_u32 sgpr", k_cmp_e64}, {"v_readlane_b32", k_readlane}, {"v_mov_b32", k_mov},
 		{"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_min_f32", k_min_f32}, {"v_cmp_gt_f32", k_cmp_f32}, {"v_cvt_f32_i32", k_cvt_i2f},
 		{"v_pk_add_f32", k_pk_add_f32}, 
-		{"v_sub_u32 sgpr src", k_sub_sgpr}, {"v_subrev_u32 sgpr src", k_subrev_sgpr}, {"v_cmp vcc, sgpr, v", k_cmp_sgpr}, {"v_min3_i32 sgpr src", k_min3_sgpr}, {"v_cmp + v_cndmask (2 instr)", k_cmp_cnd}, {"v_cndmask indep", k_cnd_only}, {"v_readlane + v_add using it", k_readlane_use}, {"v_mad_u32_u24 (x32 literal)", k_mad_u24}, {"v_mad_i32_i24 (x32 literal)", k_mad_i24}, {"v_mad_i32_i24 (vgpr)", k_mad_i24v}, {"v_sub_co_u32", k_sub_co}, {"v_max3_i32", k_max3_i32}, {"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
+		{"v_sub_u32 sgpr src", k_sub_sgpr}, {"v_subrev_u32 sgpr src", k_subrev_sgpr}, {"v_cmp vcc, sgpr, v", k_cmp_sgpr}, {"v_min3_i32 sgpr src", k_min3_sgpr}, {"v_cmp + v_cndmask (2 instr)", k_cmp_cnd}, {"v_cndmask indep", k_cnd_only}, {"v_readlane + v_add using it", k_readlane_use}, {"v_mad_u32_u24 (x32 literal)", k_mad_u24}, {"v_mad_i32_i24 (x32 literal)", k_mad_i24}, {"v_mad_i32_i24 (vgpr)", k_mad_i24v}, {"v_sub_co_u32", k_sub_co}, {"v_max3_i32", k_max3_i32}, {"ds_read_b32 broadcast x2", k_ds_b32_bc}, {"ds_read_b64 broadcast x2", k_ds_b64_bc}, {"ds_read_b96 broadcast x2", k_ds_b96_bc}, {"ds_read_b128 broadcast x2", k_ds_b128_bc}, {"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
 	};
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	{
