@@ -411,6 +411,10 @@ constexpr int SCORE_THREADS = 1024;
 #define MM2GB_SWEEP_GROUP 4
 #endif
 constexpr int SWEEP_GROUP = MM2GB_SWEEP_GROUP;
+#ifndef MM2GB_PAIR_SWEEP_GROUP
+#define MM2GB_PAIR_SWEEP_GROUP 2
+#endif
+constexpr int PAIR_SWEEP_GROUP = MM2GB_PAIR_SWEEP_GROUP;   // sources per unrolled group of the two-tile sweep
 constexpr int LUT_REJECT = 1 << 30;     // in the x128 score domain of the LUT sweep: 128*(f+16) < 2^30 is guaranteed there (FLAG_NO_LUT)
 
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
@@ -541,7 +545,7 @@ __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 // Exact while 128*(f+16) < 2^30 and coordinate differences fit 30 bits: k_window raises FLAG_NO_LUT for query positions
 // >= 2^22 (f <= y + q_span always) and the batch then runs the MODE_FAST build.
 template <bool CHECK, bool CLAMP>
-__device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty4, int jb, int k_from, const int4 *stage,
+__device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage,
                                                 const DevParams &P, const int *lut, int &bestv)
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
@@ -571,7 +575,7 @@ __device__ __forceinline__ void sweep_block_lut(const Target &T, int tx4, int ty
 				             : [b] "+v"(bestv) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
 			} else {
 				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
-				const bool take = ((unsigned)dqm[u] < lim4) & (v > bestv) & (drm[u] != -4) & (j0 + u >= T.st);
+				const bool take = ((unsigned)dqm[u] < lim4) & (v > bestv) & (drm[u] != -4) & (j0 + u >= t_st);
 				bestv = take ? v : bestv;
 			}
 		}
@@ -602,6 +606,77 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 	}
 }
 
+// MODE_LUT: a block's 64 sources go to this wave's LDS scratch once ...
+__device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
+{
+	const int k = lane_id(), js = jb + k;
+	stage[k] = make_int4(((sf + 1) << 7) + k + 1, (sq - 1) * 4, (int)((unsigned)b.x[js] << 2), (int)((unsigned)b.y[js] << 2));
+	__builtin_amdgcn_wave_barrier();                        // LDS is in-order per wave; keep the compiler from reordering
+}
+// ... and are swept against one tile ...
+struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
+__device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, const int4 *stage, const DevParams &P,
+                                                 int &best, int &arg)
+{
+	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
+	int bestv = best << 7;
+	if (P.lut_clamp) {
+		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
+		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
+	} else {
+		if (no_check) sweep_block_lut<false, false>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
+		else sweep_block_lut<true, false>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
+	}
+	const int won = bestv & 127;                            // k+1 of the source that holds the best, 0 = none of this block
+	arg = won ? jb + won - 1 : arg;
+	best = bestv >> 7;
+}
+// ... or against two tiles at once: one LDS broadcast read per source serves 128 targets (the LDS pipe, one per CU, is as
+// busy as the vector ALUs in the one-tile sweep).  Only for blocks that need neither window nor equal-position tests.
+template <bool CLAMP>
+__device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int tyb, const int4 *stage, const DevParams &P, int &bva, int &bvb)
+{
+	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
+	const unsigned long long all_lanes = __builtin_amdgcn_read_exec();
+	constexpr int G = PAIR_SWEEP_GROUP;
+	for (int kg = 0; kg < WAVE; kg += G) {
+		int4 s4[G];
+		int dqa[G], dra[G], pa[G], dqb[G], drb[G], pb[G];
+#pragma unroll
+		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
+			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
+			const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
+			pa[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (da < last4 ? da : last4) : da);
+			pb[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (db < last4 ? db : last4) : db);
+		}
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			const int ga = dra[u] < dqa[u] ? dra[u] : dqa[u], gb = drb[u] < dqb[u] ? drb[u] : dqb[u];
+			const int va = ((s4[u].y < ga ? s4[u].y : ga) << 5) + s4[u].x - pa[u];
+			const int vb = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x - pb[u];
+			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
+			             : [b] "+v"(bva) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqa[u]), [v] "v"(va) : "vcc");
+			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
+			             : [b] "+v"(bvb) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqb[u]), [v] "v"(vb) : "vcc");
+		}
+	}
+}
+__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, const int4 *stage, const DevParams &P,
+                                                  int &best_a, int &arg_a, int &best_b, int &arg_b)
+{
+	const int txa = (int)(((unsigned)TA.x - 1u) << 2), tya = (int)(((unsigned)TA.y - 1u) << 2);
+	const int txb = (int)(((unsigned)TB.x - 1u) << 2), tyb = (int)(((unsigned)TB.y - 1u) << 2);
+	int bva = best_a << 7, bvb = best_b << 7;
+	if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
+	else sweep_block_lut2<false>(txa, tya, txb, tyb, stage, P, bva, bvb);
+	const int wa = bva & 127, wb = bvb & 127;
+	arg_a = wa ? jb + wa - 1 : arg_a; best_a = bva >> 7;
+	arg_b = wb ? jb + wb - 1 : arg_b; best_b = bvb >> 7;
+}
+
 // Sweep of one full source block for either build.  `stage` is this wave's 64-entry LDS scratch (MODE_LUT only).
 // no_check: every source of the block is inside every live target's window and left of every target's x.
 template <int MODE>
@@ -609,21 +684,9 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		const int k = lane_id(), js = jb + k;
-		stage[k] = make_int4(((sf + 1) << 7) + k + 1, (sq - 1) * 4, (int)((unsigned)b.x[js] << 2), (int)((unsigned)b.y[js] << 2));
-		__builtin_amdgcn_wave_barrier();                    // LDS is in-order per wave; keep the compiler from reordering
-		const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
-		int bestv = best << 7;
-		if (P.lut_clamp) {
-			if (no_check) sweep_block_lut<false, true>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
-			else sweep_block_lut<true, true>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
-		} else {
-			if (no_check) sweep_block_lut<false, false>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
-			else sweep_block_lut<true, false>(T, tx4, ty4, jb, k_from, stage, P, lut, bestv);
-		}
-		const int won = bestv & 127;                        // k+1 of the source that holds the best, 0 = none of this block
-		arg = won ? jb + won - 1 : arg;
-		best = bestv >> 7;
+		stage_block_lut(b, jb, sf, sq, stage);
+		const TileXY xy = { T.x, T.y, T.st };
+		sweep_staged_lut(xy, jb, k_from, no_check, stage, P, best, arg);
 		__builtin_amdgcn_wave_barrier();
 	} else {
 		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
@@ -663,8 +726,11 @@ __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce,
 // The four acceptance tests are ballots combined on the scalar side with "lane > t", and one v_cndmask takes the mask.
 __device__ __forceinline__ int select_lanes(unsigned long long mask, int yes, int no)
 {
+	// a wave-uniform value may still sit in vector registers when scalar registers are short: make sure of the class
+	const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask >> 32));
+	const unsigned long long m = (unsigned long long)hi << 32 | lo;
 	int r;
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(mask));
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(m));
 	return r;
 }
 
@@ -681,13 +747,12 @@ struct TileLut {
 // scalar or/add -> v_add -> v_cmp -> select.  The chain is what bounds a team: tile t+1 cannot finish before tile t has.
 struct StepPre { int basev; unsigned long long ok; };
 
-template <bool CLAMP>
 __device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
 {
 	const int4 s4 = tl.stage[t];
 	const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
 	const unsigned dd4 = abs_diff_u32(drm, dqm);
-	const int pen = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (dd4 < tl.last4 ? dd4 : tl.last4) : dd4);
+	const int pen = *(lds_i32_ptr)(uintptr_t)(dd4 < tl.last4 ? dd4 : tl.last4);   // always clamped here: one code path, one instruction more
 	const int dg = drm < dqm ? drm : dqm;
 	StepPre pre;
 	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) - pen;
@@ -717,7 +782,7 @@ __device__ __forceinline__ bool pair_score_uniform(const DevParams &P, int xi, i
 	return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && dd <= P.bw;
 }
 
-template <bool TRACK, bool CLAMP, typename FOld>
+template <bool TRACK, typename FOld>
 __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, int4 *stage,
                                             int &best, int &arg, Keep &keep, FOld f_old)
 {
@@ -740,11 +805,11 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 		unsigned long long need = __ballot(T.live && T.st < i) >> 1;
 		if (need) {
 			int t = __builtin_ctzll(need);
-			StepPre cur = tile_pre<CLAMP>(tl, t);
+			StepPre cur = tile_pre(tl, t);
 			for (;;) {
 				need &= need - 1;
 				const int tn = need ? __builtin_ctzll(need) : t;
-				const StepPre nxt = tile_pre<CLAMP>(tl, tn);
+				const StepPre nxt = tile_pre(tl, tn);
 				tile_fin(cur, t, bcast(bestv, t), bestv);
 				if (!need) break;
 				cur = nxt; t = tn;
@@ -778,10 +843,10 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			extra = __ballot((unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && keep0 < T.st - 1);
 			extra_v = (sc + keep.f) << 7;
 		}
-		StepPre cur = tile_pre<CLAMP>(tl, 0);
+		StepPre cur = tile_pre(tl, 0);
 		for (int t = 0; t < n_here; ++t) {
 			const int j = i0 + t;
-			const StepPre nxt = tile_pre<CLAMP>(tl, t + 1 < n_here ? t + 1 : t);
+			const StepPre nxt = tile_pre(tl, t + 1 < n_here ? t + 1 : t);
 			if (mode == IN_TILE || (mode == ENTRY && !(slow >> t & 1))) {
 				// lchain.c:196-201 with the precomputed candidate; strict: (V | 127) < 128*cand  <=>  V >> 7 < cand
 				if (mode == ENTRY && (extra >> t & 1)) {
@@ -858,8 +923,7 @@ __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int 
                                         int &best, int &arg, Keep &keep, FOld f_old)
 {
 	if (MODE == MODE_LUT) {
-		if (P.lut_clamp) in_tile_lut<TRACK, true>(b, T, i0, n_here, P, stage, best, arg, keep, f_old);
-		else in_tile_lut<TRACK, false>(b, T, i0, n_here, P, stage, best, arg, keep, f_old);
+		in_tile_lut<TRACK>(b, T, i0, n_here, P, stage, best, arg, keep, f_old);
 		return;
 	}
 	const int lane = lane_id(), i = i0 + lane;
@@ -927,7 +991,7 @@ __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int 
 
 // ---- wave mode: one wave owns the chunk [cs, ce) --------------------------------------------------------------
 template <int MODE, bool TRACK>
-__device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, const int cs, const int ce)
+__device__ __forceinline__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, const int cs, const int ce)
 {
 	const int lane = lane_id();
 	Keep keep; keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
@@ -955,6 +1019,109 @@ __device__ void run_chunk(const DevBatch &b, const DevParams &P, const int *lut,
 			const int i = i0 + lane;
 			b.f[i] = arg < 0 ? T.q : best;
 			b.p[i] = arg < 0 ? 0 : i - arg;
+		}
+	}
+}
+
+// ---- table build: a wave works on TWO consecutive tiles at a time (A: anchors i0.., B: the 64 after them) ----------------
+// Blocks that lie inside every window of both tiles -- all but the edges of a sweep -- are swept against both at once, one
+// LDS broadcast read per source for 128 targets.  Edge blocks are staged once and swept per tile with the checked build.
+// Then tile A's in-tile phase, tile A as a source block for tile B, tile B's in-tile phase.
+// Registers are what limits the pair (64 VGPRs for 8 waves per SIMD): during the sweeps a tile is three values per lane plus
+// its running best; the rest of an anchor (span, strand|rid) is fetched again when the tile's in-tile phase starts.
+struct TilePair {
+	TileXY A, B;
+	int n_a, n_b;            // live anchors (n_b = 0: the chunk ends within A)
+	int lo_a, hi_a, lo_b, hi_b;   // smallest / largest window start of each tile
+	int best_a, arg_a, best_b, arg_b;
+};
+
+__device__ __forceinline__ TileXY load_xy(const DevBatch &b, int i0, int ce, int &best)
+{
+	const int i = i0 + lane_id();
+	const bool live = i < ce;
+	const int il = live ? i : ce - 1;
+	TileXY t;
+	t.x = b.x[il]; t.y = b.y[il];
+	t.st = live ? b.st[il] : INT_MAX;
+	best = (b.tag[il] & 0xff) + 1;                  // threshold form: nothing beats q_span without exceeding it
+	return t;
+}
+
+__device__ __forceinline__ TilePair load_pair(const DevBatch &b, int i0, int ce)
+{
+	TilePair t;
+	t.n_a = min(WAVE, ce - i0);
+	t.n_b = max(0, min(WAVE, ce - i0 - WAVE));
+	t.A = load_xy(b, i0, ce, t.best_a);
+	t.B = load_xy(b, t.n_b ? i0 + WAVE : i0, ce, t.best_b);
+	t.lo_a = first_lane(t.A.st); t.hi_a = bcast(t.A.st, t.n_a - 1);
+	t.lo_b = t.n_b ? first_lane(t.B.st) : INT_MAX; t.hi_b = t.n_b ? bcast(t.B.st, t.n_b - 1) : INT_MAX;
+	t.arg_a = -1; t.arg_b = -1;
+	return t;
+}
+
+// one staged block of sources before tile A against the pair
+__device__ __forceinline__ void sweep_pair_block(TilePair &t, int jb, int eq_lo, const int4 *stage, const DevParams &P)
+{
+	const bool nc_a = jb >= t.hi_a && jb + WAVE <= eq_lo;
+	const bool use_b = t.n_b > 0 && jb + WAVE > t.lo_b;                      // the block reaches into B's windows
+	const bool nc_b = use_b && jb >= t.hi_b && jb + WAVE <= eq_lo;           // (sources left of A are left of B, or share A's first x)
+	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
+	else {
+		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, stage, P, t.best_a, t.arg_a);
+		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, stage, P, t.best_b, t.arg_b);
+	}
+	__builtin_amdgcn_wave_barrier();
+}
+
+// tile A (final scores f_a, one per lane) as the last source block of tile B
+__device__ __forceinline__ void sweep_a_into_b(const DevBatch &b, TilePair &t, int cs, int i0, int f_a, int q_a, int4 *stage, const DevParams &P)
+{
+	if (i0 + WAVE <= t.lo_b) return;                                           // no window of B reaches into A
+	stage_block_lut(b, i0, f_a, q_a, stage);
+	const int eq_lo = equal_x_run_start(b, cs, i0 + WAVE, first_lane(t.B.x));
+	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, i0 >= t.hi_b && i0 + WAVE <= eq_lo, stage, P, t.best_b, t.arg_b);
+	__builtin_amdgcn_wave_barrier();
+}
+
+template <bool TRACK>
+__device__ __forceinline__ void run_chunk_pairs(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, const int cs, const int ce)
+{
+	const int lane = lane_id();
+	Keep keep; keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
+	auto f_old = [&](int jj) { return b.f[jj]; };
+	for (int i0 = cs; i0 < ce; i0 += 2 * WAVE) {
+		TilePair t = load_pair(b, i0, ce);
+		int jb = cs + ((t.lo_a - cs) & ~(WAVE - 1));
+		if (jb < i0) {
+			const int eq_lo = equal_x_run_start(b, cs, i0, first_lane(t.A.x));
+			int sf = b.f[jb + lane], sq = b.tag[jb + lane] & 0xff;
+			for (; jb < i0; jb += WAVE) {
+				// next block's scores are requested before this block is consumed
+				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
+				const int nf = b.f[jn], nq = b.tag[jn] & 0xff;
+				stage_block_lut(b, jb, sf, sq, stage);
+				sweep_pair_block(t, jb, eq_lo, stage, P);
+				sf = nf; sq = nq;
+			}
+		}
+		const Target TA = load_target(b, i0, ce, TRACK);
+		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);
+		const int f_a = t.arg_a < 0 ? TA.q : t.best_a;
+		if (TA.live) {
+			const int i = i0 + lane;
+			b.f[i] = f_a;
+			b.p[i] = t.arg_a < 0 ? 0 : i - t.arg_a;
+		}
+		if (t.n_b == 0) break;
+		sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);
+		const Target TB = load_target(b, i0 + WAVE, ce, TRACK);
+		in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);
+		if (TB.live) {
+			const int i = i0 + WAVE + lane;
+			b.f[i] = t.arg_b < 0 ? TB.q : t.best_b;
+			b.p[i] = t.arg_b < 0 ? 0 : i - t.arg_b;
 		}
 	}
 }
@@ -987,7 +1154,7 @@ __device__ __forceinline__ void team_barrier(CoopShared *sh, int team_size)
 }
 
 template <int MODE, bool TRACK>
-__device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int n_slots, CoopShared *sh,
+__device__ __forceinline__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int n_slots, CoopShared *sh,
                            const int cs, const int ce, const int wave, const int n_waves)
 {
 	const int lane = lane_id();
@@ -1037,12 +1204,72 @@ __device__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut
 	}
 }
 
+// Team mode of the table build: waves take PAIRS of tiles round-robin (run_chunk_pairs explains the pair).  Tile A is published as
+// soon as it is final, so the chain through the tiles of the chunk is as long as with single tiles.
+template <bool TRACK>
+__device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int n_slots, CoopShared *sh,
+                                 const int cs, const int ce, const int wave, const int n_waves)
+{
+	const int lane = lane_id();
+	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
+	auto wait_done = [&](int need) {
+		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(32);
+	};
+	auto f_old = [&](int jj) { const unsigned d = (unsigned)(jj - cs); return ring[(d / WAVE) % (unsigned)n_slots * WAVE + d % WAVE]; };
+	for (int pr = wave; 2 * pr < n_tiles; pr += n_waves) {
+		const int ta = 2 * pr, i0 = cs + ta * WAVE;              // tile A = tile ta of the chunk, tile B = ta + 1
+		TilePair t = load_pair(b, i0, ce);
+		int jb = cs + ((t.lo_a - cs) & ~(WAVE - 1));
+		const int eq_lo = jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(t.A.x)) : i0;
+		int slot = (int)((unsigned)((jb - cs) / WAVE) % (unsigned)n_slots);
+		for (; jb < i0; jb += WAVE) {
+			const int sq = b.tag[jb + lane] & 0xff;
+			wait_done((jb - cs) / WAVE + 1);                       // that tile's scores are in the ring
+			const int sf = ring[slot * WAVE + lane];
+			slot = slot + 1 == n_slots ? 0 : slot + 1;
+			stage_block_lut(b, jb, sf, sq, stage);
+			sweep_pair_block(t, jb, eq_lo, stage, P);
+		}
+		const int slot_a = (int)((unsigned)ta % (unsigned)n_slots), slot_b = slot_a + 1 == n_slots ? 0 : slot_a + 1;
+		wait_done(ta);                                               // every earlier tile is final
+		Keep keep;
+		if (TRACK) { keep.idx = first_lane(sh->keep[0]); keep.x = first_lane(sh->keep[1]); keep.hi = first_lane(sh->keep[2]); keep.y = first_lane(sh->keep[3]); keep.tag = first_lane(sh->keep[4]); keep.f = first_lane(sh->keep[5]); }
+		else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
+		const Target TA = load_target(b, i0, ce, TRACK);
+		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);
+		const int f_a = t.arg_a < 0 ? TA.q : t.best_a;
+		if (TA.live) {
+			const int i = i0 + lane;
+			ring[slot_a * WAVE + lane] = f_a;
+			b.f[i] = f_a;
+			b.p[i] = t.arg_a < 0 ? 0 : i - t.arg_a;
+		}
+		if (t.n_b > 0) {
+			// tile A is final: let the other waves go on (the rescue state stays here, nobody needs it before tile B is done)
+			if (lane == 0) __hip_atomic_store(&sh->done, ta + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);
+			const Target TB = load_target(b, i0 + WAVE, ce, TRACK);
+			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);
+			if (TB.live) {
+				const int i = i0 + WAVE + lane;
+				const int f_b = t.arg_b < 0 ? TB.q : t.best_b;
+				ring[slot_b * WAVE + lane] = f_b;
+				b.f[i] = f_b;
+				b.p[i] = t.arg_b < 0 ? 0 : i - t.arg_b;
+			}
+		}
+		if (TRACK && lane == 0) { sh->keep[0] = keep.idx; sh->keep[1] = keep.x; sh->keep[2] = keep.hi; sh->keep[3] = keep.y; sh->keep[4] = keep.tag; sh->keep[5] = keep.f; }
+		// publish: ring + keep writes above are ordered before the counter by the release
+		if (lane == 0) __hip_atomic_store(&sh->done, ta + (t.n_b > 0 ? 2 : 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+
 // One phase of team work: the workgroup's waves form teams of team_size (4, 8 or 16) that pull chunks from `list`.
 // first: a chunk (position in the list) already pulled for team 0 by the previous phase, or -1.
 // min_cost: a chunk cheaper than this ends the phase for the team that pulled it; its position is returned (else -1) so
 // that the next phase can start with it.  Only meaningful for a one-team phase (whole workgroup).
 template <int MODE>
-__device__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
+__device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
                           const int32_t *list, const int n_list, const int cursor, const int wave, const int team_size,
                           int first = -1, const long long min_cost = 0)
 {
@@ -1061,8 +1288,13 @@ __device__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut,
 		const int ci = first_lane(list[c]);
 		if (min_cost > 0 && b.chunk_cost[ci] < min_cost) return c;
 		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
-		if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
-		else coop_chunk<MODE, false>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+		if (MODE == MODE_LUT) {
+			if (b.chunk_track[ci] & 1) coop_chunk_pairs<true>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+			else coop_chunk_pairs<false>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+		} else {
+			if (b.chunk_track[ci] & 1) coop_chunk<MODE, true>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+			else coop_chunk<MODE, false>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
+		}
 		team_barrier(sh, team_size);
 	}
 }
@@ -1108,15 +1340,19 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		// The big-team list is served most expensive first.  A chunk that alone is more than whole_wg_pct % of a workgroup's fair
 		// share of that list gets the whole workgroup (the largest chunks decide when a small batch ends, and a team's speed
 		// is bounded by what one CU's LDS pipe and issue slots give it); the rest go to teams of big_team waves, two at a time.
+		// (One loop over the three team phases rather than three calls: the team code is large and is inlined once.)
 		int first = -1;
-		if (big_team < SCORE_THREADS / WAVE && whole_wg_pct > 0) {
-			const long long share = b.totals[2] / gridDim.x * whole_wg_pct / 100;
-			first = team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams + N_SMALL_TEAMS + 2, b.long_list, n_long, CNT_LCURSOR, wave,
-			                         SCORE_THREADS / WAVE, -1, share > 0 ? share : 1);
+		for (int phase = 0; phase < 3; ++phase) {
+			const bool whole = phase == 0, small = phase == 2;
+			if (whole && !(big_team < SCORE_THREADS / WAVE && whole_wg_pct > 0)) continue;
+			const long long share = whole ? max(1ll, (long long)(b.totals[2] / gridDim.x * whole_wg_pct / 100)) : 0;
+			CoopShared *records = small ? teams : whole ? teams + N_SMALL_TEAMS + 2 : teams + N_SMALL_TEAMS;
+			const int got = team_phase<MODE>(b, P, lut, stage, ring, ring_slots, records, small ? b.mid_list : b.long_list, small ? n_mid : n_long,
+			                                 small ? CNT_MCURSOR : CNT_LCURSOR, wave, small ? SMALL_TEAM : whole ? SCORE_THREADS / WAVE : big_team,
+			                                 whole || small ? -1 : first, share);
+			if (whole) first = got;
+			if (phase == 1 && b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 		}
-		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams + N_SMALL_TEAMS, b.long_list, n_long, CNT_LCURSOR, wave, big_team, first);
-		if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-		team_phase<MODE>(b, P, lut, stage, ring, ring_slots, teams, b.mid_list, n_mid, CNT_MCURSOR, wave, SMALL_TEAM);
 	}
 	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 	// phase 2: one wave per chunk
@@ -1128,8 +1364,13 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		if (c >= n_chunks) break;
 		const int ci = first_lane(b.order[c]);
 		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
-		if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, stage, cs, ce);
-		else run_chunk<MODE, false>(b, P, lut, stage, cs, ce);
+		if (MODE == MODE_LUT) {
+			if (b.chunk_track[ci] & 1) run_chunk_pairs<true>(b, P, lut, stage, cs, ce);
+			else run_chunk_pairs<false>(b, P, lut, stage, cs, ce);
+		} else {
+			if (b.chunk_track[ci] & 1) run_chunk<MODE, true>(b, P, lut, stage, cs, ce);
+			else run_chunk<MODE, false>(b, P, lut, stage, cs, ce);
+		}
 	}
 	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
