@@ -439,7 +439,7 @@ __global__ void k_build_lut(int *lut, DevParams P)
 {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k > P.lut_last) return;
-	lut[k] = k > P.bw ? LUT_REJECT : 128 * gap_penalty(k, 0, P);        // skip == 0 here: the dg term is +0.0f
+	lut[k] = -(k > P.bw ? LUT_REJECT : 128 * gap_penalty(k, 0, P));     // NEGATED, so that users add it; skip == 0 here: the dg term is +0.0f
 }
 
 __device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
@@ -461,7 +461,7 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 		// accepted pairs have dr >= 0 (same strand|rid, sorted by x) and dq >= 1, so the unsigned |dr-dq| is dd
 		const unsigned dd = abs_diff_u32(dr, dq);
 		const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-		sc_out = sc - (lut[idx] >> 7);          // the table stores 128*penalty for the block sweep
+		sc_out = sc + (lut[idx] >> 7);          // the table stores -128*penalty for the block sweep
 		return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0;
 	}
 	const int ddiff = (int)((unsigned)dr - (unsigned)dq);
@@ -567,7 +567,9 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
 			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
-			const int v = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x - pen[u];
+			int v = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x;      // v_lshl_add_u32 ...
+			asm("" : "+v"(v));                                            // ... then a plain add (not shift + v_add3, which measured slower)
+			v += pen[u];
 			if (!CHECK) {
 				// "bestv = max(bestv, v) in the lanes whose dq is in range": the range test goes straight into the execution
 				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement (from all_lanes, read once)
@@ -655,8 +657,12 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
 			const int ga = dra[u] < dqa[u] ? dra[u] : dqa[u], gb = drb[u] < dqb[u] ? drb[u] : dqb[u];
-			const int va = ((s4[u].y < ga ? s4[u].y : ga) << 5) + s4[u].x - pa[u];
-			const int vb = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x - pb[u];
+			int va = ((s4[u].y < ga ? s4[u].y : ga) << 5) + s4[u].x;
+			asm("" : "+v"(va));
+			va += pa[u];
+			int vb = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x;
+			asm("" : "+v"(vb));
+			vb += pb[u];
 			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
 			             : [b] "+v"(bva) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqa[u]), [v] "v"(va) : "vcc");
 			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
@@ -723,17 +729,7 @@ __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce,
 // of lane t; its score is not known until step t, so 128(f_t+1) + (t+1) is formed on the scalar side from one v_readlane of
 // lane t's running value.  Lane state: V = 128*cand + (k+1) as in the sweep; a lane without predecessor so far enters as
 // 128*q_span + 127 (one below the acceptance threshold 128(q_span+1)), so that f = V >> 7 holds for every lane at any time.
-// The four acceptance tests are ballots combined on the scalar side with "lane > t", and one v_cndmask takes the mask.
-__device__ __forceinline__ int select_lanes(unsigned long long mask, int yes, int no)
-{
-	// a wave-uniform value may still sit in vector registers when scalar registers are short: make sure of the class
-	const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask >> 32));
-	const unsigned long long m = (unsigned long long)hi << 32 | lo;
-	int r;
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(m));
-	return r;
-}
-
+// The acceptance tests are ballots combined on the scalar side with "lane > t", and one v_cndmask takes the mask.
 struct TileLut {
 	int tx4, ty4, lo;
 	unsigned lim4, last4;
@@ -755,7 +751,7 @@ __device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
 	const int pen = *(lds_i32_ptr)(uintptr_t)(dd4 < tl.last4 ? dd4 : tl.last4);   // always clamped here: one code path, one instruction more
 	const int dg = drm < dqm ? drm : dqm;
 	StepPre pre;
-	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) - pen;
+	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) + pen;          // one shift-add: the table holds negated penalties
 	const unsigned long long above = t < WAVE - 1 ? ~0ull << (t + 1) : 0ull;
 	pre.ok = __ballot((unsigned)dqm < tl.lim4) & above;
 	if (tl.edges) pre.ok &= __ballot(drm != -4) & __ballot(tl.lo <= t);   // wave-uniform: most tiles of wide-window chunks skip both
@@ -766,7 +762,10 @@ __device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, in
 {
 	const int fx = (s_bv | 127) + t + 2;                    // 128(f_t + 1) + (t + 1), scalar
 	const int v = pre.basev + fx;
-	bestv = select_lanes(pre.ok & __ballot(v > bestv), v, bestv);
+	// one select under the combined mask (making the mask the execution mask of a v_max instead measured slower here: the
+	// scalar write of exec sits in the dependent chain)
+	const unsigned long long take = pre.ok & __ballot(v > bestv);
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bestv) : "v"(bestv), "v"(v), "s"(take));
 }
 
 // lchain.c:113-138 for one pair with every input wave-uniform (single segment, no cDNA, chn_pen_skip == 0: the MODE_LUT
@@ -839,7 +838,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			const int dg = dr < dq ? dr : dq;
 			const unsigned dd = abs_diff_u32(dr, dq);
 			const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-			const int sc = (span < dg ? span : dg) - (*(lds_i32_ptr)(uintptr_t)(idx << 2) >> 7);
+			const int sc = (span < dg ? span : dg) + (*(lds_i32_ptr)(uintptr_t)(idx << 2) >> 7);
 			extra = __ballot((unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && keep0 < T.st - 1);
 			extra_v = (sc + keep.f) << 7;
 		}
