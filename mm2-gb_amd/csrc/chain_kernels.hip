@@ -42,6 +42,9 @@ __device__ __forceinline__ bool in_reach(const DevBatch &b, int j, int hi_i, uns
 	return (int)v.y == hi_i && x_i <= v.x + dist;                // positions < 2^31, dist < 2^31: no wrap
 }
 
+constexpr int WIN_SAMPLE = 32;                         // anchors per sample = ints per 128-byte line
+constexpr int WIN_MAX_SAMPLES = 512;                   // look-back of 16 K anchors; a larger max_iter probes memory beyond it
+
 // Read that owns the first anchor of every planning block: one bisection of the read offsets per block, all blocks at once
 // (done by the first thread of each k_window workgroup it put ~13 dependent loads in front of every workgroup).
 __global__ __launch_bounds__(256) void k_block_reads(DevBatch b)
@@ -61,8 +64,6 @@ __global__ __launch_bounds__(256) void k_block_reads(DevBatch b)
 // 128-byte line of x) of the max_iter anchors before it.  A window start is then found with LDS probes only -- bisection
 // over the block's own anchors, or over the samples followed by at most five probes inside the one line the answer lies in,
 // a line the block has just touched -- instead of ~25 dependent trips to L2/HBM per search.
-constexpr int WIN_SAMPLE = 32;                         // anchors per sample = ints per 128-byte line
-constexpr int WIN_MAX_SAMPLES = 512;                   // look-back of 16 K anchors; a larger max_iter probes memory beyond it
 
 __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P)
 {
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	__shared__ int s_wmax[2 * PLAN_THREADS / WAVE];
 	__shared__ int own_x[PLAN_BLOCK], own_hi[PLAN_BLOCK];
 	__shared__ int smp_x[WIN_MAX_SAMPLES], smp_hi[WIN_MAX_SAMPLES];      // sample k-1 = anchor base - 32 k
+	__shared__ int s_st[PLAN_BLOCK];                                    // results, written out coalesced at the end
 	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
 	const int n_samples = (int)min((int64_t)WIN_MAX_SAMPLES, min(base, (int64_t)P.max_iter + WIN_SAMPLE - 1) / WIN_SAMPLE);
@@ -99,20 +101,22 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	int my_cut = INT_MAX, my_clamp = 0;
 	unsigned long long my_pairs = 0;
 
-	// Each thread owns PLAN_BLOCK / PLAN_THREADS anchors, PLAN_THREADS apart: consecutive lanes, consecutive anchors (coalesced st).
+	// Each thread owns PLAN_BLOCK / PLAN_THREADS CONSECUTIVE anchors: the first gets a full search, and because window starts
+	// are monotone (st[i+1] >= st[i]) the others continue forward from their neighbour's start, usually one or two probes.
 	constexpr int PER = PLAN_BLOCK / PLAN_THREADS;
-	const int64_t i_first = base + threadIdx.x;
+	const int64_t i_first = base + (int64_t)threadIdx.x * PER;
 	const int base32 = (int)base;
 	int64_t rd = b.blk_read[blockIdx.x];              // read of the current anchor
-	int rs = 0, re = 0;
+	int rs = 0, re = 0, st_prev = 0;
 	int win[PER];
 #pragma unroll
 	for (int k = 0; k < PER; ++k) win[k] = -1;
 #pragma unroll
 	for (int k = 0; k < PER; ++k) {
-		const int64_t i64 = i_first + (int64_t)k * PLAN_THREADS;
+		const int64_t i64 = i_first + k;
 		if (i64 >= b.n) break;
 		const int i = (int)i64;
+		bool fresh = k == 0;
 		if (k == 0 || i >= re) {
 			// read that owns anchor i: last r with offsets[r] <= i (gallop forward from the last known read, then bisect)
 			int64_t lo = rd, hi = b.n_reads;
@@ -127,6 +131,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 				if (b.offsets[mid] <= i64) lo = mid; else hi = mid;
 			}
 			rd = lo; rs = (int)b.offsets[lo]; re = (int)b.offsets[lo + 1];
+			fresh = true;
 		}
 		int lb = i - P.max_iter;                      // may be negative
 		if (lb < rs) lb = rs;
@@ -135,8 +140,25 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		auto reach_own = [&](int j) { return own_hi[j - base32] == hi_i && x_i <= (unsigned)own_x[j - base32] + dist; };
 		auto reach_smp = [&](int s) { return smp_hi[s] == hi_i && x_i <= (unsigned)smp_x[s] + dist; };   // anchor base - 32 (s + 1)
 		// validity is monotone over [lb, i): false ... false true ... true.  st = first valid index, i if none.
+		auto reach_at = [&](int j) { return j >= base32 ? reach_own(j) : in_reach(b, j, hi_i, x_i, dist); };
 		int st = i;
-		if (i > lb) {
+		if (i > lb && !fresh) {
+			// first valid index >= max(neighbour's start, lb); validity is monotone, so gallop forward and bisect
+			int l = st_prev > lb ? st_prev : lb, h = i;
+			if (reach_at(l)) h = l;
+			else {
+				for (int step = 1; l + step < h; step <<= 1) {
+					if (reach_at(l + step)) { h = l + step; break; }
+					l += step;
+				}
+				while (h - l > 1) {
+					const int mid = (l + h) >> 1;
+					if (reach_at(mid)) h = mid; else l = mid;
+				}
+			}
+			st = h;
+			if (st == lb && lb > rs && lb == i - P.max_iter && in_reach(b, lb - 1, hi_i, x_i, dist)) my_clamp = 1;
+		} else if (i > lb) {
 			int l, h;                                   // invariant: l is out of reach (or lb - 1), h is in reach (or i)
 			bool in_block = true;
 			if (lb >= base32) { l = lb - 1; h = i; }
@@ -169,7 +191,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 			// the max_iter clamp bit (lchain.c:173): window would have reached further back
 			if (st == lb && lb > rs && lb == i - P.max_iter && in_reach(b, lb - 1, hi_i, x_i, dist)) my_clamp = 1;
 		}
-		b.st[i] = st;
+		s_st[i - base32] = st;
+		st_prev = st;
 		my_pairs += (unsigned)(i - st);
 		win[k] = i - st;
 		if (st == i && i < my_cut) my_cut = i;
@@ -183,6 +206,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	const int w = threadIdx.x / WAVE;
 	if (lane_id() == 0) { s_cut[w] = my_cut; s_pairs[w] = my_pairs; s_clamp[w] = my_clamp; }
 	__syncthreads();
+	for (int k = threadIdx.x; k < PLAN_BLOCK && base + k < b.n; k += PLAN_THREADS) b.st[base + k] = s_st[k];
 	int blk_cut = s_cut[0];
 	for (int k = 1; k < PLAN_THREADS / WAVE; ++k) blk_cut = min(blk_cut, s_cut[k]);
 	// widest window before the block's first cut (belongs to the chunk that started earlier) and from it on (belongs to
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 #pragma unroll
 	for (int k = 0; k < PER; ++k) {
 		if (win[k] < 0) continue;
-		if (i_first + (int64_t)k * PLAN_THREADS < blk_cut) head = max(head, win[k]); else tail = max(tail, win[k]);
+		if (i_first + k < blk_cut) head = max(head, win[k]); else tail = max(tail, win[k]);
 	}
 	for (int off = WAVE / 2; off > 0; off >>= 1) { head = max(head, __shfl_xor(head, off)); tail = max(tail, __shfl_xor(tail, off)); }
 	if (lane_id() == 0) { s_wmax[w] = head; s_wmax[PLAN_THREADS / WAVE + w] = tail; }
