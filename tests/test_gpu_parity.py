@@ -135,6 +135,28 @@ def test_rescue_state_restarts_at_every_read(engine):
         assert st["n_tracked_chunks"] >= 1
 
 
+@pytest.mark.parametrize("env", [{}, {"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "0"},
+                                 {"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "1"},
+                                 {"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "100000000"}],
+                         ids=["planner", "teams-of-8", "whole-workgroup", "teams-of-4"])
+def test_chunk_lengths_around_tile_pairs(monkeypatch, env):
+    """A wave works on two tiles of 64 anchors at a time: chunks that end inside the first tile, exactly between the two,
+    inside the second, and one anchor into the next pair -- dense (every window reaches back across tiles) and sparse, with
+    windows cut by a small max_iter so that the rescue state crosses the tile boundaries too."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    lengths = [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320]
+    dense = [sc.sort_by_x(sc.repeat_block(n, 100 + n, xwin=300, ywin=400)) for n in lengths]
+    sparse = [sc.colinear(n, 200 + n, max_gap=30) for n in lengths]
+    reads = dense + sparse
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    a = np.concatenate(reads)
+    with mm.Engine() as e:
+        for kw in (dict(), dict(max_iter=40), dict(max_iter=100, bw=50)):
+            check_batch(e, a, off, orc.default_param(**kw))
+
+
 def test_default_max_iter_repeat_block(engine):
     a = sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 41), sc.colinear(800, 42), sc.noise(3000, 43)]))
     st = check_batch(engine, a, np.array([0, len(a)], np.int64), orc.default_param())
