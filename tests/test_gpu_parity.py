@@ -155,6 +155,10 @@ def test_chunk_lengths_around_tile_pairs(monkeypatch, env):
     with mm.Engine() as e:
         for kw in (dict(), dict(max_iter=40), dict(max_iter=100, bw=50)):
             check_batch(e, a, off, orc.default_param(**kw))
+        # the planner joins short reads into one chunk; alone in its batch a read IS the chunk, so the lengths above are chunk lengths
+        prm = orc.default_param(max_iter=100)
+        for r in dense + sparse[::3]:
+            check_batch(e, r, np.array([0, len(r)], np.int64), prm, threads=1)
 
 
 def test_default_max_iter_repeat_block(engine):
