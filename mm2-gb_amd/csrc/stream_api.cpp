@@ -279,12 +279,19 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	if (g_streams.ready) free_stream_gpu((int)g_streams.slots.size());
 	if (mm2gb_config_load(gpu_config_file, &g_streams.cfg)) die(mm2gb_last_error());
 	mm2gb_config_t &cfg = g_streams.cfg;
+	// Every stream id is an engine with three HIP streams (H2D, kernels, D2H).  The HIP runtime multiplexes streams onto 4
+	// hardware queues unless told otherwise, and streams that share a queue run one after the other: four host threads then
+	// gain 1.3x over one, with enough queues 3.5x (profiles/stream_api_rate.py).  Only effective before the runtime starts,
+	// i.e. when this is the first HIP call of the process, as it is in the minimap2 host.
+	if (cfg.num_streams > 1 && !getenv("GPU_MAX_HW_QUEUES"))
+		setenv("GPU_MAX_HW_QUEUES", std::to_string(std::min(3 * cfg.num_streams + 1, 32)).c_str(), 0);
 	if (!(cfg.has_max_total_n && cfg.has_max_read)) {
-		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's 46 B/anchor footprint
+		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's footprint per anchor:
+		// 16 B of work arrays + two staging sets of 24 B (raw in, f and p out)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) die("cannot query device memory");
-		const double per_anchor = 46.0 + 16.0 / 1024;
-		const double budget = (double)total_b / cfg.num_streams * 0.9 / 2;    // half: staging and outputs live beside the work arenas
+		const double per_anchor = 64.0 + 16.0 / 1024;
+		const double budget = (double)total_b / cfg.num_streams * 0.8;
 		int64_t n = (int64_t)(budget / per_anchor);
 		if (n > 2000000000LL) n = 2000000000LL;
 		cfg.max_total_n = n;
