@@ -94,6 +94,7 @@ int Engine::set_misc(const mm2gb_misc_t *m)
 // Pick the scoring build and the LDS budget for these parameters; (re)build the penalty table on the device.
 int Engine::configure_score()
 {
+	MM2GB_HIP(hipSetDevice(device));                    // kernel attributes and the table build below belong to this engine's device
 	const bool single = !params.is_cdna && params.n_seg == 1;
 	constexpr int LUT_MAX = 8192;                       // entries; bw above this falls back to per-pair arithmetic
 	if (!single) launch.host_mode = SCORE_MODE_GENERAL;
@@ -126,8 +127,9 @@ int Engine::configure_score()
 	int64_t slots = fit_slots(params);
 	if (slots < 8) slots = 0;                                        // less than two tiles of window per small team: not worth it
 	launch.ring_slots = coop_disabled ? 0 : (int)slots;
-	const size_t need = std::max(score_lds_bytes(params, launch.host_mode, launch.ring_slots), score_lds_bytes(params, SCORE_MODE_GENERAL, launch.ring_slots));
-	if (score_set_lds_limit(need)) return fail("mm2gb: cannot raise the dynamic LDS limit of the score kernel");
+	// the limit is an attribute of the kernel, shared by every engine of the process: always the whole budget, so that engines
+	// with different parameters cannot lower it under each other's feet
+	if (score_set_lds_limit(LDS_BUDGET)) return fail("mm2gb: cannot raise the dynamic LDS limit of the score kernel");
 	if (launch.host_mode == SCORE_MODE_LUT) {
 		if (lut.ensure((size_t)(params.lut_last + 1) * 4)) return -1;
 		launch_build_lut((int*)lut.ptr, params, stream);
