@@ -570,7 +570,7 @@ __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 // >= 2^22 (f <= y + q_span always) and the batch then runs the MODE_FAST build.
 template <bool CHECK, bool CLAMP>
 __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage,
-                                                const DevParams &P, const int *lut, int &bestv)
+                                                const DevParams &P, int &bestv)
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
@@ -647,11 +647,11 @@ __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_
 	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
 	int bestv = best << 7;
 	if (P.lut_clamp) {
-		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
-		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
+		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
+		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 	} else {
-		if (no_check) sweep_block_lut<false, false>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
-		else sweep_block_lut<true, false>(T.st, tx4, ty4, jb, k_from, stage, P, nullptr, bestv);
+		if (no_check) sweep_block_lut<false, false>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
+		else sweep_block_lut<true, false>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 	}
 	const int won = bestv & 127;                            // k+1 of the source that holds the best, 0 = none of this block
 	arg = won ? jb + won - 1 : arg;
