@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--len-lo", type=int, default=5_000)
     ap.add_argument("--len-hi", type=int, default=80_000)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "e2e.json"))
+    ap.add_argument("--threads", type=int, default=8, help="second comparison with this many host threads (the reference's GPU path is -t 1 only)")
     args = ap.parse_args()
     cpu = os.path.join(ROOT, "oracle", "_ref", "minimap2_cpu")
     gpu = os.path.join(ROOT, "oracle", "_ref", "minimap2_gpuhost")
@@ -44,12 +45,26 @@ def main():
         paf_25, t_25 = run([cpu, "-t", "1", ref, reads])
         paf_gpu, t_gpu = run([gpu, "-t", "1", "--gpu-chain", "--gpu-cfg", cfg, ref, reads])
         _, t_gpu2 = run([gpu, "-t", "1", "--gpu-chain", "--gpu-cfg", cfg, ref, reads])
+        # several host threads: one stream id (engine) per thread
+        mt = {}
+        if args.threads > 1:
+            cfg_n = os.path.join(td, "cfg_n.json")
+            doc_cfg = json.load(open(cfg)); doc_cfg["num_streams"] = args.threads
+            json.dump(doc_cfg, open(cfg_n, "w"))
+            T = str(args.threads)
+            paf_inf_n, t_inf_n = run([cpu, "-t", T, "--max-chain-skip=2147483647", ref, reads])
+            paf_gpu_n, t_gpu_n = run([gpu, "-t", T, "--gpu-chain", "--gpu-cfg", cfg_n, ref, reads])
+            _, t_gpu_n2 = run([gpu, "-t", T, "--gpu-chain", "--gpu-cfg", cfg_n, ref, reads])
+            mt = {"threads": args.threads, "cpu_skip_inf_s": round(t_inf_n, 2), "gpu_chain_s": round(min(t_gpu_n, t_gpu_n2), 2),
+                  "paf_gpu_equals_cpu_skip_inf": sorted(paf_gpu_n.splitlines()) == sorted(paf_inf.splitlines()),
+                  "paf_cpu_threads_equals_one_thread": sorted(paf_inf_n.splitlines()) == sorted(paf_inf.splitlines())}
     doc = {"reads": args.reads, "bases": bases, "read_len": [args.len_lo, args.len_hi],
            "cpu_skip_inf_s": round(t_inf, 2), "cpu_skip_25_s": round(t_25, 2), "gpu_chain_s": round(min(t_gpu, t_gpu2), 2),
            "gbp_per_s": {"cpu_skip_inf": bases / t_inf / 1e9, "cpu_skip_25": bases / t_25 / 1e9, "gpu_chain": bases / min(t_gpu, t_gpu2) / 1e9},
            "paf_lines": paf_inf.count("\n"), "paf_gpu_equals_cpu_skip_inf": paf_gpu == paf_inf,
            "paf_lines_differing_skip25_vs_inf": sum(a != b for a, b in zip(paf_25.splitlines(), paf_inf.splitlines())),
-           "note": "whole program wall time incl. index build and process start-up (GPU run: incl. HIP init); -t 1"}
+           "several_threads": mt,
+           "note": "whole program wall time incl. index build and process start-up (GPU run: incl. HIP init); -t 1 unless stated"}
     json.dump(doc, open(args.out, "w"), indent=1)
     print(json.dumps(doc))
 
