@@ -409,6 +409,40 @@ def test_large_batch_properties_and_mode_agreement(monkeypatch):
         assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po))
 
 
+def test_bench_size_batch_properties():
+    """The micro-batch the bench is quoted on (BASELINE configs[3]: 100-300 kb reads, 500 M anchors, 2.7e11 pairs -- hours for
+    the oracle): size-independent properties of f and p on all of it, idempotence, the oracle on reads picked across the batch.
+    Set MM2GB_TEST_FULL_ANCHORS to run a smaller batch on a machine with less host memory."""
+    import os
+    target = int(os.environ.get("MM2GB_TEST_FULL_ANCHORS", 500_000_000))
+    import bench
+    _, n_reads, a, off = bench.shard_for_rank(mm, 0, 1, 2024, target, 100_000, 300_000, threads=32)
+    n = len(a)
+    assert n >= 0.99 * target
+    with mm.Engine() as e:
+        f, p, st = e.score(a, off)
+        assert st["n_anchors"] == n and st["n_reads"] == n_reads and st["n_pairs"] > 400 * n
+        span = ((a[:, 1] >> np.uint64(32)) & np.uint64(0xff)).astype(np.int32)
+        assert (f >= span).all()
+        has = p > 0
+        assert (f[has] > span[has]).all() and (f[~has] == span[~has]).all()
+        # predecessors: inside the read, same strand | rid, within max_dist_x, at most max_iter back (or the rescue: further, but in reach)
+        idx = np.flatnonzero(has)
+        j = idx - p[idx]
+        read_of = np.searchsorted(off, idx, side="right") - 1
+        assert (j >= off[read_of]).all()
+        assert ((a[idx, 0] >> np.uint64(32)) == (a[j, 0] >> np.uint64(32))).all()
+        assert (a[idx, 0] - a[j, 0] <= np.uint64(5000)).all()
+        del idx, j, read_of, has
+        # same inputs, same outputs (checksums: xor-folded 64-bit sums are order independent, enough for "identical arrays")
+        f2, p2, st2 = e.score(a, off)
+        assert st2["n_pairs"] == st["n_pairs"] and np.array_equal(f, f2) and np.array_equal(p, p2)
+    prm = orc.default_param()
+    for r in np.linspace(0, n_reads - 1, 7).astype(int):
+        fo, po, _ = orc.chain_fill(a[off[r]:off[r + 1]], prm)
+        assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
+
+
 def test_lchain_dp_signature_entry():
     """mm2gb_lchain_dp: same call shape as mg_lchain_dp (lchain.c:148), input consumed, outputs malloc'd."""
     import ctypes as C
