@@ -443,6 +443,26 @@ def test_bench_size_batch_properties():
         assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
 
 
+@pytest.mark.timeout(120)
+def test_unsorted_anchors_do_not_hang_or_crash(engine):
+    """Anchors sorted by x are the caller's contract (map.c:329).  Broken input must still come back: window starts stay inside
+    [read start, i] by construction, and no wait in the kernel depends on the data.  The values are unspecified."""
+    rng = np.random.default_rng(5)
+    parts = [sc.sort_by_x(np.concatenate([sc.repeat_block(6000, 91), sc.colinear(500, 92)])), sc.read_like(8000, 93)]
+    a = np.concatenate(parts)
+    off = np.array([0, len(parts[0]), len(a)], np.int64)
+    shuffled = a.copy()
+    rng.shuffle(shuffled[: len(parts[0])])                  # first read in random order, second untouched
+    engine.set_misc(mm.default_misc())
+    f, p, st = engine.score(shuffled, off)
+    assert len(f) == len(a) and st["n_anchors"] == len(a)
+    idx = np.arange(len(a))
+    assert ((p >= 0) & (p <= idx - off[np.searchsorted(off, idx, side="right") - 1])).all()      # predecessors stay inside the read
+    # the untouched read is unaffected by its neighbour
+    fo, po, _ = orc.chain_fill(parts[1], orc.default_param())
+    assert np.array_equal(f[off[1]:], fo) and np.array_equal(p[off[1]:], rel(po))
+
+
 def test_lchain_dp_signature_entry():
     """mm2gb_lchain_dp: same call shape as mg_lchain_dp (lchain.c:148), input consumed, outputs malloc'd."""
     import ctypes as C
