@@ -362,14 +362,22 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 	MM2GB_HIP(hipSetDevice(device));
 	if (begin_call()) return -1;
 	const auto t0 = std::chrono::steady_clock::now();
-	int64_t slice = 64 * 1000 * 1000;
+	// Slice size: the H2D copy (57 GB/s measured, profiles/ubench/h2d_rate.hip) is what a large batch is bound by, as long as the
+	// kernels of a slice are faster than its copy -- and a slice too small runs at the pace of its largest chunks.
+	// ~100 M anchors balance the two.  What follows the last copy is exposed (its kernels, its D2H), so the last slice is a small one.
+	int64_t slice = 96 * 1000 * 1000;
 	if (const char *v = getenv("MM2GB_SLICE_ANCHORS")) slice = std::max<int64_t>(1, atoll(v));
 	std::vector<int64_t> first(1, 0);
 	if (n > slice + slice / 2) {
+		const int64_t tail = slice / 4;                    // anchors kept for the last slice
 		int64_t acc = 0;
+		bool tail_cut = false;
 		for (int64_t r = 0; r < n_reads; ++r) {
 			acc += offsets[r + 1] - offsets[r];
-			if (acc >= slice && r + 1 < n_reads) { first.push_back(r + 1); acc = 0; }
+			const int64_t left = offsets[n_reads] - offsets[r + 1];
+			if (r + 1 >= n_reads || tail_cut) continue;
+			if (left <= tail && acc > tail) { first.push_back(r + 1); acc = 0; tail_cut = true; }             // ... [rest of a slice][tail]
+			else if (acc >= slice && left > tail + slice / 4) { first.push_back(r + 1); acc = 0; }            // a full slice, enough left for more
 		}
 	}
 	first.push_back(n_reads);
