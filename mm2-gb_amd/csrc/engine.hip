@@ -29,15 +29,18 @@ static size_t grown(size_t need, size_t have)
 int DevBuf::ensure(size_t need)
 {
 	if (need <= bytes) return 0;
+	// The new buffer is allocated BEFORE the old one is freed: a failed growth then leaves the buffer as it was (contents are
+	// never carried over: every arena is rewritten by the batch that needs it).  Only when there is no room for both is the old
+	// one given up first; if even that fails the buffer is empty (ptr null, bytes 0) and the caller must treat its capacity as lost.
 	const size_t want = grown(need, bytes);
+	void *fresh = nullptr;
+	if (hipMalloc(&fresh, want) == hipSuccess) { release(); ptr = fresh; bytes = want; return 0; }
+	(void)hipGetLastError();
+	if (hipMalloc(&fresh, need) == hipSuccess) { release(); ptr = fresh; bytes = need; return 0; }
+	(void)hipGetLastError();
 	release();
-	if (hipMalloc(&ptr, want) != hipSuccess) {        // no room for the slack: take exactly what is needed
-		(void)hipGetLastError();
-		MM2GB_HIP(hipMalloc(&ptr, need));
-		bytes = need;
-		return 0;
-	}
-	bytes = want;
+	MM2GB_HIP(hipMalloc(&ptr, need));
+	bytes = need;
 	return 0;
 }
 void DevBuf::release()
@@ -50,14 +53,14 @@ int PinnedBuf::ensure(size_t need)
 {
 	if (need <= bytes) return 0;
 	const size_t want = grown(need, bytes);
+	void *fresh = nullptr;                               // as DevBuf::ensure: a failed growth keeps the old buffer
+	if (hipHostMalloc(&fresh, want, hipHostMallocDefault) == hipSuccess) { release(); ptr = fresh; bytes = want; return 0; }
+	(void)hipGetLastError();
+	if (hipHostMalloc(&fresh, need, hipHostMallocDefault) == hipSuccess) { release(); ptr = fresh; bytes = need; return 0; }
+	(void)hipGetLastError();
 	release();
-	if (hipHostMalloc(&ptr, want, hipHostMallocDefault) != hipSuccess) {
-		(void)hipGetLastError();
-		MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
-		bytes = need;
-		return 0;
-	}
-	bytes = want;
+	MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
+	bytes = need;
 	return 0;
 }
 void PinnedBuf::release()
@@ -97,8 +100,11 @@ int Engine::configure_score()
 	MM2GB_HIP(hipSetDevice(device));                    // kernel attributes and the table build below belong to this engine's device
 	const bool single = !params.is_cdna && params.n_seg == 1;
 	constexpr int LUT_MAX = 8192;                       // entries; bw above this falls back to per-pair arithmetic
+	constexpr int LUT_MAX_DIST = 1 << 28;
 	if (!single) launch.host_mode = SCORE_MODE_GENERAL;
-	else if (params.skip == 0.0f && params.lut_last + 1 <= LUT_MAX) launch.host_mode = SCORE_MODE_LUT;
+	// the table sweep keeps coordinates x4 (and compares (unsigned)dq_lim << 2): exact only while every distance a pair can pass
+	// the range tests with stays below 2^28; a larger max_dist (user -g / -r) runs the per-pair build
+	else if (params.skip == 0.0f && params.lut_last + 1 <= LUT_MAX && params.max_dist_x < LUT_MAX_DIST && params.max_dist_y < LUT_MAX_DIST) launch.host_mode = SCORE_MODE_LUT;
 	else launch.host_mode = SCORE_MODE_FAST;
 	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS)
 	// Team modes: a team's share of the LDS ring holds the scores of the most recent tiles of its chunk and must cover the
@@ -207,12 +213,17 @@ int Engine::reserve(int64_t n, int64_t n_reads)
 		MM2GB_HIP(hipStreamSynchronize(stream));
 		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
 		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
+		// A growth that fails part-way leaves some arenas grown, some as they were and possibly one empty: the recorded capacity
+		// is dropped first and only restored when every arena has its size, so the next call reserves again instead of launching
+		// on a short (or null) buffer.
+		const int64_t had_reads = cap_reads;
+		cap_n = cap_blocks = cap_reads = 0;
 		if (x.ensure(nn * 4) || y.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
 		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4) || blk_wmax.ensure(nb * 8) || blk_read.ensure(nb * 4)) return -1;
 		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
 		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || mid_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
 		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(3 * 256 * 4)) return -1;
-		cap_n = nn; cap_blocks = nb; cap_reads = std::max(cap_reads, n_reads);
+		cap_n = nn; cap_blocks = nb; cap_reads = std::max(had_reads, n_reads);
 	}
 	return 0;
 }
@@ -382,6 +393,12 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 	}
 	first.push_back(n_reads);
 	const size_t n_sl = first.size() - 1;
+	auto drain = [&]() {                 // error path: keep the error text, wait for whatever was enqueued
+		const std::string why = last_error_cstr();
+		for (hipStream_t q : { s_in, stream, s_out }) (void)hipStreamSynchronize(q);
+		n_slots = 0;
+		set_error(why);
+	};
 	if (h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8)) return -1;
 	int64_t *lo = (int64_t*)h_slice_off.ptr;
 	size_t w = 0;
@@ -389,9 +406,10 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 		const int64_t r0 = first[k], r1 = first[k + 1];
 		const size_t at = w;
 		for (int64_t r = r0; r <= r1; ++r) lo[w++] = offsets[r] - offsets[r0];
-		if (enqueue_host(r1 - r0, lo + at, anchors + offsets[r0], offsets[r1] - offsets[r0], f + (offsets[r0] - base), p + (offsets[r0] - base))) return -1;
+		// on failure: copies of earlier slices may still be writing into the caller's f / p -- never return with those in flight
+		if (enqueue_host(r1 - r0, lo + at, anchors + offsets[r0], offsets[r1] - offsets[r0], f + (offsets[r0] - base), p + (offsets[r0] - base))) { drain(); return -1; }
 		if (slice_done && k > 0) {           // slice k is queued behind it: hand slice k-1 over once its D2H has landed
-			MM2GB_HIP(hipEventSynchronize(io[(io_seq - 2) & 1].out_done));
+			if (hipEventSynchronize(io[(io_seq - 2) & 1].out_done) != hipSuccess) { drain(); return fail("mm2gb_score_host: waiting for a slice failed"); }
 			(*slice_done)(first[k - 1], first[k]);
 		}
 	}

@@ -16,6 +16,9 @@
 #include "../../include/mm2gb_plutils.h"
 #include "engine.h"
 #include "host_chain.h"
+#include "trace.h"
+#include <sched.h>
+#include <map>
 
 // ---- host callbacks (map.c:393, map.c:428); weak so the library also loads without a minimap2 host ----
 extern "C" {
@@ -64,6 +67,7 @@ struct HostStage {
 	PinnedBuf h_raw, h_f, h_p, h_off;      // h_off: per-micro-batch offsets, each from 0
 	std::vector<int64_t> goff;             // offsets of every read in h_raw / h_f / h_p, size n_read + 1
 	mm2gb_chain_read_t *reads = nullptr;   // owned by the host
+	mm2gb_misc_t misc = {};                // the parameters this batch was LAUNCHED with: its post-pass must use the same ones
 	int  n_read = 0;
 	bool busy = false;
 	hipEvent_t done = nullptr;             // all f/p of this batch are back in h_f / h_p
@@ -119,27 +123,32 @@ static int devices_for_streams(std::vector<int> &out)
 }
 
 // Finish the batch held by `st`: wait for its scores, extract chains per read, hand the reads back.
-static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_read_t **reads_out, int *n_out)
+static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_read_t **reads_out, int *n_out, mm2gb_misc_t *misc_out)
 {
 	*reads_out = nullptr; *n_out = 0;
 	if (!st.busy) return 0;
+	TraceRange range("mm2gb:finish_batch");
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
 	const double t0 = now_ms();
-	MM2GB_HIP(hipEventSynchronize(st.done));
+	{ TraceRange wait("mm2gb:wait_scores"); MM2GB_HIP(hipEventSynchronize(st.done)); }
 	const double t_wait = now_ms();
 	mm2gb_chain_read_t *reads = st.reads;
 	const int n_read = st.n_read;
 	const int64_t *off = st.goff.data();
 	const int32_t *f = (const int32_t*)st.h_f.ptr, *p = (const int32_t*)st.h_p.ptr;
-	const mm2gb_misc_t misc = slot.eng.misc;
+	const mm2gb_misc_t misc = st.misc;                    // not the engine's current ones: a newer batch may already be in flight
+	if (misc_out) *misc_out = misc;
 	HostAlloc libc_mem;                                   // worker threads allocate from libc only
 	HostAlloc host_mem; host_mem.km = km; host_mem.use_kalloc = host_kalloc_present();
 	std::vector<uint64_t*> u_of((size_t)n_read, nullptr);
 	std::vector<mm2gb_anchor_t*> a_of((size_t)n_read, nullptr);
 	std::vector<int> nu_of((size_t)n_read, 0);
-	parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &ws) {
-		nu_of[r] = backtrack_compact(misc, reads[r].n, reads[r].a, f + off[r], p + off[r], libc_mem, ws, &u_of[r], &a_of[r]);
-	});
+	{
+		TraceRange post("mm2gb:backtrack_compact");
+		parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &ws) {
+			nu_of[r] = backtrack_compact(misc, reads[r].n, reads[r].a, f + off[r], p + off[r], libc_mem, ws, &u_of[r], &a_of[r]);
+		});
+	}
 	const double t_post = now_ms();
 	// hand-over on the calling thread: kalloc arenas are not thread-safe, so results move into the host's arena here
 	for (int r = 0; r < n_read; ++r) {
@@ -171,7 +180,9 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 	int64_t total = 0;
 	for (int r = 0; r < n_read; ++r) total += reads[r].n > 0 ? reads[r].n : 0;
 	const double t0 = now_ms();
+	TraceRange range("mm2gb:launch_batch");
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
+	st.misc = slot.eng.misc;
 	if (!st.done) MM2GB_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
 	if (st.h_raw.ensure((size_t)(total + 1) * 16) || st.h_f.ensure((size_t)(total + 1) * 4) || st.h_p.ensure((size_t)(total + 1) * 4)) return -1;
 	st.goff.resize((size_t)n_read + 1);
@@ -180,10 +191,13 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 	off[0] = 0;
 	for (int r = 0; r < n_read; ++r) off[r + 1] = off[r] + (reads[r].n > 0 ? reads[r].n : 0);
 	// pack the reads' anchor arrays into the pinned staging buffer (MM2GB_POST_THREADS host threads)
-	parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &) {
-		const int64_t n = off[r + 1] - off[r];
-		if (n) memcpy(raw + off[r], reads[r].a, (size_t)n * 16);
-	});
+	{
+		TraceRange pack("mm2gb:pack_anchors");
+		parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &) {
+			const int64_t n = off[r + 1] - off[r];
+			if (n) memcpy(raw + off[r], reads[r].a, (size_t)n * 16);
+		});
+	}
 	const double t_pack = now_ms();
 	// micro-batches: greedy split so each holds at most max_total_n anchors (plchain.cu:356-366); unlike the reference
 	// nothing is ever sent back to the CPU -- a batch simply takes as many micro-batches as it needs
@@ -206,6 +220,7 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 		const size_t base = w;
 		for (int64_t r = r0; r <= r1; ++r) local_off[w++] = off[r] - off[r0];
 		const int64_t n = off[r1] - off[r0];
+		TraceRange mb("mm2gb:enqueue_microbatch");
 		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)st.h_f.ptr + off[r0], (int32_t*)st.h_p.ptr + off[r0], false)) return -1;
 	}
 	if (slot.eng.record_outputs_done(st.done)) return -1;
@@ -225,9 +240,44 @@ static StreamSlot &slot_for(int thread_id)
 	return *g_streams.slots[thread_id];
 }
 
-// default engine for the synchronous single-read surface
-static std::mutex g_default_mu;
-static mm2gb_engine_t *g_default_engine = nullptr;
+// CPUs this process may use at once: affinity mask and cgroup quota, whichever is smaller (containers give 16 of 128 here)
+static int usable_cpus()
+{
+	int n = (int)std::thread::hardware_concurrency();
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
+	if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char quota[64]; long long period = 0;
+		if (fscanf(fp, "%63s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+			n = std::min<long long>(n, std::max<long long>(1, atoll(quota) / period));
+		fclose(fp);
+	}
+	return std::max(1, n);
+}
+
+// Engines of the synchronous single-read surface (mm2gb_lchain_dp): one per calling host thread, dealt round-robin over the
+// visible devices (MM2GB_DEVICES), so a threaded host neither queues on one mutex nor piles onto device 0.
+static std::mutex g_single_mu;
+static std::map<std::thread::id, mm2gb_engine_t*> g_single_engines;
+
+static mm2gb_engine_t *single_read_engine(const mm2gb_misc_t &misc)
+{
+	std::lock_guard<std::mutex> lock(g_single_mu);
+	auto it = g_single_engines.find(std::this_thread::get_id());
+	if (it != g_single_engines.end()) return it->second;
+	std::vector<int> devs;
+	if (devices_for_streams(devs)) return nullptr;
+	mm2gb_engine_t *e = mm2gb_engine_create(nullptr, &misc, devs[g_single_engines.size() % devs.size()]);
+	if (e) g_single_engines[std::this_thread::get_id()] = e;
+	return e;
+}
+
+static void free_single_read_engines()
+{
+	std::lock_guard<std::mutex> lock(g_single_mu);
+	for (auto &kv : g_single_engines) mm2gb_engine_destroy(kv.second);
+	g_single_engines.clear();
+}
 
 } // namespace mm2gb
 
@@ -253,14 +303,11 @@ mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_
 	misc.max_iter = max_iter; misc.max_dist_x = max_dist_x; misc.max_dist_y = max_dist_y; misc.max_skip = max_skip; misc.bw = bw;
 	misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.is_cdna = is_cdna; misc.n_seg = n_seg;
 	misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
-	std::lock_guard<std::mutex> lock(g_default_mu);
-	if (!g_default_engine) {
-		g_default_engine = mm2gb_engine_create(nullptr, &misc, 0);
-		if (!g_default_engine) { fprintf(stderr, "[Error] mm2gb_lchain_dp: %s\n", mm2gb_last_error()); exit(1); }
-	}
+	mm2gb_engine_t *eng = single_read_engine(misc);        // this thread's own engine: no lock held while the GPU works
+	if (!eng) { fprintf(stderr, "[Error] mm2gb_lchain_dp: %s\n", mm2gb_last_error()); exit(1); }
 	const int64_t off[2] = { 0, n };
 	std::vector<int32_t> f((size_t)n), p((size_t)n);
-	if (mm2gb_engine_set_misc(g_default_engine, &misc) || mm2gb_score_host(g_default_engine, 1, off, a, f.data(), p.data(), nullptr)) {
+	if (mm2gb_engine_set_misc(eng, &misc) || mm2gb_score_host(eng, 1, off, a, f.data(), p.data(), nullptr)) {
 		fprintf(stderr, "[Error] mm2gb_lchain_dp: %s\n", mm2gb_last_error()); exit(1);
 	}
 	BacktrackScratch ws;
@@ -301,7 +348,8 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	const char *pt = getenv("MM2GB_POST_THREADS");
 	// host threads for packing anchors and for backtrack + compaction; results enter the host's kalloc arena on the calling
 	// thread only, so this is safe with the single-threaded reference host
-	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 2));
+	// default: this stream's share of the CPUs the process may use (one GPU's post-pass needs ~13 CPU-equivalents to stay hidden)
+	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : std::max(1, std::min(32, usable_cpus() / std::max(1, cfg.num_streams)));
 	{ const char *dbg = getenv("MM2GB_DEBUG_PHASES"); g_streams.debug = dbg && *dbg && *dbg != '0'; }
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
@@ -332,11 +380,14 @@ void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, 
 	const bool launched = new_reads && n_new > 0;
 	if (launched && launch_stage(slot, next, new_reads, n_new)) die(mm2gb_last_error());
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
-	if (finish_stage(slot, prev, km, &done, &n_done)) die(mm2gb_last_error());
+	mm2gb_misc_t done_misc = misc;                       // the batch handed back is finished with the parameters IT was launched with
+	if (finish_stage(slot, prev, km, &done, &n_done, &done_misc)) die(mm2gb_last_error());
 	if (launched) slot.cur ^= 1;
 	*in_arr_ptr = done; *n_read_ptr = n_done;
-	if (done && post_chaining_helper)
-		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:502-507
+	if (done && post_chaining_helper) {
+		TraceRange range("mm2gb:post_chaining_helper");
+		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], done_misc, km);   // plchain.cu:502-507
+	}
 }
 
 void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t **batches, int *num_reads,
@@ -345,7 +396,7 @@ void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt,
 	StreamSlot &slot = slot_for(num_batch);
 	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
-	if (finish_stage(slot, slot.stage[slot.cur], km, &done, &n_done)) die(mm2gb_last_error());
+	if (finish_stage(slot, slot.stage[slot.cur], km, &done, &n_done, &misc)) die(mm2gb_last_error());
 	if (done && post_chaining_helper)
 		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:539-541
 	*batches = done; *num_reads = n_done;
@@ -365,8 +416,7 @@ void free_stream_gpu(int n_threads)
 	}
 	g_streams.slots.clear();
 	g_streams.ready = false;
-	std::lock_guard<std::mutex> lock(g_default_mu);
-	if (g_default_engine) { mm2gb_engine_destroy(g_default_engine); g_default_engine = nullptr; }
+	free_single_read_engines();
 }
 
 } // extern "C"

@@ -5,6 +5,8 @@ collect_pmc.sh) into the small files kept under profiles/:  <tag>_kernel_stats.c
     python profiles/summarize_round.py r01b"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_sha16: which kernel build these counters belong to)
 tag = sys.argv[1]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
@@ -71,6 +73,11 @@ traffic = {
     "source": f"profiles/{tag}_fetch_pmc.csv + {tag}_write_pmc.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {KERNEL} = MODE_LUT, "
               "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (the x2 was calibrated on k_split_soa, the pure 16 B-in / 16 B-out kernel of earlier builds, whose read showed as 8 B/anchor: profiles/earlier/r01c_fetch_pmc.csv)",
     "valu_busy_fraction": round(sq["derived"]["valu_busy"], 3),
+    "valu_insts_per_launch": sq["SQ_INSTS_VALU"],
+    "lds_idx_active_fraction": round(sq["derived"]["lds_idx_active_fraction"], 3),
+    "lds_bank_conflict_fraction": round(sq["derived"]["lds_bank_conflict_fraction_of_lds_cycles"], 3),
+    "profiled_kernel_ms": round(kernel_ms, 3),
+    "kernel_sha16": bench.kernel_sha16(),
     "valu_source": f"profiles/{tag}_sq_counters.json",
 }
 json.dump(traffic, open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)

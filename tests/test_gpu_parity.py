@@ -443,6 +443,74 @@ def test_bench_size_batch_properties():
         assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
 
 
+def test_config2_size_batch_properties():
+    """BASELINE configs[2] at its full size: synthetic ONT 10-100 kb reads, one 500 M-anchor micro-batch.  Same checks as the
+    configs[3] test above: size-independent properties on every anchor, idempotence, the oracle on reads across the batch."""
+    import os
+    target = int(os.environ.get("MM2GB_TEST_FULL_ANCHORS", 500_000_000))
+    import bench
+    _, n_reads, a, off = bench.shard_for_rank(mm, 0, 1, 2024, target, 10_000, 100_000, threads=32)
+    n = len(a)
+    assert n >= 0.99 * target
+    with mm.Engine() as e:
+        f, p, st = e.score(a, off)
+        assert st["n_anchors"] == n and st["n_reads"] == n_reads and st["n_pairs"] > 100 * n
+        span = ((a[:, 1] >> np.uint64(32)) & np.uint64(0xff)).astype(np.int32)
+        assert (f >= span).all()
+        has = p > 0
+        assert (f[has] > span[has]).all() and (f[~has] == span[~has]).all()
+        idx = np.flatnonzero(has)
+        j = idx - p[idx]
+        read_of = np.searchsorted(off, idx, side="right") - 1
+        assert (j >= off[read_of]).all()
+        assert ((a[idx, 0] >> np.uint64(32)) == (a[j, 0] >> np.uint64(32))).all()
+        assert (a[idx, 0] - a[j, 0] <= np.uint64(5000)).all()
+        assert (f[idx] <= f[j] + span[j]).all()
+        del idx, j, read_of, has
+        f2, p2, st2 = e.score(a, off)
+        assert st2["n_pairs"] == st["n_pairs"] and np.array_equal(f, f2) and np.array_equal(p, p2)
+    prm = orc.default_param()
+    for r in np.linspace(0, n_reads - 1, 9).astype(int):
+        fo, po, _ = orc.chain_fill(a[off[r]:off[r + 1]], prm)
+        assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
+
+
+def test_clamped_penalty_table_build(monkeypatch):
+    """MM2GB_LUT_CLAMP=1: the bw+2-entry penalty table with a clamped index (no LDS read ever leaves the table) instead of
+    the wide unclamped one.  Same results on saturated windows, ties, the rescue, team and wave modes."""
+    monkeypatch.setenv("MM2GB_LUT_CLAMP", "1")
+    parts = [sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 141), sc.colinear(800, 142), sc.noise(3000, 143)])),
+             sc.rescue_case(n_noise=6000, n_chain=50, seed=19), sc.read_like(9000, 144),
+             sc.sort_by_x(sc.repeat_block(6000, 177, xwin=1500, ywin=5000))]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    with mm.Engine() as e:
+        st = check_batch(e, a, off, orc.default_param())
+        assert st["n_long_chunks"] >= 2 and st["n_tracked_chunks"] >= 1
+        check_batch(e, a, off, orc.default_param(max_iter=160))
+        for path in [c for c in CASES if "ties" in c or "rescue" in c]:
+            g = golden_io.load(path)
+            if g["prm"].max_skip != orc.INT32_MAX:
+                continue
+            e.set_misc(misc_from(g["prm"]))
+            f, p, _ = e.score(g["a"], np.array([0, len(g["a"])], np.int64))
+            assert np.array_equal(f, g["f"]) and np.array_equal(p, rel(g["p"])), path
+    monkeypatch.setenv("MM2GB_NO_COOP", "1")
+    with mm.Engine() as e:
+        check_batch(e, a, off, orc.default_param())
+
+
+@pytest.mark.parametrize("dist", [(1 << 28) - 1, 1 << 28, 1 << 29, (1 << 31) - 1])
+def test_huge_max_dist_leaves_the_table_sweep_domain(dist):
+    """A user -g / -r of 2^28 and more (max_dist_x / max_dist_y): the x4 coordinates of the table sweep would wrap, so the
+    engine must pick the per-pair build by itself; windows are then bounded by max_iter alone."""
+    a = sc.sort_by_x(np.concatenate([sc.repeat_block(3000, 151), sc.colinear(900, 152), sc.noise(2000, 153)]))
+    with mm.Engine() as e:
+        check_batch(e, a, np.array([0, len(a)], np.int64), orc.default_param(max_dist_x=dist, max_dist_y=dist, max_iter=700))
+        check_batch(e, a, np.array([0, len(a)], np.int64), orc.default_param(max_dist_x=dist, max_dist_y=5000))
+
+
 @pytest.mark.timeout(120)
 def test_unsorted_anchors_do_not_hang_or_crash(engine):
     """Anchors sorted by x are the caller's contract (map.c:329).  Broken input must still come back: window starts stay inside
