@@ -55,6 +55,7 @@ typedef struct {
 	int64_t n_tracked_chunks;   /* of those, run with the max_ii rescue state machine (lchain.c:190-205) */
 	int64_t n_clamped_blocks;   /* planner blocks containing a window cut by max_iter (lchain.c:173) */
 	float   ms_h2d, ms_prep, ms_score, ms_d2h, ms_total;
+	float   ms_post;            /* device post-pass kernels (mm2gb_chain_gpu), 0 when the post-pass ran on the host */
 } mm2gb_stats_t;
 
 typedef struct mm2gb_engine mm2gb_engine_t;
@@ -109,6 +110,17 @@ int  mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offse
                       int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats);
 void mm2gb_chains_free(mm2gb_chains_t *out);
 
+/* ---- the same with the post-pass on the device too: backtrack (mg_chain_backtrack, lchain.c:27-76) and
+ *      compaction (compact_a, lchain.c:78-111) run as kernels behind the score kernel -- one wave per read, the reference's
+ *      sort order (radix_sort_128x, ksort.h:98-151) reproduced element for element -- and only chains and compacted anchors
+ *      come back over the link.  Same outputs as mm2gb_chain_host, no host threads.  One micro-batch per call.
+ *      mm2gb_post_device: the post-pass alone on device-resident scores (as mm2gb_score_device left them); results stay on the
+ *      device, the totals and the kernels' time are reported.  Synchronises the engine's stream. ---- */
+int  mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                     mm2gb_chains_t *out, mm2gb_stats_t *stats);
+int  mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
+                       const int32_t *d_f, const int32_t *d_p, int64_t *n_chains, int64_t *n_kept, float *ms);
+
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
  *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;
@@ -125,6 +137,35 @@ int  mm2gb_pool_score_host(mm2gb_pool_t *pool, int64_t n_reads, const int64_t *o
                            int32_t *f, int32_t *p, mm2gb_stats_t *stats, int64_t *first_read_of_device);
 int  mm2gb_pool_chain_host(mm2gb_pool_t *pool, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                            int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats);
+
+/* ---- batch accumulator + dispatcher (role of mm_trbuf_t, mm_trbuf_is_full and the batch rotation of worker_for,
+ *      map.c:23-157, 886-922, 1026-1075): feed reads one at a time from any number of host threads; they are grouped into batches
+ *      of at most max_total_n x micro_batch anchors / max_read x micro_batch reads (a read that would overflow the batch starts
+ *      the next one, as in map.c:887-920; a read larger than the limit is a batch of its own), closed batches are dealt to the
+ *      devices' workers as they become free (one engine + one host thread per device, nothing moves between devices), and every
+ *      read's chains come back through `done` (called on worker threads, reads of one batch in the order they were added).
+ *      min_n (gpu_config.json) routes reads with fewer anchors to a lane of their own -- batched separately, still on the GPU;
+ *      there is no CPU fallback.  post_threads > 0: host threads per device for backtrack + compaction, overlapped with the
+ *      device; 0: the device post-pass (mm2gb_chain_gpu).  mm2gb_batcher_add blocks while every batch buffer is in flight.
+ *      mm2gb_plan_batches: the grouping rule alone, for a sequence of reads added in order by one thread (no GPU needed):
+ *      writes the batch id (in order of creation) and lane (0 big, 1 small) of every read, returns the number of batches. ---- */
+typedef struct mm2gb_batcher mm2gb_batcher_t;
+typedef void (*mm2gb_read_done_fn)(void *user, int64_t read_id, int n_u, const uint64_t *u, int64_t n_a, const mm2gb_anchor_t *a);
+#define MM2GB_BATCHER_MAX_ENGINES 16
+typedef struct {
+	int64_t reads, anchors;
+	int64_t reads_per_lane[2], batches[2];                         /* [0] reads of at least min_n anchors, [1] smaller ones */
+	int64_t batches_per_engine[MM2GB_BATCHER_MAX_ENGINES];
+	int     n_engines;
+} mm2gb_batcher_stats_t;
+mm2gb_batcher_t *mm2gb_batcher_create(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int n_devices, const int *devices,
+                                      int post_threads, mm2gb_read_done_fn done, void *user);
+int  mm2gb_batcher_add(mm2gb_batcher_t *b, int64_t read_id, const mm2gb_anchor_t *a, int64_t n);
+int  mm2gb_batcher_flush(mm2gb_batcher_t *b);                     /* close the partial batches, wait until every read is delivered */
+int  mm2gb_batcher_stats(mm2gb_batcher_t *b, mm2gb_batcher_stats_t *out);
+void mm2gb_batcher_destroy(mm2gb_batcher_t *b);
+int64_t mm2gb_plan_batches(int64_t n_reads, const int64_t *n_anchors, int64_t max_total_n, int max_read, int min_n,
+                           int32_t *batch_of_read, int32_t *lane_of_read);
 
 /* ---- host post-pass on given f / relative p for ONE read (restates mg_chain_backtrack + compact_a,
  *      lchain.c:27-111, including the radix_sort_128x order, ksort.h:98-151).  Returns number of chains;

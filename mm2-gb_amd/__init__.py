@@ -43,7 +43,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_anchors", C.c_int64), ("n_reads", C.c_int64), ("n_pairs", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_long_chunks", C.c_int64), ("n_mid_chunks", C.c_int64), ("n_tracked_chunks", C.c_int64), ("n_clamped_blocks", C.c_int64),
-                ("ms_h2d", C.c_float), ("ms_prep", C.c_float), ("ms_score", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float)]
+                ("ms_h2d", C.c_float), ("ms_prep", C.c_float), ("ms_score", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
+                ("ms_post", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -63,7 +64,7 @@ _lib = None
 CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "mm2gb_config_parse", "mm2gb_config_load",
                 "mm2gb_device_count", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device",
                 "mm2gb_engine_reserve", "mm2gb_score_host", "mm2gb_score_device", "mm2gb_engine_sync", "mm2gb_engine_stats",
-                "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chains_free", "mm2gb_backtrack_host",
+                "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chain_gpu", "mm2gb_post_device", "mm2gb_chains_free", "mm2gb_backtrack_host",
                 "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
                 "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host"]
@@ -100,6 +101,9 @@ def lib():
         L.mm2gb_engine_last_kernel_ms.argtypes = [C.c_void_p]
         L.mm2gb_engine_last_kernel_ms.restype = C.c_float
         L.mm2gb_chain_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Chains), C.POINTER(Stats)]
+        L.mm2gb_chain_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Chains), C.POINTER(Stats)]
+        L.mm2gb_post_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.mm2gb_chains_free.argtypes = [C.POINTER(Chains)]
         L.mm2gb_chains_free.restype = None
         L.mm2gb_backtrack_host.argtypes = [C.POINTER(Misc), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -225,6 +229,20 @@ class Engine:
         st = Stats()
         _check(lib().mm2gb_chain_host(self._h, R, off.ctypes.data, a.ctypes.data, threads, C.byref(out), C.byref(st)))
         return _take_chains(out, R), st.as_dict()
+
+
+def _engine_chain_gpu(self, anchors, offsets):
+    """Full chaining of a batch with backtrack + compaction on the device too (mm2gb_chain_gpu): list of (u, a_out) per read."""
+    a = np.ascontiguousarray(anchors, dtype=np.uint64)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    R = len(off) - 1
+    out = Chains()
+    st = Stats()
+    _check(lib().mm2gb_chain_gpu(self._h, R, off.ctypes.data, a.ctypes.data, C.byref(out), C.byref(st)))
+    return _take_chains(out, R), st.as_dict()
+
+
+Engine.chain_gpu = _engine_chain_gpu
 
 
 def _take_chains(out, R):

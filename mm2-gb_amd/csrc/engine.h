@@ -65,6 +65,11 @@ struct Engine {
 	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
 	DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
 	DevBuf counters, totals, flags, lut, dbg;
+	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
+	int64_t cap_post_n = 0, cap_post_reads = 0;
+	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc;
+	int64_t *h_post_totals = nullptr;      // pinned: [0] chains [1] anchors kept
+	hipEvent_t post0 = nullptr, post1 = nullptr;
 	IoSet io[2];
 	uint64_t io_seq = 0;
 	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host
@@ -91,6 +96,13 @@ struct Engine {
 	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats = true);
 	int  score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int32_t *f, int32_t *p,
 	                const std::function<void(int64_t, int64_t)> *slice_done);   // sliced + overlapped, waits for the end
+	// backtrack + compaction of a scored micro-batch on the device (all pointers device pointers; d_f / d_p as enqueue() left
+	// them); enqueued on the compute stream.  Results stay in post_uoff / post_aoff / post_uout / post_aout; totals land in
+	// h_post_totals once the stream has been synchronised.
+	int  reserve_post(int64_t n_anchors, int64_t n_reads);
+	int  enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p);
+	// whole batch on host buffers, chains back, nothing but the chains crosses the link on the way back
+	int  chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out);
 	int  record_outputs_done(hipEvent_t ev);   // fires when every D2H enqueued so far has landed
 	int  sync();
 	int  collect_stats();
@@ -99,3 +111,8 @@ struct Engine {
 } // namespace mm2gb
 
 struct mm2gb_engine { mm2gb::Engine e; };
+
+namespace mm2gb {
+// pool.cpp: one engine, host buffers in, chains out, post-pass on n_threads host threads overlapped with the device
+int chain_batch_on_engine(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats);
+}

@@ -198,6 +198,11 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc })
+		b->release();
+	cap_post_n = cap_post_reads = 0;
+	if (h_post_totals) { (void)hipHostFree(h_post_totals); h_post_totals = nullptr; }
+	for (hipEvent_t *e : { &post0, &post1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
 	for (hipStream_t *s : { &s_in, &stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
@@ -276,6 +281,90 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 		last.n_anchors += n; last.n_reads += n_reads;
 	}
 	MM2GB_HIP(hipGetLastError());
+	return 0;
+}
+
+int Engine::reserve_post(int64_t n, int64_t n_reads)
+{
+	MM2GB_HIP(hipSetDevice(device));
+	if (!h_post_totals) MM2GB_HIP(hipHostMalloc((void**)&h_post_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+	for (hipEvent_t *e : { &post0, &post1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
+	if (n <= cap_post_n && n_reads <= cap_post_reads) return 0;
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	const int64_t nn = std::max<int64_t>(std::max(n, cap_post_n), 1024), nr = std::max<int64_t>(std::max(n_reads, cap_post_reads), 16);
+	const int64_t had_n = cap_post_n;
+	(void)had_n;
+	cap_post_n = cap_post_reads = 0;                    // as in reserve(): only restored when every buffer has its size
+	// per-chain arrays are sized for min_cnt = 1 (a chain per anchor): min_cnt is a per-call parameter and may drop
+	const size_t chains = (size_t)(nn + nr);
+	if (post_z.ensure((size_t)nn * 8) || post_mark.ensure((size_t)nn) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
+	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_uoff.ensure((size_t)(nr + 1) * 8) ||
+	    post_aoff.ensure((size_t)(nr + 1) * 8) || post_uout.ensure(chains * 8) || post_aout.ensure((size_t)nn * 16) || post_misc.ensure(64)) return -1;
+	cap_post_n = nn; cap_post_reads = nr;
+	return 0;
+}
+
+int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p)
+{
+	if (reserve_post(n, n_reads)) return -1;
+	PostBatch b;
+	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads; b.f = d_f; b.p = d_p;
+	b.z = (unsigned long long*)post_z.ptr; b.mark = (uint8_t*)post_mark.ptr; b.picked = (int32_t*)post_picked.ptr;
+	b.u_tmp = (unsigned long long*)post_utmp.ptr; b.heads = (ulonglong2*)post_heads.ptr;
+	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)post_uoff.ptr; b.a_off = (int64_t*)post_aoff.ptr;
+	b.u_out = (unsigned long long*)post_uout.ptr; b.a_out = (uint4*)post_aout.ptr;
+	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 32);
+	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
+	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
+	// one read per wave at a time: as many waves as the chip holds (latency-bound pointer chases; parallelism is across reads)
+	b.grid_waves = n_cu * 32;
+	if (const char *v = getenv("MM2GB_POST_WAVES")) b.grid_waves = std::max(4, atoi(v));
+	MM2GB_HIP(hipEventRecord(post0, stream));
+	launch_post(b, stream);
+	MM2GB_HIP(hipEventRecord(post1, stream));
+	MM2GB_HIP(hipMemcpyAsync(h_post_totals, post_misc.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipGetLastError());
+	return 0;
+}
+
+// Whole batch from host buffers to chains with every stage on the device: H2D of the anchors, score kernels, post-pass
+// kernels, then only offsets + chains + compacted anchors come back (the host post-pass path returns 8 B per anchor).
+int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out)
+{
+	memset(out, 0, sizeof(*out));
+	if (!offsets || n_reads < 0 || offsets[0] != 0) return fail("mm2gb_chain_gpu: offsets[0] must be 0");
+	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_chain_gpu: offsets must be non-decreasing");
+	const int64_t n = offsets[n_reads];
+	if (n > 0 && !anchors) return fail("mm2gb_chain_gpu: null buffer");
+	MM2GB_HIP(hipSetDevice(device));
+	if (begin_call()) return -1;
+	const auto t0 = std::chrono::steady_clock::now();
+	IoSet &s = io[io_seq++ & 1];
+	const size_t nn = (size_t)std::max<int64_t>(n, 1);
+	for (hipStream_t q : { s_in, stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+	if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
+	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
+	if (n > 0) MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, anchors, (size_t)n * 16, hipMemcpyHostToDevice, stream));
+	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr)) return -1;
+	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr)) return -1;
+	s.used = false;                                     // nothing of this set is in flight once the call returns
+	if (sync()) return -1;
+	const int64_t n_u = n_reads > 0 ? h_post_totals[0] : 0, n_a = n_reads > 0 ? h_post_totals[1] : 0;
+	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->u = (uint64_t*)malloc((size_t)(n_u + 1) * 8);
+	out->a = (mm2gb_anchor_t*)malloc((size_t)(n_a + 1) * 16);
+	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb_chain_gpu: out of host memory"); }
+	out->u_off[0] = out->a_off[0] = 0;
+	if (n_reads > 0) {
+		MM2GB_HIP(hipMemcpy(out->u_off, post_uoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
+		MM2GB_HIP(hipMemcpy(out->a_off, post_aoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
+		if (n_u > 0) MM2GB_HIP(hipMemcpy(out->u, post_uout.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost));
+		if (n_a > 0) MM2GB_HIP(hipMemcpy(out->a, post_aout.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost));
+	}
+	float ms = 0;
+	if (n_reads > 0 && hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
+	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	return 0;
 }
 
@@ -475,6 +564,29 @@ int mm2gb_score_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_of
 }
 
 int mm2gb_engine_sync(mm2gb_engine_t *eng) { return eng ? eng->e.sync() : fail("mm2gb: null engine"); }
+
+int mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out, mm2gb_stats_t *stats)
+{
+	if (!eng || !out) return fail("mm2gb_chain_gpu: null argument");
+	if (eng->e.chain_gpu(n_reads, offsets, anchors, out)) return -1;
+	if (stats) *stats = eng->e.last;
+	return 0;
+}
+
+int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
+                      const int32_t *d_f, const int32_t *d_p, int64_t *n_chains, int64_t *n_kept, float *ms)
+{
+	if (!eng) return fail("mm2gb: null engine");
+	Engine &e = eng->e;
+	MM2GB_HIP(hipSetDevice(e.device));
+	if (e.enqueue_post(n_reads, d_offsets, d_anchors, n_anchors, d_f, d_p)) return -1;
+	MM2GB_HIP(hipStreamSynchronize(e.stream));
+	if (n_chains) *n_chains = e.h_post_totals[0];
+	if (n_kept) *n_kept = e.h_post_totals[1];
+	float t = 0;
+	if (ms && hipEventElapsedTime(&t, e.post0, e.post1) == hipSuccess) *ms = t;
+	return 0;
+}
 
 int mm2gb_engine_stats(mm2gb_engine_t *eng, mm2gb_stats_t *stats)
 {

@@ -235,6 +235,12 @@ int chain_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_read
 }
 
 } // namespace
+
+int chain_batch_on_engine(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads, mm2gb_chains_t *out, mm2gb_stats_t *stats)
+{
+	return chain_on_engines(std::vector<mm2gb_engine_t*>(1, eng), n_reads, offsets, anchors, n_threads, out, stats);
+}
+
 } // namespace mm2gb
 
 using namespace mm2gb;

@@ -1,0 +1,342 @@
+// post_kernels.hip -- backtrack + compaction on the device: chains out of (f, p) without a trip to the host.
+//
+// What is computed is fixed by the reference's CPU code: mg_chain_backtrack / mg_chain_bk_end (lchain.c:9-76), compact_a
+// (lchain.c:78-111) and -- because the order in which equal scores are visited decides which chain an anchor ends up in --
+// the exact element order radix_sort_128x leaves (ksort.h:98-151: in-place most-significant-byte radix passes with a cycle
+// permutation, insertion sort for runs of <= 64).  None of these steps has a parallel form with the same results (the
+// permutation is a pointer chase through 256 bucket heads, a chain walk follows predecessor links and stops at anchors an
+// earlier, better chain has taken), so the parallelism is ACROSS reads: one wave per read, thousands of reads in flight,
+// the wave's 64 lanes used wherever a step is data-parallel (candidate collection, histograms, prefix sums, small-run
+// sorts, segment discovery, the final gather) and lane 0 for the two chases.  A low-occupancy, latency-bound kernel by
+// design; it runs on the engine's compute stream behind the score kernel of its micro-batch.
+//
+//   k_post_chains   per read: candidates z = (f, i) with f >= min_sc  ->  the host's sort order  ->  chain walks  ->
+//                   picked[] (anchor indices, chain by chain), u_tmp[] (score<<32 | count), n_u, n_kept
+//   k_post_scan     exclusive scans of n_u / n_kept over the reads -> u_off, a_off (+ totals)
+//   k_post_emit     per read: chains ordered by the reference position of their first anchor (same sort), u[] and the
+//                   compacted anchors written to their final place
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include <algorithm>
+#include "chain_dev.h"
+
+namespace mm2gb {
+
+namespace {
+
+constexpr int W = 64;
+constexpr int POST_THREADS = 256;               // 4 waves, one read each
+constexpr int SMALL_RUN = 64;                   // RS_MIN_SIZE, ksort.h:98
+
+__device__ __forceinline__ int lane() { return threadIdx.x & (W - 1); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void wave_sync()
+{
+	// LDS and global accesses of one wave are issued in order; the fence keeps the compiler from moving them across phases
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// Per-wave LDS scratch of a radix pass.
+struct PassLds { int cnt[256]; int head[256]; int tail[256]; };
+
+// ---- the two element kinds that get sorted the host's way ----------------------------------------------------------
+// Z: candidates of the backtrack, key = score f (lchain.c:38-41: z[k].x = f[i], z[k].y = i), packed f<<32 | i.
+// H: chain heads of the compaction, key = x of the chain's first anchor, value = offset<<32 | chain (lchain.c:94-99).
+struct ZElem {
+	using T = unsigned long long;
+	static __device__ __forceinline__ unsigned long long key(T e) { return e >> 32; }
+};
+struct HElem {
+	using T = ulonglong2;
+	static __device__ __forceinline__ unsigned long long key(const T &e) { return e.x; }
+};
+
+// Stable sort of a run of at most 64 elements by key == what rs_insertsort leaves (ksort.h:105-115): every lane holds one
+// element and counts the elements that must come before it.
+template <class E>
+__device__ __forceinline__ void small_run_sort(typename E::T *g, int lo, int len)
+{
+	const int l = lane();
+	const bool in = l < len;
+	typename E::T e = g[lo + (in ? l : 0)];
+	const unsigned long long k = E::key(e);
+	const unsigned klo = (unsigned)k, khi = (unsigned)(k >> 32);
+	// already in order (the common case at the lower levels: a run sorted one level up is seen again)
+	const unsigned plo = __shfl_up(klo, 1), phi = __shfl_up(khi, 1);
+	const unsigned long long prev = (unsigned long long)phi << 32 | plo;
+	if (__ballot(in && l > 0 && k < prev) == 0) return;
+	int rank = 0;
+	for (int m = 0; m < len; ++m) {
+		const unsigned long long km = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, m) << 32 | (unsigned)__builtin_amdgcn_readlane((int)klo, m);
+		rank += (km < k) || (km == k && m < l);
+	}
+	wave_sync();
+	if (in) g[lo + rank] = e;
+	wave_sync();
+}
+
+// One pass of rs_sort (ksort.h:116-146) over g[lo, hi) on key byte `shift`: histogram and bucket bounds with all lanes, then
+// the in-place cycle permutation exactly as the host does it -- element by element, each placement evicting the element
+// that decides the next one -- on lane 0.  Returns false when every key has the same byte (the pass moves nothing).
+template <class E>
+__device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L)
+{
+	const int l = lane();
+	for (int k = l; k < 256; k += W) L.cnt[k] = 0;
+	wave_sync();
+	for (int i = lo + l; i < hi; i += W) atomicAdd(&L.cnt[(int)(E::key(g[i]) >> shift) & 255], 1);
+	wave_sync();
+	// lane l owns buckets 4l .. 4l+3
+	const int c0 = L.cnt[4 * l], c1 = L.cnt[4 * l + 1], c2 = L.cnt[4 * l + 2], c3 = L.cnt[4 * l + 3];
+	const int len = hi - lo;
+	if (__ballot(c0 == len || c1 == len || c2 == len || c3 == len) != 0) return false;
+	int inc = c0 + c1 + c2 + c3;
+	const int own = inc;
+	for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(inc, off); if (l >= off) inc += o; }
+	int at = lo + inc - own;
+	L.head[4 * l] = at; at += c0; L.tail[4 * l] = at;
+	L.head[4 * l + 1] = at; at += c1; L.tail[4 * l + 1] = at;
+	L.head[4 * l + 2] = at; at += c2; L.tail[4 * l + 2] = at;
+	L.head[4 * l + 3] = at; at += c3; L.tail[4 * l + 3] = at;
+	wave_sync();
+	if (l == 0) {
+		for (int k = 0; k < 256; ++k) {
+			int hk = L.head[k];
+			const int tk = L.tail[k];
+			while (hk < tk) {
+				typename E::T carry = g[hk];
+				int d = (int)(E::key(carry) >> shift) & 255;
+				if (d == k) { ++hk; continue; }
+				do {
+					const typename E::T moved = carry;
+					const int hd = L.head[d];
+					carry = g[hd];
+					g[hd] = moved;
+					L.head[d] = hd + 1;
+					d = (int)(E::key(carry) >> shift) & 255;
+				} while (d != k);
+				g[hk] = carry;
+				++hk;
+			}
+		}
+	}
+	wave_sync();
+	return true;
+}
+
+// radix_sort_128x (ksort.h:147-151) of g[0, n) by key, same final element order as the host's.
+// The host recurses bucket by bucket; buckets are independent, so the same work is done here level by level: at the level of
+// key byte `shift` the array is made of runs of elements that agree on all higher key bytes; a run longer than 64 gets a
+// radix pass on this byte, a run of 2..64 is insertion-sorted (a run that was sorted one level up is seen again: a no-op).
+// Passes on bytes in which all keys of the run agree move nothing, so starting at the highest byte in which any two keys
+// differ equals the host's start at byte 7.
+template <class E>
+__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L)
+{
+	if (n <= 1) return;
+	if (n <= SMALL_RUN) { small_run_sort<E>(g, 0, n); return; }
+	const int l = lane();
+	unsigned long long any = 0, all = ~0ull;
+	for (int i = l; i < n; i += W) { const unsigned long long k = E::key(g[i]); any |= k; all &= k; }
+	for (int off = W / 2; off > 0; off >>= 1) {
+		any |= (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)any, off) | (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(any >> 32), off) << 32;
+		all &= (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)all, off) | (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(all >> 32), off) << 32;
+	}
+	const unsigned long long diff = any ^ all;
+	if (diff == 0) return;
+	int top = 56;
+	while (top > 0 && ((diff >> top) & 255) == 0) top -= 8;
+	for (int shift = top; shift >= 0; shift -= 8) {
+		// runs of equal key >> (shift + 8); at the top level the whole array is one run by construction
+		int run_lo = 0;
+		unsigned long long carry_prefix = 0;
+		for (int base = 0; base < n; base += W) {
+			const int i = base + l;
+			const bool in = i < n;
+			const unsigned long long pk = in && shift < 56 ? E::key(g[i]) >> (shift + 8) : 0;
+			unsigned long long before = (unsigned long long)(unsigned)__shfl_up((int)(unsigned)pk, 1) | (unsigned long long)(unsigned)__shfl_up((int)(unsigned)(pk >> 32), 1) << 32;
+			if (l == 0) before = carry_prefix;
+			unsigned long long starts = __ballot(in && i > 0 && pk != before);
+			carry_prefix = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)pk, W - 1) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pk >> 32), W - 1) << 32;
+			while (starts) {
+				const int q = base + __builtin_ctzll(starts);
+				starts &= starts - 1;
+				const int len = q - run_lo;
+				if (len > SMALL_RUN) radix_pass<E>(g, run_lo, q, shift, L);
+				else if (len > 1) small_run_sort<E>(g, run_lo, len);
+				run_lo = q;
+			}
+		}
+		const int len = n - run_lo;
+		if (len > SMALL_RUN) radix_pass<E>(g, run_lo, n, shift, L);
+		else if (len > 1) small_run_sort<E>(g, run_lo, len);
+		wave_sync();
+	}
+}
+
+// chains of read r hold at least max(1, min_cnt) anchors each, so at most n_r / mc of them: slot of read r in the per-chain arrays
+__device__ __forceinline__ int64_t chain_slot(int64_t off_r, int64_t r, int mc) { return off_r / mc + r; }
+
+} // namespace
+
+// --------------------------------------------------------------------------------------------------------------
+// per read: candidates, host order, chain walks (lchain.c:27-76)
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
+{
+	__shared__ PassLds lds[POST_THREADS / W];
+	PassLds &L = lds[threadIdx.x / W];
+	const int l = lane();
+	const int mc = b.min_cnt > 1 ? b.min_cnt : 1;
+	for (;;) {
+		int r = 0;
+		if (l == 0) r = atomicAdd(b.cursor, 1);
+		r = uni(r);
+		if (r >= b.n_reads) break;
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const int32_t *f = b.f + off, *p = b.p + off;
+		unsigned long long *z = b.z + off;
+		uint8_t *mark = b.mark + off;
+		int32_t *picked = b.picked + off;
+		unsigned long long *u_tmp = b.u_tmp + chain_slot(off, r, mc);
+		// candidates in index order (lchain.c:35-41) and cleared marks (lchain.c:43)
+		int n_z = 0;
+		for (int base = 0; base < n; base += W) {
+			const int i = base + l;
+			const bool in = i < n;
+			const int fi = in ? f[i] : INT_MIN;
+			if (in) mark[i] = 0;
+			const bool take = in && fi >= b.min_sc;
+			const unsigned long long m = __ballot(take);
+			if (take) z[n_z + __popcll(m & ((1ull << l) - 1))] = (unsigned long long)(unsigned)fi << 32 | (unsigned)i;
+			n_z += __popcll(m);
+		}
+		wave_sync();
+		sort_like_host<ZElem>(z, n_z, L);
+		// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
+		int n_u = 0, n_v = 0;
+		if (l == 0) {
+			for (int k = n_z - 1; k >= 0; --k) {
+				const unsigned long long zk = z[k];
+				const int start = (int)(unsigned)zk, top = (int)(zk >> 32);
+				if (mark[start] != 0) continue;
+				// mg_chain_bk_end (lchain.c:9-25): back from the chain end until an anchor that is taken, the start of the path, or an
+				// X-drop of more than max_drop below the best prefix.  Nodes go straight into picked[]; `kept` is how many of them lie
+				// before the anchor the best prefix stops at.
+				int i = start, kept = 0, visited = 0, best = 0, stop = start;
+				int pi = p[i];
+				do {
+					picked[n_v + visited++] = i;
+					i = pi ? i - pi : -1;
+					int s = top, m_i = 1;
+					if (i >= 0) { s = top - f[i]; pi = p[i]; m_i = mark[i]; }
+					if (s > best) { best = s; stop = i; kept = visited; }
+					else if (best - s > b.max_drop) break;
+					if (m_i != 0) break;
+				} while (i >= 0);
+				for (int q = 0; q < kept; ++q) mark[picked[n_v + q]] = 1;
+				const int sc = stop < 0 ? top : top - f[stop];
+				if (sc >= b.min_sc && kept > 0 && kept >= b.min_cnt) { u_tmp[n_u++] = (unsigned long long)(unsigned)sc << 32 | (unsigned)kept; n_v += kept; }
+			}
+			b.n_u[r] = n_u;
+			b.n_kept[r] = n_v;
+		}
+		wave_sync();
+	}
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// offsets of every read's chains / kept anchors in the compacted outputs
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_post_scan(PostBatch b)
+{
+	__shared__ long long s_tmp[2][1024 / W];
+	long long carry_u = 0, carry_a = 0;
+	const int w = threadIdx.x / W, l = lane();
+	for (int64_t base = 0; base < b.n_reads; base += 1024) {
+		const int64_t r = base + threadIdx.x;
+		const long long vu = r < b.n_reads ? b.n_u[r] : 0, va = r < b.n_reads ? b.n_kept[r] : 0;
+		long long iu = vu, ia = va;
+		for (int off = 1; off < W; off <<= 1) {
+			const long long ou = __shfl_up(iu, off), oa = __shfl_up(ia, off);
+			if (l >= off) { iu += ou; ia += oa; }
+		}
+		__syncthreads();
+		if (l == W - 1) { s_tmp[0][w] = iu; s_tmp[1][w] = ia; }
+		__syncthreads();
+		long long bu = 0, ba = 0, tu = 0, ta = 0;
+		for (int k = 0; k < 1024 / W; ++k) { if (k < w) { bu += s_tmp[0][k]; ba += s_tmp[1][k]; } tu += s_tmp[0][k]; ta += s_tmp[1][k]; }
+		if (r < b.n_reads) { b.u_off[r] = carry_u + bu + iu - vu; b.a_off[r] = carry_a + ba + ia - va; }
+		carry_u += tu; carry_a += ta;
+	}
+	if (threadIdx.x == 0) { b.u_off[b.n_reads] = carry_u; b.a_off[b.n_reads] = carry_a; b.totals[0] = carry_u; b.totals[1] = carry_a; }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// per read: order of compaction (lchain.c:84-110) and the gather into the final arrays
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(POST_THREADS) void k_post_emit(PostBatch b)
+{
+	__shared__ PassLds lds[POST_THREADS / W];
+	PassLds &L = lds[threadIdx.x / W];
+	const int l = lane();
+	const int mc = b.min_cnt > 1 ? b.min_cnt : 1;
+	for (;;) {
+		int r = 0;
+		if (l == 0) r = atomicAdd(b.cursor + 1, 1);
+		r = uni(r);
+		if (r >= b.n_reads) break;
+		const int n_u = b.n_u[r];
+		if (n_u == 0) continue;
+		const int64_t off = b.offsets[r];
+		const uint4 *raw = b.raw + off;
+		const int32_t *picked = b.picked + off;
+		const unsigned long long *u_tmp = b.u_tmp + chain_slot(off, r, mc);
+		ulonglong2 *heads = b.heads + chain_slot(off, r, mc);
+		unsigned long long *u_out = b.u_out + b.u_off[r];
+		uint4 *a_out = b.a_out + b.a_off[r];
+		// (x of the chain's first anchor, offset << 32 | chain): the first anchor is the last one picked (lchain.c:88-99)
+		int k_at = 0;
+		for (int base = 0; base < n_u; base += W) {
+			const int c = base + l;
+			const int cnt = c < n_u ? (int)(unsigned)u_tmp[c] : 0;
+			int inc = cnt;
+			for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc += v; }
+			const int k0 = k_at + inc - cnt;
+			if (c < n_u) {
+				const uint4 first = raw[picked[k0 + cnt - 1]];
+				heads[c] = make_ulonglong2((unsigned long long)first.y << 32 | first.x, (unsigned long long)(unsigned)k0 << 32 | (unsigned)c);
+			}
+			k_at += __builtin_amdgcn_readlane(inc, W - 1);
+		}
+		wave_sync();
+		sort_like_host<HElem>(heads, n_u, L);
+		// chains in that order; each chain's anchors from its first to its last (picked[] holds them last to first)
+		int out_at = 0;
+		for (int c = 0; c < n_u; ++c) {
+			const ulonglong2 h = heads[c];
+			const int k0 = (int)(h.y >> 32), ci = (int)(unsigned)h.y;
+			const unsigned long long u = u_tmp[ci];
+			const int cnt = (int)(unsigned)u;
+			if (l == 0) u_out[c] = u;
+			for (int j = l; j < cnt; j += W) a_out[out_at + j] = raw[picked[k0 + (cnt - 1 - j)]];
+			out_at += cnt;
+		}
+	}
+}
+
+void launch_post(const PostBatch &b, hipStream_t s)
+{
+	if (b.n_reads <= 0) return;
+	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
+	const int64_t waves = (int64_t)b.grid_waves;
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
+	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b);
+	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b);
+	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);
+}
+
+} // namespace mm2gb

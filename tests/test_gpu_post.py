@@ -1,0 +1,143 @@
+"""backtrack + compaction on the device (mm2gb_chain_gpu, csrc/post_kernels.hip) against the committed
+reference vectors, the CPU oracle and the host post-pass -- chains u[] and compacted anchors bit for bit, including the
+order radix_sort_128x leaves among equal scores (which decides what chain an anchor ends up in)."""
+import numpy as np
+import pytest
+
+import golden_io
+import orc
+import synth_cases as sc
+
+pytestmark = pytest.mark.gpu
+
+mm = pytest.importorskip("mm2gb_amd")
+
+CASES = golden_io.all_cases()
+
+
+def misc_from(prm):
+    return mm.default_misc(max_iter=prm.max_iter, max_dist_x=prm.max_dist_x, max_dist_y=prm.max_dist_y, max_skip=orc.INT32_MAX,
+                           bw=prm.bw, min_cnt=prm.min_cnt, min_score=prm.min_sc, is_cdna=prm.is_cdna, n_seg=prm.n_seg,
+                           chn_pen_gap=np.float32(prm.pen_gap), chn_pen_skip=np.float32(prm.pen_skip))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    with mm.Engine() as e:
+        yield e
+
+
+def check_against_oracle(engine, a, off, prm):
+    engine.set_misc(misc_from(prm))
+    res, st = engine.chain_gpu(a, off)
+    assert len(res) == len(off) - 1
+    for r in range(len(off) - 1):
+        o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
+        assert np.array_equal(res[r][0], o["u"]), f"read {r}: chains differ ({len(res[r][0])} vs {len(o['u'])})"
+        assert np.array_equal(res[r][1], o["a_out"]), f"read {r}: compacted anchors differ"
+    return st
+
+
+@pytest.mark.parametrize("path", [p for p in CASES], ids=golden_io.case_ids(CASES))
+def test_reference_vectors(engine, path):
+    g = golden_io.load(path)
+    prm = g["prm"]
+    if prm.max_skip != orc.INT32_MAX:
+        pytest.skip("recorded with a finite max_skip; the GPU path is exhaustive by contract")
+    a = g["a"]
+    engine.set_misc(misc_from(prm))
+    res, _ = engine.chain_gpu(a, np.array([0, len(a)], dtype=np.int64))
+    assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
+
+
+def test_empty_and_chainless_reads(engine):
+    prm = orc.default_param()
+    engine.set_misc(misc_from(prm))
+    res, _ = engine.chain_gpu(np.zeros((0, 2), np.uint64), np.array([0], np.int64))
+    assert res == []
+    res, _ = engine.chain_gpu(np.zeros((0, 2), np.uint64), np.array([0, 0, 0], np.int64))
+    assert all(len(u) == 0 and len(a) == 0 for u, a in res)
+    # reads that score but never reach min_cnt / min_sc, between reads that chain, and empty reads in between
+    r = sc.read_like(5000, 9)
+    lone = sc.noise(40, 3)
+    a = np.concatenate([lone, r, lone[:1], r])
+    off = np.array([0, 0, len(lone), len(lone) + len(r), len(lone) + len(r), len(lone) + len(r) + 1, len(a)], dtype=np.int64)
+    check_against_oracle(engine, a, off, prm)
+
+
+def test_synthetic_ont_batch(engine):
+    a, off = mm.synth_reads(7, 0, 24, 10_000, 100_000)
+    st = check_against_oracle(engine, a, off, orc.default_param())
+    assert st["ms_post"] > 0
+
+
+def test_equal_scores_follow_the_hosts_sort_order(engine):
+    """Grids and repeat blocks give thousands of chain ends with equal scores; which of them is visited first comes from the
+    in-place radix passes (ksort.h:116-146).  Runs of every size class: <= 64 (insertion sort), > 64 (passes), several levels."""
+    prm = orc.default_param()
+    parts = [sc.grid_ties(), sc.grid_ties(nx=90, ny=40, step=17), sc.sort_by_x(sc.repeat_block(9000, 5, xwin=2500, ywin=3000)),
+             sc.sort_by_x(np.concatenate([sc.repeat_block(3000, 6, xwin=300, ywin=300), sc.colinear(4000, 7)])),
+             sc.sort_by_x(sc.repeat_block(70, 8, xwin=200, ywin=200)), sc.sort_by_x(sc.repeat_block(64, 9, xwin=200, ywin=200)),
+             sc.sort_by_x(sc.repeat_block(65, 10, xwin=200, ywin=200))]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    for kw in (dict(), dict(min_cnt=1, min_sc=15), dict(min_cnt=2, min_sc=1), dict(bw=100), dict(is_cdna=1)):
+        check_against_oracle(engine, a, off, orc.default_param(**kw))
+
+
+def test_many_tiny_reads(engine):
+    rng = np.random.default_rng(99)
+    sizes = rng.integers(0, 41, 20_000)
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(sizes)
+    n = int(off[-1])
+    read_of = np.repeat(np.arange(len(sizes)), sizes)
+    pos_in_read = np.arange(n) - off[read_of]
+    x = 10_000 + pos_in_read * rng.integers(5, 30, n) + rng.integers(0, 3, n)
+    y = 100 + pos_in_read * 17 + rng.integers(0, 9, n)
+    a = sc.pack(rng.integers(0, 2, n), np.zeros(n, np.int64), x, y)
+    a = a[np.lexsort((a[:, 0], read_of))]
+    prm = orc.default_param(min_cnt=2, min_sc=20)
+    engine.set_misc(misc_from(prm))
+    res, _ = engine.chain_gpu(a, off)
+    host, _ = engine.chain(a, off, threads=4)          # the host post-pass, itself checked against the oracle elsewhere
+    for r in range(len(sizes)):
+        assert np.array_equal(res[r][0], host[r][0]) and np.array_equal(res[r][1], host[r][1]), f"read {r}"
+    for r in range(0, len(sizes), 997):
+        o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
+        assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"])
+
+
+def test_ultralong_reads_against_host_post_pass_and_oracle(engine):
+    """configs[3]-shaped reads (100-300 kb, tens of thousands of candidates per read, several radix levels)."""
+    a, off = mm.synth_reads(11, 0, 16, 100_000, 300_000)
+    prm = orc.default_param()
+    engine.set_misc(misc_from(prm))
+    res, st = engine.chain_gpu(a, off)
+    host, _ = engine.chain(a, off, threads=8)
+    for r in range(len(off) - 1):
+        assert np.array_equal(res[r][0], host[r][0]) and np.array_equal(res[r][1], host[r][1]), f"read {r}"
+    for r in (0, 7, 15):
+        o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
+        assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"])
+
+
+def test_fuzz(engine):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("MM2GB_FUZZ_SEED", 777)))
+    for it in range(int(os.environ.get("MM2GB_FUZZ_ITERS", 25))):
+        a, off, kw = sc.fuzz_case(rng)
+        check_against_oracle(engine, a, off, orc.default_param(**kw))
+
+
+def test_repeated_calls_reuse_arenas(engine):
+    a1, off1 = mm.synth_reads(5, 0, 6, 10_000, 40_000)
+    a2, off2 = mm.synth_reads(5, 6, 9, 10_000, 60_000)
+    prm = orc.default_param()
+    engine.set_misc(misc_from(prm))
+    first, _ = engine.chain_gpu(a1, off1)
+    engine.chain_gpu(a2, off2)
+    again, _ = engine.chain_gpu(a1, off1)
+    for r in range(len(off1) - 1):
+        assert np.array_equal(first[r][0], again[r][0]) and np.array_equal(first[r][1], again[r][1])
