@@ -54,6 +54,14 @@ class Chains(C.Structure):
     _fields_ = [("u_off", C.POINTER(C.c_int64)), ("u", C.POINTER(C.c_uint64)), ("a_off", C.POINTER(C.c_int64)), ("a", C.c_void_p)]
 
 
+READ_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_uint64), C.c_int64, C.c_void_p)
+
+
+class BatcherStats(C.Structure):
+    _fields_ = [("reads", C.c_int64), ("anchors", C.c_int64), ("reads_per_lane", C.c_int64 * 2), ("batches", C.c_int64 * 2),
+                ("batches_per_engine", C.c_int64 * 16), ("n_engines", C.c_int)]
+
+
 class Mm2gbError(RuntimeError):
     pass
 
@@ -67,7 +75,9 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chain_gpu", "mm2gb_post_device", "mm2gb_chains_free", "mm2gb_backtrack_host",
                 "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
                 "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
-                "mm2gb_pool_score_host", "mm2gb_pool_chain_host"]
+                "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
+                "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
+                "mm2gb_plan_batches"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -125,6 +135,15 @@ def lib():
         L.mm2gb_pool_set_misc.argtypes = [C.c_void_p, C.POINTER(Misc)]
         L.mm2gb_pool_score_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]
         L.mm2gb_pool_chain_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Chains), C.POINTER(Stats)]
+        L.mm2gb_batcher_create.restype = C.c_void_p
+        L.mm2gb_batcher_create.argtypes = [C.POINTER(Config), C.POINTER(Misc), C.c_int, C.c_void_p, C.c_int, READ_DONE_FN, C.c_void_p]
+        L.mm2gb_batcher_add.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.mm2gb_batcher_flush.argtypes = [C.c_void_p]
+        L.mm2gb_batcher_stats.argtypes = [C.c_void_p, C.POINTER(BatcherStats)]
+        L.mm2gb_batcher_destroy.argtypes = [C.c_void_p]
+        L.mm2gb_batcher_destroy.restype = None
+        L.mm2gb_plan_batches.restype = C.c_int64
+        L.mm2gb_plan_batches.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -317,6 +336,67 @@ class Pool:
         st = Stats()
         _check(lib().mm2gb_pool_chain_host(self._h, R, off.ctypes.data, a.ctypes.data, threads, C.byref(out), C.byref(st)))
         return _take_chains(out, R), st.as_dict()
+
+
+def plan_batches(n_anchors, max_total_n, max_read, min_n):
+    """The batcher's grouping rule alone (no GPU): (number of batches, batch id per read, lane per read)."""
+    n = np.ascontiguousarray(n_anchors, dtype=np.int64)
+    batch = np.empty(len(n), dtype=np.int32)
+    lane = np.empty(len(n), dtype=np.int32)
+    nb = lib().mm2gb_plan_batches(len(n), n.ctypes.data, max_total_n, max_read, min_n, batch.ctypes.data, lane.ctypes.data)
+    if nb < 0:
+        raise Mm2gbError(lib().mm2gb_last_error().decode())
+    return int(nb), batch, lane
+
+
+class Batcher:
+    """mm2gb_batcher_t: feed reads one at a time, get every read's chains back (dict read_id -> (u, a_out))."""
+
+    def __init__(self, devices=None, misc=None, config=None, post_threads=2):
+        L = lib()
+        self.misc = misc if misc is not None else default_misc()
+        self.config = config if config is not None else default_config()
+        self.results = {}
+        self.order = []
+
+        def on_done(_user, read_id, n_u, u, n_a, a):
+            uu = np.ctypeslib.as_array(u, shape=(n_u,)).copy() if n_u else np.zeros(0, np.uint64)
+            aa = (np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint64)), shape=(n_a, 2)).copy() if n_a else np.zeros((0, 2), np.uint64))
+            self.results[read_id] = (uu, aa)
+            self.order.append(read_id)
+
+        self._cb = READ_DONE_FN(on_done)          # keep alive
+        ids = np.ascontiguousarray(devices, dtype=np.int32) if devices is not None else None
+        self._h = L.mm2gb_batcher_create(C.byref(self.config), C.byref(self.misc), 0 if ids is None else len(ids),
+                                         None if ids is None else ids.ctypes.data, post_threads, self._cb, None)
+        if not self._h:
+            raise Mm2gbError(L.mm2gb_last_error().decode())
+
+    def add(self, read_id, anchors):
+        a = np.ascontiguousarray(anchors, dtype=np.uint64)
+        _check(lib().mm2gb_batcher_add(self._h, read_id, a.ctypes.data, len(a)))
+
+    def flush(self):
+        _check(lib().mm2gb_batcher_flush(self._h))
+
+    def stats(self):
+        st = BatcherStats()
+        _check(lib().mm2gb_batcher_stats(self._h, C.byref(st)))
+        return {"reads": st.reads, "anchors": st.anchors, "reads_per_lane": list(st.reads_per_lane), "batches": list(st.batches),
+                "batches_per_engine": list(st.batches_per_engine)[: st.n_engines], "n_engines": st.n_engines}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm2gb_batcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def backtrack_host(misc, anchors, f, p_rel):

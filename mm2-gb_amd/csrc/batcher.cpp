@@ -202,10 +202,15 @@ int mm2gb_batcher_add(mm2gb_batcher_t *b, int64_t read_id, const mm2gb_anchor_t 
 	std::unique_lock<std::mutex> lk(b->mu);
 	if (!b->error.empty()) return fail(b->error);
 	const int lane = b->rule.lane_of(n);
-	if (b->acc[lane] && b->rule.closes(b->acc[lane]->count(), b->acc[lane]->total(), n)) b->close(lane);
-	if (!b->acc[lane]) {
-		b->acc[lane] = b->take_free(lk);                  // blocks while every batch is in flight: back-pressure on the producers
-		if (!b->acc[lane]) return fail(b->error);
+	for (;;) {
+		if (!b->error.empty()) return fail(b->error);
+		Batch *cur = b->acc[lane];
+		if (cur && b->rule.closes(cur->count(), cur->total(), n)) { b->close(lane); continue; }
+		if (cur) break;
+		Batch *fresh = b->take_free(lk);                  // may wait (back-pressure on the producers) and lets other producers in meanwhile
+		if (!fresh) return fail(b->error);
+		if (b->acc[lane]) { b->free_list.push_back(fresh); b->cv_free.notify_one(); continue; }   // another producer opened the lane's batch first
+		b->acc[lane] = fresh;
 	}
 	Batch &acc = *b->acc[lane];
 	const int64_t at = acc.total();

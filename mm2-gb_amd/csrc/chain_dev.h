@@ -100,8 +100,11 @@ struct PostBatch {
 	uint4    *a_out;           // compacted anchors, read by read (lchain.c:78-111)
 	int64_t  *totals;          // [0] chains [1] anchors kept
 	int32_t  *cursor;          // two work cursors
+	int32_t  *order;           // n_reads: reads, largest first (the kernel ends with its longest read: start those first)
+	int32_t  *size_bins;       // 2 x 64: reads per power-of-two size class, and the fill counters of the scatter
 	int       min_cnt, min_sc, max_drop;
 	int       grid_waves;      // waves to launch (one read per wave at a time)
+	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed 100 MHz ticks of [0] candidate collection [1] sort [2] chain walks [3] emit
 };
 void launch_post(const PostBatch &b, hipStream_t s);
 

@@ -74,7 +74,13 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	__shared__ int own_x[PLAN_BLOCK], own_hi[PLAN_BLOCK];
 	__shared__ int smp_x[WIN_MAX_SAMPLES], smp_hi[WIN_MAX_SAMPLES];      // sample k-1 = anchor base - 32 k
 	__shared__ int s_st[PLAN_BLOCK];                                    // results, written out coalesced at the end
-	const int64_t base = (int64_t)blockIdx.x * PLAN_BLOCK;
+	// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 share an XCD and its L2, MI355X_MICROARCH.md): planning block =
+	// f(blockIdx) is chosen so that every XCD works through ONE contiguous eighth of the batch, in order.  The max_iter anchors a
+	// block looks back at were then read moments earlier by workgroups of the same XCD and are still in that L2; with the
+	// identity mapping they had been read by the other seven XCDs and every look-back line came from HBM again.  Speed only.
+	const unsigned nb = gridDim.x, per = nb / 8, rem = nb % 8, xcd = blockIdx.x % 8, kth = blockIdx.x / 8;
+	const unsigned blk = nb < 64 ? blockIdx.x : xcd * per + (xcd < rem ? xcd : rem) + kth;
+	const int64_t base = (int64_t)blk * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
 	const int n_samples = (int)min((int64_t)WIN_MAX_SAMPLES, min(base, (int64_t)P.max_iter + WIN_SAMPLE - 1) / WIN_SAMPLE);
 	bool any_seg = false, big_y = false;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	constexpr int PER = PLAN_BLOCK / PLAN_THREADS;
 	const int64_t i_first = base + (int64_t)threadIdx.x * PER;
 	const int base32 = (int)base;
-	int64_t rd = b.blk_read[blockIdx.x];              // read of the current anchor
+	int64_t rd = b.blk_read[blk];                     // read of the current anchor
 	int rs = 0, re = 0, st_prev = 0;
 	int win[PER];
 #pragma unroll
@@ -224,11 +230,11 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		for (int k = 1; k < PLAN_THREADS / WAVE; ++k) { my_pairs += s_pairs[k]; my_clamp |= s_clamp[k]; }
 		head = tail = 0;
 		for (int k = 0; k < PLAN_THREADS / WAVE; ++k) { head = max(head, s_wmax[k]); tail = max(tail, s_wmax[PLAN_THREADS / WAVE + k]); }
-		b.blk_wmax[2 * blockIdx.x] = head;
-		b.blk_wmax[2 * blockIdx.x + 1] = tail;
-		b.blk_firstcut[blockIdx.x] = blk_cut;
-		b.blk_pairs[blockIdx.x] = (int64_t)my_pairs;
-		b.blk_clamped[blockIdx.x] = my_clamp;
+		b.blk_wmax[2 * blk] = head;
+		b.blk_wmax[2 * blk + 1] = tail;
+		b.blk_firstcut[blk] = blk_cut;
+		b.blk_pairs[blk] = (int64_t)my_pairs;
+		b.blk_clamped[blk] = my_clamp;
 	}
 }
 

@@ -54,20 +54,30 @@ struct Engine {
 	mm2gb_misc_t   misc;
 	DevParams      params;
 	LaunchCfg      launch;
-	hipStream_t    stream = nullptr;       // kernels
+	hipStream_t    stream = nullptr;       // kernels (== work[0].stream)
 	hipStream_t    s_in = nullptr, s_out = nullptr;   // H2D / D2H of the host-buffer paths
 	int            n_cu = 256;
 
-	// work arenas (sized by capacity_n / capacity_blocks); one set: kernels of consecutive micro-batches serialise anyway
-	int64_t cap_n = 0, cap_reads = 0, cap_blocks = 0;
-	DevBuf x, y, tag, st;
-	DevBuf blk_firstcut, blk_pairs, blk_clamped, blk_wmax, blk_read;
-	DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
-	DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
-	DevBuf counters, totals, flags, lut, dbg;
+	// Work arenas of the kernels of one micro-batch (sized by cap_n / cap_blocks, grow-only).  Two sets, each with its own
+	// compute stream: consecutive micro-batches of the host-buffer paths alternate between them, so the tail of micro-batch k
+	// (a persistent kernel ends at the pace of its last few chunks) overlaps the body of micro-batch k+1 instead of idling the GPU.
+	// Device-pointer calls (mm2gb_score_device) always use set 0 = `stream`.
+	struct WorkSet {
+		hipStream_t stream = nullptr;
+		int64_t cap_n = 0, cap_reads = 0, cap_blocks = 0;
+		DevBuf x, y, tag, st;
+		DevBuf blk_firstcut, blk_pairs, blk_clamped, blk_wmax, blk_read;
+		DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
+		DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
+		DevBuf counters, totals, flags;
+		std::vector<DevBuf*> all() { return { &x, &y, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_wmax, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
+		                                      &chunk_track, &order, &long_list, &mid_list, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins, &counters, &totals, &flags }; }
+	};
+	WorkSet work[2];
+	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc;
+	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order;
 	int64_t *h_post_totals = nullptr;      // pinned: [0] chains [1] anchors kept
 	hipEvent_t post0 = nullptr, post1 = nullptr;
 	IoSet io[2];
@@ -81,19 +91,20 @@ struct Engine {
 	int n_slots = 0;
 
 	mm2gb_stats_t last = {};
-	bool misc_valid = false, coop_disabled = false, debug_phases = false;
+	bool misc_valid = false, coop_disabled = false, debug_phases = false, one_compute_stream = false;
+	int64_t dual_stream_max_n = 16 * 1000 * 1000;   // micro-batches up to this many anchors alternate between the two compute streams
 
 	int  init(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);
 	void shutdown();
 	int  set_misc(const mm2gb_misc_t *m);
 	int  configure_score();
-	int  reserve(int64_t n_anchors, int64_t n_reads);
+	int  reserve(int64_t n_anchors, int64_t n_reads, int set = 0);
 	int  begin_call();                     // start of a host-level call: resets slots and `last`
 	// host buffers (pinned for true asynchrony): H2D, kernels, D2H enqueued on three streams; returns without waiting
 	// want_stats = false: no timing events / counter read-back for this micro-batch (the drop-in boundary keeps two host
 	// batches in flight and never asks for statistics)
 	int  enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p, bool want_stats = true);
-	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats = true);
+	int  enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats = true, int set = 0);
 	int  score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int32_t *f, int32_t *p,
 	                const std::function<void(int64_t, int64_t)> *slice_done);   // sliced + overlapped, waits for the end
 	// backtrack + compaction of a scored micro-batch on the device (all pointers device pointers; d_f / d_p as enqueue() left

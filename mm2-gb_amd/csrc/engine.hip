@@ -137,9 +137,13 @@ int Engine::configure_score()
 	// with different parameters cannot lower it under each other's feet
 	if (score_set_lds_limit(LDS_BUDGET)) return fail("mm2gb: cannot raise the dynamic LDS limit of the score kernel");
 	if (launch.host_mode == SCORE_MODE_LUT) {
+		// the table is shared by both compute streams: nothing that reads the old one may be in flight, and the new one must be
+		// complete before either stream launches again (parameters change between runs, not between batches)
+		for (WorkSet &w : work) MM2GB_HIP(hipStreamSynchronize(w.stream));
 		if (lut.ensure((size_t)(params.lut_last + 1) * 4)) return -1;
 		launch_build_lut((int*)lut.ptr, params, stream);
 		MM2GB_HIP(hipGetLastError());
+		MM2GB_HIP(hipStreamSynchronize(stream));
 	}
 	return 0;
 }
@@ -171,14 +175,17 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (debug_phases && dbg.ensure((size_t)launch.score_grid * 32)) return -1;
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
-	MM2GB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	for (WorkSet &w : work) MM2GB_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+	stream = work[0].stream;
+	{ const char *v = getenv("MM2GB_ONE_COMPUTE_STREAM"); one_compute_stream = v && *v && *v != '0'; }
+	if (const char *v = getenv("MM2GB_DUAL_STREAM_MAX")) dual_stream_max_n = std::max<int64_t>(0, atoll(v));
 	MM2GB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
 	MM2GB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
 	for (IoSet &s : io)
 		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) MM2GB_HIP(hipEventCreate(e));
 	MM2GB_HIP(hipHostMalloc((void**)&h_counters, (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
 	MM2GB_HIP(hipHostMalloc((void**)&h_totals, (size_t)MAX_SLOTS * 2 * sizeof(int64_t), hipHostMallocDefault));
-	if (counters.ensure(CNT_WORDS * sizeof(int32_t)) || totals.ensure(4 * sizeof(int64_t)) || flags.ensure(4 * sizeof(unsigned))) return -1;
+	for (WorkSet &w : work) if (w.counters.ensure(CNT_WORDS * sizeof(int32_t)) || w.totals.ensure(4 * sizeof(int64_t)) || w.flags.ensure(4 * sizeof(unsigned))) return -1;
 	if (set_misc(m)) return -1;
 	return 0;
 }
@@ -186,10 +193,9 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 void Engine::shutdown()
 {
 	(void)hipSetDevice(device);
-	for (hipStream_t s : { s_in, stream, s_out }) if (s) (void)hipStreamSynchronize(s);
-	for (DevBuf *b : { &x, &y, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
-	                   &chunk_track, &order, &long_list, &mid_list, &blk_wmax, &counters, &totals, &flags, &lut, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins })
-		b->release();
+	for (hipStream_t s : { s_in, work[0].stream, work[1].stream, s_out }) if (s) (void)hipStreamSynchronize(s);
+	for (WorkSet &w : work) { for (DevBuf *b : w.all()) b->release(); w.cap_n = w.cap_reads = w.cap_blocks = 0; }
+	lut.release(); dbg.release();
 	for (IoSet &s : io) {
 		s.raw.release(); s.offsets.release(); s.f.release(); s.p.release();
 		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -198,37 +204,39 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc })
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order })
 		b->release();
 	cap_post_n = cap_post_reads = 0;
 	if (h_post_totals) { (void)hipHostFree(h_post_totals); h_post_totals = nullptr; }
 	for (hipEvent_t *e : { &post0, &post1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
-	for (hipStream_t *s : { &s_in, &stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+	for (hipStream_t *s : { &s_in, &work[0].stream, &work[1].stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+	stream = nullptr;
 	h_counters = nullptr; h_totals = nullptr;
 }
 
-int Engine::reserve(int64_t n, int64_t n_reads)
+int Engine::reserve(int64_t n, int64_t n_reads, int set)
 {
 	MM2GB_HIP(hipSetDevice(device));
 	if (n >= ((int64_t)1 << 31) - 2 * PLAN_BLOCK) return fail("mm2gb: a micro-batch is limited to 2^31 anchors (got " + std::to_string(n) + ")");
-	if (n > cap_n || n_reads > cap_reads) {
-		// wait for anything in flight before arenas move
-		MM2GB_HIP(hipStreamSynchronize(stream));
-		const int64_t nn = std::max<int64_t>(std::max(n, cap_n), 1024);
+	WorkSet &w = work[set];
+	if (n > w.cap_n || n_reads > w.cap_reads) {
+		// wait for anything in flight on this set before its arenas move
+		MM2GB_HIP(hipStreamSynchronize(w.stream));
+		const int64_t nn = std::max<int64_t>(std::max(n, w.cap_n), 1024);
 		const int64_t nb = (nn + PLAN_BLOCK - 1) / PLAN_BLOCK + 1;
 		// A growth that fails part-way leaves some arenas grown, some as they were and possibly one empty: the recorded capacity
 		// is dropped first and only restored when every arena has its size, so the next call reserves again instead of launching
 		// on a short (or null) buffer.
-		const int64_t had_reads = cap_reads;
-		cap_n = cap_blocks = cap_reads = 0;
-		if (x.ensure(nn * 4) || y.ensure(nn * 4) || tag.ensure(nn * 4) || st.ensure(nn * 4)) return -1;
-		if (blk_firstcut.ensure(nb * 4) || blk_pairs.ensure(nb * 8) || blk_clamped.ensure(nb * 4) || blk_wmax.ensure(nb * 8) || blk_read.ensure(nb * 4)) return -1;
-		if (chunk_start.ensure(nb * 4) || chunk_end.ensure(nb * 4) || chunk_cost.ensure(nb * 8) || chunk_track.ensure(nb) ||
-		    order.ensure(nb * 4) || long_list.ensure(nb * 4) || mid_list.ensure(nb * 4) || chunk_pp.ensure(nb * 8) || chunk_kk.ensure(nb * 4) || chunk_blk.ensure(nb * 4) ||
-		    tile_sums.ensure((nb / 1024 + 2) * 24) || tile_base.ensure((nb / 1024 + 2) * 24) || bins.ensure(3 * 256 * 4)) return -1;
-		cap_n = nn; cap_blocks = nb; cap_reads = std::max(had_reads, n_reads);
+		const int64_t had_reads = w.cap_reads;
+		w.cap_n = w.cap_blocks = w.cap_reads = 0;
+		if (w.x.ensure(nn * 4) || w.y.ensure(nn * 4) || w.tag.ensure(nn * 4) || w.st.ensure(nn * 4)) return -1;
+		if (w.blk_firstcut.ensure(nb * 4) || w.blk_pairs.ensure(nb * 8) || w.blk_clamped.ensure(nb * 4) || w.blk_wmax.ensure(nb * 8) || w.blk_read.ensure(nb * 4)) return -1;
+		if (w.chunk_start.ensure(nb * 4) || w.chunk_end.ensure(nb * 4) || w.chunk_cost.ensure(nb * 8) || w.chunk_track.ensure(nb) ||
+		    w.order.ensure(nb * 4) || w.long_list.ensure(nb * 4) || w.mid_list.ensure(nb * 4) || w.chunk_pp.ensure(nb * 8) || w.chunk_kk.ensure(nb * 4) || w.chunk_blk.ensure(nb * 4) ||
+		    w.tile_sums.ensure((nb / 1024 + 2) * 24) || w.tile_base.ensure((nb / 1024 + 2) * 24) || w.bins.ensure(3 * 256 * 4)) return -1;
+		w.cap_n = nn; w.cap_blocks = nb; w.cap_reads = std::max(had_reads, n_reads);
 	}
 	return 0;
 }
@@ -241,11 +249,17 @@ int Engine::begin_call()
 	return 0;
 }
 
-int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats)
+int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, int32_t *d_f, int32_t *d_p, bool want_stats, int set)
 {
 	if (n < 0 || n_reads < 0) return fail("mm2gb: negative batch size");
 	if (want_stats && n_slots >= MAX_SLOTS && sync()) return -1;      // fold what is done so far into `last`, keep counting
-	if (reserve(n, n_reads)) return -1;
+	if (reserve(n, n_reads, set)) return -1;
+	WorkSet &w = work[set];
+	hipStream_t stream = w.stream;                                    // (shadows the member: everything below belongs to this set)
+	DevBuf &x = w.x, &y = w.y, &tag = w.tag, &st = w.st, &blk_firstcut = w.blk_firstcut, &blk_pairs = w.blk_pairs, &blk_clamped = w.blk_clamped, &blk_wmax = w.blk_wmax,
+	       &blk_read = w.blk_read, &chunk_start = w.chunk_start, &chunk_end = w.chunk_end, &chunk_cost = w.chunk_cost, &chunk_track = w.chunk_track, &order = w.order,
+	       &long_list = w.long_list, &mid_list = w.mid_list, &chunk_pp = w.chunk_pp, &chunk_kk = w.chunk_kk, &chunk_blk = w.chunk_blk, &tile_sums = w.tile_sums,
+	       &tile_base = w.tile_base, &bins = w.bins, &counters = w.counters, &totals = w.totals, &flags = w.flags;
 	const int slot = want_stats ? n_slots++ : 0;
 	BatchSlot &bs = slots[slot];
 	if (want_stats) for (hipEvent_t *e : { &bs.prep0, &bs.prep1, &bs.score1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
@@ -299,7 +313,7 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	const size_t chains = (size_t)(nn + nr);
 	if (post_z.ensure((size_t)nn * 8) || post_mark.ensure((size_t)nn) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
 	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_uoff.ensure((size_t)(nr + 1) * 8) ||
-	    post_aoff.ensure((size_t)(nr + 1) * 8) || post_uout.ensure(chains * 8) || post_aout.ensure((size_t)nn * 16) || post_misc.ensure(64)) return -1;
+	    post_aoff.ensure((size_t)(nr + 1) * 8) || post_uout.ensure(chains * 8) || post_aout.ensure((size_t)nn * 16) || post_misc.ensure(2048) || post_order.ensure((size_t)nr * 4)) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
 	return 0;
 }
@@ -313,7 +327,10 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.u_tmp = (unsigned long long*)post_utmp.ptr; b.heads = (ulonglong2*)post_heads.ptr;
 	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)post_uoff.ptr; b.a_off = (int64_t*)post_aoff.ptr;
 	b.u_out = (unsigned long long*)post_uout.ptr; b.a_out = (uint4*)post_aout.ptr;
-	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 32);
+	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 16);
+	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)((char*)post_misc.ptr + 128);
+	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
+	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 64, stream));
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
 	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
 	// one read per wave at a time: as many waves as the chip holds (latency-bound pointer chases; parallelism is across reads)
@@ -341,7 +358,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	const auto t0 = std::chrono::steady_clock::now();
 	IoSet &s = io[io_seq++ & 1];
 	const size_t nn = (size_t)std::max<int64_t>(n, 1);
-	for (hipStream_t q : { s_in, stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+	for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
 	if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
 	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
 	if (n > 0) MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, anchors, (size_t)n * 16, hipMemcpyHostToDevice, stream));
@@ -378,11 +395,17 @@ int Engine::record_outputs_done(hipEvent_t ev)
 int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int32_t *h_f, int32_t *h_p, bool want_stats)
 {
 	MM2GB_HIP(hipSetDevice(device));
+	// Small micro-batches alternate between the two compute streams: one of them cannot fill the GPU (it ends at the pace of
+	// its largest chunk, run by one workgroup), so the next one's kernels start beside its tail -- 64-read batches through the
+	// boundary went from 6.2 to 4.4 ms each.  Large ones stay on one stream: two persistent launches side by side only delay
+	// the first one's D2H (200 M anchors in slices: 97 -> 147 ms with both streams, profiles/r02e_*).
+	const int set = (!one_compute_stream && n <= dual_stream_max_n) ? (int)(io_seq & 1) : 0;
 	IoSet &s = io[io_seq++ & 1];
+	hipStream_t stream = work[set].stream;
 	const size_t nn = (size_t)std::max<int64_t>(n, 1);
 	if (s.raw.bytes < nn * 16 || s.f.bytes < nn * 4 || s.p.bytes < nn * 4 || s.offsets.bytes < (size_t)(n_reads + 1) * 8) {
 		// growing a set frees its old buffers: nothing may be in flight on it
-		for (hipStream_t q : { s_in, stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+		for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
 		if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
 	}
 	// H2D may overwrite raw/offsets only after the kernels that last read this set are done
@@ -394,7 +417,7 @@ int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_
 	// kernels need the inputs, and may overwrite f/p only after the previous D2H from this set is done
 	MM2GB_HIP(hipStreamWaitEvent(stream, s.in_done, 0));
 	if (s.used) MM2GB_HIP(hipStreamWaitEvent(stream, s.out_done, 0));
-	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, want_stats)) return -1;
+	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, want_stats, set)) return -1;
 	MM2GB_HIP(hipEventRecord(s.comp_done, stream));
 	MM2GB_HIP(hipStreamWaitEvent(s_out, s.comp_done, 0));
 	MM2GB_HIP(hipEventRecord(s.out_start, s_out));
@@ -410,7 +433,7 @@ int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_
 int Engine::sync()
 {
 	MM2GB_HIP(hipSetDevice(device));
-	for (hipStream_t q : { s_in, stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+	for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
 	return collect_stats();
 }
 
@@ -484,7 +507,7 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 	const size_t n_sl = first.size() - 1;
 	auto drain = [&]() {                 // error path: keep the error text, wait for whatever was enqueued
 		const std::string why = last_error_cstr();
-		for (hipStream_t q : { s_in, stream, s_out }) (void)hipStreamSynchronize(q);
+		for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) (void)hipStreamSynchronize(q);
 		n_slots = 0;
 		set_error(why);
 	};
@@ -583,6 +606,12 @@ int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_off
 	MM2GB_HIP(hipStreamSynchronize(e.stream));
 	if (n_chains) *n_chains = e.h_post_totals[0];
 	if (n_kept) *n_kept = e.h_post_totals[1];
+	if (e.debug_phases) {
+		long long t[8] = { 0 };
+		if (hipMemcpy(t, (char*)e.post_misc.ptr + 1024, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
+			fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
+			        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);
+	}
 	float t = 0;
 	if (ms && hipEventElapsedTime(&t, e.post0, e.post1) == hipSuccess) *ms = t;
 	return 0;

@@ -53,6 +53,9 @@ struct HElem {
 	static __device__ __forceinline__ unsigned long long key(const T &e) { return e.x; }
 };
 
+__device__ __forceinline__ unsigned long long bcast_elem(unsigned long long e, int src) { return __shfl(e, src); }
+__device__ __forceinline__ ulonglong2 bcast_elem(const ulonglong2 &e, int src) { return make_ulonglong2(__shfl(e.x, src), __shfl(e.y, src)); }
+
 // Stable sort of a run of at most 64 elements by key == what rs_insertsort leaves (ksort.h:105-115): every lane holds one
 // element and counts the elements that must come before it.
 template <class E>
@@ -101,14 +104,24 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 	L.head[4 * l + 2] = at; at += c2; L.tail[4 * l + 2] = at;
 	L.head[4 * l + 3] = at; at += c3; L.tail[4 * l + 3] = at;
 	wave_sync();
-	if (l == 0) {
-		for (int k = 0; k < 256; ++k) {
-			int hk = L.head[k];
-			const int tk = L.tail[k];
-			while (hk < tk) {
-				typename E::T carry = g[hk];
+	// The host's loop, bucket by bucket: elements at the head of bucket k that already belong to k are passed over (all 64
+	// lanes look at the next 64 of them at once); the first one that does not starts a cycle, which lane 0 follows exactly as
+	// the host does -- place the carried element at the head of its bucket, pick up what was there -- until an element of
+	// bucket k turns up (ksort.h:128-139).
+	for (int k = 0; k < 256; ++k) {
+		int hk = uni(L.head[k]);
+		const int tk = uni(L.tail[k]);
+		while (hk < tk) {
+			const int i = hk + l;
+			const bool in = i < tk;
+			typename E::T e = g[in ? i : hk];
+			const unsigned long long moves = __ballot(in && ((int)(E::key(e) >> shift) & 255) != k);
+			if (moves == 0) { hk = min(hk + W, tk); continue; }
+			const int skip = __builtin_ctzll(moves);
+			hk += skip;
+			typename E::T carry = bcast_elem(e, skip);
+			if (l == 0) {
 				int d = (int)(E::key(carry) >> shift) & 255;
-				if (d == k) { ++hk; continue; }
 				do {
 					const typename E::T moved = carry;
 					const int hd = L.head[d];
@@ -118,8 +131,9 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 					d = (int)(E::key(carry) >> shift) & 255;
 				} while (d != k);
 				g[hk] = carry;
-				++hk;
 			}
+			++hk;
+			wave_sync();
 		}
 	}
 	wave_sync();
@@ -182,6 +196,27 @@ __device__ __forceinline__ int64_t chain_slot(int64_t off_r, int64_t r, int mc) 
 } // namespace
 
 // --------------------------------------------------------------------------------------------------------------
+// reads by size class, largest first (order inside a class is arbitrary: reads are independent, results do not depend on it)
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int size_class(int64_t n) { return n <= 0 ? 0 : 64 - __clzll((unsigned long long)n); }   // 0..63
+
+__global__ __launch_bounds__(256) void k_post_size_count(PostBatch b)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < b.n_reads) atomicAdd(&b.size_bins[size_class(b.offsets[r + 1] - b.offsets[r])], 1);
+}
+
+__global__ __launch_bounds__(256) void k_post_size_scatter(PostBatch b)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= b.n_reads) return;
+	const int c = size_class(b.offsets[r + 1] - b.offsets[r]);
+	int base = 0;
+	for (int k = 63; k > c; --k) base += b.size_bins[k];
+	b.order[base + atomicAdd(&b.size_bins[64 + c], 1)] = (int)r;
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // per read: candidates, host order, chain walks (lchain.c:27-76)
 // --------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
@@ -195,6 +230,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 		if (l == 0) r = atomicAdd(b.cursor, 1);
 		r = uni(r);
 		if (r >= b.n_reads) break;
+		r = uni(b.order[r]);
 		const int64_t off = b.offsets[r];
 		const int n = (int)(b.offsets[r + 1] - off);
 		const int32_t *f = b.f + off, *p = b.p + off;
@@ -202,6 +238,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 		uint8_t *mark = b.mark + off;
 		int32_t *picked = b.picked + off;
 		unsigned long long *u_tmp = b.u_tmp + chain_slot(off, r, mc);
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		// candidates in index order (lchain.c:35-41) and cleared marks (lchain.c:43)
 		int n_z = 0;
 		for (int base = 0; base < n; base += W) {
@@ -215,34 +252,58 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 			n_z += __popcll(m);
 		}
 		wave_sync();
+		const long long t1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		sort_like_host<ZElem>(z, n_z, L);
+		const long long t2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
+		// Most candidates already belong to a chain found from a better end: 64 of them are tested at once, and lane 0 only
+		// turns to those that were still free then (testing again: an earlier walk of the same group may have taken them).
 		int n_u = 0, n_v = 0;
-		if (l == 0) {
-			for (int k = n_z - 1; k >= 0; --k) {
-				const unsigned long long zk = z[k];
-				const int start = (int)(unsigned)zk, top = (int)(zk >> 32);
-				if (mark[start] != 0) continue;
-				// mg_chain_bk_end (lchain.c:9-25): back from the chain end until an anchor that is taken, the start of the path, or an
-				// X-drop of more than max_drop below the best prefix.  Nodes go straight into picked[]; `kept` is how many of them lie
-				// before the anchor the best prefix stops at.
-				int i = start, kept = 0, visited = 0, best = 0, stop = start;
-				int pi = p[i];
-				do {
-					picked[n_v + visited++] = i;
-					i = pi ? i - pi : -1;
-					int s = top, m_i = 1;
-					if (i >= 0) { s = top - f[i]; pi = p[i]; m_i = mark[i]; }
-					if (s > best) { best = s; stop = i; kept = visited; }
-					else if (best - s > b.max_drop) break;
-					if (m_i != 0) break;
-				} while (i >= 0);
-				for (int q = 0; q < kept; ++q) mark[picked[n_v + q]] = 1;
-				const int sc = stop < 0 ? top : top - f[stop];
-				if (sc >= b.min_sc && kept > 0 && kept >= b.min_cnt) { u_tmp[n_u++] = (unsigned long long)(unsigned)sc << 32 | (unsigned)kept; n_v += kept; }
+		for (int kb = n_z - 1; kb >= 0; kb -= W) {
+			const int k_l = kb - l;
+			const unsigned long long z_l = k_l >= 0 ? z[k_l] : 0;
+			unsigned long long open = __ballot(k_l >= 0 && mark[(int)(unsigned)z_l] == 0);
+			while (open) {
+				const int src = __builtin_ctzll(open);          // lowest lane = highest k
+				open &= open - 1;
+				const unsigned long long zk = bcast_elem(z_l, src);
+				if (l == 0) {
+					const int start = (int)(unsigned)zk, top = (int)(zk >> 32);
+					if (mark[start] == 0) {
+						// mg_chain_bk_end (lchain.c:9-25): back from the chain end until an anchor that is taken, the start of the path, or
+						// an X-drop of more than max_drop below the best prefix.  Nodes go straight into picked[]; `kept` is how many of
+						// them lie before the anchor the best prefix stops at.
+						int i = start, kept = 0, visited = 0, best = 0, stop = start;
+						int pi = p[i];
+						do {
+							picked[n_v + visited++] = i;
+							i = pi ? i - pi : -1;
+							int s = top, m_i = 1;
+							if (i >= 0) { s = top - f[i]; pi = p[i]; m_i = mark[i]; }
+							if (s > best) { best = s; stop = i; kept = visited; }
+							else if (best - s > b.max_drop) break;
+							if (m_i != 0) break;
+						} while (i >= 0);
+						for (int q = 0; q < kept; ++q) mark[picked[n_v + q]] = 1;
+						const int sc = stop < 0 ? top : top - f[stop];
+						if (sc >= b.min_sc && kept > 0 && kept >= b.min_cnt) { u_tmp[n_u++] = (unsigned long long)(unsigned)sc << 32 | (unsigned)kept; n_v += kept; }
+					}
+				}
+				wave_sync();
 			}
+		}
+		if (l == 0) {
 			b.n_u[r] = n_u;
 			b.n_kept[r] = n_v;
+			if (b.dbg) {
+				const long long t3 = (long long)__builtin_amdgcn_s_memrealtime();
+				atomicAdd((unsigned long long*)&b.dbg[0], (unsigned long long)(t1 - t0));
+				atomicAdd((unsigned long long*)&b.dbg[1], (unsigned long long)(t2 - t1));
+				atomicAdd((unsigned long long*)&b.dbg[2], (unsigned long long)(t3 - t2));
+				atomicMax((unsigned long long*)&b.dbg[4], (unsigned long long)(t2 - t1));
+				atomicMax((unsigned long long*)&b.dbg[5], (unsigned long long)(t3 - t2));
+				atomicMax((unsigned long long*)&b.dbg[6], (unsigned long long)(t3 - t0));
+			}
 		}
 		wave_sync();
 	}
@@ -289,8 +350,10 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_emit(PostBatch b)
 		if (l == 0) r = atomicAdd(b.cursor + 1, 1);
 		r = uni(r);
 		if (r >= b.n_reads) break;
+		r = uni(b.order[r]);
 		const int n_u = b.n_u[r];
 		if (n_u == 0) continue;
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		const int64_t off = b.offsets[r];
 		const uint4 *raw = b.raw + off;
 		const int32_t *picked = b.picked + off;
@@ -325,6 +388,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_emit(PostBatch b)
 			for (int j = l; j < cnt; j += W) a_out[out_at + j] = raw[picked[k0 + (cnt - 1 - j)]];
 			out_at += cnt;
 		}
+		if (b.dbg && l == 0) atomicAdd((unsigned long long*)&b.dbg[3], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - t0));
 	}
 }
 
@@ -332,6 +396,10 @@ void launch_post(const PostBatch &b, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;
 	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
+	(void)hipMemsetAsync(b.size_bins, 0, 128 * sizeof(int32_t), s);
+	const unsigned rgrid = (unsigned)((b.n_reads + 255) / 256);
+	hipLaunchKernelGGL(k_post_size_count, dim3(rgrid), dim3(256), 0, s, b);
+	hipLaunchKernelGGL(k_post_size_scatter, dim3(rgrid), dim3(256), 0, s, b);
 	const int64_t waves = (int64_t)b.grid_waves;
 	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
 	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b);

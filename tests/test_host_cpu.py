@@ -126,3 +126,36 @@ def test_synth_matches_oracle_pairs_scale():
     a, off = mm.synth_reads(1, 0, 4, 100_000, 300_000)
     _, _, pairs = orc.chain_fill_many(a, off, orc.default_param(), threads=4)
     assert 50 < pairs / off[-1] < 3000
+
+
+def test_batch_grouping_rule_matches_the_reference_accumulator():
+    """mm2gb_plan_batches (the batcher's rule, no GPU): a read that would take the batch past max_total_n anchors starts the next
+    batch (map.c:887-920 moves it to the pending batch), max_read closes a batch by count (map.c:954), a read larger than the
+    limit is a batch of its own, and reads under min_n travel in a lane of their own without closing the big reads' batches."""
+    rng = np.random.default_rng(3)
+    n = rng.integers(0, 900, 500).astype(np.int64)
+    n[::50] = 5000                                     # larger than the anchor limit
+    nb, batch, lane = mm.plan_batches(n, 3000, 40, 0)
+    assert (lane == 0).all() and nb == batch.max() + 1 and (np.diff(batch) >= 0).all()
+    # straightforward restatement of the rule
+    want, cur, cnt, tot = [], -1, 0, 0
+    for v in n:
+        if cur < 0 or cnt >= 40 or tot + v > 3000:
+            cur, cnt, tot = cur + 1, 0, 0
+        want.append(cur); cnt += 1; tot += v
+    assert batch.tolist() == want
+    for b in range(nb):
+        sel = batch == b
+        assert sel.sum() <= 40 and (n[sel].sum() <= 3000 or sel.sum() == 1)
+    # min_n: two lanes, each with the same rule applied to its own reads; ids in order of creation
+    nb2, batch2, lane2 = mm.plan_batches(n, 3000, 40, 100)
+    assert ((n < 100) == (lane2 == 1)).all()
+    for ln in (0, 1):
+        sub = n[lane2 == ln]
+        _, bsub, _ = mm.plan_batches(sub, 3000, 40, 0)
+        ids = batch2[lane2 == ln]
+        assert (np.unique(ids, return_inverse=True)[1] == bsub).all()
+    assert nb2 == len(np.unique(batch2))
+    # no limits: one batch
+    assert mm.plan_batches(n, 0, 0, 0)[0] == 1
+    assert mm.plan_batches(np.zeros(0, np.int64), 10, 10, 0)[0] == 0
