@@ -121,6 +121,25 @@ int  mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offset
 int  mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
                        const int32_t *d_f, const int32_t *d_p, int64_t *n_chains, int64_t *n_kept, float *ms);
 
+/* ---- RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369, called per read from post_chaining_helper, map.c:444-456,
+ *      on the anchors the first chaining kept, sorted by x).  Parameters in the order of mg_lchain_rmq's argument list.
+ *      mm2gb_rmq_chain_gpu: a batch of reads; score fill, backtrack and compaction all on the device.  The reference resolves
+ *      ties between equal range-minimum priorities by the shape of its AVL tree (krmq.h:110-147), which no closed form
+ *      reproduces: n_tied[r] (optional) counts the anchors of read r where that happened; the chains of a read with
+ *      n_tied[r] != 0 may differ from the reference's and are for the caller to discard (mm2gb_lchain_rmq does).
+ *      max_chn_skip is ignored: the device path is exhaustive (== INT32_MAX), like mm2gb_lchain_dp.
+ *      mm2gb_lchain_rmq: one read, signature and ownership of mg_lchain_rmq; a read that met a tie is handed to the host's own
+ *      mg_lchain_rmq when the library is linked into minimap2 (weak import), otherwise the call fails loudly. ---- */
+typedef struct {
+	int max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc;
+	float chn_pen_gap, chn_pen_skip;
+} mm2gb_rmq_param_t;
+int  mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                         mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats);
+mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
+                                 float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km);
+void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls);   /* single-read calls so far, and how many of them met a tie */
+
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
  *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;

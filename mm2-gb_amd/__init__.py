@@ -54,6 +54,12 @@ class Chains(C.Structure):
     _fields_ = [("u_off", C.POINTER(C.c_int64)), ("u", C.POINTER(C.c_uint64)), ("a_off", C.POINTER(C.c_int64)), ("a", C.c_void_p)]
 
 
+class RmqParam(C.Structure):
+    """mm2gb_rmq_param_t == the leading arguments of mg_lchain_rmq (lchain.c:250-251)."""
+    _fields_ = [("max_dist", C.c_int), ("max_dist_inner", C.c_int), ("bw", C.c_int), ("max_chn_skip", C.c_int), ("cap_rmq_size", C.c_int),
+                ("min_cnt", C.c_int), ("min_sc", C.c_int), ("chn_pen_gap", C.c_float), ("chn_pen_skip", C.c_float)]
+
+
 READ_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_uint64), C.c_int64, C.c_void_p)
 
 
@@ -77,7 +83,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
-                "mm2gb_plan_batches"]
+                "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -135,6 +141,11 @@ def lib():
         L.mm2gb_pool_set_misc.argtypes = [C.c_void_p, C.POINTER(Misc)]
         L.mm2gb_pool_score_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]
         L.mm2gb_pool_chain_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Chains), C.POINTER(Stats)]
+        L.mm2gb_rmq_chain_gpu.argtypes = [C.c_void_p, C.POINTER(RmqParam), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Chains), C.c_void_p, C.POINTER(Stats)]
+        L.mm2gb_lchain_rmq.restype = C.c_void_p
+        L.mm2gb_lchain_rmq.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p]
+        L.mm2gb_lchain_rmq_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mm2gb_lchain_rmq_counts.restype = None
         L.mm2gb_batcher_create.restype = C.c_void_p
         L.mm2gb_batcher_create.argtypes = [C.POINTER(Config), C.POINTER(Misc), C.c_int, C.c_void_p, C.c_int, READ_DONE_FN, C.c_void_p]
         L.mm2gb_batcher_add.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
@@ -262,6 +273,29 @@ def _engine_chain_gpu(self, anchors, offsets):
 
 
 Engine.chain_gpu = _engine_chain_gpu
+
+
+def default_rmq_param(**kw):
+    """What post_chaining_helper passes to mg_lchain_rmq for map-ont defaults (map.c:450-451), max_chain_skip = infinity."""
+    d = dict(max_dist=5000, max_dist_inner=1000, bw=20000, max_chn_skip=INT32_MAX, cap_rmq_size=100000, min_cnt=3, min_sc=40,
+             chn_pen_gap=np.float32(0.8 * 0.01 * 15), chn_pen_skip=np.float32(0.0))
+    d.update(kw)
+    return RmqParam(**d)
+
+
+def _engine_rmq_chain(self, anchors, offsets, prm):
+    """RMQ re-chaining of a batch on the device (mm2gb_rmq_chain_gpu): list of (u, a_out) per read, n_tied per read, stats."""
+    a = np.ascontiguousarray(anchors, dtype=np.uint64)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    R = len(off) - 1
+    out = Chains()
+    st = Stats()
+    tied = np.zeros(max(R, 1), dtype=np.int32)
+    _check(lib().mm2gb_rmq_chain_gpu(self._h, C.byref(prm), R, off.ctypes.data, a.ctypes.data, C.byref(out), tied.ctypes.data, C.byref(st)))
+    return _take_chains(out, R), tied[:R], st.as_dict()
+
+
+Engine.rmq_chain = _engine_rmq_chain
 
 
 def _take_chains(out, R):

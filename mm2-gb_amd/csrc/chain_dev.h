@@ -108,6 +108,20 @@ struct PostBatch {
 };
 void launch_post(const PostBatch &b, hipStream_t s);
 
+// RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369) of reads whose anchors are already chained once: score fill on the device.
+struct RmqParams { int max_dist, max_dist_inner, bw, cap_rmq_size; float pen_gap, pen_skip; };
+struct RmqBatch {
+	const uint4   *raw;        // anchors, sorted by x within each read
+	const int64_t *offsets;
+	int64_t        n, n_reads;
+	int32_t *f, *p;            // out: score, i - predecessor (0 = none)
+	double  *key;              // scratch, n: f + 0.5 * gap * (x + y), the negated priority of lchain.c:284
+	int32_t *n_tied;           // out, per read: anchors whose range-minimum was shared by several elements (see post_kernels.hip)
+	int32_t *cursor;
+	int      grid_waves;
+};
+void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);
+
 void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s);
 void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s);
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s);

@@ -77,7 +77,7 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order;
+	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order, rmq_tied;
 	int64_t *h_post_totals = nullptr;      // pinned: [0] chains [1] anchors kept
 	hipEvent_t post0 = nullptr, post1 = nullptr;
 	IoSet io[2];
@@ -111,9 +111,13 @@ struct Engine {
 	// them); enqueued on the compute stream.  Results stay in post_uoff / post_aoff / post_uout / post_aout; totals land in
 	// h_post_totals once the stream has been synchronised.
 	int  reserve_post(int64_t n_anchors, int64_t n_reads);
-	int  enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p);
+	int  enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
+	                  const mm2gb_rmq_param_t *rmq = nullptr);   // rmq given: thresholds of the re-chaining call (lchain.c:355) instead of misc's
 	// whole batch on host buffers, chains back, nothing but the chains crosses the link on the way back
-	int  chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out);
+	// rmq given: the score fill is mg_lchain_rmq's (k_rmq_fill) instead of the chaining DP; n_tied (optional, n_reads entries)
+	// receives, per read, the number of anchors whose range-minimum was tied (results for such a read are not the reference's)
+	int  chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out,
+	               const mm2gb_rmq_param_t *rmq = nullptr, int32_t *n_tied = nullptr);
 	int  record_outputs_done(hipEvent_t ev);   // fires when every D2H enqueued so far has landed
 	int  sync();
 	int  collect_stats();

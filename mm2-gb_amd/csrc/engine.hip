@@ -204,7 +204,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order })
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order, &rmq_tied })
 		b->release();
 	cap_post_n = cap_post_reads = 0;
 	if (h_post_totals) { (void)hipHostFree(h_post_totals); h_post_totals = nullptr; }
@@ -318,7 +318,8 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	return 0;
 }
 
-int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p)
+int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
+                         const mm2gb_rmq_param_t *rmq)
 {
 	if (reserve_post(n, n_reads)) return -1;
 	PostBatch b;
@@ -333,6 +334,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 64, stream));
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
 	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
+	if (rmq) { b.min_cnt = rmq->min_cnt; b.min_sc = rmq->min_sc; b.max_drop = rmq->bw; }   // lchain.c:253,355
 	// one read per wave at a time: as many waves as the chip holds (latency-bound pointer chases; parallelism is across reads)
 	b.grid_waves = n_cu * 32;
 	if (const char *v = getenv("MM2GB_POST_WAVES")) b.grid_waves = std::max(4, atoi(v));
@@ -346,7 +348,8 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 
 // Whole batch from host buffers to chains with every stage on the device: H2D of the anchors, score kernels, post-pass
 // kernels, then only offsets + chains + compacted anchors come back (the host post-pass path returns 8 B per anchor).
-int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out)
+int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out,
+                      const mm2gb_rmq_param_t *rmq, int32_t *n_tied)
 {
 	memset(out, 0, sizeof(*out));
 	if (!offsets || n_reads < 0 || offsets[0] != 0) return fail("mm2gb_chain_gpu: offsets[0] must be 0");
@@ -362,8 +365,21 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
 	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
 	if (n > 0) MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, anchors, (size_t)n * 16, hipMemcpyHostToDevice, stream));
-	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr)) return -1;
-	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr)) return -1;
+	if (!rmq) {
+		if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr)) return -1;
+	} else {
+		// mg_lchain_rmq's fill instead of the chaining DP; its key scratch shares the post-pass's candidate array (used after it)
+		if (reserve_post(n, n_reads) || rmq_tied.ensure((size_t)std::max<int64_t>(n_reads, 1) * 4)) return -1;
+		RmqBatch rb;
+		rb.raw = (const uint4*)s.raw.ptr; rb.offsets = (const int64_t*)s.offsets.ptr; rb.n = n; rb.n_reads = n_reads;
+		rb.f = (int32_t*)s.f.ptr; rb.p = (int32_t*)s.p.ptr; rb.key = (double*)post_z.ptr; rb.n_tied = (int32_t*)rmq_tied.ptr;
+		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;
+		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
+		launch_rmq_fill(rb, rp, stream);
+		MM2GB_HIP(hipGetLastError());
+		last.n_anchors += n; last.n_reads += n_reads;
+	}
+	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, rmq)) return -1;
 	s.used = false;                                     // nothing of this set is in flight once the call returns
 	if (sync()) return -1;
 	const int64_t n_u = n_reads > 0 ? h_post_totals[0] : 0, n_a = n_reads > 0 ? h_post_totals[1] : 0;
@@ -378,6 +394,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		MM2GB_HIP(hipMemcpy(out->a_off, post_aoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
 		if (n_u > 0) MM2GB_HIP(hipMemcpy(out->u, post_uout.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost));
 		if (n_a > 0) MM2GB_HIP(hipMemcpy(out->a, post_aout.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost));
+		if (rmq && n_tied) MM2GB_HIP(hipMemcpy(n_tied, rmq_tied.ptr, (size_t)n_reads * 4, hipMemcpyDeviceToHost));
 	}
 	float ms = 0;
 	if (n_reads > 0 && hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
@@ -592,6 +609,16 @@ int mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets
 {
 	if (!eng || !out) return fail("mm2gb_chain_gpu: null argument");
 	if (eng->e.chain_gpu(n_reads, offsets, anchors, out)) return -1;
+	if (stats) *stats = eng->e.last;
+	return 0;
+}
+
+int mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                        mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats)
+{
+	if (!eng || !out || !prm) return fail("mm2gb_rmq_chain_gpu: null argument");
+	if (prm->max_dist < 0 || prm->bw < 0 || prm->cap_rmq_size < 0) return fail("mm2gb_rmq_chain_gpu: negative parameter");
+	if (eng->e.chain_gpu(n_reads, offsets, anchors, out, prm, n_tied)) return -1;
 	if (stats) *stats = eng->e.last;
 	return 0;
 }

@@ -392,6 +392,170 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_emit(PostBatch b)
 	}
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// RMQ re-chaining: the score fill of mg_lchain_rmq (lchain.c:273-350), one wave per read.
+// The reference keeps the anchors in reach in two balanced trees ordered by (query position, index) and asks them for the
+// element of minimal pri = -(f + 0.5 * gap * (x + y)) in a query-position range (krmq.h).  What the trees hold when anchor i
+// is processed are index ranges -- [st, i0) and [st_inner, i0), with i0 the first anchor sharing a[i].x and st / st_inner
+// advanced by the eviction loops of lchain.c:293-310 -- so the same definition is evaluated here by the wave's 64 lanes
+// scanning those ranges: an arg-max of the (double) key over the outer range, then, unless that pair is an exact diagonal
+// extension, the best-scoring pair over the inner range in descending (y, index) order (lchain.c:320-341 with
+// max_chn_skip = infinity, as everywhere on the GPU path).
+// One thing is not a function of the definition: WHICH element krmq_rmq returns when several in-range elements share the
+// minimal pri depends on the shape of the reference's AVL tree (krmq.h:110-147).  Such anchors are counted in n_tied[read];
+// the host side does not use the device's answer for a read with n_tied != 0 (stream_api.cpp: mm2gb_lchain_rmq).
+// --------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float rmq_log2(float v)       // mg_log2, mmpriv.h:118-126
+{
+	unsigned u = __float_as_uint(v);
+	float r = (float)(((u >> 23) & 255u) - 128u);
+	u = (u & ~(255u << 23)) + (127u << 23);
+	const float m = __uint_as_float(u);
+	r += (-0.34484843f * m + 2.02466578f) * m - 0.67487759f;
+	return r;
+}
+
+// comput_sc_simple, lchain.c:232-248
+__device__ __forceinline__ int rmq_pair_score(unsigned xi, int yi, unsigned xj, int yj, int q_span_j, const RmqParams &P, bool &exact, int &width)
+{
+	const int dq = yi - yj, dr = (int)(xi - xj);
+	const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+	int sc = q_span_j < dg ? q_span_j : dg;
+	width = dd;
+	exact = dd == 0 && dg <= q_span_j;
+	if (dd != 0 || dq > q_span_j) {
+		const float lin = P.pen_gap * (float)dd + P.pen_skip * (float)dg;
+		const float lg = dd >= 1 ? rmq_log2((float)(dd + 1)) : 0.0f;
+		sc -= (int)(lin + .5f * lg);
+	}
+	return sc;
+}
+
+// number of leading lanes (from lane 0) whose bit is CLEAR in `stay`, 64 if none is set.  Written with 32-bit halves on purpose:
+// with __builtin_ctzll the loop test on the result was compiled to a 64-bit scalar compare and the kernel hung (ROCm 7.2).
+__device__ __forceinline__ int leading_out(unsigned long long stay)
+{
+	const unsigned lo = (unsigned)stay, hi = (unsigned)(stay >> 32);
+	return lo ? __builtin_ctz(lo) : hi ? 32 + __builtin_ctz(hi) : W;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+{
+	const unsigned long long u = __double_as_longlong(v);
+	const unsigned lo = __shfl_xor((int)(unsigned)u, m), hi = __shfl_xor((int)(unsigned)(u >> 32), m);
+	return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+
+} // namespace
+
+__global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams P)
+{
+	const int l = lane();
+	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
+	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;   // lchain.c:265
+	const double half_gap = 0.5 * (double)P.pen_gap;
+	const int per = POST_THREADS / W;
+	for (int64_t r = (int64_t)blockIdx.x * per + uni(threadIdx.x / W); r < b.n_reads; r += (int64_t)gridDim.x * per) {
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const uint4 *a = b.raw + off;
+		int32_t *f = b.f + off, *p = b.p + off;
+		double *key = b.key + off;
+		int i0 = 0, st = 0, st_in = 0, tied = 0;
+		for (int i = 0; i < n; ++i) {
+			const uint4 ai = a[i];                                        // same address in every lane
+			const int yi = (int)ai.z, q_i = (int)(ai.w & 0xffu);
+			if (i0 < i) { const uint4 a0 = a[i0]; if (a0.x != ai.x || a0.y != ai.y) i0 = i; }               // lchain.c:279-292
+			i0 = uni(i0);
+			// eviction (lchain.c:293-310): the conditions hold for a prefix of [st, i), so 64 candidates are tested at once.
+			// (Loop control is made explicitly wave-uniform: an earlier form with `for (;;) ... break` on the ballot's result hung.)
+			int adv;
+			do {
+				const int j = st + l;
+				bool out = false;
+				if (j < i) { const uint2 xj = *(const uint2*)&a[j]; out = xj.y != ai.y || ai.x > xj.x + (unsigned)max_dist || (i0 > j ? i0 - j : 0) > P.cap_rmq_size; }
+				const unsigned long long stay = ~__ballot(out);
+				adv = uni(leading_out(stay));
+				st += adv;
+			} while (adv == W);
+			if (max_inner > 0)
+				do {
+					const int j = st_in + l;
+					bool out = false;
+					if (j < i) { const uint2 xj = *(const uint2*)&a[j]; out = xj.y != ai.y || ai.x > xj.x + (unsigned)max_inner || (i0 > j ? i0 - j : 0) > P.cap_rmq_size; }
+					const unsigned long long stay = ~__ballot(out);
+					adv = uni(leading_out(stay));
+					st_in += adv;
+				} while (adv == W);
+			int max_f = q_i, max_j = -1;
+			// the range-minimum (lchain.c:311-315): closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index)
+			double bk = 0.0;
+			int bj = -1, by = 0, cnt = 0;
+			for (int j = st + l; j < i0; j += W) {
+				const int yj = (int)a[j].z;
+				if (!((yj > yi - max_dist && yj < yi) || (yj == yi && j == 0))) continue;
+				const double k = key[j];
+				if (bj < 0 || k > bk) { bk = k; bj = j; by = yj; cnt = 1; }
+				else if (k == bk) { ++cnt; if (yj > by || (yj == by && j > bj)) { bj = j; by = yj; } }
+			}
+			for (int m = W / 2; m > 0; m >>= 1) {
+				const double ok = shfl_xor_f64(bk, m);
+				const int oj = __shfl_xor(bj, m), oy = __shfl_xor(by, m), oc = __shfl_xor(cnt, m);
+				if (oj >= 0) {
+					if (bj < 0 || ok > bk) { bk = ok; bj = oj; by = oy; cnt = oc; }
+					else if (ok == bk) { cnt += oc; if (oy > by || (oy == by && oj > bj)) { bj = oj; by = oy; } }
+				}
+			}
+			bj = uni(bj);
+			if (bj >= 0) {
+				if (uni(cnt) > 1) ++tied;
+				const uint4 aj = a[bj];
+				bool exact; int width;
+				const int sc = f[bj] + rmq_pair_score(ai.x, yi, aj.x, (int)aj.z, (int)(aj.w & 0xffu), P, exact, width);
+				if (width <= P.bw && sc > max_f) { max_f = sc; max_j = bj; }
+				if (!exact && max_inner > 0 && st_in < i0 && yi > 0) {
+					// lchain.c:320-341: every inner-tree element with y in [yi - max_inner, yi - 1], from the largest (y, index) down;
+					// strict '>' keeps the first of equal scores, i.e. the largest (y, index)
+					int bs = INT_MIN, cj = -1, cy = 0;
+					for (int j = st_in + l; j < i0; j += W) {
+						const uint4 aj2 = a[j];
+						const int yj = (int)aj2.z;
+						if (yj > yi - 1 || yj < yi - max_inner) continue;
+						bool ex2; int w2;
+						const int s2 = f[j] + rmq_pair_score(ai.x, yi, aj2.x, yj, (int)(aj2.w & 0xffu), P, ex2, w2);
+						if (w2 > P.bw) continue;
+						if (s2 > bs || (s2 == bs && (yj > cy || (yj == cy && j > cj)))) { bs = s2; cj = j; cy = yj; }
+					}
+					for (int m = W / 2; m > 0; m >>= 1) {
+						const int os = __shfl_xor(bs, m), oj = __shfl_xor(cj, m), oy = __shfl_xor(cy, m);
+						if (oj >= 0 && (cj < 0 || os > bs || (os == bs && (oy > cy || (oy == cy && oj > cj))))) { bs = os; cj = oj; cy = oy; }
+					}
+					cj = uni(cj); bs = uni(bs);
+					if (cj >= 0 && bs > max_f) { max_f = bs; max_j = cj; }
+				}
+			}
+			if (l == 0) {                                                                              // lchain.c:346 (+ the key of lchain.c:284)
+				f[i] = max_f;
+				p[i] = max_j < 0 ? 0 : i - max_j;
+				key[i] = (double)max_f + half_gap * (double)((int)ai.x + (int)ai.z);
+			}
+			wave_sync();
+		}
+		if (l == 0) b.n_tied[r] = tied;
+	}
+}
+
+void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
+{
+	if (b.n_reads <= 0) return;
+	(void)hipMemsetAsync(b.cursor, 0, sizeof(int32_t), s);
+	const int per = POST_THREADS / W;
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, ((int64_t)b.grid_waves + per - 1) / per));
+	hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
+}
+
 void launch_post(const PostBatch &b, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;

@@ -24,6 +24,11 @@
 extern "C" {
 mm2gb_Misc build_misc(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, const int64_t qlen_sum, const int n_seg) __attribute__((weak));
 void post_chaining_helper(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *read, mm2gb_Misc misc, void *km) __attribute__((weak));
+// the host's own re-chaining (lchain.c:250): takes the reads whose range-minimum met a tie (include/mm2gb_chain.h).  Two names: the
+// plain one when the library is simply linked next to lchain.c, the __real_ one when the host was linked with
+// -Wl,--wrap=mg_lchain_rmq so that its calls land in __wrap_mg_lchain_rmq below.
+mm2gb_anchor_t *mg_lchain_rmq(int, int, int, int, int, int, int, float, float, int64_t, mm2gb_anchor_t*, int*, uint64_t**, void*) __attribute__((weak));
+mm2gb_anchor_t *__real_mg_lchain_rmq(int, int, int, int, int, int, int, float, float, int64_t, mm2gb_anchor_t*, int*, uint64_t**, void*) __attribute__((weak));
 }
 
 // Layout of the records shared with the host, as a C compiler lays out gpu/plutils.h:19-73 on x86-64 (checked against the
@@ -319,6 +324,68 @@ mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// one read, mg_lchain_rmq's signature (lchain.c:250-369)
+// ---------------------------------------------------------------------------------------------------------------
+static std::atomic<int64_t> g_rmq_calls(0), g_rmq_tied_calls(0);
+
+mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
+                                 float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km)
+{
+	HostAlloc mem; mem.km = km; mem.use_kalloc = host_kalloc_present();
+	if (!mem.use_kalloc && km) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: a kalloc arena was passed but the host allocator is not linked\n"); exit(1); }
+	if (_u) *_u = 0, *n_u_ = 0;
+	if (n == 0 || a == 0) { mem.release(a); return 0; }                       // lchain.c:260-263
+	mm2gb_misc_t misc = {};                                                   // the engine wants one; the re-chaining call carries its own thresholds
+	misc.max_iter = 5000; misc.max_dist_x = max_dist; misc.max_dist_y = max_dist; misc.max_skip = max_chn_skip; misc.bw = std::min(bw, 8000);
+	misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.n_seg = 1; misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
+	mm2gb_engine_t *eng = single_read_engine(misc);
+	if (!eng) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+	const mm2gb_rmq_param_t prm = { max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip };
+	const int64_t off[2] = { 0, n };
+	mm2gb_chains_t out;
+	int32_t tied = 0;
+	if (mm2gb_rmq_chain_gpu(eng, &prm, 1, off, a, &out, &tied, nullptr)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+	g_rmq_calls.fetch_add(1);
+	if (tied != 0) {
+		// the reference's answer depends on the shape of its tree here: ask the reference (it consumes a[] like we would)
+		mm2gb_chains_free(&out);
+		g_rmq_tied_calls.fetch_add(1);
+		auto host_fn = __real_mg_lchain_rmq ? __real_mg_lchain_rmq : mg_lchain_rmq;
+		if (!host_fn) {
+			fprintf(stderr, "[Error] mm2gb_lchain_rmq: %d anchors of this read tie on the range-minimum priority; the reference breaks such ties by the shape of its "
+			                "AVL tree (krmq.h), so the read needs the host's mg_lchain_rmq, which is not linked\n", tied);
+			exit(1);
+		}
+		return host_fn(max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip, n, a, n_u_, _u, km);
+	}
+	const int n_u = (int)out.u_off[1];
+	uint64_t *u = nullptr; mm2gb_anchor_t *res = nullptr;
+	if (n_u > 0) {
+		u = (uint64_t*)mem.alloc((size_t)n_u * 8);
+		res = (mm2gb_anchor_t*)mem.alloc((size_t)out.a_off[1] * 16);
+		memcpy(u, out.u, (size_t)n_u * 8); memcpy(res, out.a, (size_t)out.a_off[1] * 16);
+	}
+	mm2gb_chains_free(&out);
+	mem.release(a);                                                          // input is consumed (lchain.c:357-360,109)
+	*n_u_ = n_u; *_u = u;
+	return res;
+}
+
+// link-time interposition for an unmodified host: -Wl,--wrap=mg_lchain_rmq sends map.c:450's call here
+mm2gb_anchor_t *__wrap_mg_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
+                                     float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km)
+{
+	return mm2gb_lchain_rmq(max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip, n, a, n_u_, _u, km);
+}
+
+// how many single-read re-chaining calls there were, and how many of them went to the host because of a tie
+void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls)
+{
+	if (calls) *calls = g_rmq_calls.load();
+	if (tied_calls) *tied_calls = g_rmq_tied_calls.load();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // the reference's boundary
 // ---------------------------------------------------------------------------------------------------------------
 void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_config_file[], mm2gb_Misc misc)
@@ -417,6 +484,9 @@ void free_stream_gpu(int n_threads)
 	g_streams.slots.clear();
 	g_streams.ready = false;
 	free_single_read_engines();
+	if (const char *v = getenv("MM2GB_RMQ_REPORT"))
+		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls on the device: %lld, of which handed to the host because of a tie: %lld\n",
+		                             (long long)g_rmq_calls.load(), (long long)g_rmq_tied_calls.load());
 }
 
 } // extern "C"

@@ -52,6 +52,8 @@ static void *next_symbol(const char *name)
 }
 
 /* accessors for in-process users (ctypes) */
+/* arm the f/p recorder for a direct call into the reference that reaches mg_chain_backtrack (mg_lchain_rmq, lchain.c:355) */
+void cap_arm(int on) { tl_in_dp = on; if (on) tl_n = -1; }
 int64_t cap_last_n(void) { return tl_n; }
 const int32_t *cap_last_f(void) { return tl_f; }
 const int64_t *cap_last_p(void) { return tl_p; }

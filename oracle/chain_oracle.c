@@ -316,6 +316,124 @@ orc_anchor_t *orc_lchain_dp(const orc_param_t *prm, int64_t n, const orc_anchor_
 
 void orc_free(void *ptr) { free(ptr); }
 
+/* ------------------------------------------------------------------------------------------------
+ * RMQ re-chaining (lchain.c:219-369)
+ * ------------------------------------------------------------------------------------------------ */
+int32_t orc_rmq_pair_score(const orc_anchor_t *ai, const orc_anchor_t *aj, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)
+{   /* comput_sc_simple, lchain.c:232-248 */
+	int32_t dq = (int32_t)ai->y - (int32_t)aj->y, dr, dd, dg, q_span, sc;
+	dr = (int32_t)(ai->x - aj->x);
+	*width = dd = dr > dq ? dr - dq : dq - dr;
+	dg = dr < dq ? dr : dq;
+	q_span = a_qspan(aj);
+	sc = q_span < dg ? q_span : dg;
+	if (exact) *exact = (dd == 0 && dg <= q_span);
+	if (dd || dq > q_span) {
+		float lin_pen = pen_gap * (float)dd + pen_skip * (float)dg;
+		float log_pen = dd >= 1 ? orc_log2_approx(dd + 1) : 0.0f;
+		sc -= (int)(lin_pen + .5f * log_pen);
+	}
+	return sc;
+}
+
+typedef struct { int32_t y; int64_t j; } rmq_cand_t;
+static int rmq_cand_desc(const void *pa, const void *pb)
+{   /* descending (y, index): the order krmq_itr_prev walks the inner tree (lchain.c:227, 323-341) */
+	const rmq_cand_t *a = (const rmq_cand_t*)pa, *b = (const rmq_cand_t*)pb;
+	if (a->y != b->y) return a->y < b->y ? 1 : -1;
+	return a->j < b->j ? 1 : a->j > b->j ? -1 : 0;
+}
+
+int64_t orc_rmq_fill(const orc_rmq_param_t *prm, int64_t n, const orc_anchor_t *a, int32_t *f, int64_t *p, int64_t *n_tied)
+{
+	int32_t max_dist = prm->max_dist, max_dist_inner = prm->max_dist_inner;
+	int64_t i, i0 = 0, st = 0, st_inner = 0, n_scored = 0, tied = 0;
+	int32_t *t = (int32_t*)calloc(n > 0 ? n : 1, sizeof(int32_t));
+	rmq_cand_t *cand = (rmq_cand_t*)malloc((n > 0 ? n : 1) * sizeof(rmq_cand_t));
+	if (max_dist < prm->bw) max_dist = prm->bw;                                                   /* lchain.c:264 */
+	if (max_dist_inner <= 0 || max_dist_inner >= max_dist) max_dist_inner = 0;                    /* lchain.c:265 */
+	for (i = 0; i < n; ++i) {
+		int64_t max_j = -1, j;
+		int32_t q_span = a_qspan(&a[i]), max_f = q_span, yi = (int32_t)a[i].y;
+		/* lchain.c:279-292: every anchor before the run of equal x that holds i is in the trees (until evicted) */
+		if (i0 < i && a[i0].x != a[i].x) i0 = i;
+		/* lchain.c:293-300 and 301-310: trees hold [st, i0) and [st_inner, i0); their sizes are i0 - st */
+		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist || (i0 > st ? i0 - st : 0) > prm->cap_rmq_size)) ++st;
+		if (max_dist_inner > 0)
+			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + (uint64_t)max_dist_inner || (i0 > st_inner ? i0 - st_inner : 0) > prm->cap_rmq_size)) ++st_inner;
+		/* lchain.c:311-315: closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] in (y, index) order */
+		{
+			int64_t best_j = -1, n_best = 0;
+			double best_key = 0.0;
+			for (j = st; j < i0; ++j) {
+				const int32_t yj = (int32_t)a[j].y;
+				double key;
+				if (!((yj > yi - max_dist && yj < yi) || (yj == yi && j == 0))) continue;
+				key = f[j] + 0.5 * prm->pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y);                /* -pri, lchain.c:284 */
+				if (best_j < 0 || key > best_key) { best_key = key; best_j = j; n_best = 1; }
+				else if (key == best_key) { ++n_best; if (yj > (int32_t)a[best_j].y || (yj == (int32_t)a[best_j].y && j > best_j)) best_j = j; }
+			}
+			if (best_j >= 0) {
+				int32_t sc, exact, width, n_skip = 0;
+				if (n_best > 1) ++tied;
+				j = best_j;
+				sc = f[j] + orc_rmq_pair_score(&a[i], &a[j], prm->pen_gap, prm->pen_skip, &exact, &width);
+				++n_scored;
+				if (width <= prm->bw && sc > max_f) max_f = sc, max_j = j;
+				if (!exact && max_dist_inner > 0 && st_inner < i0 && yi > 0) {                          /* lchain.c:320: root_inner != 0 <=> the inner tree is not empty */
+					int64_t nc = 0, k;
+					for (j = st_inner; j < i0; ++j) {
+						const int32_t yj = (int32_t)a[j].y;
+						if (yj <= yi - 1 && yj >= yi - max_dist_inner) { cand[nc].y = yj; cand[nc].j = j; ++nc; }
+					}
+					qsort(cand, nc, sizeof(rmq_cand_t), rmq_cand_desc);
+					for (k = 0; k < nc; ++k) {                                                              /* lchain.c:328-341 */
+						j = cand[k].j;
+						sc = f[j] + orc_rmq_pair_score(&a[i], &a[j], prm->pen_gap, prm->pen_skip, 0, &width);
+						++n_scored;
+						if (width <= prm->bw) {
+							if (sc > max_f) {
+								max_f = sc, max_j = j;
+								if (n_skip > 0) --n_skip;
+							} else if (t[j] == (int32_t)i) {
+								if (++n_skip > prm->max_chn_skip) break;
+							}
+							if (p[j] >= 0) t[p[j]] = i;
+						}
+					}
+				}
+			}
+		}
+		f[i] = max_f, p[i] = max_j;                                                                  /* lchain.c:346 */
+	}
+	free(t); free(cand);
+	if (n_tied) *n_tied = tied;
+	return n_scored;
+}
+
+orc_anchor_t *orc_lchain_rmq(const orc_rmq_param_t *prm, int64_t n, const orc_anchor_t *a, int32_t *n_u_, uint64_t **u_out,
+                             int32_t *f_out, int64_t *p_out, int64_t *n_tied)
+{
+	int32_t *f, *v, n_u = 0, n_v = 0;
+	int64_t *p;
+	uint64_t *u;
+	orc_anchor_t *out;
+	*n_u_ = 0; *u_out = 0;
+	if (n_tied) *n_tied = 0;
+	if (n == 0 || a == 0) return 0;                                                                /* lchain.c:260-263 */
+	f = (int32_t*)malloc(n * sizeof(int32_t)); p = (int64_t*)malloc(n * sizeof(int64_t)); v = (int32_t*)malloc(n * sizeof(int32_t));
+	orc_rmq_fill(prm, n, a, f, p, n_tied);
+	if (f_out) memcpy(f_out, f, n * sizeof(int32_t));
+	if (p_out) memcpy(p_out, p, n * sizeof(int64_t));
+	u = orc_backtrack(n, f, p, v, prm->min_cnt, prm->min_sc, prm->bw, &n_u, &n_v);                 /* max_drop = bw, lchain.c:253,355 */
+	free(f); free(p);
+	*n_u_ = n_u; *u_out = u;
+	if (n_u == 0) { free(v); return 0; }
+	out = orc_compact(n_u, u, n_v, v, a);
+	free(v);
+	return out;
+}
+
 /* ---- many reads on several host threads: the CPU baseline of bench.py (reads dealt dynamically, one call of
  *      orc_chain_fill per read, like kt_for over reads in map.c:1323) ---- */
 typedef struct {

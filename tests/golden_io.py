@@ -25,3 +25,16 @@ def all_cases(prefix=""):
 
 def case_ids(paths):
     return [os.path.basename(p)[:-4] for p in paths]
+
+
+def load_rmq(path):
+    """tests/golden/rmq/*.npz (oracle/gen_golden_rmq.py): the reference's mg_lchain_rmq on one read."""
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    d = meta["param"]
+    prm = orc.RmqParam(**{k: (np.float32(v) if k.startswith("pen_") else int(v)) for k, v in d.items()})
+    return dict(name=os.path.basename(path)[:-4], a=z["a"], f=z["f"], p=z["p"].astype(np.int64), u=z["u"], a_out=z["a_out"], prm=prm, tied=meta["tied"])
+
+
+def rmq_cases():
+    return sorted(glob.glob(os.path.join(GOLD, "rmq", "*.npz")))

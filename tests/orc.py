@@ -28,6 +28,20 @@ class Stats(C.Structure):
                 ("n_pairs", "n_scored", "n_clamped", "n_rescue_eval", "n_rescue_taken", "n_rescan")]
 
 
+class RmqParam(C.Structure):
+    """orc_rmq_param_t == the leading arguments of mg_lchain_rmq (lchain.c:250-251)."""
+    _fields_ = [("max_dist", C.c_int32), ("max_dist_inner", C.c_int32), ("bw", C.c_int32), ("max_chn_skip", C.c_int32),
+                ("cap_rmq_size", C.c_int32), ("min_cnt", C.c_int32), ("min_sc", C.c_int32), ("pen_gap", C.c_float), ("pen_skip", C.c_float)]
+
+
+def default_rmq_param(**kw):
+    """What post_chaining_helper passes for map-ont defaults (map.c:450-451, options.c:24-55, k = 15), max_chain_skip = infinity."""
+    d = dict(max_dist=5000, max_dist_inner=1000, bw=20000, max_chn_skip=INT32_MAX, cap_rmq_size=100000, min_cnt=3, min_sc=40,
+             pen_gap=np.float32(0.8 * 0.01 * 15), pen_skip=np.float32(0.0))
+    d.update(kw)
+    return RmqParam(**d)
+
+
 def default_param(**kw):
     """map-ont / no-preset defaults (options.c:24-36, map.c:408-409 with k=15), max_skip = infinity."""
     d = dict(max_dist_x=5000, max_dist_y=5000, bw=500, max_skip=INT32_MAX, max_iter=5000,
@@ -75,6 +89,11 @@ def lib():
         L.orc_chain_fill_reads_mt.argtypes = [C.POINTER(Param), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_free.restype = None
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_rmq_fill.restype = C.c_int64
+        L.orc_rmq_fill.argtypes = [C.POINTER(RmqParam), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.orc_lchain_rmq.restype = C.c_void_p
+        L.orc_lchain_rmq.argtypes = [C.POINTER(RmqParam), C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -154,6 +173,32 @@ def backtrack_compact(a, f, p, prm):
     return u, a_out
 
 
+def lchain_rmq(a, prm):
+    """Full mg_lchain_rmq restatement.  Returns dict(u, a_out, f, p, n_tied)."""
+    a = as_anchors(a)
+    n = a.shape[0]
+    f = np.empty(n, dtype=np.int32)
+    p = np.empty(n, dtype=np.int64)
+    n_u = C.c_int32(0)
+    u_ptr = C.c_void_p(0)
+    tied = C.c_int64(0)
+    L = lib()
+    out = L.orc_lchain_rmq(C.byref(prm), n, a.ctypes.data, C.byref(n_u), C.byref(u_ptr), f.ctypes.data, p.ctypes.data, C.byref(tied))
+    nu = n_u.value
+    if nu > 0:
+        u = np.ctypeslib.as_array(C.cast(u_ptr, C.POINTER(C.c_uint64)), shape=(nu,)).copy()
+        n_out = int((u & 0xffffffff).sum())
+        a_out = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(n_out, 2)).copy()
+    else:
+        u = np.zeros(0, dtype=np.uint64)
+        a_out = np.zeros((0, 2), dtype=np.uint64)
+    if u_ptr.value:
+        L.orc_free(u_ptr)
+    if out:
+        L.orc_free(out)
+    return dict(u=u, a_out=a_out, f=f, p=p, n_tied=tied.value)
+
+
 def radix_sort_x(arr):
     arr = as_anchors(arr).copy()
     lib().orc_radix_sort_x(arr.ctypes.data, arr.ctypes.data + arr.nbytes)
@@ -224,6 +269,41 @@ def ref_lchain_dp(a, prm):
     os.environ.pop("MM2GB_CAPTURE", None)
     out = cap.mg_lchain_dp(prm.max_dist_x, prm.max_dist_y, prm.bw, prm.max_skip, prm.max_iter, prm.min_cnt, prm.min_sc,
                            prm.pen_gap, prm.pen_skip, prm.is_cdna, prm.n_seg, n, buf, C.byref(n_u), C.byref(u_ptr), None)
+    assert cap.cap_last_n() == n
+    f = np.ctypeslib.as_array(cap.cap_last_f(), shape=(n,)).copy()
+    p = np.ctypeslib.as_array(cap.cap_last_p(), shape=(n,)).copy()
+    nu = n_u.value
+    if nu > 0:
+        u = np.ctypeslib.as_array(C.cast(u_ptr, C.POINTER(C.c_uint64)), shape=(nu,)).copy()
+        n_out = int((u & 0xffffffff).sum())
+        a_out = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(n_out, 2)).copy()
+        _libc.free(out)
+    else:
+        u = np.zeros(0, dtype=np.uint64)
+        a_out = np.zeros((0, 2), dtype=np.uint64)
+    if u_ptr.value:
+        _libc.free(u_ptr)
+    return dict(u=u, a_out=a_out, f=f, p=p)
+
+
+def ref_lchain_rmq(a, prm):
+    """Run the REFERENCE's mg_lchain_rmq (lchain.c:250) on a copy of `a`; f/p come from the capture hooks."""
+    cap, ref = ref_libs()
+    a = as_anchors(a)
+    n = a.shape[0]
+    if n == 0:
+        return dict(u=np.zeros(0, np.uint64), a_out=np.zeros((0, 2), np.uint64), f=np.zeros(0, np.int32), p=np.zeros(0, np.int64))
+    ref.mg_lchain_rmq.restype = C.c_void_p
+    ref.mg_lchain_rmq.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p]
+    cap.cap_arm.argtypes = [C.c_int]
+    buf = _libc.malloc(a.nbytes)           # consumed by the reference
+    C.memmove(buf, a.ctypes.data, a.nbytes)
+    n_u = C.c_int(0)
+    u_ptr = C.c_void_p(0)
+    cap.cap_arm(1)
+    out = ref.mg_lchain_rmq(prm.max_dist, prm.max_dist_inner, prm.bw, prm.max_chn_skip, prm.cap_rmq_size, prm.min_cnt, prm.min_sc,
+                            prm.pen_gap, prm.pen_skip, n, buf, C.byref(n_u), C.byref(u_ptr), None)
+    cap.cap_arm(0)
     assert cap.cap_last_n() == n
     f = np.ctypeslib.as_array(cap.cap_last_f(), shape=(n,)).copy()
     p = np.ctypeslib.as_array(cap.cap_last_p(), shape=(n,)).copy()

@@ -99,6 +99,28 @@ def test_simulated_long_reads_paf_diff_empty(tmp_path):
 
 
 @needs_host
+def test_rmq_rechaining_on_the_device_paf_diff_empty(tmp_path):
+    """The same host linked with -Wl,--wrap=mg_lchain_rmq (oracle/Makefile target gpuhost_rmq; sources untouched): every
+    re-chaining call of post_chaining_helper (map.c:450) lands in the library's device path; reads whose
+    range-minimum meets a tie go back to the host's own function.  Same PAF as the reference CPU path."""
+    import json
+    import re
+    import sim_reads
+    host_rmq = HOST + "_rmq"
+    if not os.path.exists(host_rmq):
+        pytest.fail("oracle/_ref/minimap2_gpuhost_rmq is missing (make -C oracle gpuhost_rmq where the reference checkout exists)")
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    r = subprocess.run([host_rmq, "-t", "1", "--gpu-chain", "--gpu-cfg", CFG, ref, reads], capture_output=True, timeout=900,
+                       env=dict(os.environ, MM2GB_RMQ_REPORT="1"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode() == open(os.path.join(GOLD, "sim160_inf.paf")).read()
+    m = re.search(r"mg_lchain_rmq calls on the device: (\d+), of which handed to the host because of a tie: (\d+)", r.stderr.decode())
+    assert m and int(m.group(1)) > 20 and int(m.group(2)) < int(m.group(1)), r.stderr.decode()[-500:]
+
+
+@needs_host
 def test_multithreaded_host_one_stream_per_thread(tmp_path):
     """-t 3 with num_streams = 3: every host thread drives its own engine/stream through the boundary at the same time
     (the reference supports -t 1 only, README.md:46-47).  Same PAF as the single-threaded CPU path."""

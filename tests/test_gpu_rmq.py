@@ -1,0 +1,92 @@
+"""RMQ re-chaining on the device (mm2gb_rmq_chain_gpu / mm2gb_lchain_rmq, k_rmq_fill in csrc/post_kernels.hip)
+against the reference's own vectors and the CPU oracle.  Reads without a tie on the range-minimum priority must give the
+reference's chains bit for bit; reads with one must be REPORTED (the reference breaks such ties by the shape of its AVL tree)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_io
+import orc
+import synth_cases as sc
+
+pytestmark = pytest.mark.gpu
+
+mm = pytest.importorskip("mm2gb_amd")
+
+CASES = golden_io.rmq_cases()
+
+
+def to_lib(prm):
+    return mm.RmqParam(max_dist=prm.max_dist, max_dist_inner=prm.max_dist_inner, bw=prm.bw, max_chn_skip=prm.max_chn_skip, cap_rmq_size=prm.cap_rmq_size,
+                       min_cnt=prm.min_cnt, min_sc=prm.min_sc, chn_pen_gap=np.float32(prm.pen_gap), chn_pen_skip=np.float32(prm.pen_skip))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    with mm.Engine() as e:
+        yield e
+
+
+def first_pass(a):
+    o = orc.lchain_dp(a, orc.default_param(), want_fp=False)
+    return orc.radix_sort_x(o["a_out"]) if len(o["a_out"]) else o["a_out"]
+
+
+@pytest.mark.parametrize("path", CASES, ids=golden_io.case_ids(CASES))
+def test_reference_vectors(engine, path):
+    g = golden_io.load_rmq(path)
+    if g["prm"].max_chn_skip != orc.INT32_MAX:
+        pytest.skip("recorded with a finite max_chn_skip; the device path is exhaustive by contract")
+    res, tied, _ = engine.rmq_chain(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]))
+    assert int(tied[0]) == g["tied"]
+    if g["tied"] == 0:
+        assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
+
+
+def test_batch_against_the_oracle(engine):
+    """A batch of reads re-chained in one call: tie counts equal the oracle's, chains equal the oracle's (which uses the same
+    stated tie rule, so tied reads agree with IT too)."""
+    a, off = mm.synth_reads(41, 0, 40, 10_000, 120_000)
+    reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(40)]
+    reads.insert(7, np.zeros((0, 2), np.uint64))
+    rng = np.random.default_rng(3)
+    reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(900, 1), np.zeros(900, np.int64), 1000 + rng.integers(0, 150, 900), 100 + rng.integers(0, 150, 900)))))
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    for kw in (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05))):
+        prm = orc.default_rmq_param(**kw)
+        res, tied, st = engine.rmq_chain(allr, o2, to_lib(prm))
+        n_with_ties = 0
+        for r, x in enumerate(reads):
+            o = orc.lchain_rmq(x, prm)
+            assert int(tied[r]) == o["n_tied"], (kw, r)
+            n_with_ties += o["n_tied"] > 0
+            assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r)
+        assert n_with_ties >= 1 and st["ms_post"] > 0
+
+
+def test_single_read_entry_with_the_reference_signature(engine):
+    g = golden_io.load_rmq([p for p in CASES if p.endswith("several_chains.npz")][0])
+    L = mm.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    a = np.ascontiguousarray(g["a"])
+    buf = libc.malloc(a.nbytes)
+    C.memmove(buf, a.ctypes.data, a.nbytes)
+    prm = g["prm"]
+    n_u, u_ptr = C.c_int(0), C.c_void_p(0)
+    out = L.mm2gb_lchain_rmq(prm.max_dist, prm.max_dist_inner, prm.bw, prm.max_chn_skip, prm.cap_rmq_size, prm.min_cnt, prm.min_sc,
+                             prm.pen_gap, prm.pen_skip, len(a), buf, C.byref(n_u), C.byref(u_ptr), None)
+    assert n_u.value == len(g["u"])
+    u = np.ctypeslib.as_array(C.cast(u_ptr, C.POINTER(C.c_uint64)), shape=(n_u.value,)).copy()
+    a_out = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(len(g["a_out"]), 2)).copy()
+    assert np.array_equal(u, g["u"]) and np.array_equal(a_out, g["a_out"])
+    libc.free(u_ptr)
+    libc.free(out)
+    calls, tied = C.c_int64(0), C.c_int64(0)
+    L.mm2gb_lchain_rmq_counts(C.byref(calls), C.byref(tied))
+    assert calls.value >= 1 and tied.value == 0

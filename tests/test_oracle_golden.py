@@ -69,3 +69,15 @@ def test_empty_and_single():
     one = np.array([[5 << 32 | 100, 15 << 32 | 50]], dtype=np.uint64)
     f, p, st = orc.chain_fill(one, prm)
     assert f.tolist() == [15] and p.tolist() == [-1] and st["n_pairs"] == 0
+
+
+@pytest.mark.parametrize("path", golden_io.rmq_cases(), ids=golden_io.case_ids(golden_io.rmq_cases()))
+def test_rmq_oracle_matches_reference_vectors(path):
+    """orc_lchain_rmq (brute-force restatement of mg_lchain_rmq, lchain.c:250-369) against what the reference computed.  Where the
+    reference had to break a tie by the shape of its tree the oracle must SAY so (n_tied > 0) and is not compared."""
+    g = golden_io.load_rmq(path)
+    o = orc.lchain_rmq(g["a"], g["prm"])
+    assert o["n_tied"] == g["tied"]
+    if g["tied"] == 0:
+        assert np.array_equal(o["f"], g["f"]) and np.array_equal(o["p"], g["p"])
+        assert np.array_equal(o["u"], g["u"]) and np.array_equal(o["a_out"], g["a_out"])

@@ -60,3 +60,28 @@ def test_pair_score_exhaustive_small_grid():
         lg = np.float32(orc.lib().orc_log2_approx(float(dd + 1))) if dd >= 1 else np.float32(0)
         exp = 15 - int(np.float32(lin + np.float32(0.5) * lg)) if dd else 15
         assert sc_ == exp
+
+
+def test_rmq_oracle_vs_reference_on_rechaining_inputs():
+    """The RMQ restatement against the reference's mg_lchain_rmq, in-process, on what post_chaining_helper hands it: anchors kept
+    by the first chaining, re-sorted by x (map.c:444-451).  Every case without a tie must agree in f, p, chains and anchors; with
+    finite max_chn_skip, a small tree cap, no inner tree and other distances too."""
+    import mm2gb_amd as mm
+    n_cases = n_tied = 0
+    for seed in range(4):
+        a, off = mm.synth_reads(100 + seed, 0, 3, 10_000, 60_000)
+        for r in range(3):
+            o1 = orc.lchain_dp(a[off[r]:off[r + 1]], orc.default_param(), want_fp=False)
+            if not len(o1["a_out"]):
+                continue
+            x = orc.ref_radix_sort(o1["a_out"])
+            for kw in (dict(), dict(max_chn_skip=25), dict(cap_rmq_size=40), dict(max_dist_inner=0), dict(bw=500, max_dist=2000, max_dist_inner=300)):
+                prm = orc.default_rmq_param(**kw)
+                o, rf = orc.lchain_rmq(x, prm), orc.ref_lchain_rmq(x, prm)
+                n_cases += 1
+                if o["n_tied"]:
+                    n_tied += 1
+                    continue
+                assert np.array_equal(o["f"], rf["f"]) and np.array_equal(o["p"], rf["p"]), (seed, r, kw)
+                assert np.array_equal(o["u"], rf["u"]) and np.array_equal(o["a_out"], rf["a_out"]), (seed, r, kw)
+    assert n_cases >= 40 and n_tied < n_cases // 2
