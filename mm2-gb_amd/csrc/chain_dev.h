@@ -81,47 +81,6 @@ struct LaunchCfg {
 	int     wide_window;     // mean window from which a big team pays; narrower heavy chunks get 4-wave teams
 };
 
-// Everything the device post-pass (post_kernels.hip: backtrack + compaction, lchain.c:9-111) needs for one micro-batch.
-// Chains of a read hold at least mc = max(1, min_cnt) anchors, so read r has at most n_r / mc of them: the per-chain arrays
-// (u_tmp, heads) give read r the slots from offsets[r] / mc + r on.
-struct PostBatch {
-	const uint4   *raw;        // anchors (mm128_t)
-	const int64_t *offsets;    // n_reads + 1
-	int64_t        n, n_reads;
-	const int32_t *f, *p;      // scores and relative predecessors, as k_score leaves them
-	unsigned long long *z;     // n: candidates (f << 32 | i), sorted in place
-	uint8_t  *mark;            // n: the host's t[] (lchain.c:43)
-	int32_t  *picked;          // n: the host's v[] (lchain.c:65)
-	unsigned long long *u_tmp; // n / mc + n_reads: chains in the order they were found
-	ulonglong2 *heads;         // n / mc + n_reads: (x of first anchor, offset << 32 | chain) for the order of compaction
-	int32_t  *n_u, *n_kept;    // per read
-	int64_t  *u_off, *a_off;   // n_reads + 1: exclusive scans of the two
-	unsigned long long *u_out; // chains, read by read, in output order (lchain.c:145: score << 32 | count)
-	uint4    *a_out;           // compacted anchors, read by read (lchain.c:78-111)
-	int64_t  *totals;          // [0] chains [1] anchors kept
-	int32_t  *cursor;          // two work cursors
-	int32_t  *order;           // n_reads: reads, largest first (the kernel ends with its longest read: start those first)
-	int32_t  *size_bins;       // 2 x 64: reads per power-of-two size class, and the fill counters of the scatter
-	int       min_cnt, min_sc, max_drop;
-	int       grid_waves;      // waves to launch (one read per wave at a time)
-	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed 100 MHz ticks of [0] candidate collection [1] sort [2] chain walks [3] emit
-};
-void launch_post(const PostBatch &b, hipStream_t s);
-
-// RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369) of reads whose anchors are already chained once: score fill on the device.
-struct RmqParams { int max_dist, max_dist_inner, bw, cap_rmq_size; float pen_gap, pen_skip; };
-struct RmqBatch {
-	const uint4   *raw;        // anchors, sorted by x within each read
-	const int64_t *offsets;
-	int64_t        n, n_reads;
-	int32_t *f, *p;            // out: score, i - predecessor (0 = none)
-	double  *key;              // scratch, n: f + 0.5 * gap * (x + y), the negated priority of lchain.c:284
-	int32_t *n_tied;           // out, per read: anchors whose range-minimum was shared by several elements (see post_kernels.hip)
-	int32_t *cursor;
-	int      grid_waves;
-};
-void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);
-
 void launch_window(const DevBatch &b, const DevParams &P, hipStream_t s);
 void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s);
 void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, hipStream_t s);

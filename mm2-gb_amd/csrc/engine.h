@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../include/mm2gb_chain.h"
 #include "chain_dev.h"
+#include "post_dev.h"
 
 namespace mm2gb {
 

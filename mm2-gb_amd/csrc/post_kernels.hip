@@ -20,6 +20,7 @@
 #include <limits.h>
 #include <algorithm>
 #include "chain_dev.h"
+#include "post_dev.h"
 
 namespace mm2gb {
 

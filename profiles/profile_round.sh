@@ -4,7 +4,7 @@
 # 1. rocprofv3 --kernel-trace --stats of `python bench.py` (3 steps + 1 warmup)  -> gpurun_out/<tag>_stats/
 # 2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (1 step + 1 warmup)       -> gpurun_out/<tag>_fetch/, _write/
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
