@@ -150,6 +150,12 @@ int Engine::configure_score()
 
 int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 {
+	// An engine has up to four HIP streams (H2D, two compute, D2H) whose whole point is to run at the same time.  The HIP runtime
+	// multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and streams that share a queue run one after the
+	// other: next to a framework's own streams the engine's copies and kernels then serialise (200 M anchors through
+	// mm2gb_score_host: 146 ms instead of 92 ms, profiles/README.md).  Only effective before the runtime starts, so hosts
+	// that initialise HIP first (PyTorch) should export it themselves; bench.py does.
+	if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	int n_dev = 0;
 	MM2GB_HIP(hipGetDeviceCount(&n_dev));
 	if (dev < 0 || dev >= n_dev) return fail("mm2gb: device " + std::to_string(dev) + " not present (" + std::to_string(n_dev) + " visible)");
