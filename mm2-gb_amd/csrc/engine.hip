@@ -420,8 +420,8 @@ int Engine::enqueue_host(int64_t n_reads, const int64_t *h_offsets, const mm2gb_
 	MM2GB_HIP(hipSetDevice(device));
 	// Small micro-batches alternate between the two compute streams: one of them cannot fill the GPU (it ends at the pace of
 	// its largest chunk, run by one workgroup), so the next one's kernels start beside its tail -- 64-read batches through the
-	// boundary went from 6.2 to 4.4 ms each.  Large ones stay on one stream: two persistent launches side by side only delay
-	// the first one's D2H (200 M anchors in slices: 97 -> 147 ms with both streams, profiles/r02e_*).
+	// boundary went from 6.2 to 4.1 ms each.  Large ones stay on one stream: with ~100 M-anchor slices alternating was a wash
+	// (400 M anchors: 148 vs 153 ms; 200 M: 87 vs 93 ms; but 64 M-anchor slices 178 vs 160 ms and the chains call 146 vs 136 ms).
 	const int set = (!one_compute_stream && n <= dual_stream_max_n) ? (int)(io_seq & 1) : 0;
 	IoSet &s = io[io_seq++ & 1];
 	hipStream_t stream = work[set].stream;
