@@ -78,7 +78,7 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order, rmq_tied;
+	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order, post_up4, post_up16, rmq_tied;
 	int64_t *h_post_totals = nullptr;      // pinned: [0] chains [1] anchors kept
 	hipEvent_t post0 = nullptr, post1 = nullptr;
 	IoSet io[2];

@@ -210,7 +210,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order, &rmq_tied })
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied })
 		b->release();
 	cap_post_n = cap_post_reads = 0;
 	if (h_post_totals) { (void)hipHostFree(h_post_totals); h_post_totals = nullptr; }
@@ -319,7 +319,8 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	const size_t chains = (size_t)(nn + nr);
 	if (post_z.ensure((size_t)nn * 8) || post_mark.ensure((size_t)nn) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
 	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_uoff.ensure((size_t)(nr + 1) * 8) ||
-	    post_aoff.ensure((size_t)(nr + 1) * 8) || post_uout.ensure(chains * 8) || post_aout.ensure((size_t)nn * 16) || post_misc.ensure(2048) || post_order.ensure((size_t)nr * 4)) return -1;
+	    post_aoff.ensure((size_t)(nr + 1) * 8) || post_uout.ensure(chains * 8) || post_aout.ensure((size_t)nn * 16) || post_misc.ensure(2048) || post_order.ensure((size_t)nr * 4) ||
+	    post_up4.ensure((size_t)nn * 4) || post_up16.ensure((size_t)nn * 4)) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
 	return 0;
 }
@@ -331,6 +332,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	PostBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads; b.f = d_f; b.p = d_p;
 	b.z = (unsigned long long*)post_z.ptr; b.mark = (uint8_t*)post_mark.ptr; b.picked = (int32_t*)post_picked.ptr;
+	b.up4 = (int32_t*)post_up4.ptr; b.up16 = (int32_t*)post_up16.ptr;
 	b.u_tmp = (unsigned long long*)post_utmp.ptr; b.heads = (ulonglong2*)post_heads.ptr;
 	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)post_uoff.ptr; b.a_off = (int64_t*)post_aoff.ptr;
 	b.u_out = (unsigned long long*)post_uout.ptr; b.a_out = (uint4*)post_aout.ptr;

@@ -18,6 +18,7 @@ struct PostBatch {
 	unsigned long long *z;     // n: candidates (f << 32 | i), sorted in place
 	uint8_t  *mark;            // n: the host's t[] (lchain.c:43)
 	int32_t  *picked;          // n: the host's v[] (lchain.c:65)
+	int32_t  *up4, *up16;      // n each: distance to the anchor 4 / 16 predecessor links down the path (0 = path ends before)
 	unsigned long long *u_tmp; // n / mc + n_reads: chains in the order they were found
 	ulonglong2 *heads;         // n / mc + n_reads: (x of first anchor, offset << 32 | chain) for the order of compaction
 	int32_t  *n_u, *n_kept;    // per read

@@ -54,6 +54,18 @@ struct HElem {
 	static __device__ __forceinline__ unsigned long long key(const T &e) { return e.x; }
 };
 
+// index of the lowest / highest set bit of a non-zero 64-bit mask, from 32-bit halves (see leading_out below for why)
+__device__ __forceinline__ int first_set(unsigned long long m)
+{
+	const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+	return lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);
+}
+__device__ __forceinline__ int first_set_from_top(unsigned long long m)       // number of leading zeros
+{
+	const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+	return hi ? __builtin_clz(hi) : 32 + __builtin_clz(lo);
+}
+
 __device__ __forceinline__ unsigned long long bcast_elem(unsigned long long e, int src) { return __shfl(e, src); }
 __device__ __forceinline__ ulonglong2 bcast_elem(const ulonglong2 &e, int src) { return make_ulonglong2(__shfl(e.x, src), __shfl(e.y, src)); }
 
@@ -218,6 +230,21 @@ __global__ __launch_bounds__(256) void k_post_size_scatter(PostBatch b)
 }
 
 // --------------------------------------------------------------------------------------------------------------
+// lifting tables of the predecessor links: up4[i] / up16[i] = distance from anchor i to the anchor 4 / 16 links down its path
+// (0 = the path is shorter).  p is relative and never leaves the read, so this is one pass over all anchors of the batch per level.
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_lift(PostBatch b, int level)
+{
+	const int32_t *src = level == 0 ? b.p : b.up4;
+	int32_t *dst = level == 0 ? b.up4 : b.up16;
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		int64_t t = g;
+		for (int k = 0; k < 4 && t >= 0; ++k) { const int rj = src[t]; t = rj ? t - rj : -1; }
+		dst[g] = t < 0 ? 0 : (int32_t)(g - t);
+	}
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // per read: candidates, host order, chain walks (lchain.c:27-76)
 // --------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
@@ -259,36 +286,77 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 		// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
 		// Most candidates already belong to a chain found from a better end: 64 of them are tested at once, and lane 0 only
 		// turns to those that were still free then (testing again: an earlier walk of the same group may have taken them).
+		// A walk (mg_chain_bk_end, lchain.c:9-25: back from the chain end until an anchor that is taken, the start of the path, or an
+		// X-drop of more than max_drop below the best prefix) is a chain of dependent loads, one memory round trip per anchor.  Its
+		// first steps are taken one at a time (most walks end within a few: the next anchor already belongs to a better chain);
+		// a walk that goes on is taken 64 anchors at a time: lane j finds the j-th anchor down the path through the lifting tables
+		// (p, p^4, p^16: at most 9 dependent loads instead of j), and what the sequential loop decides step by step -- the running
+		// best prefix, the first step that ends the walk -- becomes a prefix maximum and a ballot over the wave.
+		const int32_t *up4 = b.up4 + off, *up16 = b.up16 + off;
 		int n_u = 0, n_v = 0;
 		for (int kb = n_z - 1; kb >= 0; kb -= W) {
 			const int k_l = kb - l;
 			const unsigned long long z_l = k_l >= 0 ? z[k_l] : 0;
 			unsigned long long open = __ballot(k_l >= 0 && mark[(int)(unsigned)z_l] == 0);
 			while (open) {
-				const int src = __builtin_ctzll(open);          // lowest lane = highest k
+				const int src = first_set(open);                 // lowest lane = highest k
 				open &= open - 1;
 				const unsigned long long zk = bcast_elem(z_l, src);
-				if (l == 0) {
-					const int start = (int)(unsigned)zk, top = (int)(zk >> 32);
-					if (mark[start] == 0) {
-						// mg_chain_bk_end (lchain.c:9-25): back from the chain end until an anchor that is taken, the start of the path, or
-						// an X-drop of more than max_drop below the best prefix.  Nodes go straight into picked[]; `kept` is how many of
-						// them lie before the anchor the best prefix stops at.
-						int i = start, kept = 0, visited = 0, best = 0, stop = start;
-						int pi = p[i];
-						do {
-							picked[n_v + visited++] = i;
-							i = pi ? i - pi : -1;
-							int s = top, m_i = 1;
-							if (i >= 0) { s = top - f[i]; pi = p[i]; m_i = mark[i]; }
-							if (s > best) { best = s; stop = i; kept = visited; }
-							else if (best - s > b.max_drop) break;
-							if (m_i != 0) break;
-						} while (i >= 0);
-						for (int q = 0; q < kept; ++q) mark[picked[n_v + q]] = 1;
-						const int sc = stop < 0 ? top : top - f[stop];
-						if (sc >= b.min_sc && kept > 0 && kept >= b.min_cnt) { u_tmp[n_u++] = (unsigned long long)(unsigned)sc << 32 | (unsigned)kept; n_v += kept; }
+				const int start = (int)(unsigned)zk, top = (int)(zk >> 32);
+				int pc = p[start];                               // (requested together with the mark: one round trip)
+				if (uni(mark[start]) != 0) continue;             // taken by an earlier walk of this group of candidates
+				// every lane runs the same steps on the same addresses (one transaction per load); `kept` is how many of the visited
+				// anchors lie before the one the best prefix stops at; an anchor's own link is fetched with its score and mark, so a
+				// step is one round trip
+				int cur = start, kept = 0, visited = 0, best = 0;
+				bool ended = false;
+				for (int step = 0; step < 4 && !ended; ++step) {
+					if (l == 0) picked[n_v + visited] = cur;
+					++visited;
+					const int next = pc ? cur - pc : -1;
+					int s = top, m = 1;
+					if (next >= 0) { s = top - f[next]; m = mark[next]; pc = p[next]; }
+					if (s > best) { best = s; kept = visited; }
+					else if (best - s > b.max_drop) ended = true;
+					if (m != 0) ended = true;
+					cur = next;
+				}
+				ended = uni(ended); cur = uni(cur); visited = uni(visited); best = uni(best); kept = uni(kept);
+				while (!ended) {
+					// lane j: the anchor j links down the path from cur
+					int t = cur;
+					for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
+					for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
+					for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = p[t]; t = rj ? t - rj : -1; }
+					const bool valid = t >= 0;
+					const int pt = valid ? p[t] : 0, next = pt ? t - pt : -1;
+					int s = top, m = 1;
+					if (next >= 0) { s = top - f[next]; m = mark[next]; }
+					// best prefix BEFORE this lane's step
+					int inc = valid ? s : INT_MIN;
+					for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
+					int before = __shfl_up(inc, 1);
+					before = l == 0 ? best : max(best, before);
+					const bool newmax = valid && s > before;
+					const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
+					const unsigned long long endm = __ballot(ends);
+					const int jb = endm ? first_set(endm) : W;             // the step that ends the walk (all of it is still taken)
+					if (valid && l <= jb) picked[n_v + visited + l] = t;
+					const unsigned long long nm = __ballot(newmax && l <= jb);
+					if (nm) {
+						const int last = 63 - first_set_from_top(nm);
+						best = __shfl(s, last);
+						kept = visited + last + 1;
 					}
+					if (jb < W) { visited += jb + 1; ended = true; }
+					else { visited += W; cur = __shfl(next, W - 1); }
+				}
+				wave_sync();
+				for (int q = l; q < kept; q += W) mark[picked[n_v + q]] = 1;
+				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
+				if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
+					if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
+					++n_u; n_v += kept;
 				}
 				wave_sync();
 			}
@@ -567,6 +635,9 @@ void launch_post(const PostBatch &b, hipStream_t s)
 	hipLaunchKernelGGL(k_post_size_scatter, dim3(rgrid), dim3(256), 0, s, b);
 	const int64_t waves = (int64_t)b.grid_waves;
 	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
+	const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n + 255) / 256, 256 * 64));
+	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0);
+	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1);
 	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b);
 	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b);
 	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);
