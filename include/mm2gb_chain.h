@@ -140,6 +140,23 @@ mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int m
                                  float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km);
 void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls);   /* single-read calls so far, and how many of them met a tie */
 
+/* ---- the formats either side of the path, on the device with the reference's exact orders:
+ *      mm2gb_sort_seeds_gpu: the seed sort of collect_seed_hits (map.c:329): every read's anchors sorted by x IN PLACE exactly as
+ *      radix_sort_128x leaves them (order of equal x included), so unsorted seeds can go straight into the chaining calls;
+ *      mm2gb_gen_regs_gpu: mm_gen_regs (hit.c:52-88): one hit record per chain -- best score first, ties by the hash of the first
+ *      anchor and the read's hash (map.c:590-592), coordinates and fuzzy lengths of hit.c:8-38.  mm2gb_reg_t is the leading
+ *      72 bytes of mm_reg1_t (minimap.h:104-119), i.e. everything but the alignment pointer; regs must hold
+ *      chains->u_off[n_reads] records.  qlen / hash: one per read. ---- */
+typedef struct {
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
+	uint32_t flags;          /* mm_reg1_t's bit-field word: rev = bit 10 */
+	uint32_t hash;
+	float div;
+} mm2gb_reg_t;
+int  mm2gb_sort_seeds_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors);
+int  mm2gb_gen_regs_gpu(mm2gb_engine_t *eng, int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash,
+                        int is_qstrand, mm2gb_reg_t *regs);
+
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
  *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;

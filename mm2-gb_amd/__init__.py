@@ -83,7 +83,8 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
-                "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts"]
+                "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
+                "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -146,6 +147,8 @@ def lib():
         L.mm2gb_lchain_rmq.argtypes = [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_void_p]
         L.mm2gb_lchain_rmq_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mm2gb_lchain_rmq_counts.restype = None
+        L.mm2gb_sort_seeds_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mm2gb_gen_regs_gpu.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Chains), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mm2gb_batcher_create.restype = C.c_void_p
         L.mm2gb_batcher_create.argtypes = [C.POINTER(Config), C.POINTER(Misc), C.c_int, C.c_void_p, C.c_int, READ_DONE_FN, C.c_void_p]
         L.mm2gb_batcher_add.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
@@ -296,6 +299,35 @@ def _engine_rmq_chain(self, anchors, offsets, prm):
 
 
 Engine.rmq_chain = _engine_rmq_chain
+
+REG_DTYPE = np.dtype([(k, "<i4") for k in "id cnt rid score qs qe rs re parent subsc as_ mlen blen n_sub score0".split()] +
+                     [("flags", "<u4"), ("hash", "<u4"), ("div", "<f4")])      # mm2gb_reg_t
+
+
+def _engine_sort_seeds(self, anchors, offsets):
+    """mm2gb_sort_seeds_gpu: every read's anchors sorted by x the way radix_sort_128x leaves them; returns the sorted copy."""
+    a = np.ascontiguousarray(anchors, dtype=np.uint64).copy()
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    _check(lib().mm2gb_sort_seeds_gpu(self._h, len(off) - 1, off.ctypes.data, a.ctypes.data))
+    return a
+
+
+def _engine_gen_regs(self, chains, qlen, hashes, is_qstrand=0):
+    """mm2gb_gen_regs_gpu on a list of (u, a_out) per read: list of REG_DTYPE arrays."""
+    R = len(chains)
+    u_off = np.zeros(R + 1, np.int64); a_off = np.zeros(R + 1, np.int64)
+    u_off[1:] = np.cumsum([len(u) for u, _ in chains]); a_off[1:] = np.cumsum([len(a) for _, a in chains])
+    u_all = np.ascontiguousarray(np.concatenate([u for u, _ in chains]) if R else np.zeros(0, np.uint64), dtype=np.uint64)
+    a_all = np.ascontiguousarray(np.concatenate([a for _, a in chains]) if R else np.zeros((0, 2), np.uint64), dtype=np.uint64)
+    ch = Chains(u_off.ctypes.data_as(C.POINTER(C.c_int64)), u_all.ctypes.data_as(C.POINTER(C.c_uint64)), a_off.ctypes.data_as(C.POINTER(C.c_int64)), a_all.ctypes.data)
+    ql = np.ascontiguousarray(qlen, dtype=np.int32); hs = np.ascontiguousarray(hashes, dtype=np.uint32)
+    regs = np.zeros(int(u_off[-1]), dtype=REG_DTYPE)
+    _check(lib().mm2gb_gen_regs_gpu(self._h, R, C.byref(ch), ql.ctypes.data, hs.ctypes.data, int(is_qstrand), regs.ctypes.data))
+    return [regs[u_off[r]:u_off[r + 1]] for r in range(R)]
+
+
+Engine.sort_seeds = _engine_sort_seeds
+Engine.gen_regs = _engine_gen_regs
 
 
 def _take_chains(out, R):

@@ -78,7 +78,7 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order, post_up4, post_up16, rmq_tied;
+	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order, post_up4, post_up16, rmq_tied, reg_out;
 	int64_t *h_post_totals = nullptr;      // pinned: [0] chains [1] anchors kept
 	hipEvent_t post0 = nullptr, post1 = nullptr;
 	IoSet io[2];
@@ -119,6 +119,8 @@ struct Engine {
 	// receives, per read, the number of anchors whose range-minimum was tied (results for such a read are not the reference's)
 	int  chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out,
 	               const mm2gb_rmq_param_t *rmq = nullptr, int32_t *n_tied = nullptr);
+	int  sort_seeds(int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors);
+	int  gen_regs(int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash, int is_qstrand, mm2gb_reg_t *regs);
 	int  record_outputs_done(hipEvent_t ev);   // fires when every D2H enqueued so far has landed
 	int  sync();
 	int  collect_stats();

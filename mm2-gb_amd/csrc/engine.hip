@@ -210,7 +210,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied })
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &reg_out })
 		b->release();
 	cap_post_n = cap_post_reads = 0;
 	if (h_post_totals) { (void)hipHostFree(h_post_totals); h_post_totals = nullptr; }
@@ -407,6 +407,61 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	float ms = 0;
 	if (n_reads > 0 && hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
 	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	return 0;
+}
+
+// Seed sort (map.c:329) of every read's anchors, in place in the caller's host array: H2D, one wave per read, D2H.
+int Engine::sort_seeds(int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors)
+{
+	if (!offsets || n_reads < 0 || offsets[0] != 0) return fail("mm2gb_sort_seeds_gpu: offsets[0] must be 0");
+	for (int64_t r = 0; r < n_reads; ++r) {
+		if (offsets[r + 1] < offsets[r]) return fail("mm2gb_sort_seeds_gpu: offsets must be non-decreasing");
+		if (offsets[r + 1] - offsets[r] >= ((int64_t)1 << 31)) return fail("mm2gb_sort_seeds_gpu: a read is limited to 2^31 anchors");
+	}
+	const int64_t n = offsets[n_reads];
+	if (n == 0 || n_reads == 0) return 0;
+	if (!anchors) return fail("mm2gb_sort_seeds_gpu: null buffer");
+	MM2GB_HIP(hipSetDevice(device));
+	IoSet &s = io[0];
+	for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+	if (s.raw.ensure((size_t)n * 16) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
+	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, anchors, (size_t)n * 16, hipMemcpyHostToDevice, stream));
+	SortBatch sb;
+	sb.a = (ulonglong2*)s.raw.ptr; sb.offsets = (const int64_t*)s.offsets.ptr; sb.n_reads = n_reads; sb.cursor = nullptr; sb.grid_waves = n_cu * 32;
+	launch_sort_x(sb, stream);
+	MM2GB_HIP(hipGetLastError());
+	MM2GB_HIP(hipMemcpyAsync(anchors, s.raw.ptr, (size_t)n * 16, hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	return 0;
+}
+
+// mm_gen_regs (hit.c:52-88) for every read of a batch of chains.
+int Engine::gen_regs(int64_t n_reads, const mm2gb_chains_t *ch, const int32_t *qlen, const uint32_t *hash, int is_qstrand, mm2gb_reg_t *regs)
+{
+	if (!ch || n_reads < 0 || (n_reads > 0 && (!ch->u_off || !ch->a_off || !qlen || !hash))) return fail("mm2gb_gen_regs_gpu: null argument");
+	if (n_reads == 0) return 0;
+	const int64_t n_u = ch->u_off[n_reads], n_a = ch->a_off[n_reads];
+	if (n_u == 0) return 0;
+	if (!regs || !ch->u || !ch->a) return fail("mm2gb_gen_regs_gpu: null buffer");
+	static_assert(sizeof(RegRecord) == sizeof(mm2gb_reg_t) && sizeof(mm2gb_reg_t) == 72, "hit record layout");
+	MM2GB_HIP(hipSetDevice(device));
+	if (reserve_post(std::max<int64_t>(n_a, n_u), n_reads) || reg_out.ensure((size_t)n_u * sizeof(RegRecord))) return -1;
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	MM2GB_HIP(hipMemcpyAsync(post_uoff.ptr, ch->u_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(post_aoff.ptr, ch->a_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(post_uout.ptr, ch->u, (size_t)n_u * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(post_aout.ptr, ch->a, (size_t)n_a * 16, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(post_nu.ptr, qlen, (size_t)n_reads * 4, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(post_nkept.ptr, hash, (size_t)n_reads * 4, hipMemcpyHostToDevice, stream));
+	RegBatch rb;
+	rb.u_off = (const int64_t*)post_uoff.ptr; rb.a_off = (const int64_t*)post_aoff.ptr; rb.u = (const unsigned long long*)post_uout.ptr; rb.a = (const uint4*)post_aout.ptr;
+	rb.qlen = (const int32_t*)post_nu.ptr; rb.hash = (const uint32_t*)post_nkept.ptr; rb.n_reads = n_reads;
+	rb.z = (ulonglong2*)post_heads.ptr; rb.regs = (RegRecord*)reg_out.ptr; rb.cursor = nullptr; rb.is_qstrand = is_qstrand; rb.grid_waves = n_cu * 32;
+	launch_gen_regs(rb, stream);
+	MM2GB_HIP(hipGetLastError());
+	MM2GB_HIP(hipMemcpyAsync(regs, reg_out.ptr, (size_t)n_u * sizeof(RegRecord), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipStreamSynchronize(stream));
 	return 0;
 }
 
@@ -629,6 +684,17 @@ int mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64
 	if (eng->e.chain_gpu(n_reads, offsets, anchors, out, prm, n_tied)) return -1;
 	if (stats) *stats = eng->e.last;
 	return 0;
+}
+
+int mm2gb_sort_seeds_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors)
+{
+	return eng ? eng->e.sort_seeds(n_reads, offsets, anchors) : fail("mm2gb: null engine");
+}
+
+int mm2gb_gen_regs_gpu(mm2gb_engine_t *eng, int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash,
+                       int is_qstrand, mm2gb_reg_t *regs)
+{
+	return eng ? eng->e.gen_regs(n_reads, chains, qlen, hash, is_qstrand, regs) : fail("mm2gb: null engine");
 }
 
 int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,

@@ -49,4 +49,34 @@ struct RmqBatch {
 };
 void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);
 
+// Formats either side of the path: the seed sort upstream (radix_sort_128x of the collected anchors, map.c:329) and the
+// conversion of chains into hit records downstream (mm_gen_regs, hit.c:52-88).
+struct SortBatch {
+	ulonglong2    *a;          // anchors (x, y), sorted in place by x within each read, exactly as radix_sort_128x leaves them
+	const int64_t *offsets;
+	int64_t        n_reads;
+	int32_t       *cursor;
+	int            grid_waves;
+};
+void launch_sort_x(const SortBatch &b, hipStream_t s);
+
+struct RegRecord {             // the leading 72 bytes of mm_reg1_t (minimap.h:104-119)
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
+	uint32_t flags, hash;
+	float div;
+};
+struct RegBatch {
+	const int64_t *u_off, *a_off;      // n_reads + 1 each
+	const unsigned long long *u;       // chains, read by read (score << 32 | count)
+	const uint4   *a;                  // compacted anchors, read by read
+	const int32_t *qlen;               // per read
+	const uint32_t *hash;              // per read (map.c:590-592)
+	int64_t        n_reads;
+	ulonglong2    *z;                  // scratch: one per chain
+	RegRecord     *regs;               // out: one per chain, at u_off
+	int32_t       *cursor;
+	int            is_qstrand, grid_waves;
+};
+void launch_gen_regs(const RegBatch &b, hipStream_t s);
+
 } // namespace mm2gb

@@ -625,6 +625,123 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 	hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Either side of the path (N4).  k_sort_x: the seed sort of collect_seed_hits (map.c:329), one wave per read, the same exact
+// device form of radix_sort_128x that orders the chains.  k_gen_regs: mm_gen_regs (hit.c:52-88): chains ordered by
+// (score, hash of the first anchor) with the same sort, best first, then coordinates and fuzzy lengths (hit.c:8-38), one lane
+// per chain.
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(POST_THREADS) void k_sort_x(SortBatch b)
+{
+	__shared__ PassLds lds[POST_THREADS / W];
+	PassLds &L = lds[threadIdx.x / W];
+	const int per = POST_THREADS / W;
+	for (int64_t r = (int64_t)blockIdx.x * per + uni(threadIdx.x / W); r < b.n_reads; r += (int64_t)gridDim.x * per) {
+		const int64_t off = b.offsets[r];
+		sort_like_host<HElem>(b.a + off, (int)(b.offsets[r + 1] - off), L);
+	}
+}
+
+namespace {
+__device__ __forceinline__ unsigned long long hit_hash64(unsigned long long key)   // hit.c:40-50
+{
+	key = (~key + (key << 21));
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4));
+	key = key ^ key >> 28;
+	key = (key + (key << 31));
+	return key;
+}
+} // namespace
+
+__global__ __launch_bounds__(POST_THREADS) void k_gen_regs(RegBatch b)
+{
+	__shared__ PassLds lds[POST_THREADS / W];
+	PassLds &L = lds[threadIdx.x / W];
+	const int l = lane();
+	const int per = POST_THREADS / W;
+	for (int64_t r = (int64_t)blockIdx.x * per + uni(threadIdx.x / W); r < b.n_reads; r += (int64_t)gridDim.x * per) {
+		const int64_t uo = b.u_off[r];
+		const int n_u = (int)(b.u_off[r + 1] - uo);
+		if (n_u == 0) continue;
+		const unsigned long long *u = b.u + uo;
+		const uint4 *a = b.a + b.a_off[r];
+		ulonglong2 *z = b.z + uo;
+		RegRecord *regs = b.regs + uo;
+		const unsigned hash = b.hash[r];
+		const int qlen = b.qlen[r];
+		// hit.c:63-69: key = chain record with the hash of its first anchor folded into the low half; value = offset << 32 | count
+		int k_at = 0;
+		for (int base = 0; base < n_u; base += W) {
+			const int c = base + l;
+			const unsigned long long uc = c < n_u ? u[c] : 0;
+			const int cnt = (int)(unsigned)uc;
+			int inc = cnt;
+			for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc += v; }
+			const int k0 = k_at + inc - cnt;
+			if (c < n_u) {
+				const uint4 f0 = a[k0];
+				const unsigned long long ax = (unsigned long long)f0.y << 32 | f0.x, ay = (unsigned long long)f0.w << 32 | f0.z;
+				const unsigned h = (unsigned)hit_hash64((hit_hash64(ax) + hit_hash64(ay)) ^ hash);
+				z[c] = make_ulonglong2(uc ^ h, (unsigned long long)(unsigned)k0 << 32 | (unsigned)cnt);
+			}
+			k_at += __builtin_amdgcn_readlane(inc, W - 1);
+		}
+		wave_sync();
+		sort_like_host<HElem>(z, n_u, L);
+		wave_sync();
+		// hit.c:70-86 (largest key first), 22-38, 8-20
+		for (int i = l; i < n_u; i += W) {
+			const ulonglong2 zi = z[n_u - 1 - i];
+			const int as = (int)(zi.y >> 32), cnt = (int)(unsigned)zi.y;
+			RegRecord ri = {};
+			ri.id = i; ri.parent = -1;
+			ri.score = ri.score0 = (int)(zi.x >> 32);
+			ri.hash = (unsigned)zi.x;
+			ri.cnt = cnt; ri.as = as; ri.div = -1.0f;
+			const uint4 first = a[as], last = a[as + cnt - 1];
+			const int q_span = (int)(first.w & 0xffu);
+			const bool rev = first.y >> 31;
+			if (rev) ri.flags |= 1u << 10;
+			ri.rid = (int)(first.y & 0x7fffffffu);
+			ri.rs = (int)first.x + 1 > q_span ? (int)first.x + 1 - q_span : 0;
+			ri.re = (int)last.x + 1;
+			if (!rev || b.is_qstrand) { ri.qs = (int)first.z + 1 - q_span; ri.qe = (int)last.z + 1; }
+			else { ri.qs = qlen - ((int)last.z + 1); ri.qe = qlen - ((int)first.z + 1 - q_span); }
+			int mlen = q_span, blen = q_span;
+			uint4 prev = first;
+			for (int j = as + 1; j < as + cnt; ++j) {
+				const uint4 cur = a[j];
+				const int span = (int)(cur.w & 0xffu), tl = (int)cur.x - (int)prev.x, ql = (int)cur.z - (int)prev.z;
+				blen += tl > ql ? tl : ql;
+				mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+				prev = cur;
+			}
+			ri.mlen = cnt > 0 ? mlen : 0; ri.blen = cnt > 0 ? blen : 0;
+			regs[i] = ri;
+		}
+		wave_sync();
+	}
+}
+
+void launch_sort_x(const SortBatch &b, hipStream_t s)
+{
+	if (b.n_reads <= 0) return;
+	const int per = POST_THREADS / W;
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, ((int64_t)b.grid_waves + per - 1) / per));
+	hipLaunchKernelGGL(k_sort_x, dim3(grid), dim3(POST_THREADS), 0, s, b);
+}
+
+void launch_gen_regs(const RegBatch &b, hipStream_t s)
+{
+	if (b.n_reads <= 0) return;
+	const int per = POST_THREADS / W;
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, ((int64_t)b.grid_waves + per - 1) / per));
+	hipLaunchKernelGGL(k_gen_regs, dim3(grid), dim3(POST_THREADS), 0, s, b);
+}
+
 void launch_post(const PostBatch &b, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;

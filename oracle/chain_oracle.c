@@ -317,6 +317,69 @@ orc_anchor_t *orc_lchain_dp(const orc_param_t *prm, int64_t n, const orc_anchor_
 void orc_free(void *ptr) { free(ptr); }
 
 /* ------------------------------------------------------------------------------------------------
+ * chains -> hit records (hit.c:8-88)
+ * ------------------------------------------------------------------------------------------------ */
+static uint64_t orc_hash64(uint64_t key)   /* hit.c:40-50 */
+{
+	key = (~key + (key << 21));
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4));
+	key = key ^ key >> 28;
+	key = (key + (key << 31));
+	return key;
+}
+
+void orc_gen_regs(uint32_t hash, int32_t qlen, int32_t n_u, const uint64_t *u, const orc_anchor_t *a, int is_qstrand, orc_reg_t *r)
+{
+	orc_anchor_t *z, tmp;
+	int32_t i, k;
+	if (n_u == 0) return;
+	z = (orc_anchor_t*)malloc((size_t)n_u * sizeof(orc_anchor_t));
+	for (i = k = 0; i < n_u; ++i) {                                              /* hit.c:63-69 */
+		uint32_t h = (uint32_t)orc_hash64((orc_hash64(a[k].x) + orc_hash64(a[k].y)) ^ hash);
+		z[i].x = u[i] ^ h;
+		z[i].y = (uint64_t)k << 32 | (int32_t)u[i];
+		k += (int32_t)u[i];
+	}
+	orc_radix_sort_x(z, z + n_u);
+	for (i = 0; i < n_u >> 1; ++i) tmp = z[i], z[i] = z[n_u - 1 - i], z[n_u - 1 - i] = tmp;   /* larger score first */
+	memset(r, 0, (size_t)n_u * sizeof(orc_reg_t));
+	for (i = 0; i < n_u; ++i) {                                                  /* hit.c:75-86, 22-38, 8-20 */
+		orc_reg_t *ri = &r[i];
+		int32_t as = (int32_t)(z[i].y >> 32), cnt = (int32_t)z[i].y, q_span, j;
+		ri->id = i; ri->parent = -1;
+		ri->score = ri->score0 = (int32_t)(z[i].x >> 32);
+		ri->hash = (uint32_t)z[i].x;
+		ri->cnt = cnt; ri->as = as; ri->div = -1.0f;
+		q_span = a_qspan(&a[as]);
+		if (a[as].x >> 63) ri->flags |= 1u << 10;
+		ri->rid = (int32_t)(a[as].x << 1 >> 33);
+		ri->rs = (int32_t)a[as].x + 1 > q_span ? (int32_t)a[as].x + 1 - q_span : 0;
+		ri->re = (int32_t)a[as + cnt - 1].x + 1;
+		if (!(a[as].x >> 63) || is_qstrand) {
+			ri->qs = (int32_t)a[as].y + 1 - q_span;
+			ri->qe = (int32_t)a[as + cnt - 1].y + 1;
+		} else {
+			ri->qs = qlen - ((int32_t)a[as + cnt - 1].y + 1);
+			ri->qe = qlen - ((int32_t)a[as].y + 1 - q_span);
+		}
+		ri->mlen = ri->blen = 0;
+		if (cnt > 0) {
+			ri->mlen = ri->blen = q_span;
+			for (j = as + 1; j < as + cnt; ++j) {
+				int span = a_qspan(&a[j]);
+				int tl = (int32_t)a[j].x - (int32_t)a[j - 1].x, ql = (int32_t)a[j].y - (int32_t)a[j - 1].y;
+				ri->blen += tl > ql ? tl : ql;
+				ri->mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+			}
+		}
+	}
+	free(z);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * RMQ re-chaining (lchain.c:219-369)
  * ------------------------------------------------------------------------------------------------ */
 int32_t orc_rmq_pair_score(const orc_anchor_t *ai, const orc_anchor_t *aj, float pen_gap, float pen_skip, int32_t *exact, int32_t *width)

@@ -42,6 +42,16 @@ def default_rmq_param(**kw):
     return RmqParam(**d)
 
 
+class Reg(C.Structure):
+    """orc_reg_t: the leading 72 bytes of mm_reg1_t (minimap.h:104-119)."""
+    _fields_ = [(k, C.c_int32) for k in "id cnt rid score qs qe rs re parent subsc as_ mlen blen n_sub score0".split()] + \
+               [("flags", C.c_uint32), ("hash", C.c_uint32), ("div", C.c_float)]
+
+
+REG_DTYPE = np.dtype([(k, "<i4") for k in "id cnt rid score qs qe rs re parent subsc as_ mlen blen n_sub score0".split()] +
+                     [("flags", "<u4"), ("hash", "<u4"), ("div", "<f4")])
+
+
 def default_param(**kw):
     """map-ont / no-preset defaults (options.c:24-36, map.c:408-409 with k=15), max_skip = infinity."""
     d = dict(max_dist_x=5000, max_dist_y=5000, bw=500, max_skip=INT32_MAX, max_iter=5000,
@@ -89,6 +99,8 @@ def lib():
         L.orc_chain_fill_reads_mt.argtypes = [C.POINTER(Param), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_free.restype = None
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_gen_regs.restype = None
+        L.orc_gen_regs.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_rmq_fill.restype = C.c_int64
         L.orc_rmq_fill.argtypes = [C.POINTER(RmqParam), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.orc_lchain_rmq.restype = C.c_void_p
@@ -197,6 +209,33 @@ def lchain_rmq(a, prm):
     if out:
         L.orc_free(out)
     return dict(u=u, a_out=a_out, f=f, p=p, n_tied=tied.value)
+
+
+def gen_regs(u, a_out, qlen, hash_, is_qstrand=0):
+    """mm_gen_regs restatement: structured array (REG_DTYPE), one record per chain."""
+    u = np.ascontiguousarray(u, dtype=np.uint64)
+    a = as_anchors(a_out)
+    r = np.zeros(len(u), dtype=REG_DTYPE)
+    if len(u):
+        lib().orc_gen_regs(int(hash_) & 0xffffffff, int(qlen), len(u), u.ctypes.data, a.ctypes.data, int(is_qstrand), r.ctypes.data)
+    return r
+
+
+def ref_gen_regs(u, a_out, qlen, hash_, is_qstrand=0):
+    """The REFERENCE's mm_gen_regs (hit.c:52, from oracle/_ref/libminimap2ref.so): the leading 72 bytes of every mm_reg1_t."""
+    ref = C.CDLL(os.path.join(REF_DIR, "libminimap2ref.so"))
+    ref.mm_gen_regs.restype = C.c_void_p
+    ref.mm_gen_regs.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    u = np.ascontiguousarray(u, dtype=np.uint64).copy()
+    a = as_anchors(a_out).copy()
+    r = np.zeros(len(u), dtype=REG_DTYPE)
+    if len(u) == 0:
+        return r
+    out = ref.mm_gen_regs(None, int(hash_) & 0xffffffff, int(qlen), len(u), u.ctypes.data, a.ctypes.data, int(is_qstrand))
+    raw = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(len(u) * 80,)).reshape(len(u), 80)     # sizeof(mm_reg1_t) = 80
+    r[:] = np.frombuffer(np.ascontiguousarray(raw[:, :72]).tobytes(), dtype=REG_DTYPE)
+    _libc.free(out)
+    return r
 
 
 def radix_sort_x(arr):

@@ -85,3 +85,23 @@ def test_rmq_oracle_vs_reference_on_rechaining_inputs():
                 assert np.array_equal(o["f"], rf["f"]) and np.array_equal(o["p"], rf["p"]), (seed, r, kw)
                 assert np.array_equal(o["u"], rf["u"]) and np.array_equal(o["a_out"], rf["a_out"]), (seed, r, kw)
     assert n_cases >= 40 and n_tied < n_cases // 2
+
+
+def test_gen_regs_oracle_vs_reference():
+    """orc_gen_regs against the reference's mm_gen_regs (hit.c:52-88, libminimap2ref.so): the leading 72 bytes of every mm_reg1_t,
+    for few and for many chains (> 64: the radix passes of the score sort), both strand conventions."""
+    import mm2gb_amd as mm
+    import synth_cases as sc
+    rng = np.random.default_rng(2)
+    a, off = mm.synth_reads(9, 0, 6, 10_000, 120_000)
+    cases = [(a[off[r]:off[r + 1]], orc.default_param()) for r in range(6)]
+    cases.append((sc.sort_by_x(np.concatenate([sc.repeat_block(3000, 5, xwin=900, ywin=900), sc.colinear(300, 6)])), orc.default_param(min_cnt=2, min_sc=20)))
+    n_many = 0
+    for x, prm in cases:
+        o = orc.lchain_dp(x, prm, want_fp=False)
+        for is_q in (0, 1):
+            h, qlen = int(rng.integers(0, 2**32)), int(rng.integers(100_000, 200_000))
+            got, want = orc.gen_regs(o["u"], o["a_out"], qlen, h, is_q), orc.ref_gen_regs(o["u"], o["a_out"], qlen, h, is_q)
+            assert np.array_equal(got, want)
+            n_many += len(want) > 64
+    assert n_many >= 1
