@@ -78,8 +78,16 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_uoff, post_aoff, post_uout, post_aout, post_misc, post_order, post_up4, post_up16, rmq_tied, reg_out;
-	int64_t *h_post_totals = nullptr;      // pinned: [0] chains [1] anchors kept
+	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_order, post_up4, post_up16, rmq_tied, reg_out;
+	// what the post-pass leaves for the host, two sets: the boundary keeps two batches in flight (the results of batch k are
+	// fetched after batch k+1 has been launched)
+	struct PostOut {
+		DevBuf u_off, a_off, u_out, a_out;
+		int64_t *h_totals = nullptr;       // pinned: [0] chains [1] anchors kept
+		hipEvent_t done = nullptr;         // post kernels of the batch that owns this set have finished, totals are in h_totals
+	} post_out[2];
+	DevBuf &post_uoff = post_out[0].u_off, &post_aoff = post_out[0].a_off, &post_uout = post_out[0].u_out, &post_aout = post_out[0].a_out;
+	int64_t *&h_post_totals = post_out[0].h_totals;
 	hipEvent_t post0 = nullptr, post1 = nullptr;
 	IoSet io[2];
 	uint64_t io_seq = 0;
@@ -113,7 +121,11 @@ struct Engine {
 	// h_post_totals once the stream has been synchronised.
 	int  reserve_post(int64_t n_anchors, int64_t n_reads);
 	int  enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
-	                  const mm2gb_rmq_param_t *rmq = nullptr);   // rmq given: thresholds of the re-chaining call (lchain.c:355) instead of misc's
+	                  const mm2gb_rmq_param_t *rmq = nullptr, int out_set = 0);   // rmq given: thresholds of the re-chaining call (lchain.c:355) instead of misc's
+	// the boundary's device post-pass: host anchors in (page-locked), H2D + score kernels + post kernels enqueued, nothing waited
+	// for; fetch_chains() waits for that batch and copies its chains out (exact sizes)
+	int  enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int out_set);
+	int  fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out);
 	// whole batch on host buffers, chains back, nothing but the chains crosses the link on the way back
 	// rmq given: the score fill is mg_lchain_rmq's (k_rmq_fill) instead of the chaining DP; n_tied (optional, n_reads entries)
 	// receives, per read, the number of anchors whose range-minimum was tied (results for such a read are not the reference's)

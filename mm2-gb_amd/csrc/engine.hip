@@ -210,10 +210,14 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_uoff, &post_aoff, &post_uout, &post_aout, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &reg_out })
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &reg_out,
+	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
 	cap_post_n = cap_post_reads = 0;
-	if (h_post_totals) { (void)hipHostFree(h_post_totals); h_post_totals = nullptr; }
+	for (PostOut &po : post_out) {
+		if (po.h_totals) { (void)hipHostFree(po.h_totals); po.h_totals = nullptr; }
+		if (po.done) { (void)hipEventDestroy(po.done); po.done = nullptr; }
+	}
 	for (hipEvent_t *e : { &post0, &post1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
@@ -307,7 +311,10 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 int Engine::reserve_post(int64_t n, int64_t n_reads)
 {
 	MM2GB_HIP(hipSetDevice(device));
-	if (!h_post_totals) MM2GB_HIP(hipHostMalloc((void**)&h_post_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+	for (PostOut &po : post_out) {
+		if (!po.h_totals) MM2GB_HIP(hipHostMalloc((void**)&po.h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+		if (!po.done) MM2GB_HIP(hipEventCreateWithFlags(&po.done, hipEventDisableTiming));
+	}
 	for (hipEvent_t *e : { &post0, &post1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
 	if (n <= cap_post_n && n_reads <= cap_post_reads) return 0;
 	MM2GB_HIP(hipStreamSynchronize(stream));
@@ -326,16 +333,25 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 }
 
 int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
-                         const mm2gb_rmq_param_t *rmq)
+                         const mm2gb_rmq_param_t *rmq, int out_set)
 {
 	if (reserve_post(n, n_reads)) return -1;
+	PostOut &po = post_out[out_set];
+	if (out_set != 0) {                                                  // set 0 is sized by reserve_post
+		const size_t need_off = (size_t)(cap_post_reads + 1) * 8, need_u = (size_t)(cap_post_n + cap_post_reads) * 8, need_a = (size_t)cap_post_n * 16;
+		if (po.u_off.bytes < need_off || po.a_off.bytes < need_off || po.u_out.bytes < need_u || po.a_out.bytes < need_a) {
+			MM2GB_HIP(hipStreamSynchronize(stream));
+			MM2GB_HIP(hipStreamSynchronize(s_out));
+			if (po.u_off.ensure(need_off) || po.a_off.ensure(need_off) || po.u_out.ensure(need_u) || po.a_out.ensure(need_a)) return -1;
+		}
+	}
 	PostBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads; b.f = d_f; b.p = d_p;
 	b.z = (unsigned long long*)post_z.ptr; b.mark = (uint8_t*)post_mark.ptr; b.picked = (int32_t*)post_picked.ptr;
 	b.up4 = (int32_t*)post_up4.ptr; b.up16 = (int32_t*)post_up16.ptr;
 	b.u_tmp = (unsigned long long*)post_utmp.ptr; b.heads = (ulonglong2*)post_heads.ptr;
-	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)post_uoff.ptr; b.a_off = (int64_t*)post_aoff.ptr;
-	b.u_out = (unsigned long long*)post_uout.ptr; b.a_out = (uint4*)post_aout.ptr;
+	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)po.u_off.ptr; b.a_off = (int64_t*)po.a_off.ptr;
+	b.u_out = (unsigned long long*)po.u_out.ptr; b.a_out = (uint4*)po.a_out.ptr;
 	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 16);
 	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)((char*)post_misc.ptr + 128);
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
@@ -349,8 +365,56 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	MM2GB_HIP(hipEventRecord(post0, stream));
 	launch_post(b, stream);
 	MM2GB_HIP(hipEventRecord(post1, stream));
-	MM2GB_HIP(hipMemcpyAsync(h_post_totals, post_misc.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipMemcpyAsync(po.h_totals, post_misc.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipEventRecord(po.done, stream));
 	MM2GB_HIP(hipGetLastError());
+	return 0;
+}
+
+int Engine::enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int out_set)
+{
+	MM2GB_HIP(hipSetDevice(device));
+	IoSet &s = io[io_seq++ & 1];
+	const size_t nn = (size_t)std::max<int64_t>(n, 1);
+	if (s.raw.bytes < nn * 16 || s.f.bytes < nn * 4 || s.p.bytes < nn * 4 || s.offsets.bytes < (size_t)(n_reads + 1) * 8) {
+		for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+		if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
+	}
+	// always compute stream 0: the post-pass's work arrays exist once
+	if (s.used) MM2GB_HIP(hipStreamWaitEvent(s_in, s.comp_done, 0));
+	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, h_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s_in));
+	if (n > 0) MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, h_anchors, (size_t)n * 16, hipMemcpyHostToDevice, s_in));
+	MM2GB_HIP(hipEventRecord(s.in_done, s_in));
+	MM2GB_HIP(hipStreamWaitEvent(stream, s.in_done, 0));
+	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, false, 0)) return -1;
+	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, nullptr, out_set)) return -1;
+	MM2GB_HIP(hipEventRecord(s.comp_done, stream));
+	MM2GB_HIP(hipEventRecord(s.out_done, stream));                       // (no D2H of f / p on this path: "outputs done" == kernels done)
+	s.used = true;
+	return 0;
+}
+
+int Engine::fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out)
+{
+	memset(out, 0, sizeof(*out));
+	MM2GB_HIP(hipSetDevice(device));
+	PostOut &po = post_out[out_set];
+	MM2GB_HIP(hipEventSynchronize(po.done));
+	const int64_t n_u = n_reads > 0 ? po.h_totals[0] : 0, n_a = n_reads > 0 ? po.h_totals[1] : 0;
+	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->u = (uint64_t*)malloc((size_t)(n_u + 1) * 8);
+	out->a = (mm2gb_anchor_t*)malloc((size_t)(n_a + 1) * 16);
+	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb: out of host memory"); }
+	out->u_off[0] = out->a_off[0] = 0;
+	if (n_reads > 0) {
+		// on the D2H stream: the compute stream may already be busy with the next batch
+		MM2GB_HIP(hipMemcpyAsync(out->u_off, po.u_off.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipMemcpyAsync(out->a_off, po.a_off.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s_out));
+		if (n_u > 0) MM2GB_HIP(hipMemcpyAsync(out->u, po.u_out.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost, s_out));
+		if (n_a > 0) MM2GB_HIP(hipMemcpyAsync(out->a, po.a_out.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipStreamSynchronize(s_out));
+	}
 	return 0;
 }
 

@@ -75,6 +75,8 @@ struct HostStage {
 	mm2gb_misc_t misc = {};                // the parameters this batch was LAUNCHED with: its post-pass must use the same ones
 	int  n_read = 0;
 	bool busy = false;
+	bool device_post = false;              // this batch's backtrack + compaction run as kernels; its chains wait in engine post set `post_set`
+	int  post_set = 0;
 	hipEvent_t done = nullptr;             // all f/p of this batch are back in h_f / h_p
 };
 
@@ -92,6 +94,7 @@ static struct {
 	mm2gb_config_t cfg;
 	mm2gb_misc_t   misc;
 	int  post_threads = 1;
+	bool post_on_device = false;           // MM2GB_POST=gpu (or MM2GB_POST_THREADS=0): no host post-pass threads at all
 	bool ready = false;
 	bool debug = false;                    // MM2GB_DEBUG_PHASES: where a batch's host time goes, on stderr
 } g_streams;
@@ -135,11 +138,39 @@ static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_r
 	TraceRange range("mm2gb:finish_batch");
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
 	const double t0 = now_ms();
-	{ TraceRange wait("mm2gb:wait_scores"); MM2GB_HIP(hipEventSynchronize(st.done)); }
+	if (!st.device_post) { TraceRange wait("mm2gb:wait_scores"); MM2GB_HIP(hipEventSynchronize(st.done)); }
 	const double t_wait = now_ms();
 	mm2gb_chain_read_t *reads = st.reads;
 	const int n_read = st.n_read;
 	const int64_t *off = st.goff.data();
+	if (st.device_post) {
+		// the chains were made on the device (post_kernels.hip): fetch them (exact sizes) and move them into the host's arena
+		mm2gb_chains_t ch;
+		if (slot.eng.fetch_chains(st.post_set, n_read, &ch)) return -1;
+		const double t_fetch = now_ms();
+		if (misc_out) *misc_out = st.misc;
+		HostAlloc host_mem; host_mem.km = km; host_mem.use_kalloc = host_kalloc_present();
+		for (int r = 0; r < n_read; ++r) {
+			mm2gb_chain_read_t &rd = reads[r];
+			const int n_u = (int)(ch.u_off[r + 1] - ch.u_off[r]);
+			const int64_t n_a = ch.a_off[r + 1] - ch.a_off[r];
+			uint64_t *u = nullptr; mm2gb_anchor_t *a_new = nullptr;
+			if (n_u > 0) {
+				u = (uint64_t*)host_mem.alloc((size_t)n_u * 8);
+				a_new = (mm2gb_anchor_t*)host_mem.alloc((size_t)n_a * 16);
+				memcpy(u, ch.u + ch.u_off[r], (size_t)n_u * 8); memcpy(a_new, ch.a + ch.a_off[r], (size_t)n_a * 16);
+			}
+			host_mem.release(rd.a);
+			rd.a = a_new; rd.u = u; rd.n_u = n_u;
+		}
+		mm2gb_chains_free(&ch);
+		st.busy = false; st.reads = nullptr; st.n_read = 0; st.device_post = false;
+		*reads_out = reads; *n_out = n_read;
+		if (g_streams.debug)
+			fprintf(stderr, "[mm2gb stream] finish (device post-pass): %d reads, %lld anchors | wait + fetch chains %.2f ms | hand-over %.2f ms\n",
+			        n_read, (long long)off[n_read], t_fetch - t0, now_ms() - t_fetch);
+		return 0;
+	}
 	const int32_t *f = (const int32_t*)st.h_f.ptr, *p = (const int32_t*)st.h_p.ptr;
 	const mm2gb_misc_t misc = st.misc;                    // not the engine's current ones: a newer batch may already be in flight
 	if (misc_out) *misc_out = misc;
@@ -226,9 +257,16 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 		for (int64_t r = r0; r <= r1; ++r) local_off[w++] = off[r] - off[r0];
 		const int64_t n = off[r1] - off[r0];
 		TraceRange mb("mm2gb:enqueue_microbatch");
+		if (g_streams.post_on_device && n_mb == 1) {
+			// scores never leave the device: post kernels follow the score kernel, the chains are fetched when the batch is finished
+			st.post_set = slot.cur ^ 1;                              // == the index of this stage: stage k's results live in post set k
+			if (slot.eng.enqueue_host_chains(r1 - r0, local_off + base, raw + off[r0], n, st.post_set)) return -1;
+			st.device_post = true;
+			continue;
+		}
 		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)st.h_f.ptr + off[r0], (int32_t*)st.h_p.ptr + off[r0], false)) return -1;
 	}
-	if (slot.eng.record_outputs_done(st.done)) return -1;
+	if (!st.device_post && slot.eng.record_outputs_done(st.done)) return -1;
 	st.reads = reads; st.n_read = n_read; st.busy = true;
 	if (g_streams.debug)
 		fprintf(stderr, "[mm2gb stream] launch: %d reads, %lld anchors, %zu micro-batch(es) | pack %.2f ms | enqueue %.2f ms\n",
@@ -418,6 +456,7 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	// default: this stream's share of the CPUs the process may use (one GPU's post-pass needs ~13 CPU-equivalents to stay hidden)
 	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : std::max(1, std::min(32, usable_cpus() / std::max(1, cfg.num_streams)));
 	{ const char *dbg = getenv("MM2GB_DEBUG_PHASES"); g_streams.debug = dbg && *dbg && *dbg != '0'; }
+	{ const char *pm = getenv("MM2GB_POST"); g_streams.post_on_device = (pm && strcmp(pm, "gpu") == 0) || (pt && atoi(pt) == 0); }
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
 	for (int s = 0; s < cfg.num_streams; ++s) {
