@@ -519,14 +519,20 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m)
 
 } // namespace
 
+// One WORKGROUP (4 waves) per read: the ranges a query scans hold thousands of anchors inside repeats, so 256 lanes scan them; every
+// wave keeps the (wave-uniform) state of the DP for itself -- same loads, same arithmetic -- and only the two arg-max reductions
+// cross waves, through LDS.
 __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams P)
 {
-	const int l = lane();
+	constexpr int NW = POST_THREADS / W;
+	__shared__ double s_key[2][NW];
+	__shared__ int s_j[2][NW], s_y[2][NW], s_cnt[2][NW];
+	__shared__ int s_sc[2][NW], s_cj[2][NW], s_cy[2][NW];
+	const int l = lane(), w = uni(threadIdx.x / W), tid = threadIdx.x;
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
 	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;   // lchain.c:265
 	const double half_gap = 0.5 * (double)P.pen_gap;
-	const int per = POST_THREADS / W;
-	for (int64_t r = (int64_t)blockIdx.x * per + uni(threadIdx.x / W); r < b.n_reads; r += (int64_t)gridDim.x * per) {
+	for (int64_t r = blockIdx.x; r < b.n_reads; r += gridDim.x) {
 		const int64_t off = b.offsets[r];
 		const int n = (int)(b.offsets[r + 1] - off);
 		const uint4 *a = b.raw + off;
@@ -534,12 +540,14 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 		double *key = b.key + off;
 		int i0 = 0, st = 0, st_in = 0, tied = 0;
 		for (int i = 0; i < n; ++i) {
+			const int par = i & 1;                                        // reduction slots alternate: one barrier per reduction
 			const uint4 ai = a[i];                                        // same address in every lane
 			const int yi = (int)ai.z, q_i = (int)(ai.w & 0xffu);
 			if (i0 < i) { const uint4 a0 = a[i0]; if (a0.x != ai.x || a0.y != ai.y) i0 = i; }               // lchain.c:279-292
 			i0 = uni(i0);
-			// eviction (lchain.c:293-310): the conditions hold for a prefix of [st, i), so 64 candidates are tested at once.
-			// (Loop control is made explicitly wave-uniform: an earlier form with `for (;;) ... break` on the ballot's result hung.)
+			// eviction (lchain.c:293-310): the conditions hold for a prefix of [st, i), so 64 candidates are tested at once (by
+			// every wave for itself).  Loop control is explicitly wave-uniform and the bit scan is done on 32-bit halves: an
+			// earlier form with `for (;;) ... break` on __builtin_ctzll of the ballot hung (ROCm 7.2).
 			int adv;
 			do {
 				const int j = st + l;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 			// the range-minimum (lchain.c:311-315): closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index)
 			double bk = 0.0;
 			int bj = -1, by = 0, cnt = 0;
-			for (int j = st + l; j < i0; j += W) {
+			for (int j = st + tid; j < i0; j += POST_THREADS) {
 				const int yj = (int)a[j].z;
 				if (!((yj > yi - max_dist && yj < yi) || (yj == yi && j == 0))) continue;
 				const double k = key[j];
@@ -577,51 +585,71 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 					else if (ok == bk) { cnt += oc; if (oy > by || (oy == by && oj > bj)) { bj = oj; by = oy; } }
 				}
 			}
+			if (l == 0) { s_key[par][w] = bk; s_j[par][w] = bj; s_y[par][w] = by; s_cnt[par][w] = cnt; }
+			__syncthreads();
+			bk = s_key[par][0]; bj = s_j[par][0]; by = s_y[par][0]; cnt = s_cnt[par][0];
+			for (int q = 1; q < NW; ++q) {
+				const double ok = s_key[par][q];
+				const int oj = s_j[par][q], oy = s_y[par][q], oc = s_cnt[par][q];
+				if (oj >= 0) {
+					if (bj < 0 || ok > bk) { bk = ok; bj = oj; by = oy; cnt = oc; }
+					else if (ok == bk) { cnt += oc; if (oy > by || (oy == by && oj > bj)) { bj = oj; by = oy; } }
+				}
+			}
 			bj = uni(bj);
+			bool inner = false;
 			if (bj >= 0) {
 				if (uni(cnt) > 1) ++tied;
 				const uint4 aj = a[bj];
 				bool exact; int width;
 				const int sc = f[bj] + rmq_pair_score(ai.x, yi, aj.x, (int)aj.z, (int)(aj.w & 0xffu), P, exact, width);
 				if (width <= P.bw && sc > max_f) { max_f = sc; max_j = bj; }
-				if (!exact && max_inner > 0 && st_in < i0 && yi > 0) {
-					// lchain.c:320-341: every inner-tree element with y in [yi - max_inner, yi - 1], from the largest (y, index) down;
-					// strict '>' keeps the first of equal scores, i.e. the largest (y, index)
-					int bs = INT_MIN, cj = -1, cy = 0;
-					for (int j = st_in + l; j < i0; j += W) {
-						const uint4 aj2 = a[j];
-						const int yj = (int)aj2.z;
-						if (yj > yi - 1 || yj < yi - max_inner) continue;
-						bool ex2; int w2;
-						const int s2 = f[j] + rmq_pair_score(ai.x, yi, aj2.x, yj, (int)(aj2.w & 0xffu), P, ex2, w2);
-						if (w2 > P.bw) continue;
-						if (s2 > bs || (s2 == bs && (yj > cy || (yj == cy && j > cj)))) { bs = s2; cj = j; cy = yj; }
-					}
-					for (int m = W / 2; m > 0; m >>= 1) {
-						const int os = __shfl_xor(bs, m), oj = __shfl_xor(cj, m), oy = __shfl_xor(cy, m);
-						if (oj >= 0 && (cj < 0 || os > bs || (os == bs && (oy > cy || (oy == cy && oj > cj))))) { bs = os; cj = oj; cy = oy; }
-					}
-					cj = uni(cj); bs = uni(bs);
-					if (cj >= 0 && bs > max_f) { max_f = bs; max_j = cj; }
-				}
+				inner = !exact && max_inner > 0 && st_in < i0 && yi > 0;
 			}
-			if (l == 0) {                                                                              // lchain.c:346 (+ the key of lchain.c:284)
+			inner = uni(inner);
+			if (inner) {
+				// lchain.c:320-341: every inner-tree element with y in [yi - max_inner, yi - 1], from the largest (y, index) down;
+				// strict '>' keeps the first of equal scores, i.e. the largest (y, index)
+				int bs = INT_MIN, cj = -1, cy = 0;
+				for (int j = st_in + tid; j < i0; j += POST_THREADS) {
+					const uint4 aj2 = a[j];
+					const int yj = (int)aj2.z;
+					if (yj > yi - 1 || yj < yi - max_inner) continue;
+					bool ex2; int w2;
+					const int s2 = f[j] + rmq_pair_score(ai.x, yi, aj2.x, yj, (int)(aj2.w & 0xffu), P, ex2, w2);
+					if (w2 > P.bw) continue;
+					if (s2 > bs || (s2 == bs && (yj > cy || (yj == cy && j > cj)))) { bs = s2; cj = j; cy = yj; }
+				}
+				for (int m = W / 2; m > 0; m >>= 1) {
+					const int os = __shfl_xor(bs, m), oj = __shfl_xor(cj, m), oy = __shfl_xor(cy, m);
+					if (oj >= 0 && (cj < 0 || os > bs || (os == bs && (oy > cy || (oy == cy && oj > cj))))) { bs = os; cj = oj; cy = oy; }
+				}
+				if (l == 0) { s_sc[par][w] = bs; s_cj[par][w] = cj; s_cy[par][w] = cy; }
+				__syncthreads();
+				bs = s_sc[par][0]; cj = s_cj[par][0]; cy = s_cy[par][0];
+				for (int q = 1; q < NW; ++q) {
+					const int os = s_sc[par][q], oj = s_cj[par][q], oy = s_cy[par][q];
+					if (oj >= 0 && (cj < 0 || os > bs || (os == bs && (oy > cy || (oy == cy && oj > cj))))) { bs = os; cj = oj; cy = oy; }
+				}
+				cj = uni(cj); bs = uni(bs);
+				if (cj >= 0 && bs > max_f) { max_f = bs; max_j = cj; }
+			}
+			if (tid == 0) {                                                                            // lchain.c:346 (+ the key of lchain.c:284)
 				f[i] = max_f;
 				p[i] = max_j < 0 ? 0 : i - max_j;
 				key[i] = (double)max_f + half_gap * (double)((int)ai.x + (int)ai.z);
 			}
-			wave_sync();
+			__threadfence_block();
+			__syncthreads();                                                                           // f / key of anchor i before any wave scans it
 		}
-		if (l == 0) b.n_tied[r] = tied;
+		if (tid == 0) b.n_tied[r] = tied;
 	}
 }
 
 void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;
-	(void)hipMemsetAsync(b.cursor, 0, sizeof(int32_t), s);
-	const int per = POST_THREADS / W;
-	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, ((int64_t)b.grid_waves + per - 1) / per));
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(b.n_reads, (int64_t)b.grid_waves / (POST_THREADS / W)));
 	hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
 }
 
