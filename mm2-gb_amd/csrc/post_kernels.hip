@@ -39,18 +39,23 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
-// Per-wave LDS scratch of a radix pass.
-struct PassLds { int cnt[256]; int head[256]; int tail[256]; };
+// Per-wave LDS scratch of a radix pass: bucket counts and bounds, and a small cache of the elements at every bucket's head -- the
+// cycle permutation reads one element per step from 256 slowly advancing heads, LINE_BYTES of each are kept here so that most
+// steps are an LDS read instead of a memory round trip.
+constexpr int LINE_BYTES = 32;
+struct alignas(16) PassLds { int cnt[256]; int head[256]; int tail[256]; int tag[256]; unsigned long long line[256 * LINE_BYTES / 8]; };
 
 // ---- the two element kinds that get sorted the host's way ----------------------------------------------------------
 // Z: candidates of the backtrack, key = score f (lchain.c:38-41: z[k].x = f[i], z[k].y = i), packed f<<32 | i.
 // H: chain heads of the compaction, key = x of the chain's first anchor, value = offset<<32 | chain (lchain.c:94-99).
 struct ZElem {
 	using T = unsigned long long;
+	static constexpr int LINE = LINE_BYTES / 8;                     // elements of one bucket head kept in LDS
 	static __device__ __forceinline__ unsigned long long key(T e) { return e >> 32; }
 };
 struct HElem {
 	using T = ulonglong2;
+	static constexpr int LINE = LINE_BYTES / 16;
 	static __device__ __forceinline__ unsigned long long key(const T &e) { return e.x; }
 };
 
@@ -100,7 +105,7 @@ template <class E>
 __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L)
 {
 	const int l = lane();
-	for (int k = l; k < 256; k += W) L.cnt[k] = 0;
+	for (int k = l; k < 256; k += W) { L.cnt[k] = 0; L.tag[k] = -1; }
 	wave_sync();
 	for (int i = lo + l; i < hi; i += W) atomicAdd(&L.cnt[(int)(E::key(g[i]) >> shift) & 255], 1);
 	wave_sync();
@@ -133,18 +138,25 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 			const int skip = __builtin_ctzll(moves);
 			hk += skip;
 			typename E::T carry = bcast_elem(e, skip);
-			if (l == 0) {
-				int d = (int)(E::key(carry) >> shift) & 255;
-				do {
-					const typename E::T moved = carry;
-					const int hd = L.head[d];
-					carry = g[hd];
-					g[hd] = moved;
-					L.head[d] = hd + 1;
-					d = (int)(E::key(carry) >> shift) & 255;
-				} while (d != k);
-				g[hk] = carry;
+			// the cycle, wave-uniform: the element at the head of the destination bucket comes from that bucket's cached line
+			// (LINE elements from the head's aligned position on, fetched by LINE lanes when the head enters a new line).  Cached
+			// slots at or beyond a head are still the originals -- only a consumed head position is ever written.
+			typename E::T *line = (typename E::T*)L.line;
+			int d = uni((int)(E::key(carry) >> shift) & 255);
+			while (d != k) {
+				const int hd = uni(L.head[d]);
+				const int base = hd & ~(E::LINE - 1);
+				if (uni(L.tag[d]) != base) {
+					if (l < E::LINE) line[d * E::LINE + l] = g[min(base + l, hi - 1)];
+					if (l == 0) L.tag[d] = base;
+					wave_sync();
+				}
+				const typename E::T next = line[d * E::LINE + (hd - base)];
+				if (l == 0) { g[hd] = carry; L.head[d] = hd + 1; }
+				carry = next;
+				d = uni((int)(E::key(carry) >> shift) & 255);
 			}
+			if (l == 0) g[hk] = carry;
 			++hk;
 			wave_sync();
 		}
