@@ -772,8 +772,12 @@ int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_off
 	if (n_chains) *n_chains = e.h_post_totals[0];
 	if (n_kept) *n_kept = e.h_post_totals[1];
 	if (e.debug_phases) {
-		long long t[8] = { 0 };
+		long long t[24] = { 0 };
 		if (hipMemcpy(t, (char*)e.post_misc.ptr + 1024, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
+			fprintf(stderr, "[mm2gb post-pass] sort levels: %.1f / %.1f / %.1f / %.1f ms; radix passes %lld over %lld elements, small runs %lld\n", t[13] / 1e5, t[14] / 1e5, t[15] / 1e5, t[16] / 1e5, t[17], t[18], t[19]);
+		if (t[6])
+			fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld, candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[12]);
+		if (t[6])
 			fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
 			        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);
 	}

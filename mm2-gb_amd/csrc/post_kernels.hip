@@ -29,6 +29,10 @@ namespace {
 constexpr int W = 64;
 constexpr int POST_THREADS = 256;               // 4 waves, one read each
 constexpr int SMALL_RUN = 64;                   // RS_MIN_SIZE, ksort.h:98
+#ifndef MM2GB_POST_SPEC
+#define MM2GB_POST_SPEC 4
+#endif
+constexpr int SPEC = MM2GB_POST_SPEC;                         // steps of a chain walk every candidate of a group takes ahead of its turn
 
 __device__ __forceinline__ int lane() { return threadIdx.x & (W - 1); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -40,10 +44,14 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // Per-wave LDS scratch of a radix pass: bucket counts and bounds, and a small cache of the elements at every bucket's head -- the
-// cycle permutation reads one element per step from 256 slowly advancing heads, LINE_BYTES of each are kept here so that most
-// steps are an LDS read instead of a memory round trip.
-constexpr int LINE_BYTES = 32;
-struct alignas(16) PassLds { int cnt[256]; int head[256]; int tail[256]; int tag[256]; unsigned long long line[256 * LINE_BYTES / 8]; };
+// cycle permutation reads one element per step from 256 slowly advancing heads; the LINE_BYTES that follow `anchor` (a position
+// the head has passed or is at) are kept here for every bucket, so that most steps are an LDS read instead of a memory round
+// trip, and all 256 lines are fetched together (one round trip for the lot) when a head runs off its line.
+#ifndef MM2GB_POST_LINE
+#define MM2GB_POST_LINE 32
+#endif
+constexpr int LINE_BYTES = MM2GB_POST_LINE;
+struct alignas(16) PassLds { int cnt[256]; int head[256]; int tail[256]; int anchor[256]; unsigned long long line[256 * LINE_BYTES / 8]; };
 
 // ---- the two element kinds that get sorted the host's way ----------------------------------------------------------
 // Z: candidates of the backtrack, key = score f (lchain.c:38-41: z[k].x = f[i], z[k].y = i), packed f<<32 | i.
@@ -98,14 +106,32 @@ __device__ __forceinline__ void small_run_sort(typename E::T *g, int lo, int len
 	wave_sync();
 }
 
+// The elements [head, head + LINE) of every bucket that is not full yet, into the LDS lines: all lanes, one memory round trip.
+// Positions at or beyond a head still hold what they held when the pass began -- only a consumed head position is ever written --
+// so a line stays valid until the head has moved past it.
+template <class E>
+__device__ __forceinline__ void fetch_all_lines(const typename E::T *g, PassLds &L)
+{
+	typename E::T *line = (typename E::T*)L.line;
+	const int l = lane();
+#pragma unroll
+	for (int it = 0; it < 256 * E::LINE / W; ++it) {
+		const int slot = it * W + l, d = slot / E::LINE, j = slot % E::LINE;
+		const int hd = L.head[d];
+		if (hd + j < L.tail[d]) line[slot] = g[hd + j];
+		if (j == 0) L.anchor[d] = hd;
+	}
+	wave_sync();
+}
+
 // One pass of rs_sort (ksort.h:116-146) over g[lo, hi) on key byte `shift`: histogram and bucket bounds with all lanes, then
 // the in-place cycle permutation exactly as the host does it -- element by element, each placement evicting the element
-// that decides the next one -- on lane 0.  Returns false when every key has the same byte (the pass moves nothing).
+// that decides the next one.  Returns false when every key has the same byte (the pass moves nothing).
 template <class E>
 __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L)
 {
 	const int l = lane();
-	for (int k = l; k < 256; k += W) { L.cnt[k] = 0; L.tag[k] = -1; }
+	for (int k = l; k < 256; k += W) L.cnt[k] = 0;
 	wave_sync();
 	for (int i = lo + l; i < hi; i += W) atomicAdd(&L.cnt[(int)(E::key(g[i]) >> shift) & 255], 1);
 	wave_sync();
@@ -122,8 +148,10 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 	L.head[4 * l + 2] = at; at += c2; L.tail[4 * l + 2] = at;
 	L.head[4 * l + 3] = at; at += c3; L.tail[4 * l + 3] = at;
 	wave_sync();
+	fetch_all_lines<E>(g, L);
+	int since = 0;                                          // cycle steps since all lines were fetched together
 	// The host's loop, bucket by bucket: elements at the head of bucket k that already belong to k are passed over (all 64
-	// lanes look at the next 64 of them at once); the first one that does not starts a cycle, which lane 0 follows exactly as
+	// lanes look at the next 64 of them at once); the first one that does not starts a cycle, which is followed exactly as
 	// the host does -- place the carried element at the head of its bucket, pick up what was there -- until an element of
 	// bucket k turns up (ksort.h:128-139).
 	for (int k = 0; k < 256; ++k) {
@@ -138,22 +166,28 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 			const int skip = __builtin_ctzll(moves);
 			hk += skip;
 			typename E::T carry = bcast_elem(e, skip);
-			// the cycle, wave-uniform: the element at the head of the destination bucket comes from that bucket's cached line
-			// (LINE elements from the head's aligned position on, fetched by LINE lanes when the head enters a new line).  Cached
-			// slots at or beyond a head are still the originals -- only a consumed head position is ever written.
+			// the cycle, wave-uniform: the element at the head of the destination bucket comes from that bucket's line.  A head that
+			// has run off its line gets the next LINE elements (one round trip for this bucket alone), or -- if the last fetch of all
+			// lines is a while ago -- every bucket does: keys spread over many buckets then cost one round trip per few hundred steps,
+			// keys that crowd into one bucket no more than they did.
 			typename E::T *line = (typename E::T*)L.line;
 			int d = uni((int)(E::key(carry) >> shift) & 255);
 			while (d != k) {
 				const int hd = uni(L.head[d]);
-				const int base = hd & ~(E::LINE - 1);
-				if (uni(L.tag[d]) != base) {
-					if (l < E::LINE) line[d * E::LINE + l] = g[min(base + l, hi - 1)];
-					if (l == 0) L.tag[d] = base;
-					wave_sync();
+				int at_line = hd - uni(L.anchor[d]);
+				if (at_line >= E::LINE) {
+					if (since >= 64) { fetch_all_lines<E>(g, L); since = 0; }
+					else {
+						if (l < E::LINE && hd + l < hi) line[d * E::LINE + l] = g[hd + l];
+						if (l == 0) L.anchor[d] = hd;
+						wave_sync();
+					}
+					at_line = 0;
 				}
-				const typename E::T next = line[d * E::LINE + (hd - base)];
+				const typename E::T next = line[d * E::LINE + at_line];
 				if (l == 0) { g[hd] = carry; L.head[d] = hd + 1; }
 				carry = next;
+				++since;
 				d = uni((int)(E::key(carry) >> shift) & 255);
 			}
 			if (l == 0) g[hk] = carry;
@@ -172,7 +206,7 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 // Passes on bytes in which all keys of the run agree move nothing, so starting at the highest byte in which any two keys
 // differ equals the host's start at byte 7.
 template <class E>
-__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L)
+__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L, long long *dbg = nullptr)
 {
 	if (n <= 1) return;
 	if (n <= SMALL_RUN) { small_run_sort<E>(g, 0, n); return; }
@@ -187,6 +221,7 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 	if (diff == 0) return;
 	int top = 56;
 	while (top > 0 && ((diff >> top) & 255) == 0) top -= 8;
+	long long tlev = dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0, d_pass = 0, d_elems = 0, d_small = 0;
 	for (int shift = top; shift >= 0; shift -= 8) {
 		// runs of equal key >> (shift + 8); at the top level the whole array is one run by construction
 		int run_lo = 0;
@@ -203,15 +238,26 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 				const int q = base + __builtin_ctzll(starts);
 				starts &= starts - 1;
 				const int len = q - run_lo;
-				if (len > SMALL_RUN) radix_pass<E>(g, run_lo, q, shift, L);
-				else if (len > 1) small_run_sort<E>(g, run_lo, len);
+				if (len > SMALL_RUN) { radix_pass<E>(g, run_lo, q, shift, L); ++d_pass; d_elems += len; }
+				else if (len > 1) { small_run_sort<E>(g, run_lo, len); ++d_small; }
 				run_lo = q;
 			}
 		}
 		const int len = n - run_lo;
-		if (len > SMALL_RUN) radix_pass<E>(g, run_lo, n, shift, L);
-		else if (len > 1) small_run_sort<E>(g, run_lo, len);
+		if (len > SMALL_RUN) { radix_pass<E>(g, run_lo, n, shift, L); ++d_pass; d_elems += len; }
+		else if (len > 1) { small_run_sort<E>(g, run_lo, len); ++d_small; }
 		wave_sync();
+		if (dbg && lane() == 0) {
+			const long long tn = (long long)__builtin_amdgcn_s_memrealtime();
+			const int lvl = (top - shift) / 8;
+			atomicAdd((unsigned long long*)&dbg[13 + (lvl < 3 ? lvl : 3)], (unsigned long long)(tn - tlev));
+			tlev = tn;
+		}
+	}
+	if (dbg && lane() == 0) {
+		atomicAdd((unsigned long long*)&dbg[17], (unsigned long long)d_pass);
+		atomicAdd((unsigned long long*)&dbg[18], (unsigned long long)d_elems);
+		atomicAdd((unsigned long long*)&dbg[19], (unsigned long long)d_small);
 	}
 }
 
@@ -293,86 +339,141 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 		}
 		wave_sync();
 		const long long t1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-		sort_like_host<ZElem>(z, n_z, L);
+		sort_like_host<ZElem>(z, n_z, L, b.dbg);
 		const long long t2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
-		// Most candidates already belong to a chain found from a better end: 64 of them are tested at once, and lane 0 only
-		// turns to those that were still free then (testing again: an earlier walk of the same group may have taken them).
 		// A walk (mg_chain_bk_end, lchain.c:9-25: back from the chain end until an anchor that is taken, the start of the path, or an
-		// X-drop of more than max_drop below the best prefix) is a chain of dependent loads, one memory round trip per anchor.  Its
-		// first steps are taken one at a time (most walks end within a few: the next anchor already belongs to a better chain);
-		// a walk that goes on is taken 64 anchors at a time: lane j finds the j-th anchor down the path through the lifting tables
-		// (p, p^4, p^16: at most 9 dependent loads instead of j), and what the sequential loop decides step by step -- the running
-		// best prefix, the first step that ends the walk -- becomes a prefix maximum and a ballot over the wave.
+		// X-drop of more than max_drop below the best prefix) is a chain of dependent loads, one memory round trip per anchor, and
+		// walks depend on each other through the marks.  Candidates are handled 64 at a time, in the host's order.
 		const int32_t *up4 = b.up4 + off, *up16 = b.up16 + off;
 		int n_u = 0, n_v = 0;
+		long long dbg_load = 0, dbg_longt = 0, dbg_groups = 0, dbg_open = 0, dbg_long = 0;
 		for (int kb = n_z - 1; kb >= 0; kb -= W) {
 			const int k_l = kb - l;
 			const unsigned long long z_l = k_l >= 0 ? z[k_l] : 0;
-			unsigned long long open = __ballot(k_l >= 0 && mark[(int)(unsigned)z_l] == 0);
-			while (open) {
-				const int src = first_set(open);                 // lowest lane = highest k
-				open &= open - 1;
-				const unsigned long long zk = bcast_elem(z_l, src);
-				const int start = (int)(unsigned)zk, top = (int)(zk >> 32);
-				int pc = p[start];                               // (requested together with the mark: one round trip)
-				if (uni(mark[start]) != 0) continue;             // taken by an earlier walk of this group of candidates
-				// every lane runs the same steps on the same addresses (one transaction per load); `kept` is how many of the visited
-				// anchors lie before the one the best prefix stops at; an anchor's own link is fetched with its score and mark, so a
-				// step is one round trip
-				int cur = start, kept = 0, visited = 0, best = 0;
-				bool ended = false;
-				for (int step = 0; step < 4 && !ended; ++step) {
-					if (l == 0) picked[n_v + visited] = cur;
-					++visited;
-					const int next = pc ? cur - pc : -1;
-					int s = top, m = 1;
-					if (next >= 0) { s = top - f[next]; m = mark[next]; pc = p[next]; }
-					if (s > best) { best = s; kept = visited; }
-					else if (best - s > b.max_drop) ended = true;
-					if (m != 0) ended = true;
-					cur = next;
-				}
-				ended = uni(ended); cur = uni(cur); visited = uni(visited); best = uni(best); kept = uni(kept);
-				while (!ended) {
-					// lane j: the anchor j links down the path from cur
-					int t = cur;
-					for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
-					for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
-					for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = p[t]; t = rj ? t - rj : -1; }
-					const bool valid = t >= 0;
-					const int pt = valid ? p[t] : 0, next = pt ? t - pt : -1;
-					int s = top, m = 1;
-					if (next >= 0) { s = top - f[next]; m = mark[next]; }
-					// best prefix BEFORE this lane's step
-					int inc = valid ? s : INT_MIN;
-					for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
-					int before = __shfl_up(inc, 1);
-					before = l == 0 ? best : max(best, before);
-					const bool newmax = valid && s > before;
-					const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
-					const unsigned long long endm = __ballot(ends);
-					const int jb = endm ? first_set(endm) : W;             // the step that ends the walk (all of it is still taken)
-					if (valid && l <= jb) picked[n_v + visited + l] = t;
-					const unsigned long long nm = __ballot(newmax && l <= jb);
-					if (nm) {
-						const int last = 63 - first_set_from_top(nm);
-						best = __shfl(s, last);
-						kept = visited + last + 1;
+			const int n0 = (int)(unsigned)z_l, top_l = (int)(z_l >> 32);
+			unsigned long long pending = __ballot(k_l >= 0);
+			while (pending) {
+				// Every pending candidate that is still free takes the first SPEC steps of its own walk, all lanes at once: SPEC + 1 memory
+				// round trips for the group instead of for each candidate.  Scores and links never change; marks only ever get set, which
+				// can only end a walk earlier -- so a lane may stop loading where its walk would end with the marks it sees now.
+				wave_sync();
+				const long long ta = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+				int m0 = 1, nx[SPEC], sx[SPEC], mx[SPEC];
+#pragma unroll
+				for (int j = 0; j < SPEC; ++j) { nx[j] = -1; sx[j] = top_l; mx[j] = 1; }
+				if ((pending >> l) & 1) {
+					m0 = mark[n0];
+					int pc = p[n0];
+					if (m0 == 0) {
+						int cur = n0, best = 0;
+						bool ended = false;
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							if (!ended) {
+								const int next = pc ? cur - pc : -1;
+								nx[j] = next;
+								if (next >= 0) { sx[j] = top_l - f[next]; mx[j] = mark[next]; pc = p[next]; }
+								if (sx[j] > best) best = sx[j];
+								else if (best - sx[j] > b.max_drop) ended = true;
+								if (mx[j] != 0) ended = true;
+								cur = next;
+							}
+						}
 					}
-					if (jb < W) { visited += jb + 1; ended = true; }
-					else { visited += W; cur = __shfl(next, W - 1); }
 				}
-				wave_sync();
-				for (int q = l; q < kept; q += W) mark[picked[n_v + q]] = 1;
-				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
-				if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
-					if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
-					++n_u; n_v += kept;
+				// The candidates in order, on wave-uniform copies of their lane's values -- no memory round trip for a walk that ends
+				// within SPEC steps.  What an earlier walk of the group takes is set in the later lanes' copies of the marks.
+				unsigned long long open = __ballot(m0 == 0);
+				bool stale = false;
+				if (b.dbg) { dbg_load += (long long)__builtin_amdgcn_s_memrealtime() - ta; ++dbg_groups; dbg_open += __popcll(open); }
+				while (open != 0 && !stale) {
+					const int src = first_set(open);                 // lowest lane = highest k
+					open &= open - 1;
+					if (__builtin_amdgcn_readlane(m0, src) != 0) continue;   // taken by an earlier walk of this group
+					const int top = __builtin_amdgcn_readlane(top_l, src), c0 = __builtin_amdgcn_readlane(n0, src);
+					int cn[SPEC], cs[SPEC], cm[SPEC];
+#pragma unroll
+					for (int j = 0; j < SPEC; ++j) {
+						cn[j] = __builtin_amdgcn_readlane(nx[j], src); cs[j] = __builtin_amdgcn_readlane(sx[j], src); cm[j] = __builtin_amdgcn_readlane(mx[j], src);
+					}
+					// `kept` is how many of the visited anchors lie before the one the best prefix stops at
+					int cur = c0, kept = 0, visited = 0, best = 0;
+					bool ended = false;
+#pragma unroll
+					for (int j = 0; j < SPEC; ++j) {
+						if (!ended) {
+							if (l == 0) picked[n_v + visited] = cur;
+							++visited;
+							if (cs[j] > best) { best = cs[j]; kept = visited; }
+							else if (best - cs[j] > b.max_drop) ended = true;
+							if (cm[j] != 0) ended = true;
+							cur = cn[j];
+						}
+					}
+					if (ended) {
+						// at most SPEC anchors taken: marked from the registers, and noted in the lanes that come later
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							if (j < kept) {
+								const int v = j == 0 ? c0 : cn[j - 1];
+								if (l == 0) mark[v] = 1;
+								m0 |= n0 == v;
+#pragma unroll
+								for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
+							}
+						}
+					} else {
+						// a walk that goes on: 64 anchors at a time, lane j finds the j-th anchor down the path through the lifting tables
+						// (p, p^4, p^16: at most 9 dependent loads instead of j); what the sequential loop decides step by step -- the running
+						// best prefix, the first step that ends the walk -- becomes a prefix maximum and a ballot over the wave.  It may take
+						// anchors the other lanes have looked at: they look again afterwards.
+						stale = true;
+						wave_sync();
+						const long long tl = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+						++dbg_long;
+						while (!ended) {
+							int t = cur;
+							for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
+							for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
+							for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = p[t]; t = rj ? t - rj : -1; }
+							const bool valid = t >= 0;
+							const int pt = valid ? p[t] : 0, next = pt ? t - pt : -1;
+							int s = top, m = 1;
+							if (next >= 0) { s = top - f[next]; m = mark[next]; }
+							// best prefix BEFORE this lane's step
+							int inc = valid ? s : INT_MIN;
+							for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
+							int before = __shfl_up(inc, 1);
+							before = l == 0 ? best : max(best, before);
+							const bool newmax = valid && s > before;
+							const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
+							const unsigned long long endm = __ballot(ends);
+							const int jb = endm ? first_set(endm) : W;             // the step that ends the walk (all of it is still taken)
+							if (valid && l <= jb) picked[n_v + visited + l] = t;
+							const unsigned long long nm = __ballot(newmax && l <= jb);
+							if (nm) {
+								const int last = 63 - first_set_from_top(nm);
+								best = __shfl(s, last);
+								kept = visited + last + 1;
+							}
+							if (jb < W) { visited += jb + 1; ended = true; }
+							else { visited += W; cur = __shfl(next, W - 1); }
+						}
+						wave_sync();
+						for (int q = l; q < kept; q += W) mark[picked[n_v + q]] = 1;
+						if (b.dbg) dbg_longt += (long long)__builtin_amdgcn_s_memrealtime() - tl;
+					}
+					// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
+					if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
+						if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
+						++n_u; n_v += kept;
+					}
 				}
-				wave_sync();
+				pending = stale ? open : 0;
 			}
 		}
+		wave_sync();
 		if (l == 0) {
 			b.n_u[r] = n_u;
 			b.n_kept[r] = n_v;
@@ -384,6 +485,12 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 				atomicMax((unsigned long long*)&b.dbg[4], (unsigned long long)(t2 - t1));
 				atomicMax((unsigned long long*)&b.dbg[5], (unsigned long long)(t3 - t2));
 				atomicMax((unsigned long long*)&b.dbg[6], (unsigned long long)(t3 - t0));
+				atomicAdd((unsigned long long*)&b.dbg[7], (unsigned long long)dbg_load);
+				atomicAdd((unsigned long long*)&b.dbg[8], (unsigned long long)dbg_longt);
+				atomicAdd((unsigned long long*)&b.dbg[9], (unsigned long long)dbg_groups);
+				atomicAdd((unsigned long long*)&b.dbg[10], (unsigned long long)dbg_open);
+				atomicAdd((unsigned long long*)&b.dbg[11], (unsigned long long)dbg_long);
+				atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z);
 			}
 		}
 		wave_sync();
