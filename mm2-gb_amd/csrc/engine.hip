@@ -355,7 +355,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 16);
 	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)((char*)post_misc.ptr + 128);
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
-	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 64, stream));
+	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream));
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
 	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
 	if (rmq) { b.min_cnt = rmq->min_cnt; b.min_sc = rmq->min_sc; b.max_drop = rmq->bw; }   // lchain.c:253,355
@@ -772,9 +772,11 @@ int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_off
 	if (n_chains) *n_chains = e.h_post_totals[0];
 	if (n_kept) *n_kept = e.h_post_totals[1];
 	if (e.debug_phases) {
-		long long t[24] = { 0 };
+		long long t[48] = { 0 };
 		if (hipMemcpy(t, (char*)e.post_misc.ptr + 1024, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
-			fprintf(stderr, "[mm2gb post-pass] sort levels: %.1f / %.1f / %.1f / %.1f ms; radix passes %lld over %lld elements, small runs %lld\n", t[13] / 1e5, t[14] / 1e5, t[15] / 1e5, t[16] / 1e5, t[17], t[18], t[19]);
+			for (int lv = 0; lv < 3; ++lv)
+				fprintf(stderr, "[mm2gb post-pass] sort level %d: %.1f ms; %lld radix passes over %lld elements: %lld cycles, %lld steps, refills of one line %lld, of all lines %lld\n",
+				        lv, t[13 + lv] / 1e5, t[24 + 6 * lv + 5], t[24 + 6 * lv + 4], t[24 + 6 * lv + 3], t[24 + 6 * lv], t[24 + 6 * lv + 1], t[24 + 6 * lv + 2]);
 		if (t[6])
 			fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld, candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[12]);
 		if (t[6])

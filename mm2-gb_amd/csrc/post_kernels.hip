@@ -43,27 +43,35 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
-// Per-wave LDS scratch of a radix pass: bucket counts and bounds, and a small cache of the elements at every bucket's head -- the
-// cycle permutation reads one element per step from 256 slowly advancing heads; the LINE_BYTES that follow `anchor` (a position
-// the head has passed or is at) are kept here for every bucket, so that most steps are an LDS read instead of a memory round
-// trip, and all 256 lines are fetched together (one round trip for the lot) when a head runs off its line.
-#ifndef MM2GB_POST_LINE
-#define MM2GB_POST_LINE 32
+// Per-wave LDS scratch of a radix pass: bucket bounds, and a cache of the elements at every bucket's head -- the cycle
+// permutation reads one element per step from 256 slowly advancing heads.  Every bucket owns a line of the cache whose length
+// grows with the bucket's share of the keys (a bucket that takes half of the steps gets half of the spare space), holding the
+// elements that follow `anchor` (a position the head is at or has passed).  Most steps are then an LDS read instead of a memory
+// round trip, and when a head runs off its line all lines are fetched again together: one round trip for the lot, every few
+// hundred steps whatever the distribution of the keys.
+#ifndef MM2GB_POST_LINE_BYTES
+#define MM2GB_POST_LINE_BYTES 6144
 #endif
-constexpr int LINE_BYTES = MM2GB_POST_LINE;
-struct alignas(16) PassLds { int cnt[256]; int head[256]; int tail[256]; int anchor[256]; unsigned long long line[256 * LINE_BYTES / 8]; };
+constexpr int LINE_STORE_BYTES = MM2GB_POST_LINE_BYTES;
+struct alignas(16) PassLds {
+	int where[256];              // histogram first; then line start | line length << 16
+	int head[256], tail[256], anchor[256];
+	unsigned long long line[LINE_STORE_BYTES / 8];
+	unsigned char owner[LINE_STORE_BYTES / 8];   // bucket of every line slot
+	unsigned long long burst[2 * W];             // 64 elements of whichever bucket ran off its line last (keys come in bursts)
+};
 
 // ---- the two element kinds that get sorted the host's way ----------------------------------------------------------
 // Z: candidates of the backtrack, key = score f (lchain.c:38-41: z[k].x = f[i], z[k].y = i), packed f<<32 | i.
 // H: chain heads of the compaction, key = x of the chain's first anchor, value = offset<<32 | chain (lchain.c:94-99).
 struct ZElem {
 	using T = unsigned long long;
-	static constexpr int LINE = LINE_BYTES / 8;                     // elements of one bucket head kept in LDS
+	static constexpr int SLOTS = LINE_STORE_BYTES / 8, LINE_MIN = 2;   // line slots of a wave; shortest line
 	static __device__ __forceinline__ unsigned long long key(T e) { return e >> 32; }
 };
 struct HElem {
 	using T = ulonglong2;
-	static constexpr int LINE = LINE_BYTES / 16;
+	static constexpr int SLOTS = LINE_STORE_BYTES / 16, LINE_MIN = 1;
 	static __device__ __forceinline__ unsigned long long key(const T &e) { return e.x; }
 };
 
@@ -79,6 +87,14 @@ __device__ __forceinline__ int first_set_from_top(unsigned long long m)       //
 	return hi ? __builtin_clz(hi) : 32 + __builtin_clz(lo);
 }
 
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int by)
+{
+	return (unsigned long long)(unsigned)__shfl_up((int)(unsigned)v, by) | (unsigned long long)(unsigned)__shfl_up((int)(unsigned)(v >> 32), by) << 32;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src)   // src wave-uniform
+{
+	return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32;
+}
 __device__ __forceinline__ unsigned long long bcast_elem(unsigned long long e, int src) { return __shfl(e, src); }
 __device__ __forceinline__ ulonglong2 bcast_elem(const ulonglong2 &e, int src) { return make_ulonglong2(__shfl(e.x, src), __shfl(e.y, src)); }
 
@@ -106,20 +122,33 @@ __device__ __forceinline__ void small_run_sort(typename E::T *g, int lo, int len
 	wave_sync();
 }
 
-// The elements [head, head + LINE) of every bucket that is not full yet, into the LDS lines: all lanes, one memory round trip.
-// Positions at or beyond a head still hold what they held when the pass began -- only a consumed head position is ever written --
-// so a line stays valid until the head has moved past it.
+// Every bucket's line filled from its head on: all lanes, one memory round trip (every load is issued before the first one is
+// waited for).  Positions at or beyond a head still hold what they held when the pass began -- only a consumed head position is
+// ever written -- so a line stays valid until the head has moved past it.  Positions past the end of a bucket are read too
+// (clamped to the array) and never used: a head stops at its bucket's tail.
 template <class E>
-__device__ __forceinline__ void fetch_all_lines(const typename E::T *g, PassLds &L)
+__device__ __forceinline__ void fetch_all_lines(const typename E::T *g, int last, int used, PassLds &L)
 {
 	typename E::T *line = (typename E::T*)L.line;
 	const int l = lane();
+	constexpr int ITERS = E::SLOTS / W;
+	typename E::T v[ITERS];
+	int hd[ITERS], d[ITERS], j[ITERS];
 #pragma unroll
-	for (int it = 0; it < 256 * E::LINE / W; ++it) {
-		const int slot = it * W + l, d = slot / E::LINE, j = slot % E::LINE;
-		const int hd = L.head[d];
-		if (hd + j < L.tail[d]) line[slot] = g[hd + j];
-		if (j == 0) L.anchor[d] = hd;
+	for (int it = 0; it < ITERS; ++it) {
+		const int slot = min(it * W + l, used - 1);
+		d[it] = L.owner[slot];
+		j[it] = slot - (L.where[d[it]] & 0xffff);
+		hd[it] = L.head[d[it]];
+		v[it] = g[min(hd[it] + j[it], last)];
+	}
+#pragma unroll
+	for (int it = 0; it < ITERS; ++it) {
+		const int slot = it * W + l;
+		if (slot < used) {
+			line[slot] = v[it];
+			if (j[it] == 0) L.anchor[d[it]] = hd[it];
+		}
 	}
 	wave_sync();
 }
@@ -128,15 +157,21 @@ __device__ __forceinline__ void fetch_all_lines(const typename E::T *g, PassLds 
 // the in-place cycle permutation exactly as the host does it -- element by element, each placement evicting the element
 // that decides the next one.  Returns false when every key has the same byte (the pass moves nothing).
 template <class E>
-__device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L)
+__device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L, long long *dbg = nullptr)
 {
 	const int l = lane();
-	for (int k = l; k < 256; k += W) L.cnt[k] = 0;
+	for (int k = l; k < 256; k += W) L.where[k] = 0;
 	wave_sync();
-	for (int i = lo + l; i < hi; i += W) atomicAdd(&L.cnt[(int)(E::key(g[i]) >> shift) & 255], 1);
+	for (int base = lo; base < hi; base += 4 * W) {
+		unsigned long long key[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) key[u] = E::key(g[min(base + u * W + l, hi - 1)]);
+#pragma unroll
+		for (int u = 0; u < 4; ++u) if (base + u * W + l < hi) atomicAdd(&L.where[(int)(key[u] >> shift) & 255], 1);
+	}
 	wave_sync();
 	// lane l owns buckets 4l .. 4l+3
-	const int c0 = L.cnt[4 * l], c1 = L.cnt[4 * l + 1], c2 = L.cnt[4 * l + 2], c3 = L.cnt[4 * l + 3];
+	const int c0 = L.where[4 * l], c1 = L.where[4 * l + 1], c2 = L.where[4 * l + 2], c3 = L.where[4 * l + 3];
 	const int len = hi - lo;
 	if (__ballot(c0 == len || c1 == len || c2 == len || c3 == len) != 0) return false;
 	int inc = c0 + c1 + c2 + c3;
@@ -147,9 +182,26 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 	L.head[4 * l + 1] = at; at += c1; L.tail[4 * l + 1] = at;
 	L.head[4 * l + 2] = at; at += c2; L.tail[4 * l + 2] = at;
 	L.head[4 * l + 3] = at; at += c3; L.tail[4 * l + 3] = at;
+	// line lengths: LINE_MIN each, the rest of the slots by share of the keys
+	constexpr int SPARE = E::SLOTS - 256 * E::LINE_MIN;
+	const int cap[4] = { E::LINE_MIN + (int)((long long)c0 * SPARE / len), E::LINE_MIN + (int)((long long)c1 * SPARE / len),
+	                     E::LINE_MIN + (int)((long long)c2 * SPARE / len), E::LINE_MIN + (int)((long long)c3 * SPARE / len) };
+	int cinc = cap[0] + cap[1] + cap[2] + cap[3];
+	const int cown = cinc;
+	for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(cinc, off); if (l >= off) cinc += o; }
+	const int used = __builtin_amdgcn_readlane(cinc, W - 1);
+	int cat = cinc - cown;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		L.where[4 * l + q] = cat | cap[q] << 16;
+		for (int j = 0; j < cap[q]; ++j) L.owner[cat + j] = (unsigned char)(4 * l + q);
+		cat += cap[q];
+	}
 	wave_sync();
-	fetch_all_lines<E>(g, L);
+	fetch_all_lines<E>(g, hi - 1, used, L);
 	int since = 0;                                          // cycle steps since all lines were fetched together
+	int d_steps = 0, d_one = 0, d_all = 1, d_cycles = 0;
+	int burst_d = -1, burst_at = 0;                         // bucket and first position of the burst line
 	// The host's loop, bucket by bucket: elements at the head of bucket k that already belong to k are passed over (all 64
 	// lanes look at the next 64 of them at once); the first one that does not starts a cycle, which is followed exactly as
 	// the host does -- place the carried element at the head of its bucket, pick up what was there -- until an element of
@@ -157,52 +209,69 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 	for (int k = 0; k < 256; ++k) {
 		int hk = uni(L.head[k]);
 		const int tk = uni(L.tail[k]);
-		while (hk < tk) {
+		for (; hk < tk; hk += W) {
+			// the next 64 elements of bucket k: those that belong elsewhere start a cycle each, in order.  Nothing but the end of such a
+			// cycle writes into this part of the array (at the position the cycle started from), so one load serves them all.
 			const int i = hk + l;
 			const bool in = i < tk;
 			typename E::T e = g[in ? i : hk];
-			const unsigned long long moves = __ballot(in && ((int)(E::key(e) >> shift) & 255) != k);
-			if (moves == 0) { hk = min(hk + W, tk); continue; }
-			const int skip = __builtin_ctzll(moves);
-			hk += skip;
+			unsigned long long moves = __ballot(in && ((int)(E::key(e) >> shift) & 255) != k);
+			while (((unsigned)moves | (unsigned)(moves >> 32)) != 0) {
+			const int skip = first_set(moves);
+			moves &= moves - 1;
+			++d_cycles;
 			typename E::T carry = bcast_elem(e, skip);
-			// the cycle, wave-uniform: the element at the head of the destination bucket comes from that bucket's line.  A head that
-			// has run off its line gets the next LINE elements (one round trip for this bucket alone), or -- if the last fetch of all
-			// lines is a while ago -- every bucket does: keys spread over many buckets then cost one round trip per few hundred steps,
-			// keys that crowd into one bucket no more than they did.
-			typename E::T *line = (typename E::T*)L.line;
+			// the cycle, wave-uniform: the element at the head of the destination bucket comes from that bucket's line
+			typename E::T *line = (typename E::T*)L.line, *burst = (typename E::T*)L.burst;
 			int d = uni((int)(E::key(carry) >> shift) & 255);
 			while (d != k) {
 				const int hd = uni(L.head[d]);
-				int at_line = hd - uni(L.anchor[d]);
-				if (at_line >= E::LINE) {
-					if (since >= 64) { fetch_all_lines<E>(g, L); since = 0; }
-					else {
-						if (l < E::LINE && hd + l < hi) line[d * E::LINE + l] = g[hd + l];
-						if (l == 0) L.anchor[d] = hd;
-						wave_sync();
-					}
-					at_line = 0;
+				typename E::T next;
+				if (d == burst_d && hd - burst_at < W) next = burst[hd - burst_at];
+				else {
+					const int wh = uni(L.where[d]);
+					const int l0 = wh & 0xffff, ln = wh >> 16;
+					int at_line = hd - uni(L.anchor[d]);
+					if (at_line >= ln) {
+						// off the line: all lines again, unless that was done a moment ago -- then the keys come in a burst for
+						// this bucket, and its next 64 elements go to the burst line
+						if (since >= 64) { fetch_all_lines<E>(g, hi - 1, used, L); since = 0; ++d_all; next = line[l0]; }
+						else {
+							++d_one;
+							burst[l] = g[min(hd + l, hi - 1)];
+							burst_d = d; burst_at = hd;
+							wave_sync();
+							next = burst[0];
+						}
+					} else next = line[l0 + at_line];
 				}
-				const typename E::T next = line[d * E::LINE + at_line];
 				if (l == 0) { g[hd] = carry; L.head[d] = hd + 1; }
 				carry = next;
-				++since;
+				++since; ++d_steps;
 				d = uni((int)(E::key(carry) >> shift) & 255);
 			}
-			if (l == 0) g[hk] = carry;
-			++hk;
+			if (l == 0) g[hk + skip] = carry;
+			}
 			wave_sync();
 		}
 	}
 	wave_sync();
+	if (dbg && l == 0) {
+		atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)d_steps);
+		atomicAdd((unsigned long long*)&dbg[1], (unsigned long long)d_one);
+		atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)d_all);
+		atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)d_cycles);
+		atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(hi - lo));
+		atomicAdd((unsigned long long*)&dbg[5], 1ull);
+	}
 	return true;
 }
 
 // radix_sort_128x (ksort.h:147-151) of g[0, n) by key, same final element order as the host's.
 // The host recurses bucket by bucket; buckets are independent, so the same work is done here level by level: at the level of
 // key byte `shift` the array is made of runs of elements that agree on all higher key bytes; a run longer than 64 gets a
-// radix pass on this byte, a run of 2..64 is insertion-sorted (a run that was sorted one level up is seen again: a no-op).
+// radix pass on this byte, a run of 2..64 is insertion-sorted (stable: rs_insertsort, ksort.h:105-115; a run that was sorted
+// one level up is seen again: a no-op).
 // Passes on bytes in which all keys of the run agree move nothing, so starting at the highest byte in which any two keys
 // differ equals the host's start at byte 7.
 template <class E>
@@ -223,29 +292,55 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 	while (top > 0 && ((diff >> top) & 255) == 0) top -= 8;
 	long long tlev = dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0, d_pass = 0, d_elems = 0, d_small = 0;
 	for (int shift = top; shift >= 0; shift -= 8) {
-		// runs of equal key >> (shift + 8); at the top level the whole array is one run by construction
-		int run_lo = 0;
-		unsigned long long carry_prefix = 0;
-		for (int base = 0; base < n; base += W) {
-			const int i = base + l;
+		// runs of equal key >> (shift + 8); at the top level the whole array is one run by construction.  The array is taken 64
+		// elements at a time from the start of a run: a run that does not end within them gets its radix pass; otherwise ALL the
+		// runs that end within them are insertion-sorted together -- every lane ranks its element among those of its own run --
+		// with one load and one store for the lot (short runs are many: one round trip each would be the whole cost).
+		int pos = 0;
+		while (pos < n) {
+			const int i = pos + l, n_in = min(W, n - pos);
 			const bool in = i < n;
-			const unsigned long long pk = in && shift < 56 ? E::key(g[i]) >> (shift + 8) : 0;
-			unsigned long long before = (unsigned long long)(unsigned)__shfl_up((int)(unsigned)pk, 1) | (unsigned long long)(unsigned)__shfl_up((int)(unsigned)(pk >> 32), 1) << 32;
-			if (l == 0) before = carry_prefix;
-			unsigned long long starts = __ballot(in && i > 0 && pk != before);
-			carry_prefix = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)pk, W - 1) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pk >> 32), W - 1) << 32;
-			while (starts) {
-				const int q = base + __builtin_ctzll(starts);
-				starts &= starts - 1;
-				const int len = q - run_lo;
-				if (len > SMALL_RUN) { radix_pass<E>(g, run_lo, q, shift, L); ++d_pass; d_elems += len; }
-				else if (len > 1) { small_run_sort<E>(g, run_lo, len); ++d_small; }
-				run_lo = q;
+			const typename E::T e = g[in ? i : n - 1];
+			const unsigned long long k = E::key(e);
+			const unsigned long long pk = shift < 56 ? k >> (shift + 8) : 0;
+			const bool has_after = pos + W < n;
+			const unsigned long long pk_after = has_after && shift < 56 ? E::key(g[pos + W]) >> (shift + 8) : 0;
+			const unsigned long long pk_prev = shfl_up64(pk, 1), k_prev = shfl_up64(k, 1);
+			const bool start = in && (l == 0 || pk != pk_prev);
+			const unsigned long long starts = __ballot(start);
+			const bool tail_open = has_after && pk_after == readlane64(pk, n_in - 1);   // the last run goes on beyond these 64
+			if (tail_open && (starts & (starts - 1)) == 0) {
+				// a single run of more than 64 elements: where it ends
+				const unsigned long long pk0 = readlane64(pk, 0);
+				int q = pos + W, adv;
+				do {
+					const int i2 = q + l;
+					const unsigned long long out = __ballot(i2 >= n || (shift < 56 ? E::key(g[i2]) >> (shift + 8) : 0) != pk0);
+					adv = ((unsigned)out | (unsigned)(out >> 32)) ? first_set(out) : W;
+					q += adv;
+				} while (adv == W);
+				radix_pass<E>(g, pos, q, shift, L, dbg ? dbg + 24 + 6 * min((top - shift) / 8, 2) : nullptr);
+				++d_pass; d_elems += q - pos;
+				pos = q;
+				continue;
 			}
+			const int end_c = tail_open ? 63 - first_set_from_top(starts) : n_in;   // the open run (if any) starts the next 64
+			const int rs = 63 - __clzll(starts & ((2ull << l) - 1));                // where this lane's run starts
+			const bool act = l < end_c;
+			if (__ballot(act && !start && k < k_prev) != 0) {
+				int rank = 0;
+				for (int m = 0; m < end_c; ++m) {
+					const unsigned long long km = readlane64(k, m);
+					const int rsm = __builtin_amdgcn_readlane(rs, m);
+					rank += (rsm == rs) & ((km < k) | ((km == k) & (m < l)));
+				}
+				wave_sync();
+				if (act) g[pos + rs + rank] = e;
+				++d_small;
+			}
+			wave_sync();
+			pos += end_c;
 		}
-		const int len = n - run_lo;
-		if (len > SMALL_RUN) { radix_pass<E>(g, run_lo, n, shift, L); ++d_pass; d_elems += len; }
-		else if (len > 1) { small_run_sort<E>(g, run_lo, len); ++d_small; }
 		wave_sync();
 		if (dbg && lane() == 0) {
 			const long long tn = (long long)__builtin_amdgcn_s_memrealtime();
