@@ -58,7 +58,6 @@ struct alignas(16) PassLds {
 	int head[256], tail[256], anchor[256];
 	unsigned long long line[LINE_STORE_BYTES / 8];
 	unsigned char owner[LINE_STORE_BYTES / 8];   // bucket of every line slot
-	unsigned long long burst[2 * W];             // 64 elements of whichever bucket ran off its line last (keys come in bursts)
 };
 
 // ---- the two element kinds that get sorted the host's way ----------------------------------------------------------
@@ -201,7 +200,6 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 	fetch_all_lines<E>(g, hi - 1, used, L);
 	int since = 0;                                          // cycle steps since all lines were fetched together
 	int d_steps = 0, d_one = 0, d_all = 1, d_cycles = 0;
-	int burst_d = -1, burst_at = 0;                         // bucket and first position of the burst line
 	// The host's loop, bucket by bucket: elements at the head of bucket k that already belong to k are passed over (all 64
 	// lanes look at the next 64 of them at once); the first one that does not starts a cycle, which is followed exactly as
 	// the host does -- place the carried element at the head of its bucket, pick up what was there -- until an element of
@@ -222,29 +220,24 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 			++d_cycles;
 			typename E::T carry = bcast_elem(e, skip);
 			// the cycle, wave-uniform: the element at the head of the destination bucket comes from that bucket's line
-			typename E::T *line = (typename E::T*)L.line, *burst = (typename E::T*)L.burst;
+			typename E::T *line = (typename E::T*)L.line;
 			int d = uni((int)(E::key(carry) >> shift) & 255);
 			while (d != k) {
-				const int hd = uni(L.head[d]);
-				typename E::T next;
-				if (d == burst_d && hd - burst_at < W) next = burst[hd - burst_at];
-				else {
-					const int wh = uni(L.where[d]);
-					const int l0 = wh & 0xffff, ln = wh >> 16;
-					int at_line = hd - uni(L.anchor[d]);
-					if (at_line >= ln) {
-						// off the line: all lines again, unless that was done a moment ago -- then the keys come in a burst for
-						// this bucket, and its next 64 elements go to the burst line
-						if (since >= 64) { fetch_all_lines<E>(g, hi - 1, used, L); since = 0; ++d_all; next = line[l0]; }
-						else {
-							++d_one;
-							burst[l] = g[min(hd + l, hi - 1)];
-							burst_d = d; burst_at = hd;
-							wave_sync();
-							next = burst[0];
-						}
-					} else next = line[l0 + at_line];
+				const int hd = uni(L.head[d]), wh = uni(L.where[d]);
+				const int l0 = wh & 0xffff, ln = wh >> 16;
+				int at_line = hd - uni(L.anchor[d]);
+				if (at_line >= ln) {
+					// off the line: all lines again, unless that was done a moment ago (then this line alone)
+					if (since >= 64) { fetch_all_lines<E>(g, hi - 1, used, L); since = 0; ++d_all; }
+					else {
+						++d_one;
+						for (int j = l; j < ln; j += W) line[l0 + j] = g[min(hd + j, hi - 1)];
+						if (l == 0) L.anchor[d] = hd;
+						wave_sync();
+					}
+					at_line = 0;
 				}
+				const typename E::T next = line[l0 + at_line];
 				if (l == 0) { g[hd] = carry; L.head[d] = hd + 1; }
 				carry = next;
 				++since; ++d_steps;
