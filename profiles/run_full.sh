@@ -15,3 +15,5 @@ d = json.load(open("gpurun_out/${TAG}_bench_default.json"))
 print(json.dumps(d["roofline"])[:700]); print(d["value"], d["ms_per_step"], d["post_pass_device"]["ms"], d["host_path"]["scores_only"]["seconds"], d["host_path"]["chains_rank0_alone"]["seconds"], d["cpu_baseline"]["value"], d["e2e"])
 d = json.load(open("gpurun_out/${TAG}_bench_force_dist.json")); print("force dist:", d["config"]["rendezvous"], d["value"])
 PY
+python profiles/stream_api_rate.py --out $O/${TAG}s_stream_api_rate.json > $O/${TAG}s_stream_api_rate.log 2>&1; echo "stream rate rc=$?"; grep reads_per_batch $O/${TAG}s_stream_api_rate.log | cut -c1-230
+MM2GB_POST=gpu python profiles/stream_api_rate.py --out $O/${TAG}s_stream_api_rate_device_post.json > $O/${TAG}s_stream_api_rate_device_post.log 2>&1; echo "stream rate (device post) rc=$?"; grep reads_per_batch $O/${TAG}s_stream_api_rate_device_post.log | cut -c1-230
