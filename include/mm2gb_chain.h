@@ -154,6 +154,19 @@ typedef struct {
 	float div;
 } mm2gb_reg_t;
 int  mm2gb_sort_seeds_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors);
+/*      mm2gb_collect_seeds_gpu: collect_seed_hits (map.c:295-331) with skip_seed (map.c:205-227): the matches mm_collect_matches
+ *      (seed.c:98) returned for every read -- seeds[] = the leading 16 bytes of each mm_seed_t (mmpriv.h:40-46), read by read
+ *      (seed_off: n_reads + 1), hits[] = the arrays mm_seed_t::cr points at, seed by seed (hit_off: n_seeds + 1) -- become anchors
+ *      (map.c:311-324), dropped hits removed, every read's anchors sorted as radix_sort_128x leaves them (map.c:329): the input of the
+ *      chaining calls.  opt_flag: the MM_F_* bits of mm_mapopt_t::flag that the function looks at (NO_DIAG, NO_DUAL, FOR_ONLY,
+ *      REV_ONLY, QSTRAND; others ignored).  qlen: per read.  Name tests (strcmp(qname, name), map.c:211) are given as ranks in one
+ *      common order -- q_rank per read, ref_rank per reference sequence, equal names <=> equal ranks; both may be NULL when neither
+ *      NO_DIAG nor NO_DUAL is set.  ref_len (per reference sequence) is needed for NO_DIAG and QSTRAND.  anchors must hold
+ *      hit_off[n_seeds] elements; anchor_off (n_reads + 1) receives where each read's anchors begin. ---- */
+typedef struct { uint32_t n, q_pos, span_flt, seg_tandem; } mm2gb_seed_t;
+int  mm2gb_collect_seeds_gpu(mm2gb_engine_t *eng, int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds,
+                             const int64_t *hit_off, const uint64_t *hits, const int32_t *qlen, const int32_t *q_rank,
+                             int32_t n_ref, const int32_t *ref_len, const int32_t *ref_rank, int64_t *anchor_off, mm2gb_anchor_t *anchors);
 int  mm2gb_gen_regs_gpu(mm2gb_engine_t *eng, int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash,
                         int is_qstrand, mm2gb_reg_t *regs);
 

@@ -84,7 +84,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
-                "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu"]
+                "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -148,6 +148,8 @@ def lib():
         L.mm2gb_lchain_rmq_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mm2gb_lchain_rmq_counts.restype = None
         L.mm2gb_sort_seeds_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mm2gb_collect_seeds_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mm2gb_gen_regs_gpu.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Chains), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mm2gb_batcher_create.restype = C.c_void_p
         L.mm2gb_batcher_create.argtypes = [C.POINTER(Config), C.POINTER(Misc), C.c_int, C.c_void_p, C.c_int, READ_DONE_FN, C.c_void_p]
@@ -312,6 +314,30 @@ def _engine_sort_seeds(self, anchors, offsets):
     return a
 
 
+def _engine_collect_seeds(self, flag, reads, ref_len=None, ref_rank=None):
+    """mm2gb_collect_seeds_gpu.  reads: list of dicts with seeds (n,4) uint32, hits (uint64), qlen and optionally q_rank.
+    Returns one sorted anchor array (m,2) uint64 per read."""
+    R = len(reads)
+    seed_off = np.zeros(R + 1, np.int64)
+    seed_off[1:] = np.cumsum([len(r["seeds"]) for r in reads])
+    seeds = np.ascontiguousarray(np.concatenate([np.asarray(r["seeds"], np.uint32).reshape(-1, 4) for r in reads]) if R else np.zeros((0, 4), np.uint32), dtype=np.uint32)
+    hit_off = np.zeros(len(seeds) + 1, np.int64)
+    np.cumsum(seeds[:, 0], out=hit_off[1:])
+    hits = np.ascontiguousarray(np.concatenate([np.asarray(r["hits"], np.uint64) for r in reads]) if R else np.zeros(0, np.uint64), dtype=np.uint64)
+    qlen = np.ascontiguousarray([r["qlen"] for r in reads], dtype=np.int32)
+    have_rank = any("q_rank" in r for r in reads)
+    q_rank = np.ascontiguousarray([r.get("q_rank", 0) for r in reads], dtype=np.int32) if have_rank else None
+    rl = np.ascontiguousarray(ref_len, dtype=np.int32) if ref_len is not None else None
+    rr = np.ascontiguousarray(ref_rank, dtype=np.int32) if ref_rank is not None else None
+    n_ref = len(rl) if rl is not None else (len(rr) if rr is not None else 0)
+    a_off = np.zeros(R + 1, np.int64)
+    out = np.zeros((max(len(hits), 1), 2), np.uint64)
+    _check(lib().mm2gb_collect_seeds_gpu(self._h, int(flag), R, seed_off.ctypes.data, seeds.ctypes.data, hit_off.ctypes.data, hits.ctypes.data, qlen.ctypes.data,
+                                         q_rank.ctypes.data if q_rank is not None else None, n_ref, rl.ctypes.data if rl is not None else None,
+                                         rr.ctypes.data if rr is not None else None, a_off.ctypes.data, out.ctypes.data))
+    return [out[a_off[r]:a_off[r + 1]].copy() for r in range(R)]
+
+
 def _engine_gen_regs(self, chains, qlen, hashes, is_qstrand=0):
     """mm2gb_gen_regs_gpu on a list of (u, a_out) per read: list of REG_DTYPE arrays."""
     R = len(chains)
@@ -327,6 +353,7 @@ def _engine_gen_regs(self, chains, qlen, hashes, is_qstrand=0):
 
 
 Engine.sort_seeds = _engine_sort_seeds
+Engine.collect_seeds = _engine_collect_seeds
 Engine.gen_regs = _engine_gen_regs
 
 

@@ -79,6 +79,7 @@ struct Engine {
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
 	DevBuf post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_order, post_up4, post_up16, rmq_tied, reg_out;
+	DevBuf sd_seeds, sd_seed_off, sd_hit_off, sd_hits, sd_qlen, sd_q_rank, sd_ref_len, sd_ref_rank, sd_seed_read, sd_tmp, sd_n_kept, sd_a_off, sd_out;   // mm2gb_collect_seeds_gpu
 	// what the post-pass leaves for the host, two sets: the boundary keeps two batches in flight (the results of batch k are
 	// fetched after batch k+1 has been launched)
 	struct PostOut {
@@ -131,6 +132,8 @@ struct Engine {
 	// receives, per read, the number of anchors whose range-minimum was tied (results for such a read are not the reference's)
 	int  chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out,
 	               const mm2gb_rmq_param_t *rmq = nullptr, int32_t *n_tied = nullptr);
+	int  collect_seeds(int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds, const int64_t *hit_off, const uint64_t *hits,
+	                   const int32_t *qlen, const int32_t *q_rank, int32_t n_ref, const int32_t *ref_len, const int32_t *ref_rank, int64_t *anchor_off, mm2gb_anchor_t *anchors);
 	int  sort_seeds(int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors);
 	int  gen_regs(int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash, int is_qstrand, mm2gb_reg_t *regs);
 	int  record_outputs_done(hipEvent_t ev);   // fires when every D2H enqueued so far has landed

@@ -211,6 +211,7 @@ void Engine::shutdown()
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
 	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &reg_out,
+	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
 	cap_post_n = cap_post_reads = 0;
@@ -500,6 +501,57 @@ int Engine::sort_seeds(int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *
 	return 0;
 }
 
+// collect_seed_hits (map.c:295-331) for every read of a batch: matches in, sorted anchors out.
+int Engine::collect_seeds(int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds, const int64_t *hit_off, const uint64_t *hits,
+                          const int32_t *qlen, const int32_t *q_rank, int32_t n_ref, const int32_t *ref_len, const int32_t *ref_rank, int64_t *anchor_off, mm2gb_anchor_t *anchors)
+{
+	constexpr int64_t F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_QSTRAND = 0x100000000LL;
+	if (n_reads < 0 || !seed_off || !anchor_off || seed_off[0] != 0) return fail("mm2gb_collect_seeds_gpu: seed_off[0] must be 0");
+	anchor_off[0] = 0;
+	if (n_reads == 0) return 0;
+	for (int64_t r = 0; r < n_reads; ++r) if (seed_off[r + 1] < seed_off[r]) return fail("mm2gb_collect_seeds_gpu: seed_off must be non-decreasing");
+	const int64_t n_seeds = seed_off[n_reads];
+	if (!qlen || !hit_off || (n_seeds > 0 && !seeds) || hit_off[0] != 0) return fail("mm2gb_collect_seeds_gpu: null argument, or hit_off[0] is not 0");
+	for (int64_t k = 0; k < n_seeds; ++k) if (hit_off[k + 1] - hit_off[k] != (int64_t)seeds[k].n) return fail("mm2gb_collect_seeds_gpu: hit_off does not match the seeds' hit counts");
+	const int64_t n_hits = hit_off[n_seeds];
+	for (int64_t r = 0; r < n_reads; ++r) if (hit_off[seed_off[r + 1]] - hit_off[seed_off[r]] >= ((int64_t)1 << 31)) return fail("mm2gb_collect_seeds_gpu: a read is limited to 2^31 hits");
+	const bool names = (opt_flag & (F_NO_DIAG | F_NO_DUAL)) != 0 && q_rank != nullptr;
+	if (names && (!ref_rank || n_ref <= 0)) return fail("mm2gb_collect_seeds_gpu: NO_DIAG / NO_DUAL need ref_rank");
+	if (((opt_flag & F_QSTRAND) || (names && (opt_flag & F_NO_DIAG))) && (!ref_len || n_ref <= 0)) return fail("mm2gb_collect_seeds_gpu: QSTRAND / NO_DIAG need ref_len");
+	if (n_hits == 0) { for (int64_t r = 0; r < n_reads; ++r) anchor_off[r + 1] = 0; return 0; }
+	if (!hits || !anchors) return fail("mm2gb_collect_seeds_gpu: null buffer");
+	if (ref_len || ref_rank)
+		for (int64_t h = 0; h < n_hits; ++h) if ((int64_t)(hits[h] >> 32) >= n_ref) return fail("mm2gb_collect_seeds_gpu: a hit names a reference sequence >= n_ref");
+	MM2GB_HIP(hipSetDevice(device));
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	const size_t nr = (size_t)n_reads, ns = (size_t)std::max<int64_t>(n_seeds, 1), nh = (size_t)n_hits, nf = (size_t)std::max<int32_t>(n_ref, 1);
+	if (sd_seeds.ensure(ns * 16) || sd_seed_off.ensure((nr + 1) * 8) || sd_hit_off.ensure((ns + 1) * 8) || sd_hits.ensure(nh * 8) || sd_qlen.ensure(nr * 4) ||
+	    sd_q_rank.ensure(nr * 4) || sd_ref_len.ensure(nf * 4) || sd_ref_rank.ensure(nf * 4) || sd_seed_read.ensure(ns * 4) || sd_tmp.ensure(nh * 16) ||
+	    sd_n_kept.ensure(nr * 4) || sd_a_off.ensure((nr + 1) * 8) || sd_out.ensure(nh * 16)) return -1;
+	MM2GB_HIP(hipMemcpyAsync(sd_seeds.ptr, seeds, (size_t)n_seeds * 16, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(sd_seed_off.ptr, seed_off, (nr + 1) * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(sd_hit_off.ptr, hit_off, (size_t)(n_seeds + 1) * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(sd_hits.ptr, hits, nh * 8, hipMemcpyHostToDevice, stream));
+	MM2GB_HIP(hipMemcpyAsync(sd_qlen.ptr, qlen, nr * 4, hipMemcpyHostToDevice, stream));
+	if (names) MM2GB_HIP(hipMemcpyAsync(sd_q_rank.ptr, q_rank, nr * 4, hipMemcpyHostToDevice, stream));
+	if (ref_len) MM2GB_HIP(hipMemcpyAsync(sd_ref_len.ptr, ref_len, (size_t)n_ref * 4, hipMemcpyHostToDevice, stream));
+	if (names) MM2GB_HIP(hipMemcpyAsync(sd_ref_rank.ptr, ref_rank, (size_t)n_ref * 4, hipMemcpyHostToDevice, stream));
+	SeedBatch sb;
+	sb.seeds = (const SeedRecord*)sd_seeds.ptr; sb.seed_off = (const int64_t*)sd_seed_off.ptr; sb.hit_off = (const int64_t*)sd_hit_off.ptr;
+	sb.hits = (const unsigned long long*)sd_hits.ptr; sb.qlen = (const int32_t*)sd_qlen.ptr; sb.q_rank = names ? (const int32_t*)sd_q_rank.ptr : nullptr;
+	sb.ref_len = ref_len ? (const int32_t*)sd_ref_len.ptr : nullptr; sb.ref_rank = names ? (const int32_t*)sd_ref_rank.ptr : nullptr;
+	sb.n_reads = n_reads; sb.n_seeds = n_seeds; sb.n_hits = n_hits; sb.flag = (long long)opt_flag;
+	sb.seed_read = (int32_t*)sd_seed_read.ptr; sb.tmp = (ulonglong2*)sd_tmp.ptr; sb.n_kept = (int32_t*)sd_n_kept.ptr;
+	sb.anchor_off = (int64_t*)sd_a_off.ptr; sb.out = (ulonglong2*)sd_out.ptr; sb.grid_waves = n_cu * 32;
+	static_assert(sizeof(SeedRecord) == sizeof(mm2gb_seed_t) && sizeof(mm2gb_seed_t) == 16, "seed record layout");
+	launch_collect_seeds(sb, stream);
+	MM2GB_HIP(hipGetLastError());
+	MM2GB_HIP(hipMemcpyAsync(anchor_off, sd_a_off.ptr, (nr + 1) * 8, hipMemcpyDeviceToHost, stream));
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	if (anchor_off[n_reads] > 0) MM2GB_HIP(hipMemcpy(anchors, sd_out.ptr, (size_t)anchor_off[n_reads] * 16, hipMemcpyDeviceToHost));
+	return 0;
+}
+
 // mm_gen_regs (hit.c:52-88) for every read of a batch of chains.
 int Engine::gen_regs(int64_t n_reads, const mm2gb_chains_t *ch, const int32_t *qlen, const uint32_t *hash, int is_qstrand, mm2gb_reg_t *regs)
 {
@@ -753,6 +805,13 @@ int mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64
 int mm2gb_sort_seeds_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors)
 {
 	return eng ? eng->e.sort_seeds(n_reads, offsets, anchors) : fail("mm2gb: null engine");
+}
+
+int mm2gb_collect_seeds_gpu(mm2gb_engine_t *eng, int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds,
+                            const int64_t *hit_off, const uint64_t *hits, const int32_t *qlen, const int32_t *q_rank,
+                            int32_t n_ref, const int32_t *ref_len, const int32_t *ref_rank, int64_t *anchor_off, mm2gb_anchor_t *anchors)
+{
+	return eng ? eng->e.collect_seeds(opt_flag, n_reads, seed_off, seeds, hit_off, hits, qlen, q_rank, n_ref, ref_len, ref_rank, anchor_off, anchors) : fail("mm2gb: null engine");
 }
 
 int mm2gb_gen_regs_gpu(mm2gb_engine_t *eng, int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash,

@@ -60,6 +60,27 @@ struct SortBatch {
 };
 void launch_sort_x(const SortBatch &b, hipStream_t s);
 
+// Seed matches -> anchors (collect_seed_hits, map.c:295-331, with skip_seed, map.c:205-227): every hit of every seed becomes an anchor
+// unless the options drop it; a read's anchors keep the order (seed, hit) and are then sorted like the host's (launch_sort_x).
+struct SeedRecord { uint32_t n, q_pos, span_flt, seg_tandem; };   // the leading 16 bytes of mm_seed_t (mmpriv.h:40-46)
+struct SeedBatch {
+	const SeedRecord *seeds;           // all reads' seeds, read by read
+	const int64_t *seed_off;           // n_reads + 1
+	const int64_t *hit_off;            // n_seeds + 1: seed k owns hits[hit_off[k] .. hit_off[k+1])
+	const unsigned long long *hits;    // rid << 32 | pos << 1 | strand (what mm_seed_t::cr points at)
+	const int32_t *qlen, *q_rank;      // per read (q_rank may be null: no name tests)
+	const int32_t *ref_len, *ref_rank; // per reference sequence (may be null unless the options need them)
+	int64_t        n_reads, n_seeds, n_hits;
+	long long      flag;               // MM_F_NO_DIAG | MM_F_NO_DUAL | MM_F_FOR_ONLY | MM_F_REV_ONLY | MM_F_QSTRAND (minimap.h)
+	int32_t       *seed_read;          // scratch, n_seeds: read of every seed
+	ulonglong2    *tmp;                // scratch, n_hits: anchors at their hit's position (x = ~0: dropped)
+	int32_t       *n_kept;             // scratch, n_reads
+	int64_t       *anchor_off;         // out, n_reads + 1
+	ulonglong2    *out;                // out, n_hits: the reads' anchors back to back, sorted
+	int            grid_waves;
+};
+void launch_collect_seeds(const SeedBatch &b, hipStream_t s);
+
 struct RegRecord {             // the leading 72 bytes of mm_reg1_t (minimap.h:104-119)
 	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
 	uint32_t flags, hash;

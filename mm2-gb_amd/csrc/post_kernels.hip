@@ -877,6 +877,136 @@ __global__ __launch_bounds__(POST_THREADS) void k_sort_x(SortBatch b)
 	}
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Seed matches -> anchors (collect_seed_hits, map.c:295-331).  k_seed_reads: which read a seed belongs to.  k_seed_expand: one
+// thread per hit -- its seed by bisection of hit_off, the tests of skip_seed (map.c:205-227), the anchor (map.c:311-324) written at
+// the hit's own position.  k_seed_compact: one wave per read closes the gaps of dropped hits (order kept: the sort that follows is
+// not stable and depends on it) and counts; k_seed_offsets: exclusive scan of the counts; k_seed_pack: the reads back to back.
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seed_reads(SeedBatch b)
+{
+	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < b.n_seeds; k += (int64_t)gridDim.x * blockDim.x) {
+		int64_t lo = 0, hi = b.n_reads;                   // invariant: seed_off[lo] <= k < seed_off[hi]
+		while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (b.seed_off[mid] <= k) lo = mid; else hi = mid; }
+		b.seed_read[k] = (int32_t)lo;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_seed_expand(SeedBatch b)
+{
+	constexpr long long F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_FOR_ONLY = 0x100000, F_REV_ONLY = 0x200000, F_QSTRAND = 0x100000000LL;   // minimap.h:8-9,28-29,40
+	for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < b.n_hits; h += (int64_t)gridDim.x * blockDim.x) {
+		int64_t lo = 0, hi = b.n_seeds;                   // invariant: hit_off[lo] <= h < hit_off[hi]  (seeds without hits are passed over)
+		while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (b.hit_off[mid] <= h) lo = mid; else hi = mid; }
+		const SeedRecord q = b.seeds[lo];
+		const int rd = b.seed_read[lo];
+		const int qlen = b.qlen[rd];
+		const unsigned long long r = b.hits[h];
+		const unsigned q_span = q.span_flt & 0x7fffffffu, seg_id = q.seg_tandem & 0x7fffffffu;
+		const int rpos = (int)((unsigned)r >> 1);
+		const bool same_strand = (r & 1) == (q.q_pos & 1);
+		bool skip = false, is_self = false;
+		if (b.q_rank && (b.flag & (F_NO_DIAG | F_NO_DUAL))) {                          // map.c:208-219
+			const int rid = (int)(r >> 32), qr = b.q_rank[rd], rr = b.ref_rank[rid];
+			if ((b.flag & F_NO_DIAG) && qr == rr && b.ref_len[rid] == qlen) {
+				if ((unsigned)r >> 1 == (q.q_pos >> 1)) skip = true;
+				else if (same_strand) is_self = true;
+			}
+			if (!skip && (b.flag & F_NO_DUAL) && qr > rr) skip = true;
+		}
+		if (!skip && (b.flag & (F_FOR_ONLY | F_REV_ONLY))) {                            // map.c:220-226
+			if (same_strand) skip = (b.flag & F_REV_ONLY) != 0;
+			else skip = (b.flag & F_FOR_ONLY) != 0;
+		}
+		ulonglong2 a;
+		if (skip) a = make_ulonglong2(~0ull, ~0ull);
+		else {
+			if (same_strand) {                                                          // map.c:311-313
+				a.x = (r & 0xffffffff00000000ULL) | (unsigned)rpos;
+				a.y = (unsigned long long)q_span << 32 | q.q_pos >> 1;
+			} else if (!(b.flag & F_QSTRAND)) {                                         // map.c:314-316
+				a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (unsigned)rpos;
+				a.y = (unsigned long long)q_span << 32 | (unsigned)(qlen - (int)((q.q_pos >> 1) + 1 - q_span) - 1);
+			} else {                                                                    // map.c:317-321
+				const int len = b.ref_len[r >> 32];
+				a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (unsigned)(len - (rpos + 1 - (int)q_span) - 1);
+				a.y = (unsigned long long)q_span << 32 | q.q_pos >> 1;
+			}
+			a.y |= (unsigned long long)seg_id << 48;                                    // MM_SEED_SEG_SHIFT
+			if (q.seg_tandem >> 31) a.y |= 1ULL << 42;                                  // MM_SEED_TANDEM
+			if (is_self) a.y |= 1ULL << 43;                                             // MM_SEED_SELF
+		}
+		b.tmp[h] = a;
+	}
+}
+
+__global__ __launch_bounds__(POST_THREADS) void k_seed_compact(SeedBatch b)
+{
+	const int per = POST_THREADS / W, l = lane();
+	for (int64_t r = (int64_t)blockIdx.x * per + uni(threadIdx.x / W); r < b.n_reads; r += (int64_t)gridDim.x * per) {
+		const int64_t h0 = b.hit_off[b.seed_off[r]], h1 = b.hit_off[b.seed_off[r + 1]];
+		int64_t at = h0;
+		for (int64_t base = h0; base < h1; base += W) {
+			const int64_t i = base + l;
+			const bool in = i < h1;
+			const ulonglong2 a = b.tmp[in ? i : h0];
+			const bool keep = in && !(a.x == ~0ull && a.y == ~0ull);
+			const unsigned long long m = __ballot(keep);
+			wave_sync();                                  // every lane has read its element before any lane writes (at <= base)
+			if (keep) b.tmp[at + __popcll(m & ((1ull << l) - 1))] = a;
+			at += __popcll(m);
+			wave_sync();
+		}
+		if (l == 0) b.n_kept[r] = (int32_t)(at - h0);
+	}
+}
+
+__global__ __launch_bounds__(1024) void k_seed_offsets(SeedBatch b)
+{
+	__shared__ long long s_tmp[1024 / W];
+	long long carry = 0;
+	const int w = threadIdx.x / W, l = lane();
+	for (int64_t base = 0; base < b.n_reads; base += 1024) {
+		const int64_t r = base + threadIdx.x;
+		const long long v = r < b.n_reads ? b.n_kept[r] : 0;
+		long long inc = v;
+		for (int off = 1; off < W; off <<= 1) { const long long o = __shfl_up(inc, off); if (l >= off) inc += o; }
+		__syncthreads();
+		if (l == W - 1) s_tmp[w] = inc;
+		__syncthreads();
+		long long before = 0, total = 0;
+		for (int k = 0; k < 1024 / W; ++k) { if (k < w) before += s_tmp[k]; total += s_tmp[k]; }
+		if (r < b.n_reads) b.anchor_off[r] = carry + before + inc - v;
+		carry += total;
+	}
+	if (threadIdx.x == 0) b.anchor_off[b.n_reads] = carry;
+}
+
+__global__ __launch_bounds__(POST_THREADS) void k_seed_pack(SeedBatch b)
+{
+	const int per = POST_THREADS / W, l = lane();
+	for (int64_t r = (int64_t)blockIdx.x * per + uni(threadIdx.x / W); r < b.n_reads; r += (int64_t)gridDim.x * per) {
+		const int64_t h0 = b.hit_off[b.seed_off[r]], o0 = b.anchor_off[r];
+		const int n = b.n_kept[r];
+		for (int j = l; j < n; j += W) b.out[o0 + j] = b.tmp[h0 + j];
+	}
+}
+
+void launch_collect_seeds(const SeedBatch &b, hipStream_t s)
+{
+	if (b.n_reads <= 0) return;
+	const int per = POST_THREADS / W;
+	const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, ((int64_t)b.grid_waves + per - 1) / per));
+	if (b.n_seeds > 0) hipLaunchKernelGGL(k_seed_reads, dim3((unsigned)std::min<int64_t>((b.n_seeds + 255) / 256, 65536)), dim3(256), 0, s, b);
+	if (b.n_hits > 0) hipLaunchKernelGGL(k_seed_expand, dim3((unsigned)std::min<int64_t>((b.n_hits + 255) / 256, 262144)), dim3(256), 0, s, b);
+	hipLaunchKernelGGL(k_seed_compact, dim3(rgrid), dim3(POST_THREADS), 0, s, b);
+	hipLaunchKernelGGL(k_seed_offsets, dim3(1), dim3(1024), 0, s, b);
+	hipLaunchKernelGGL(k_seed_pack, dim3(rgrid), dim3(POST_THREADS), 0, s, b);
+	SortBatch sb;
+	sb.a = b.out; sb.offsets = b.anchor_off; sb.n_reads = b.n_reads; sb.cursor = nullptr; sb.grid_waves = b.grid_waves;
+	launch_sort_x(sb, s);
+}
+
 namespace {
 __device__ __forceinline__ unsigned long long hit_hash64(unsigned long long key)   // hit.c:40-50
 {

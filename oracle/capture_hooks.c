@@ -21,6 +21,16 @@
  *   u64     u[n_u]
  *   int64   n_out
  *   u64     a_out[n_out][2]
+ *
+ * Seed matches (mm_collect_matches, seed.c:98, called by collect_seed_hits map.c:301) go to $MM2GB_CAPTURE_SEEDS:
+ *   char    magic[8] = "MMSEED1\0"
+ *   int32   qlen, n_m
+ *   u32     seed[n_m][4]        the leading 16 bytes of every mm_seed_t (mmpriv.h:40-46)
+ *   u64     hits[sum of seed.n] the arrays mm_seed_t::cr points at, concatenated
+ *   -- followed, when the matches reach chaining, by the anchors collect_seed_hits made of them (map.c:329 -> :523):
+ *   char    magic[8] = "MMANCH1\0"
+ *   int64   n
+ *   u64     a[n][2]
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -34,6 +44,7 @@ typedef struct { uint64_t x, y; } cap128_t;
 typedef cap128_t *(*lchain_dp_fn)(int, int, int, int, int, int, int, float, float, int, int, int64_t, cap128_t*, int*, uint64_t**, void*);
 typedef uint64_t *(*backtrack_fn)(void*, int64_t, const int32_t*, const int64_t*, int32_t*, int32_t*, int32_t, int32_t, int32_t, int32_t*, int32_t*);
 
+static __thread int      tl_seed_pending = 0;
 static __thread int      tl_in_dp = 0;
 static __thread int32_t *tl_f = 0;
 static __thread int64_t *tl_p = 0;
@@ -83,6 +94,17 @@ cap128_t *mg_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int
 	cap128_t *in_copy = 0, *out;
 	int64_t n_out = 0, i;
 	if (!real) real = (lchain_dp_fn)next_symbol("mg_lchain_dp");
+	if (tl_seed_pending) {                                  /* the anchors made of the matches recorded last */
+		const char *spath = getenv("MM2GB_CAPTURE_SEEDS");
+		FILE *sp = spath ? fopen(spath, "ab") : 0;
+		tl_seed_pending = 0;
+		if (sp) {
+			fwrite("MMANCH1", 1, 8, sp);
+			fwrite(&n, 8, 1, sp);
+			if (n > 0) fwrite(a, sizeof(cap128_t), (size_t)n, sp);
+			fclose(sp);
+		}
+	}
 	if (path && n > 0 && a) {
 		in_copy = (cap128_t*)malloc((size_t)n * sizeof(cap128_t));
 		memcpy(in_copy, a, (size_t)n * sizeof(cap128_t));
@@ -110,4 +132,30 @@ cap128_t *mg_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_skip, int
 	}
 	free(in_copy);
 	return out;
+}
+
+/* the leading fields of mm_seed_t (mmpriv.h:40-46), x86-64 layout: 16 bytes of counters and bit-fields, then the pointer */
+typedef struct { uint32_t w[4]; const uint64_t *cr; } cap_seed_t;
+typedef cap_seed_t *(*collect_matches_fn)(void*, int*, int, int, int, int, const void*, const void*, int64_t*, int*, int*, uint64_t**);
+
+cap_seed_t *mm_collect_matches(void *km, int *n_m_, int qlen, int max_occ, int max_max_occ, int dist, const void *mi, const void *mv,
+                               int64_t *n_a, int *rep_len, int *n_mini_pos, uint64_t **mini_pos)
+{
+	static collect_matches_fn real = 0;
+	const char *path = getenv("MM2GB_CAPTURE_SEEDS");
+	cap_seed_t *m;
+	if (!real) real = (collect_matches_fn)next_symbol("mm_collect_matches");
+	m = real(km, n_m_, qlen, max_occ, max_max_occ, dist, mi, mv, n_a, rep_len, n_mini_pos, mini_pos);
+	if (path) {
+		FILE *fp = fopen(path, "ab");
+		int32_t hdr[2] = { qlen, *n_m_ }, i;
+		if (!fp) { perror("[capture_hooks] MM2GB_CAPTURE_SEEDS"); abort(); }
+		fwrite("MMSEED1", 1, 8, fp);
+		fwrite(hdr, 4, 2, fp);
+		for (i = 0; i < *n_m_; ++i) fwrite(m[i].w, 4, 4, fp);
+		for (i = 0; i < *n_m_; ++i) if (m[i].w[0]) fwrite(m[i].cr, 8, m[i].w[0], fp);
+		fclose(fp);
+		tl_seed_pending = 1;
+	}
+	return m;
 }

@@ -316,6 +316,61 @@ orc_anchor_t *orc_lchain_dp(const orc_param_t *prm, int64_t n, const orc_anchor_
 
 void orc_free(void *ptr) { free(ptr); }
 
+/* ---- seed matches -> anchors: collect_seed_hits (map.c:295-331) with skip_seed (map.c:205-227) ------------------------------
+ * One read.  seeds[k] is the first 16 bytes of the k-th mm_seed_t (mmpriv.h:40-46: n, q_pos, q_span:31|flt:1, seg_id:31|is_tandem:1),
+ * its reference hits are hits[hit_off[k] .. hit_off[k+1]) (what mm_seed_t::cr points at: rid<<32 | pos<<1 | strand, index.c).
+ * Name comparisons (strcmp(qname, s->name), map.c:211) are given as ranks in a common order: equal names <=> equal ranks,
+ * qname > name <=> q_rank > ref_rank[rid].  Returns the number of anchors written to out[] (capacity: all hits), sorted as
+ * radix_sort_128x leaves them (map.c:329). */
+int64_t orc_collect_seeds(int64_t flag, int32_t qlen, int32_t q_rank, int64_t n_seeds, const orc_seed_t *seeds, const int64_t *hit_off,
+                          const uint64_t *hits, const int32_t *ref_len, const int32_t *ref_rank, orc_anchor_t *out)
+{
+	const int64_t F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_FOR_ONLY = 0x100000, F_REV_ONLY = 0x200000, F_QSTRAND = 0x100000000LL; /* minimap.h:8-9,28-29,40 */
+	int64_t n_a = 0, k, h;
+	for (k = 0; k < n_seeds; ++k) {
+		const orc_seed_t *q = &seeds[k];
+		const uint32_t q_span = q->span_flt & 0x7fffffffu, seg_id = q->seg_tandem & 0x7fffffffu, is_tandem = q->seg_tandem >> 31;
+		for (h = hit_off[k]; h < hit_off[k + 1]; ++h) {
+			const uint64_t r = hits[h];
+			const int32_t rpos = (int32_t)((uint32_t)r >> 1);                       /* map.c:307 */
+			const int same_strand = (r & 1) == (q->q_pos & 1);
+			int is_self = 0, skip = 0;
+			if (ref_rank && (flag & (F_NO_DIAG | F_NO_DUAL))) {                      /* map.c:208-219 (qname != NULL) */
+				const int32_t rid = (int32_t)(r >> 32);
+				const int cmp = q_rank < ref_rank[rid] ? -1 : q_rank > ref_rank[rid];
+				if ((flag & F_NO_DIAG) && cmp == 0 && ref_len[rid] == qlen) {
+					if ((uint32_t)r >> 1 == (q->q_pos >> 1)) skip = 1;
+					else if (same_strand) is_self = 1;
+				}
+				if (!skip && (flag & F_NO_DUAL) && cmp > 0) skip = 1;
+			}
+			if (!skip && (flag & (F_FOR_ONLY | F_REV_ONLY))) {                      /* map.c:220-226 */
+				if (same_strand) { if (flag & F_REV_ONLY) skip = 1; }
+				else if (flag & F_FOR_ONLY) skip = 1;
+			}
+			if (skip) continue;
+			orc_anchor_t *p = &out[n_a++];
+			if (same_strand) {                                                       /* map.c:311-313 */
+				p->x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				p->y = (uint64_t)q_span << 32 | q->q_pos >> 1;
+			} else if (!(flag & F_QSTRAND)) {                                        /* map.c:314-316 */
+				p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				p->y = (uint64_t)q_span << 32 | (uint32_t)(qlen - (int32_t)((q->q_pos >> 1) + 1 - q_span) - 1);
+			} else {                                                                 /* map.c:317-321 */
+				const int32_t len = ref_len[r >> 32];
+				p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)(len - (rpos + 1 - (int32_t)q_span) - 1);
+				p->y = (uint64_t)q_span << 32 | q->q_pos >> 1;
+			}
+			p->y |= (uint64_t)seg_id << 48;                                          /* map.c:322, MM_SEED_SEG_SHIFT */
+			if (is_tandem) p->y |= 1ULL << 42;                                       /* MM_SEED_TANDEM */
+			if (is_self) p->y |= 1ULL << 43;                                         /* MM_SEED_SELF */
+		}
+	}
+	orc_radix_sort_x(out, out + n_a);                                                /* map.c:329 */
+	return n_a;
+}
+
+
 /* ------------------------------------------------------------------------------------------------
  * chains -> hit records (hit.c:8-88)
  * ------------------------------------------------------------------------------------------------ */

@@ -38,3 +38,15 @@ def load_rmq(path):
 
 def rmq_cases():
     return sorted(glob.glob(os.path.join(GOLD, "rmq", "*.npz")))
+
+
+def load_seeds(path):
+    """tests/golden/seeds/*.npz (oracle/gen_golden_seeds.py): what the reference's collect_seed_hits was given and returned."""
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    return dict(name=os.path.basename(path)[:-4], seeds=z["seeds"], hits=z["hits"], hit_off=z["hit_off"], a=z["a"], flag=int(meta["flag"]),
+                qlen=int(meta["qlen"]), q_rank=int(meta.get("q_rank", 0)), ref_rank=meta.get("ref_rank"), ref_len=meta.get("ref_len"))
+
+
+def seed_cases():
+    return sorted(glob.glob(os.path.join(GOLD, "seeds", "*.npz")))

@@ -106,6 +106,8 @@ def lib():
         L.orc_lchain_rmq.restype = C.c_void_p
         L.orc_lchain_rmq.argtypes = [C.POINTER(RmqParam), C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.orc_collect_seeds.restype = C.c_int64
+        L.orc_collect_seeds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -394,3 +396,43 @@ def read_capture(path):
                     pen_gap=float(fl[0]), pen_skip=float(fl[1]), is_cdna=int(ints[7]), n_seg=int(ints[8]))
         recs.append(dict(prm=prm, a=a, f=f, p=p, u=u, a_out=a_out))
     return recs
+
+
+# minimap.h:8-9,28-29,40: the option bits collect_seed_hits / skip_seed look at
+MM_F_NO_DIAG, MM_F_NO_DUAL, MM_F_FOR_ONLY, MM_F_REV_ONLY, MM_F_QSTRAND = 0x001, 0x002, 0x100000, 0x200000, 0x100000000
+
+
+def collect_seeds(flag, qlen, seeds, hit_off, hits, q_rank=0, ref_len=None, ref_rank=None):
+    """The oracle's collect_seed_hits (map.c:295-331) for one read: seeds (n,4) uint32 = leading 16 bytes of mm_seed_t,
+    hits = the concatenated cr arrays, hit_off (n+1,) int64.  Returns the sorted anchors (m,2) uint64."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(-1, 4)
+    hit_off = np.ascontiguousarray(hit_off, dtype=np.int64)
+    hits = np.ascontiguousarray(hits, dtype=np.uint64)
+    out = np.empty((max(len(hits), 1), 2), dtype=np.uint64)
+    rl = np.ascontiguousarray(ref_len, dtype=np.int32) if ref_len is not None else None
+    rr = np.ascontiguousarray(ref_rank, dtype=np.int32) if ref_rank is not None else None
+    n = lib().orc_collect_seeds(int(flag), int(qlen), int(q_rank), len(seeds), seeds.ctypes.data, hit_off.ctypes.data, hits.ctypes.data,
+                                rl.ctypes.data if rl is not None else None, rr.ctypes.data if rr is not None else None, out.ctypes.data)
+    return out[:n].copy()
+
+
+def read_seed_capture(path):
+    """Parse $MM2GB_CAPTURE_SEEDS (oracle/capture_hooks.c): one dict per mm_collect_matches call that reached chaining."""
+    recs = []
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    off = 0
+    while off < len(blob):
+        magic = blob[off:off + 7]; off += 8
+        if magic == b"MMSEED1":
+            qlen, n_m = (int(v) for v in np.frombuffer(blob, dtype="<i4", count=2, offset=off)); off += 8
+            seeds = np.frombuffer(blob, dtype="<u4", count=4 * n_m, offset=off).reshape(n_m, 4).copy(); off += 16 * n_m
+            nh = int(seeds[:, 0].sum())
+            hits = np.frombuffer(blob, dtype="<u8", count=nh, offset=off).copy(); off += 8 * nh
+            hit_off = np.zeros(n_m + 1, dtype=np.int64); np.cumsum(seeds[:, 0], out=hit_off[1:])
+            recs.append(dict(qlen=qlen, seeds=seeds, hits=hits, hit_off=hit_off, a=None))
+        else:
+            assert magic == b"MMANCH1", "bad seed capture magic"
+            n = int(np.frombuffer(blob, dtype="<i8", count=1, offset=off)[0]); off += 8
+            recs[-1]["a"] = np.frombuffer(blob, dtype="<u8", count=2 * n, offset=off).reshape(n, 2).copy(); off += 16 * n
+    return [r for r in recs if r["a"] is not None]

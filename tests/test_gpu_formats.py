@@ -1,9 +1,11 @@
-"""SURVEY 8(f) N4, the two formats either side of the path that do not need an index: the seed sort upstream
-(radix_sort_128x of collect_seed_hits, map.c:329) and chains -> hit records downstream (mm_gen_regs, hit.c:52-88), on the
-device, against the oracle (pinned to the compiled reference in tests/test_oracle_vs_ref.py)."""
+"""SURVEY 8(f) N4, the formats either side of the path that do not need an index: seed matches -> anchors and the seed sort
+upstream (collect_seed_hits, map.c:295-331) and chains -> hit records downstream (mm_gen_regs, hit.c:52-88), on the device,
+against the reference's vectors and the oracle (pinned to the compiled reference in tests/test_oracle_golden.py and
+tests/test_oracle_vs_ref.py)."""
 import numpy as np
 import pytest
 
+import golden_io
 import orc
 import synth_cases as sc
 
@@ -61,3 +63,66 @@ def test_unsorted_seeds_to_hit_records(engine):
             assert np.array_equal(regs[r], want), f"read {r}: hit records differ"
             n_many += len(want) > 64
         assert n_many >= 1
+
+
+def test_seed_matches_to_anchors_reference_vectors(engine):
+    """Every recorded call of the reference's collect_seed_hits, all in ONE batch (reads with different option bits go in separate
+    calls: the bits are per call): anchors bit-identical, order of equal x included."""
+    cases = [golden_io.load_seeds(p) for p in golden_io.seed_cases()]
+    assert cases
+    groups = {}
+    for g in cases:
+        key = (g["flag"], tuple(g["ref_rank"] or ()), tuple(g["ref_len"] or ()))
+        groups.setdefault(key, []).append(g)
+    for (flag, ref_rank, ref_len), gs in groups.items():
+        reads = [dict(seeds=g["seeds"], hits=g["hits"], qlen=g["qlen"], **({"q_rank": g["q_rank"]} if ref_rank else {})) for g in gs]
+        got = engine.collect_seeds(flag, reads, ref_len=list(ref_len) or None, ref_rank=list(ref_rank) or None)
+        for g, a in zip(gs, got):
+            assert a.shape == g["a"].shape and np.array_equal(a, g["a"]), g["name"]
+
+
+def random_matches(rng, n_seeds, qlen, n_ref, max_hits, ref_len):
+    """Seed matches as mm_collect_matches could return them: any q_pos / strand, spans, segment ids, tandem bits, hit lists of any
+    length incl. empty, hits on the diagonal of a same-length reference sequence."""
+    seeds = np.zeros((n_seeds, 4), np.uint32)
+    n = rng.integers(0, max_hits + 1, n_seeds)
+    n[rng.random(n_seeds) < 0.2] = 0
+    span = rng.integers(5, 29, n_seeds)
+    qp = rng.integers(span, qlen, n_seeds)                    # last base of the k-mer
+    seeds[:, 0] = n
+    seeds[:, 1] = qp << 1 | rng.integers(0, 2, n_seeds)
+    seeds[:, 2] = span | (rng.integers(0, 2, n_seeds) << 31)
+    seeds[:, 3] = rng.integers(0, 3, n_seeds) | (rng.integers(0, 2, n_seeds) << 31)
+    hits = []
+    for k in range(n_seeds):
+        rid = rng.integers(0, n_ref, n[k])
+        pos = np.array([rng.integers(int(span[k]), ref_len[r]) for r in rid], dtype=np.int64)
+        diag = rng.random(n[k]) < 0.15
+        pos[diag] = qp[k]                                       # same position as in the query: what NO_DIAG looks for
+        hits.append((rid.astype(np.uint64) << np.uint64(32)) | (pos.astype(np.uint64) << np.uint64(1)) | rng.integers(0, 2, n[k]).astype(np.uint64))
+    return seeds, (np.concatenate(hits) if hits else np.zeros(0, np.uint64)).astype(np.uint64)
+
+
+@pytest.mark.parametrize("flag", [0, orc.MM_F_FOR_ONLY, orc.MM_F_REV_ONLY, orc.MM_F_QSTRAND, orc.MM_F_NO_DIAG, orc.MM_F_NO_DUAL,
+                                  orc.MM_F_NO_DIAG | orc.MM_F_NO_DUAL | orc.MM_F_QSTRAND, orc.MM_F_NO_DIAG | orc.MM_F_FOR_ONLY])
+def test_seed_matches_to_anchors_fuzz(engine, flag):
+    """Random matches under every combination of option bits the function looks at, reads of 0 .. 40 k hits, against the oracle."""
+    rng = np.random.default_rng(100 + (flag & 0xffff) + (flag >> 20))
+    n_ref = 7
+    ref_len = [int(v) for v in rng.integers(4000, 60000, n_ref)]
+    ref_rank = [int(v) for v in rng.permutation(n_ref)]
+    ref_rank[3] = ref_rank[5]                                   # two sequences with the same name
+    reads = []
+    for r in range(40):
+        qlen = ref_len[r % n_ref] if r % 3 == 0 else int(rng.integers(500, 70000))
+        n_seeds = 0 if r == 7 else int(rng.integers(1, 1500))
+        seeds, hits = random_matches(rng, n_seeds, qlen, n_ref, 1 if r == 11 else 40, ref_len)
+        reads.append(dict(seeds=seeds, hits=hits, qlen=qlen, q_rank=ref_rank[r % n_ref] if r % 2 == 0 else int(rng.integers(0, n_ref))))
+    got = engine.collect_seeds(flag, reads, ref_len=ref_len, ref_rank=ref_rank)
+    kept = 0
+    for r, rd in enumerate(reads):
+        hit_off = np.zeros(len(rd["seeds"]) + 1, np.int64); np.cumsum(rd["seeds"][:, 0], out=hit_off[1:])
+        want = orc.collect_seeds(flag, rd["qlen"], rd["seeds"], hit_off, rd["hits"], q_rank=rd["q_rank"], ref_len=ref_len, ref_rank=ref_rank)
+        assert got[r].shape == want.shape and np.array_equal(got[r], want), f"read {r}"
+        kept += len(want)
+    assert kept > 0

@@ -81,3 +81,12 @@ def test_rmq_oracle_matches_reference_vectors(path):
     if g["tied"] == 0:
         assert np.array_equal(o["f"], g["f"]) and np.array_equal(o["p"], g["p"])
         assert np.array_equal(o["u"], g["u"]) and np.array_equal(o["a_out"], g["a_out"])
+
+
+@pytest.mark.parametrize("path", golden_io.seed_cases(), ids=golden_io.case_ids(golden_io.seed_cases()))
+def test_seed_collection_oracle_matches_reference_vectors(path):
+    """orc_collect_seeds (collect_seed_hits + skip_seed, map.c:205-227,295-331) against the anchors the reference made of the same
+    matches: both strands, --for-only / --rev-only, the name tests of -X (diagonal dropped, self flag, dual pairs)."""
+    g = golden_io.load_seeds(path)
+    a = orc.collect_seeds(g["flag"], g["qlen"], g["seeds"], g["hit_off"], g["hits"], q_rank=g["q_rank"], ref_len=g["ref_len"], ref_rank=g["ref_rank"])
+    assert a.shape == g["a"].shape and np.array_equal(a, g["a"])
