@@ -123,6 +123,22 @@ def test_ultralong_reads_against_host_post_pass_and_oracle(engine):
         assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"])
 
 
+@pytest.mark.parametrize("lens,n_reads", [((100_000, 300_000), 600), ((10_000, 100_000), 2500)], ids=["config3_reads", "config2_reads"])
+def test_large_batches_device_post_equals_host_post(engine, lens, n_reads):
+    """Tens of millions of anchors, every size class of read, the largest reads of the bench mix: the chains of the device post-pass
+    against the host post-pass (itself checked against the oracle and the reference vectors), every read, every element."""
+    a, off = mm.synth_reads(23, 0, n_reads, lens[0], lens[1], threads=16)
+    engine.set_misc(misc_from(orc.default_param()))
+    res, st = engine.chain_gpu(a, off)
+    host, _ = engine.chain(a, off, threads=16)
+    assert len(res) == len(host) == n_reads
+    n_chains = 0
+    for r in range(n_reads):
+        assert np.array_equal(res[r][0], host[r][0]) and np.array_equal(res[r][1], host[r][1]), f"read {r}"
+        n_chains += len(res[r][0])
+    assert n_chains > n_reads
+
+
 def test_fuzz(engine):
     import os
     rng = np.random.default_rng(int(os.environ.get("MM2GB_FUZZ_SEED", 777)))
