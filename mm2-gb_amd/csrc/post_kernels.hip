@@ -32,7 +32,8 @@ constexpr int SMALL_RUN = 64;                   // RS_MIN_SIZE, ksort.h:98
 #ifndef MM2GB_POST_SPEC
 #define MM2GB_POST_SPEC 4
 #endif
-constexpr int SPEC = MM2GB_POST_SPEC;                         // steps of a chain walk every candidate of a group takes ahead of its turn
+constexpr int SPEC = MM2GB_POST_SPEC;
+static_assert(SPEC == 4, "the walk resolution spells out four look-ahead steps");                         // steps of a chain walk every candidate of a group takes ahead of its turn
 
 __device__ __forceinline__ int lane() { return threadIdx.x & (W - 1); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -448,13 +449,14 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 				wave_sync();
 				const long long ta = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 				int m0 = 1, nx[SPEC], sx[SPEC], mx[SPEC];
+				int own_kept = 0, own_best = 0, own_ended = 0, touched = 0;   // the lane's own walk as far as it can tell now
 #pragma unroll
 				for (int j = 0; j < SPEC; ++j) { nx[j] = -1; sx[j] = top_l; mx[j] = 1; }
 				if ((pending >> l) & 1) {
 					m0 = mark[n0];
 					int pc = p[n0];
 					if (m0 == 0) {
-						int cur = n0, best = 0;
+						int cur = n0, best = 0, kept = 0;
 						bool ended = false;
 #pragma unroll
 						for (int j = 0; j < SPEC; ++j) {
@@ -462,12 +464,13 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 								const int next = pc ? cur - pc : -1;
 								nx[j] = next;
 								if (next >= 0) { sx[j] = top_l - f[next]; mx[j] = mark[next]; pc = p[next]; }
-								if (sx[j] > best) best = sx[j];
+								if (sx[j] > best) { best = sx[j]; kept = j + 1; }
 								else if (best - sx[j] > b.max_drop) ended = true;
 								if (mx[j] != 0) ended = true;
 								cur = next;
 							}
 						}
+						own_kept = kept; own_best = best; own_ended = ended;
 					}
 				}
 				// The candidates in order, on wave-uniform copies of their lane's values -- no memory round trip for a walk that ends
@@ -479,7 +482,30 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 					const int src = first_set(open);                 // lowest lane = highest k
 					open &= open - 1;
 					if (__builtin_amdgcn_readlane(m0, src) != 0) continue;   // taken by an earlier walk of this group
-					const int top = __builtin_amdgcn_readlane(top_l, src), c0 = __builtin_amdgcn_readlane(n0, src);
+					const int c0 = __builtin_amdgcn_readlane(n0, src);
+					if (__builtin_amdgcn_readlane(own_ended, src) != 0 && __builtin_amdgcn_readlane(touched, src) == 0) {
+						// no earlier walk of the group took any anchor this lane looked at: its own evaluation stands (most candidates:
+						// one or two anchors, then an anchor that was taken long ago)
+						const int kept = __builtin_amdgcn_readlane(own_kept, src), best = __builtin_amdgcn_readlane(own_best, src);
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							if (j < kept) {
+								const int v = j == 0 ? c0 : __builtin_amdgcn_readlane(nx[j > 0 ? j - 1 : 0], src);
+								if (l == 0) { picked[n_v + j] = v; mark[v] = 1; }
+								const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
+								touched |= hit;
+								m0 |= n0 == v;
+#pragma unroll
+								for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
+							}
+						}
+						if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
+							if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
+							++n_u; n_v += kept;
+						}
+						continue;
+					}
+					const int top = __builtin_amdgcn_readlane(top_l, src);
 					int cn[SPEC], cs[SPEC], cm[SPEC];
 #pragma unroll
 					for (int j = 0; j < SPEC; ++j) {
@@ -506,6 +532,8 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 							if (j < kept) {
 								const int v = j == 0 ? c0 : cn[j - 1];
 								if (l == 0) mark[v] = 1;
+								const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
+								touched |= hit;
 								m0 |= n0 == v;
 #pragma unroll
 								for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
