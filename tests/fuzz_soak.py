@@ -1,4 +1,4 @@
-"""Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N] [--teams]
+"""Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N] [--teams] [--post] [--big N]
 Runs tests/synth_cases.fuzz_case batches through the HIP path and the oracle; the first batch that differs is written
 to gpurun_out/fuzz_fail_<seed>_<iteration>.npz (anchors, offsets, GPU f/p, parameters) and the exit code is 1.
 --teams adds three engines whose planner thresholds send every chunk that fits the LDS ring to the big (8/16-wave) teams and to
@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("seeds", type=int, nargs="+")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--teams", action="store_true")
+ap.add_argument("--post", action="store_true", help="also the device post-pass (mm2gb_chain_gpu): chains and compacted anchors against the host post-pass of the same scores")
 ap.add_argument("--big", type=int, default=0, help="per seed, also this many batches of bench-like reads (10-100 kb, ~1-2 M anchors) with random parameters")
 args = ap.parse_args()
 out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
@@ -28,6 +29,22 @@ def make_engine(env):
     for k in env:
         del os.environ[k]
     return e
+
+
+def post_differs(eng, a, off, prm, what):
+    """mm2gb_chain_gpu (scores + device post-pass) against mm2gb_chain_host (same scores, host post-pass); True and a dump if they differ."""
+    global failed
+    if prm.n_seg > 1 and False:
+        return False
+    dev, _ = eng.chain_gpu(a, off)
+    host, _ = eng.chain(a, off, threads=8)
+    for r in range(len(off) - 1):
+        if not (np.array_equal(dev[r][0], host[r][0]) and np.array_equal(dev[r][1], host[r][1])):
+            print("POST-PASS differs:", what, "read", r, "chains", len(dev[r][0]), len(host[r][0]), flush=True)
+            np.savez(os.path.join(out_dir, "fuzz_fail_post.npz"), a=a, off=off, prm=json.dumps(orc.param_to_dict(prm), default=float))
+            failed = True
+            return True
+    return False
 
 
 engines = [("default", make_engine({}))]
@@ -47,6 +64,8 @@ for seed in args.seeds:
             eng.set_misc(misc_from(prm))
             f, p, st = eng.score(a, off)
             seen[name][0] += st["n_long_chunks"]; seen[name][1] += st["n_mid_chunks"]
+            if args.post and name == "default":
+                post_differs(eng, a, off, prm, f"seed {seed} iteration {it}")
             bad = np.flatnonzero((f != fo) | (p != po_rel))
             if bad.size or st["n_pairs"] != pairs:
                 plain = {k: float(v) for k, v in kw.items()}
@@ -72,6 +91,8 @@ for seed in args.seeds:
         for name, eng in engines:
             eng.set_misc(misc_from(prm))
             f, p, st = eng.score(a, off)
+            if args.post and name == "default" and not post_differs(eng, a, off, prm, f"BIG seed {seed} iteration {it}"):
+                pass
             bad = np.flatnonzero((f != fo) | (p != po_rel))
             if bad.size or st["n_pairs"] != pairs:
                 plain = {k: float(v) for k, v in kw.items()}
