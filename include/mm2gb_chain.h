@@ -170,6 +170,30 @@ int  mm2gb_collect_seeds_gpu(mm2gb_engine_t *eng, int64_t opt_flag, int64_t n_re
 int  mm2gb_gen_regs_gpu(mm2gb_engine_t *eng, int64_t n_reads, const mm2gb_chains_t *chains, const int32_t *qlen, const uint32_t *hash,
                         int is_qstrand, mm2gb_reg_t *regs);
 
+/* ---- from sequence to seed matches on the host (csrc/seeding.cpp), the reference's definitions to the letter:
+ *      mm2gb_sketch: mm_sketch (sketch.c:77-143, no homopolymer compression): pairs (hash << 8 | span, rid << 32 | last_pos << 1 | strand);
+ *      mm2gb_index_*: every minimizer of the reference sequences -> its occurrences in ascending order, what mm_idx_get returns
+ *      (index.c:81-98, 213-262); mid_occ as mm_mapopt_update computes it (options.c:78-84, index.c:186-211);
+ *      mm2gb_collect_matches: mm_collect_matches (seed.c:98-131, with seed.c:5-96) for one read of one segment: the arrays
+ *      mm2gb_collect_seeds_gpu takes, plus rep_len and the minimizer positions the host's mapq / divergence estimates use.
+ *      Free a matches record with mm2gb_matches_free, a sketch with mm2gb_free. ---- */
+typedef struct mm2gb_index mm2gb_index_t;
+typedef struct { int32_t mid_occ, max_max_occ, occ_dist; float q_occ_frac; } mm2gb_seed_opt_t;   /* mm_mapopt_t: mid_occ, max_max_occ, occ_dist, q_occ_frac */
+typedef struct {
+	int32_t n_seeds, rep_len, n_mini_pos, pad_;
+	int64_t n_hits;
+	mm2gb_seed_t *seeds;      /* n_seeds */
+	uint64_t *hits;           /* n_hits: seed 0's, seed 1's, ... */
+	uint64_t *mini_pos;       /* n_mini_pos: q_span << 32 | position of the minimizer's last base (seed.c:125) */
+} mm2gb_matches_t;
+int  mm2gb_sketch(const char *seq, int32_t len, int w, int k, uint32_t rid, uint64_t **out_xy, int64_t *n_out);
+mm2gb_index_t *mm2gb_index_build(int k, int w, int32_t n_seq, const char *const *seqs, const int32_t *lens, int n_threads);
+void mm2gb_index_destroy(mm2gb_index_t *ix);
+int64_t mm2gb_index_size(const mm2gb_index_t *ix, int64_t *n_occurrences);     /* distinct minimizers */
+int32_t mm2gb_index_mid_occ(const mm2gb_index_t *ix, float mid_occ_frac, int32_t min_mid_occ, int32_t max_mid_occ);
+int  mm2gb_collect_matches(const mm2gb_index_t *ix, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out);
+void mm2gb_matches_free(mm2gb_matches_t *m);
+
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
  *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;

@@ -84,7 +84,8 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
-                "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu"]
+                "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -148,6 +149,18 @@ def lib():
         L.mm2gb_lchain_rmq_counts.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mm2gb_lchain_rmq_counts.restype = None
         L.mm2gb_sort_seeds_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.mm2gb_sketch.argtypes = [C.c_char_p, C.c_int32, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.mm2gb_index_build.restype = C.c_void_p
+        L.mm2gb_index_build.argtypes = [C.c_int, C.c_int, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_int]
+        L.mm2gb_index_destroy.restype = None
+        L.mm2gb_index_destroy.argtypes = [C.c_void_p]
+        L.mm2gb_index_size.restype = C.c_int64
+        L.mm2gb_index_size.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.mm2gb_index_mid_occ.restype = C.c_int32
+        L.mm2gb_index_mid_occ.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32]
+        L.mm2gb_collect_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.mm2gb_matches_free.restype = None
+        L.mm2gb_matches_free.argtypes = [C.c_void_p]
         L.mm2gb_collect_seeds_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mm2gb_gen_regs_gpu.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Chains), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -523,3 +536,67 @@ def synth_reads(seed, first_read, n_reads, len_lo, len_hi, threads=8):
     a = np.empty((n, 2), dtype=np.uint64)
     _check(L.mm2gb_synth_fill(seed, first_read, n_reads, len_lo, len_hi, off.ctypes.data, a.ctypes.data, threads))
     return a, off
+
+
+# ---- from sequence to seed matches on the host (csrc/seeding.cpp) ------------------------------------------------------------
+class SeedOpt(C.Structure):
+    _fields_ = [("mid_occ", C.c_int32), ("max_max_occ", C.c_int32), ("occ_dist", C.c_int32), ("q_occ_frac", C.c_float)]
+
+
+class Matches(C.Structure):
+    _fields_ = [("n_seeds", C.c_int32), ("rep_len", C.c_int32), ("n_mini_pos", C.c_int32), ("pad_", C.c_int32), ("n_hits", C.c_int64),
+                ("seeds", C.c_void_p), ("hits", C.c_void_p), ("mini_pos", C.c_void_p)]
+
+
+def sketch(seq, w=10, k=15, rid=0):
+    """mm2gb_sketch: the (w,k)-minimizers of a sequence (bytes) as an (n,2) uint64 array (x = hash << 8 | span, y = rid << 32 | pos << 1 | strand)."""
+    ptr, n = C.c_void_p(), C.c_int64()
+    _check(lib().mm2gb_sketch(seq, len(seq), w, k, rid, C.byref(ptr), C.byref(n)))
+    out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(max(n.value, 1) * 2,))[:n.value * 2].reshape(-1, 2).copy()
+    lib().mm2gb_free(ptr)
+    return out
+
+
+class SeedIndex:
+    """Minimizer index of reference sequences (list of bytes) with the look-up semantics of the reference's mm_idx_get."""
+
+    def __init__(self, seqs, k=15, w=10, threads=4):
+        self._seqs = [bytes(s) for s in seqs]
+        arr = (C.c_char_p * len(self._seqs))(*self._seqs)
+        lens = np.ascontiguousarray([len(s) for s in self._seqs], dtype=np.int32)
+        self.lens = lens
+        self._h = lib().mm2gb_index_build(k, w, len(self._seqs), arr, lens.ctypes.data, threads)
+        if not self._h:
+            raise Mm2gbError(lib().mm2gb_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().mm2gb_index_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def size(self):
+        occ = C.c_int64()
+        return int(lib().mm2gb_index_size(self._h, C.byref(occ))), int(occ.value)
+
+    def mid_occ(self, frac=2e-4, min_mid_occ=10, max_mid_occ=1000000):
+        return int(lib().mm2gb_index_mid_occ(self._h, frac, min_mid_occ, max_mid_occ))
+
+    def matches(self, seq, mid_occ, max_max_occ=4095, occ_dist=500, q_occ_frac=0.01):
+        """mm2gb_collect_matches for one read: dict(seeds (n,4) uint32, hits uint64, qlen, rep_len, mini_pos) -- the record Engine.collect_seeds takes."""
+        opt = SeedOpt(int(mid_occ), int(max_max_occ), int(occ_dist), float(q_occ_frac))
+        m = Matches()
+        _check(lib().mm2gb_collect_matches(self._h, bytes(seq), len(seq), C.byref(opt), C.byref(m)))
+        def take(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+        out = dict(seeds=take(m.seeds, m.n_seeds * 4, np.uint32).reshape(-1, 4), hits=take(m.hits, m.n_hits, np.uint64), qlen=len(seq),
+                   rep_len=int(m.rep_len), mini_pos=take(m.mini_pos, m.n_mini_pos, np.uint64))
+        lib().mm2gb_matches_free(C.byref(m))
+        return out

@@ -24,9 +24,10 @@
  *
  * Seed matches (mm_collect_matches, seed.c:98, called by collect_seed_hits map.c:301) go to $MM2GB_CAPTURE_SEEDS:
  *   char    magic[8] = "MMSEED1\0"
- *   int32   qlen, n_m
+ *   int32   qlen, n_m, rep_len, n_mini_pos
  *   u32     seed[n_m][4]        the leading 16 bytes of every mm_seed_t (mmpriv.h:40-46)
  *   u64     hits[sum of seed.n] the arrays mm_seed_t::cr points at, concatenated
+ *   u64     mini_pos[n_mini_pos]
  *   -- followed, when the matches reach chaining, by the anchors collect_seed_hits made of them (map.c:329 -> :523):
  *   char    magic[8] = "MMANCH1\0"
  *   int64   n
@@ -148,12 +149,13 @@ cap_seed_t *mm_collect_matches(void *km, int *n_m_, int qlen, int max_occ, int m
 	m = real(km, n_m_, qlen, max_occ, max_max_occ, dist, mi, mv, n_a, rep_len, n_mini_pos, mini_pos);
 	if (path) {
 		FILE *fp = fopen(path, "ab");
-		int32_t hdr[2] = { qlen, *n_m_ }, i;
+		int32_t hdr[4] = { qlen, *n_m_, *rep_len, *n_mini_pos }, i;
 		if (!fp) { perror("[capture_hooks] MM2GB_CAPTURE_SEEDS"); abort(); }
 		fwrite("MMSEED1", 1, 8, fp);
-		fwrite(hdr, 4, 2, fp);
+		fwrite(hdr, 4, 4, fp);
 		for (i = 0; i < *n_m_; ++i) fwrite(m[i].w, 4, 4, fp);
 		for (i = 0; i < *n_m_; ++i) if (m[i].w[0]) fwrite(m[i].cr, 8, m[i].w[0], fp);
+		if (*n_mini_pos > 0) fwrite(*mini_pos, 8, (size_t)*n_mini_pos, fp);
 		fclose(fp);
 		tl_seed_pending = 1;
 	}

@@ -44,8 +44,8 @@ def run(tgt, qry, extra):
 
 
 def save(name, k, r, flag, source, **names):
-    meta = dict(flag=int(flag), qlen=int(r["qlen"]), source=source, record=k, **names)
-    np.savez_compressed(os.path.join(OUT, f"{name}_{k}.npz"), seeds=r["seeds"], hits=r["hits"], hit_off=r["hit_off"], a=r["a"],
+    meta = dict(flag=int(flag), qlen=int(r["qlen"]), rep_len=int(r["rep_len"]), source=source, record=k, **names)
+    np.savez_compressed(os.path.join(OUT, f"{name}_{k}.npz"), seeds=r["seeds"], hits=r["hits"], hit_off=r["hit_off"], a=r["a"], mini_pos=r["mini_pos"],
                         meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
 
 
@@ -63,15 +63,19 @@ if __name__ == "__main__":
         for k, r in enumerate(recs):
             save(name, k, r, orc.MM_F_NO_DIAG | orc.MM_F_NO_DUAL, f"{tgt} x {qry} -X", q_rank=q_rank, ref_rank=ref_rank, ref_len=ref_len)
         print(f"{name}: {len(recs)} records, {sum(len(r['hits']) for r in recs)} hits, {sum(len(r['a']) for r in recs)} anchors")
-    # simulated long reads on a random genome with repeats (tests/sim_reads.py): seeds that hit many places
+    # simulated long reads on a random genome with repeats and tandem arrays (tests/sim_reads.py): of 150 reads the first four and the
+    # first six that cross an array (minimizers above mid_occ: dropped or thinned out, rep_len > 0); files are named by read number
     with tempfile.TemporaryDirectory() as td:
         ref_fa, reads_fa = os.path.join(td, "ref.fa"), os.path.join(td, "reads.fa")
-        sim_reads.simulate(ref_fa, reads_fa, seed=5, n_reads=8, len_lo=3_000, len_hi=20_000)
+        sim_reads.simulate(ref_fa, reads_fa, seed=5, n_reads=150, len_lo=3_000, len_hi=20_000)
         for name, extra, flag in (("sim", [], 0), ("sim_for", ["--for-only"], orc.MM_F_FOR_ONLY)):
             recs = run(ref_fa, reads_fa, extra)
-            for k, r in enumerate(recs):
-                save(name, k, r, flag, "tests/sim_reads.py seed=5 " + " ".join(extra))
-            print(f"{name}: {len(recs)} records, {sum(len(r['hits']) for r in recs)} hits, {sum(len(r['a']) for r in recs)} anchors")
+            assert len(recs) == 150
+            rep = [k for k, r in enumerate(recs) if r["rep_len"] > 0][:6]
+            pick = sorted(set([0, 1, 2, 3] + rep)) if name == "sim" else rep[:2] + [0]
+            for k in pick:
+                save(name, k, recs[k], flag, "tests/sim_reads.py seed=5 n_reads=150 " + " ".join(extra))
+            print(f"{name}: reads {pick}, {sum(len(recs[k]['hits']) for k in pick)} hits, rep_len {[recs[k]['rep_len'] for k in pick]}")
     # a small genome with repeat copies against itself, -X: off-diagonal same-strand hits of a sequence on itself carry MM_SEED_SELF,
     # and of two different sequences only the pair (smaller name -> larger name) is kept
     with tempfile.TemporaryDirectory() as td:

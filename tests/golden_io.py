@@ -45,7 +45,8 @@ def load_seeds(path):
     z = np.load(path)
     meta = json.loads(bytes(z["meta"]).decode())
     return dict(name=os.path.basename(path)[:-4], seeds=z["seeds"], hits=z["hits"], hit_off=z["hit_off"], a=z["a"], flag=int(meta["flag"]),
-                qlen=int(meta["qlen"]), q_rank=int(meta.get("q_rank", 0)), ref_rank=meta.get("ref_rank"), ref_len=meta.get("ref_len"))
+                qlen=int(meta["qlen"]), q_rank=int(meta.get("q_rank", 0)), ref_rank=meta.get("ref_rank"), ref_len=meta.get("ref_len"),
+                rep_len=int(meta["rep_len"]), mini_pos=z["mini_pos"], source=meta["source"], record=int(meta["record"]))
 
 
 def seed_cases():

@@ -425,12 +425,13 @@ def read_seed_capture(path):
     while off < len(blob):
         magic = blob[off:off + 7]; off += 8
         if magic == b"MMSEED1":
-            qlen, n_m = (int(v) for v in np.frombuffer(blob, dtype="<i4", count=2, offset=off)); off += 8
+            qlen, n_m, rep_len, n_mp = (int(v) for v in np.frombuffer(blob, dtype="<i4", count=4, offset=off)); off += 16
             seeds = np.frombuffer(blob, dtype="<u4", count=4 * n_m, offset=off).reshape(n_m, 4).copy(); off += 16 * n_m
             nh = int(seeds[:, 0].sum())
             hits = np.frombuffer(blob, dtype="<u8", count=nh, offset=off).copy(); off += 8 * nh
+            mini_pos = np.frombuffer(blob, dtype="<u8", count=n_mp, offset=off).copy(); off += 8 * n_mp
             hit_off = np.zeros(n_m + 1, dtype=np.int64); np.cumsum(seeds[:, 0], out=hit_off[1:])
-            recs.append(dict(qlen=qlen, seeds=seeds, hits=hits, hit_off=hit_off, a=None))
+            recs.append(dict(qlen=qlen, seeds=seeds, hits=hits, hit_off=hit_off, rep_len=rep_len, mini_pos=mini_pos, a=None))
         else:
             assert magic == b"MMANCH1", "bad seed capture magic"
             n = int(np.frombuffer(blob, dtype="<i8", count=1, offset=off)[0]); off += 8

@@ -126,3 +126,17 @@ def test_seed_matches_to_anchors_fuzz(engine, flag):
         assert got[r].shape == want.shape and np.array_equal(got[r], want), f"read {r}"
         kept += len(want)
     assert kept > 0
+
+
+def test_sequence_to_sorted_anchors(engine):
+    """The whole producer side without the reference: FASTA -> minimizers -> index look-up -> matches (host, csrc/seeding.cpp) -> anchors,
+    sorted (device) == the anchors the reference handed to its chaining for the same sequences."""
+    import os
+    from test_seeding_cpu import read_fasta, DATA
+    for case, tgt, qry in (("mt", "MT-human.fa", "MT-orang.fa"), ("inv", "t-inv.fa", "q-inv.fa")):
+        with mm.SeedIndex([s for _, s in read_fasta(os.path.join(DATA, tgt))]) as ix:
+            reads = [ix.matches(s, ix.mid_occ()) for _, s in read_fasta(os.path.join(DATA, qry))]
+            got = engine.collect_seeds(0, reads)
+            for k, a in enumerate(got):
+                g = golden_io.load_seeds(os.path.join(golden_io.GOLD, "seeds", f"{case}_{k}.npz"))
+                assert np.array_equal(a, g["a"]), f"{case} read {k}"
