@@ -194,6 +194,27 @@ int32_t mm2gb_index_mid_occ(const mm2gb_index_t *ix, float mid_occ_frac, int32_t
 int  mm2gb_collect_matches(const mm2gb_index_t *ix, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out);
 void mm2gb_matches_free(mm2gb_matches_t *m);
 
+/* ---- reads in, PAF out (csrc/mapper.cpp): seeding on host threads, anchors / chaining / re-chaining / hit records on the
+ *      device, primary-secondary decisions, divergence, mapping quality and the PAF line on the host, written from scratch after
+ *      mm_map_frag (map.c:630-790) for single-segment reads without base-level alignment.  Options: the fields of mm_mapopt_t this
+ *      path looks at, mm2gb_map_opt_init sets the defaults of mm_mapopt_init (options.c:15-75); chaining runs at max-chain-skip =
+ *      infinity (the GPU path's contract).  paf: malloc'd text, one line per hit in read order (free with mm2gb_free). ---- */
+typedef struct {
+	int64_t flag;              /* MM_F_FOR_ONLY | MM_F_REV_ONLY only */
+	int32_t seed, mid_occ, min_mid_occ, max_mid_occ, max_max_occ, occ_dist;
+	float   mid_occ_frac, q_occ_frac;
+	int32_t min_cnt, min_chain_score, bw, bw_long, max_gap, max_gap_ref, max_chain_iter;
+	int32_t rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
+	float   rmq_rescue_ratio, chain_gap_scale, chain_skip_scale;
+	float   mask_level; int32_t mask_len; float pri_ratio; int32_t best_n;
+	int32_t host_threads;
+} mm2gb_map_opt_t;
+typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; } mm2gb_map_stats_t;
+void mm2gb_map_opt_init(mm2gb_map_opt_t *opt);
+int  mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
+                     const mm2gb_map_opt_t *opt, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
+                     char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats);
+
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
  *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;

@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -600,3 +600,46 @@ class SeedIndex:
                    rep_len=int(m.rep_len), mini_pos=take(m.mini_pos, m.n_mini_pos, np.uint64))
         lib().mm2gb_matches_free(C.byref(m))
         return out
+
+
+class MapOpt(C.Structure):
+    _fields_ = [("flag", C.c_int64), ("seed", C.c_int32), ("mid_occ", C.c_int32), ("min_mid_occ", C.c_int32), ("max_mid_occ", C.c_int32),
+                ("max_max_occ", C.c_int32), ("occ_dist", C.c_int32), ("mid_occ_frac", C.c_float), ("q_occ_frac", C.c_float),
+                ("min_cnt", C.c_int32), ("min_chain_score", C.c_int32), ("bw", C.c_int32), ("bw_long", C.c_int32), ("max_gap", C.c_int32),
+                ("max_gap_ref", C.c_int32), ("max_chain_iter", C.c_int32), ("rmq_inner_dist", C.c_int32), ("rmq_size_cap", C.c_int32),
+                ("rmq_rescue_size", C.c_int32), ("rmq_rescue_ratio", C.c_float), ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
+                ("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32), ("host_threads", C.c_int32)]
+
+
+class MapStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_reads", "n_mapped", "n_anchors", "n_chains", "n_rechained", "n_rmq_tied")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def map_opt(**kw):
+    o = MapOpt()
+    lib().mm2gb_map_opt_init(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def map_reads(engine, index, ref_names, reads, opt=None, k=15):
+    """mm2gb_map_reads: reads = list of (name, sequence bytes); returns (PAF text, stats dict).  index: a SeedIndex of the references."""
+    L = lib()
+    L.mm2gb_map_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                  C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
+    opt = opt or map_opt()
+    rn = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    names = (C.c_char_p * len(reads))(*[n.encode() for n, _ in reads])
+    seqs_b = [bytes(s) for _, s in reads]
+    seqs = (C.c_char_p * len(reads))(*seqs_b)
+    lens = np.ascontiguousarray([len(s) for s in seqs_b], dtype=np.int32)
+    out, n, st = C.c_void_p(), C.c_int64(), MapStats()
+    _check(L.mm2gb_map_reads(engine._h, index._h, k, rn, index.lens.ctypes.data, len(ref_names), C.byref(opt), len(reads), names, seqs, lens.ctypes.data,
+                             C.byref(out), C.byref(n), C.byref(st)))
+    text = C.string_at(out, n.value).decode()
+    L.mm2gb_free(out)
+    return text, st.as_dict()
