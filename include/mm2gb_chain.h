@@ -136,6 +136,11 @@ typedef struct {
 } mm2gb_rmq_param_t;
 int  mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                          mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats);
+/* The same on host threads with the range question answered by a segment tree (csrc/rmq_host.cpp): O(log n) per anchor where the kernel
+ * scans the window -- the form for the re-chaining call of map.c:697-708, whose window is bw_long = 20 000 bases.  max_chn_skip must
+ * be INT32_MAX.  n_tied as above. */
+int  mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
+                          mm2gb_chains_t *out, int32_t *n_tied);
 mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
                                  float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km);
 void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls);   /* single-read calls so far, and how many of them met a tie */
@@ -209,7 +214,7 @@ typedef struct {
 	float   mask_level; int32_t mask_len; float pri_ratio; int32_t best_n;
 	int32_t host_threads;
 } mm2gb_map_opt_t;
-typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; } mm2gb_map_stats_t;
+typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; double s_seed, s_anchors, s_chain, s_rechain, s_regs, s_post; } mm2gb_map_stats_t;   /* s_*: seconds per stage */
 void mm2gb_map_opt_init(mm2gb_map_opt_t *opt);
 int  mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
                      const mm2gb_map_opt_t *opt, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,

@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -314,6 +314,19 @@ def _engine_rmq_chain(self, anchors, offsets, prm):
 
 
 Engine.rmq_chain = _engine_rmq_chain
+
+
+def rmq_chain_host(anchors, offsets, prm, threads=4):
+    """mm2gb_rmq_chain_host: the same re-chaining on host threads (segment tree): list of (u, a_out) per read, n_tied per read."""
+    L = lib()
+    L.mm2gb_rmq_chain_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    a = np.ascontiguousarray(anchors, dtype=np.uint64)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    R = len(off) - 1
+    out = Chains()
+    tied = np.zeros(max(R, 1), dtype=np.int32)
+    _check(L.mm2gb_rmq_chain_host(C.byref(prm), R, off.ctypes.data, a.ctypes.data, int(threads), C.byref(out), tied.ctypes.data))
+    return _take_chains(out, R), tied[:R]
 
 REG_DTYPE = np.dtype([(k, "<i4") for k in "id cnt rid score qs qe rs re parent subsc as_ mlen blen n_sub score0".split()] +
                      [("flags", "<u4"), ("hash", "<u4"), ("div", "<f4")])      # mm2gb_reg_t
@@ -612,10 +625,11 @@ class MapOpt(C.Structure):
 
 
 class MapStats(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in ("n_reads", "n_mapped", "n_anchors", "n_chains", "n_rechained", "n_rmq_tied")]
+    _fields_ = [(k, C.c_int64) for k in ("n_reads", "n_mapped", "n_anchors", "n_chains", "n_rechained", "n_rmq_tied")] + \
+               [(k, C.c_double) for k in ("s_seed", "s_anchors", "s_chain", "s_rechain", "s_regs", "s_post")]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        return {k: (round(getattr(self, k), 4) if k.startswith("s_") else int(getattr(self, k))) for k, _ in self._fields_}
 
 
 def map_opt(**kw):

@@ -2,7 +2,7 @@
 // from scratch to give the reference's output for single-segment reads mapped without base-level alignment (no -a / -c).
 //
 //   per batch of reads:   matches (seeding.cpp, host threads)  ->  anchors, sorted (device: collect_seed_hits)  ->  chains (device:
-//   chaining DP + backtrack)  ->  re-chaining of reads whose chains look broken (device: mg_lchain_rmq's fill + backtrack, map.c:697-708)
+//   chaining DP + backtrack)  ->  re-chaining of reads whose chains look broken (host threads: mg_lchain_rmq's fill as a segment tree, map.c:697-708)
 //   ->  hit records (device: mm_gen_regs)  ->  per read on the host: primary / secondary (mm_set_parent, hit.c:125-198), which
 //   secondaries stay (mm_select_sub, hit.c:272-295, mm_sync_regs hit.c:247-270), divergence estimate (mm_est_err, esterr.c:31-64),
 //   mm_filter_strand_retained (hit.c:297-309), mapping quality (mm_set_mapq, hit.c:420-466), PAF line (format.c:274-321).
@@ -12,6 +12,7 @@
 // re-chaining met a priority tie is reported: its chains may differ from the reference's there.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -246,6 +247,9 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	if (opt.mid_occ <= 0) opt.mid_occ = mm2gb_index_mid_occ(ix, opt.mid_occ_frac, opt.min_mid_occ, opt.max_mid_occ);   // options.c:78-84
 	if (opt.bw_long < opt.bw) opt.bw_long = opt.bw;
 	mm2gb_map_stats_t st_local; memset(&st_local, 0, sizeof st_local);
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_mark = now();
+	auto lap = [&](double &slot) { const double t = now(); slot += t - t_mark; t_mark = t; };
 	*paf_out = nullptr; *paf_len = 0;
 	const size_t R = (size_t)n_reads;
 	std::vector<int32_t> ref_len_v(ref_lens, ref_lens + n_ref);
@@ -265,6 +269,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		if (bad) { for (auto &m : mt) mm2gb_matches_free(&m); return -1; }
 	}
 	auto free_matches = [&]() { for (auto &m : mt) mm2gb_matches_free(&m); };
+	lap(st_local.s_seed);
 
 	// 2. anchors, sorted, on the device
 	std::vector<int64_t> seed_off(R + 1, 0);
@@ -285,6 +290,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	if (mm2gb_collect_seeds_gpu(eng, opt.flag, n_reads, seed_off.data(), seeds.data(), hit_off.data(), hits.data(), qlen.data(), nullptr, n_ref, nullptr, nullptr,
 	                            a_off.data(), anchors.data())) { free_matches(); return -1; }
 	st_local.n_anchors = a_off[R];
+	lap(st_local.s_anchors);
 
 	// 3. chains on the device; map.c:393-426 for the parameters (the GPU path chains with max-chain-skip = infinity)
 	mm2gb_misc_t misc;
@@ -301,6 +307,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	std::vector<uint64_t> u(ch.u, ch.u + u_off[R]);
 	std::vector<mm2gb_anchor_t> ca(ch.a, ch.a + c_off[R]);
 	mm2gb_chains_free(&ch);
+	lap(st_local.s_chain);
 	std::vector<int32_t> redo;
 	if (opt.bw_long > opt.bw) {
 		for (size_t r = 0; r < R; ++r) {
@@ -323,7 +330,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		const mm2gb_rmq_param_t rp = { opt.max_gap, opt.rmq_inner_dist, opt.bw_long, INT32_MAX, opt.rmq_size_cap, opt.min_cnt, opt.min_chain_score, misc.chn_pen_gap, misc.chn_pen_skip };
 		mm2gb_chains_t rc; memset(&rc, 0, sizeof rc);
 		std::vector<int32_t> tied(redo.size(), 0);
-		if (mm2gb_rmq_chain_gpu(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), &rc, tied.data(), nullptr)) { free_matches(); return -1; }
+		// on host threads: the window of this call is bw_long bases wide, a tree beats the kernel's window scan by orders of magnitude (csrc/rmq_host.cpp)
+		if (mm2gb_rmq_chain_host(&rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, tied.data())) { free_matches(); return -1; }
 		// splice the re-chained reads back in
 		std::vector<int64_t> nu_off(R + 1, 0), nc_off(R + 1, 0);
 		std::vector<int> which(R, -1);
@@ -346,6 +354,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		u.swap(nu); ca.swap(nc); u_off.swap(nu_off); c_off.swap(nc_off);
 	}
 	st_local.n_chains = u_off[R];
+	lap(st_local.s_rechain);
 
 	// 5. hit records on the device (hit.c:52-88); the hash of map.c:660-662
 	std::vector<uint32_t> hash(R);
@@ -360,6 +369,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		if (mm2gb_gen_regs_gpu(eng, n_reads, &view, qlen.data(), hash.data(), 0, regs.data())) { free_matches(); return -1; }
 	}
 
+	lap(st_local.s_regs);
 	// 6. per read on the host
 	std::vector<std::string> lines(R);
 	{
@@ -394,6 +404,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		for (auto &th : pool) th.join();
 	}
 	free_matches();
+	lap(st_local.s_post);
 	size_t total = 0;
 	for (const auto &l : lines) total += l.size();
 	char *buf = (char*)malloc(total + 1);

@@ -373,16 +373,23 @@ mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int m
 	if (!mem.use_kalloc && km) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: a kalloc arena was passed but the host allocator is not linked\n"); exit(1); }
 	if (_u) *_u = 0, *n_u_ = 0;
 	if (n == 0 || a == 0) { mem.release(a); return 0; }                       // lchain.c:260-263
-	mm2gb_misc_t misc = {};                                                   // the engine wants one; the re-chaining call carries its own thresholds
-	misc.max_iter = 5000; misc.max_dist_x = max_dist; misc.max_dist_y = max_dist; misc.max_skip = max_chn_skip; misc.bw = std::min(bw, 8000);
-	misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.n_seg = 1; misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
-	mm2gb_engine_t *eng = single_read_engine(misc);
-	if (!eng) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
 	const mm2gb_rmq_param_t prm = { max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip };
 	const int64_t off[2] = { 0, n };
 	mm2gb_chains_t out;
 	int32_t tied = 0;
-	if (mm2gb_rmq_chain_gpu(eng, &prm, 1, off, a, &out, &tied, nullptr)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+	// One read at a time: the fill is a chain of n dependent steps either way.  On the host it is O(log n) per step (segment tree,
+	// csrc/rmq_host.cpp); the kernel scans the window at every step and is for batches of reads with narrow windows (MM2GB_RMQ=gpu forces it).
+	static const bool on_device = [] { const char *v = getenv("MM2GB_RMQ"); return v && strcmp(v, "gpu") == 0; }();
+	if (!on_device && max_chn_skip == INT32_MAX) {
+		if (mm2gb_rmq_chain_host(&prm, 1, off, a, 1, &out, &tied)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+	} else {
+		mm2gb_misc_t misc = {};                                               // the engine wants one; the re-chaining call carries its own thresholds
+		misc.max_iter = 5000; misc.max_dist_x = max_dist; misc.max_dist_y = max_dist; misc.max_skip = max_chn_skip; misc.bw = std::min(bw, 8000);
+		misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.n_seg = 1; misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
+		mm2gb_engine_t *eng = single_read_engine(misc);
+		if (!eng) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+		if (mm2gb_rmq_chain_gpu(eng, &prm, 1, off, a, &out, &tied, nullptr)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+	}
 	g_rmq_calls.fetch_add(1);
 	if (tied != 0) {
 		// the reference's answer depends on the shape of its tree here: ask the reference (it consumes a[] like we would)

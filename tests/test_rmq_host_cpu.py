@@ -1,0 +1,57 @@
+"""The host form of RMQ re-chaining (csrc/rmq_host.cpp: mg_lchain_rmq's fill with a segment tree over (y, index) ranks, lchain.c:250-369)
+against the reference's own vectors and the CPU oracle.  No GPU needed."""
+import numpy as np
+import pytest
+
+import golden_io
+import orc
+import synth_cases as sc
+
+mm = pytest.importorskip("mm2gb_amd")
+
+CASES = golden_io.rmq_cases()
+
+
+def to_lib(prm):
+    return mm.RmqParam(max_dist=prm.max_dist, max_dist_inner=prm.max_dist_inner, bw=prm.bw, max_chn_skip=prm.max_chn_skip, cap_rmq_size=prm.cap_rmq_size,
+                       min_cnt=prm.min_cnt, min_sc=prm.min_sc, chn_pen_gap=np.float32(prm.pen_gap), chn_pen_skip=np.float32(prm.pen_skip))
+
+
+def first_pass(a):
+    o = orc.lchain_dp(a, orc.default_param(), want_fp=False)
+    return orc.radix_sort_x(o["a_out"]) if len(o["a_out"]) else o["a_out"]
+
+
+@pytest.mark.parametrize("path", CASES, ids=golden_io.case_ids(CASES))
+def test_reference_vectors(path):
+    g = golden_io.load_rmq(path)
+    if g["prm"].max_chn_skip != orc.INT32_MAX:
+        pytest.skip("recorded with a finite max_chn_skip; this form is exhaustive by contract")
+    res, tied = mm.rmq_chain_host(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]), threads=1)
+    assert int(tied[0]) == g["tied"]
+    if g["tied"] == 0:
+        assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
+
+
+def test_batch_against_the_oracle():
+    """Reads re-chained in one call on several threads, under the parameter sets the device test uses plus the real call's (bw = bw_long
+    = 20 000, map.c:704): tie counts and chains equal the oracle's (same stated tie rule)."""
+    a, off = mm.synth_reads(41, 0, 24, 10_000, 90_000)
+    reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(24)]
+    reads.insert(7, np.zeros((0, 2), np.uint64))
+    rng = np.random.default_rng(3)
+    reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(900, 1), np.zeros(900, np.int64), 1000 + rng.integers(0, 150, 900), 100 + rng.integers(0, 150, 900)))))
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    for kw in (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(bw=20000, max_dist=5000, max_dist_inner=1000),
+               dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05))):
+        prm = orc.default_rmq_param(**kw)
+        res, tied = mm.rmq_chain_host(allr, o2, to_lib(prm), threads=4)
+        n_with_ties = 0
+        for r, x in enumerate(reads):
+            o = orc.lchain_rmq(x, prm)
+            assert int(tied[r]) == o["n_tied"], (kw, r)
+            n_with_ties += o["n_tied"] > 0
+            assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r)
+        assert n_with_ties >= 1
