@@ -2,14 +2,13 @@
 // from scratch to give the reference's output for single-segment reads mapped without base-level alignment (no -a / -c).
 //
 //   per batch of reads:   matches (seeding.cpp, host threads)  ->  anchors, sorted (device: collect_seed_hits)  ->  chains (device:
-//   chaining DP + backtrack)  ->  re-chaining of reads whose chains look broken (host threads: mg_lchain_rmq's fill as a segment tree, map.c:697-708)
+//   chaining DP + backtrack)  ->  re-chaining of reads whose chains look broken (host threads: mg_lchain_rmq with the reference's tree, csrc/rmq_host.cpp, map.c:697-708)
 //   ->  hit records (device: mm_gen_regs)  ->  per read on the host: primary / secondary (mm_set_parent, hit.c:125-198), which
 //   secondaries stay (mm_select_sub, hit.c:272-295, mm_sync_regs hit.c:247-270), divergence estimate (mm_est_err, esterr.c:31-64),
 //   mm_filter_strand_retained (hit.c:297-309), mapping quality (mm_set_mapq, hit.c:420-466), PAF line (format.c:274-321).
 //
 // Not reproduced: more than one query segment, base-level alignment and everything that depends on it (inversions, cs/MD, SAM),
-// ALT contigs, the heap variant of seed collection, homopolymer-compressed indexes, --qstrand, multi-part indexes.  A read whose RMQ
-// re-chaining met a priority tie is reported: its chains may differ from the reference's there.
+// ALT contigs, the heap variant of seed collection, homopolymer-compressed indexes, --qstrand, multi-part indexes.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -330,7 +329,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		const mm2gb_rmq_param_t rp = { opt.max_gap, opt.rmq_inner_dist, opt.bw_long, INT32_MAX, opt.rmq_size_cap, opt.min_cnt, opt.min_chain_score, misc.chn_pen_gap, misc.chn_pen_skip };
 		mm2gb_chains_t rc; memset(&rc, 0, sizeof rc);
 		std::vector<int32_t> tied(redo.size(), 0);
-		// on host threads: the window of this call is bw_long bases wide, a tree beats the kernel's window scan by orders of magnitude (csrc/rmq_host.cpp)
+		// on host threads: the window of this call is bw_long bases wide, a tree beats the kernel's window scan by orders of magnitude, and
+		// this tree breaks priority ties as the reference's does (csrc/rmq_host.cpp)
 		if (mm2gb_rmq_chain_host(&rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, tied.data())) { free_matches(); return -1; }
 		// splice the re-chained reads back in
 		std::vector<int64_t> nu_off(R + 1, 0), nc_off(R + 1, 0);

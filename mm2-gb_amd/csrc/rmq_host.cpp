@@ -3,11 +3,12 @@
 // The reference keeps the anchors within max_dist of the current one in a balanced tree ordered by (y, index) and asks it for the
 // element of smallest priority in a y-range (krmq.h): O(log n) per anchor.  The device kernel k_rmq_fill answers the same question by
 // scanning the window -- fine for windows of a few hundred anchors, hopeless for the re-chaining call of map.c:697-708, whose window
-// is bw_long = 20 000 bases wide (thousands of anchors, scanned once per anchor, one anchor after the other).  Here the range
-// question goes to a segment tree over the anchors' ranks in (y, index) order: a leaf is live while its anchor is inside the window;
-// a node keeps the best key below it, where it sits (larger rank wins ties) and how many leaves share it.  Same answers as the
-// reference whenever the best key in range is unique; when several elements tie the reference's choice depends on the shape of its
-// tree, and the read is counted in n_tied, exactly like the device form.
+// is bw_long = 20 000 bases wide (thousands of anchors, scanned once per anchor, one anchor after the other).
+// When several elements in range share the smallest priority, WHICH of them the reference returns depends on the shape of its tree
+// and on how it keeps each subtree's minimum (krmq.h:146-150: a node, then its left subtree's, then its right subtree's, each
+// replacing the other only if strictly smaller) and walks the two search paths (krmq.h:108-148).  So the tree here is that tree: an
+// AVL tree with the same insertion, deletion and rotation rules and the same bookkeeping, on arrays indexed by anchor number
+// (ShapeTree below) -- the chains are then the reference's for every read, ties included; nothing is left to report.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -46,85 +47,243 @@ inline int pair_score(const mm2gb_anchor_t &ai, const mm2gb_anchor_t &aj, float 
 	return sc;
 }
 
-struct Node { double key; int rank, cnt; };    // cnt == 0: nothing live below
+// The reference's tree (krmq.h) on arrays.  Node = anchor index; node n is scratch (the stand-in root of a deletion, krmq.h:262).
+// kid[0] / kid[1]: left / right child (-1: none); low[v]: the node of smallest priority in v's subtree, ties as described above;
+// tilt: AVL balance factor (right height - left height); count: nodes in the subtree.
+struct ShapeTree {
+	const mm2gb_anchor_t *a = nullptr;
+	std::vector<int> kid[2], low;
+	std::vector<signed char> tilt;
+	std::vector<unsigned> count;
+	std::vector<double> pri;
+	int root = -1, scratch = 0;
+	static constexpr int MAX_DEPTH = 64;
 
-inline Node better(const Node &a, const Node &b)
-{
-	if (a.cnt == 0) return b;
-	if (b.cnt == 0) return a;
-	if (a.key > b.key) return a;
-	if (b.key > a.key) return b;
-	Node r = a.rank > b.rank ? a : b;
-	r.cnt = a.cnt + b.cnt;
-	return r;
-}
+	void reset(const mm2gb_anchor_t *anchors, int n)
+	{
+		a = anchors; root = -1; scratch = n;
+		for (auto *v : { &kid[0], &kid[1], &low }) v->assign((size_t)n + 1, -1);
+		tilt.assign((size_t)n + 1, 0); count.assign((size_t)n + 1, 0); pri.assign((size_t)n + 1, 0.0);
+	}
+	// order of (y, index) pairs (lchain.c:225): the key of node v is (y of anchor v, v)
+	int order(int y, int64_t i, int v) const
+	{
+		const int yv = (int32_t)a[v].y;
+		return y < yv ? -1 : y > yv ? 1 : (i > v) - (i < v);
+	}
+	bool lower(int u, int v) const { return pri[(size_t)u] < pri[(size_t)v]; }              // lchain.c:226
+	unsigned below(int v, int side) const { const int c = kid[side][(size_t)v]; return c < 0 ? 0u : count[(size_t)c]; }
+	// krmq.h:146-150
+	void refresh_low(int v, int first, int second)
+	{
+		int m = (first < 0 || lower(v, low[(size_t)first])) ? v : low[(size_t)first];
+		m = (second < 0 || lower(m, low[(size_t)second])) ? m : low[(size_t)second];
+		low[(size_t)v] = m;
+	}
+	// krmq.h:151-163: (a,(b,c)q)p => ((a,b)p,c)q for side == 0, mirrored for side == 1
+	int rotate_once(int p, int side)
+	{
+		const int other = 1 - side, q = kid[other][(size_t)p], keep = low[(size_t)p];
+		const unsigned was = count[(size_t)p];
+		count[(size_t)p] -= count[(size_t)q] - below(q, side);
+		count[(size_t)q] = was;
+		refresh_low(p, kid[side][(size_t)p], kid[side][(size_t)q]);
+		low[(size_t)q] = keep;
+		kid[other][(size_t)p] = kid[side][(size_t)q];
+		kid[side][(size_t)q] = p;
+		return q;
+	}
+	// krmq.h:164-187: (a,((b,c)r,d)q)p => ((a,b)p,(c,d)q)r
+	int rotate_twice(int p, int side)
+	{
+		const int other = 1 - side, q = kid[other][(size_t)p], r = kid[side][(size_t)q], keep = low[(size_t)p];
+		const unsigned inner = below(r, side);
+		count[(size_t)r] = count[(size_t)p];
+		count[(size_t)p] -= count[(size_t)q] - inner;
+		count[(size_t)q] -= inner + 1;
+		refresh_low(p, kid[side][(size_t)p], kid[side][(size_t)r]);
+		refresh_low(q, kid[other][(size_t)q], kid[other][(size_t)r]);
+		low[(size_t)r] = keep;
+		kid[other][(size_t)p] = kid[side][(size_t)r];
+		kid[side][(size_t)r] = p;
+		kid[side][(size_t)q] = kid[other][(size_t)r];
+		kid[other][(size_t)r] = q;
+		const int lean = side == 0 ? +1 : -1;
+		if (tilt[(size_t)r] == lean) { tilt[(size_t)q] = 0; tilt[(size_t)p] = (signed char)-lean; }
+		else if (tilt[(size_t)r] == 0) tilt[(size_t)q] = tilt[(size_t)p] = 0;
+		else { tilt[(size_t)q] = (signed char)lean; tilt[(size_t)p] = 0; }
+		tilt[(size_t)r] = 0;
+		return r;
+	}
+	// krmq.h:189-240
+	void insert(int x, double priority)
+	{
+		unsigned char turn[MAX_DEPTH];
+		int path[MAX_DEPTH];
+		int pivot = root, above_pivot = -1, p = root, q = -1, top = 0, len = 0, side = 0;
+		for (; p >= 0; q = p, p = kid[side][(size_t)p]) {
+			const int c = order((int32_t)a[x].y, x, p);
+			if (tilt[(size_t)p] != 0) { above_pivot = q; pivot = p; top = 0; }
+			turn[top++] = (unsigned char)(side = c > 0);
+			path[len++] = p;
+		}
+		pri[(size_t)x] = priority;
+		tilt[(size_t)x] = 0; count[(size_t)x] = 1; kid[0][(size_t)x] = kid[1][(size_t)x] = -1; low[(size_t)x] = x;
+		if (q < 0) root = x; else kid[side][(size_t)q] = x;
+		if (pivot < 0) return;
+		for (int i = 0; i < len; ++i) ++count[(size_t)path[i]];
+		for (int i = len - 1; i >= 0; --i) {
+			refresh_low(path[i], kid[0][(size_t)path[i]], kid[1][(size_t)path[i]]);
+			if (low[(size_t)path[i]] != x) break;
+		}
+		top = 0;
+		for (p = pivot; p != x; p = kid[turn[top]][(size_t)p], ++top) tilt[(size_t)p] += turn[top] == 0 ? -1 : +1;
+		if (tilt[(size_t)pivot] > -2 && tilt[(size_t)pivot] < 2) return;
+		side = tilt[(size_t)pivot] < 0;
+		const int lean = side == 0 ? +1 : -1;
+		q = kid[1 - side][(size_t)pivot];
+		int r;
+		if (tilt[(size_t)q] == lean) { r = rotate_once(pivot, side); tilt[(size_t)q] = tilt[(size_t)pivot] = 0; }
+		else r = rotate_twice(pivot, side);
+		if (above_pivot < 0) root = r; else kid[pivot != kid[0][(size_t)above_pivot]][(size_t)above_pivot] = r;
+	}
+	// krmq.h:242-325 for a node that is in the tree
+	void erase(int x)
+	{
+		if (root < 0) return;
+		int path[MAX_DEPTH];
+		unsigned char turn[MAX_DEPTH];
+		const int f = scratch;
+		kid[0][(size_t)f] = root; kid[1][(size_t)f] = -1; low[(size_t)f] = low[(size_t)root]; tilt[(size_t)f] = tilt[(size_t)root];
+		count[(size_t)f] = count[(size_t)root]; pri[(size_t)f] = pri[(size_t)root];
+		int d = 0, p = f;
+		for (int c = -1; c != 0; c = order((int32_t)a[x].y, x, p)) {
+			const int side = c > 0;
+			turn[d] = (unsigned char)side; path[d++] = p;
+			p = kid[side][(size_t)p];
+			if (p < 0) return;
+		}
+		for (int i = 1; i < d; ++i) --count[(size_t)path[i]];
+		if (kid[1][(size_t)p] < 0) kid[turn[d - 1]][(size_t)path[d - 1]] = kid[0][(size_t)p];
+		else {
+			int q = kid[1][(size_t)p];
+			if (kid[0][(size_t)q] < 0) {
+				kid[0][(size_t)q] = kid[0][(size_t)p];
+				tilt[(size_t)q] = tilt[(size_t)p];
+				kid[turn[d - 1]][(size_t)path[d - 1]] = q;
+				path[d] = q; turn[d++] = 1;
+				count[(size_t)q] = count[(size_t)p] - 1;
+			} else {
+				int r;
+				const int e = d++;
+				for (;;) {
+					turn[d] = 0; path[d++] = q;
+					r = kid[0][(size_t)q];
+					if (kid[0][(size_t)r] < 0) break;
+					q = r;
+				}
+				kid[0][(size_t)r] = kid[0][(size_t)p];
+				kid[0][(size_t)q] = kid[1][(size_t)r];
+				kid[1][(size_t)r] = kid[1][(size_t)p];
+				tilt[(size_t)r] = tilt[(size_t)p];
+				kid[turn[e - 1]][(size_t)path[e - 1]] = r;
+				path[e] = r; turn[e] = 1;
+				for (int i = e + 1; i < d; ++i) --count[(size_t)path[i]];
+				count[(size_t)r] = count[(size_t)p] - 1;
+			}
+		}
+		for (int i = d - 1; i >= 0; --i) refresh_low(path[i], kid[0][(size_t)path[i]], kid[1][(size_t)path[i]]);
+		while (--d > 0) {
+			const int q = path[d], side = turn[d], other = 1 - side;
+			const int b1 = side ? -1 : 1, b2 = side ? -2 : 2;
+			tilt[(size_t)q] += (signed char)b1;
+			if (tilt[(size_t)q] == b1) break;
+			if (tilt[(size_t)q] == b2) {
+				const int r = kid[other][(size_t)q];
+				if (tilt[(size_t)r] == -b1) kid[turn[d - 1]][(size_t)path[d - 1]] = rotate_twice(q, side);
+				else {
+					kid[turn[d - 1]][(size_t)path[d - 1]] = rotate_once(q, side);
+					if (tilt[(size_t)r] == 0) { tilt[(size_t)r] = (signed char)-b1; tilt[(size_t)q] = (signed char)b1; break; }
+					tilt[(size_t)r] = tilt[(size_t)q] = 0;
+				}
+			}
+		}
+		root = kid[0][(size_t)f];
+	}
+	// krmq.h:108-148: the node of smallest priority among those with (y_lo, i_lo) <= key <= (y_hi, i_hi), -1 if none
+	int lowest_between(int y_lo, int64_t i_lo, int y_hi, int64_t i_hi) const
+	{
+		if (root < 0) return -1;
+		int path[2][MAX_DEPTH], went[2][MAX_DEPTH], len[2] = { 0, 0 };
+		for (int side = 0; side < 2; ++side)
+			for (int p = root; p >= 0;) {
+				const int c = side == 0 ? order(y_lo, i_lo, p) : order(y_hi, i_hi, p);
+				path[side][len[side]] = p; went[side][len[side]++] = c;
+				if (c < 0) p = kid[0][(size_t)p]; else if (c > 0) p = kid[1][(size_t)p]; else break;
+			}
+		int fork = 0;
+		for (; fork < len[0] && fork < len[1]; ++fork)
+			if (path[0][fork] == path[1][fork] && went[0][fork] <= 0 && went[1][fork] >= 0) break;
+		if (fork == len[0] || fork == len[1]) return -1;
+		int m = path[0][fork];
+		for (int i = fork + 1; i < len[0]; ++i)
+			if (went[0][i] <= 0) {
+				const int v = path[0][i], c = kid[1][(size_t)v];
+				if (lower(v, m)) m = v;
+				if (c >= 0 && lower(low[(size_t)c], m)) m = low[(size_t)c];
+			}
+		for (int i = fork + 1; i < len[1]; ++i)
+			if (went[1][i] >= 0) {
+				const int v = path[1][i], c = kid[0][(size_t)v];
+				if (lower(v, m)) m = v;
+				if (c >= 0 && lower(low[(size_t)c], m)) m = low[(size_t)c];
+			}
+		return m;
+	}
+	unsigned size() const { return root < 0 ? 0u : count[(size_t)root]; }
+};
 
-struct FillScratch { std::vector<Node> tree; std::vector<int> rank_of, by_rank; std::vector<int> ys; std::vector<uint64_t> inner; };   // inner: y << 32 | index of the inner window's anchors, ascending
+struct FillScratch { ShapeTree tree; std::vector<uint64_t> inner; };   // inner: y << 32 | index of the inner window's anchors, ascending
 
-// f[n], p_rel[n] (i - predecessor, 0 = none); returns the number of anchors whose range-minimum was shared by several elements
-int64_t rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws)
+// f[n], p_rel[n] (i - predecessor, 0 = none) of one read
+void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws)
 {
 	const int n = (int)n64;
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                                   // lchain.c:264
 	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;         // lchain.c:265
 	const double half_gap = 0.5 * (double)P.chn_pen_gap;
-	// ranks in (y, index) order
-	ws.by_rank.resize((size_t)n); ws.rank_of.resize((size_t)n); ws.ys.resize((size_t)n);
-	for (int j = 0; j < n; ++j) ws.by_rank[(size_t)j] = j;
-	std::sort(ws.by_rank.begin(), ws.by_rank.end(), [&](int u, int v) { const int yu = (int32_t)a[u].y, yv = (int32_t)a[v].y; return yu != yv ? yu < yv : u < v; });
-	for (int k = 0; k < n; ++k) { ws.rank_of[(size_t)ws.by_rank[(size_t)k]] = k; ws.ys[(size_t)k] = (int32_t)a[ws.by_rank[(size_t)k]].y; }
-	int leaves = 1;
-	while (leaves < n) leaves <<= 1;
-	ws.tree.assign((size_t)2 * leaves, Node{ 0.0, -1, 0 });
-	auto set_leaf = [&](int rank, const Node &v) {
-		size_t at = (size_t)(leaves + rank);
-		ws.tree[at] = v;
-		for (at >>= 1; at >= 1; at >>= 1) ws.tree[at] = better(ws.tree[2 * at], ws.tree[2 * at + 1]);
-	};
-	auto best_in = [&](int lo, int hi) {                     // ranks [lo, hi)
-		Node res{ 0.0, -1, 0 };
-		for (size_t l = (size_t)(leaves + lo), r = (size_t)(leaves + hi); l < r; l >>= 1, r >>= 1) {
-			if (l & 1) res = better(res, ws.tree[l++]);
-			if (r & 1) res = better(res, ws.tree[--r]);
-		}
-		return res;
-	};
-	int64_t tied = 0;
-	int i0 = 0, st = 0, st_in = 0;
+	ShapeTree &tree = ws.tree;
+	tree.reset(a, n);
 	ws.inner.clear();
 	auto inner_key = [&](int j) { return (uint64_t)(uint32_t)(int32_t)a[j].y << 32 | (uint32_t)j; };   // query positions are non-negative
+	int i0 = 0, st = 0, st_in = 0;
 	for (int i = 0; i < n; ++i) {
 		const int yi = (int32_t)a[i].y, q_i = (int)(a[i].y >> 32 & 0xff);
 		if (i0 < i && a[i0].x != a[i].x) {                     // lchain.c:279-292: the anchors before the run of equal x that holds i go in
 			for (int j = i0; j < i; ++j) {
-				set_leaf(ws.rank_of[(size_t)j], Node{ (double)f[j] + half_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y), ws.rank_of[(size_t)j], 1 });
-				if (max_inner > 0 && j >= st_in) { const uint64_t k = inner_key(j); ws.inner.insert(std::lower_bound(ws.inner.begin(), ws.inner.end(), k), k); }
+				tree.insert(j, -((double)f[j] + half_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y)));          // lchain.c:284
+				if (max_inner > 0) { const uint64_t k = inner_key(j); ws.inner.insert(std::lower_bound(ws.inner.begin(), ws.inner.end(), k), k); }
 			}
 			i0 = i;
 		}
 		// lchain.c:293-310: out of reach (other strand | reference, too far back) or too many in the tree
-		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist || (i0 > st ? i0 - st : 0) > P.cap_rmq_size)) {
-			if (st < i0) set_leaf(ws.rank_of[(size_t)st], Node{ 0.0, -1, 0 });
+		while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist || (int64_t)tree.size() > P.cap_rmq_size)) {
+			if (st < i0) tree.erase(st);
 			++st;
 		}
 		if (max_inner > 0)
-			while (st_in < i && (a[i].x >> 32 != a[st_in].x >> 32 || a[i].x > a[st_in].x + (uint64_t)max_inner || (i0 > st_in ? i0 - st_in : 0) > P.cap_rmq_size)) {
-				if (st_in < i0) { const uint64_t k = inner_key(st_in); ws.inner.erase(std::lower_bound(ws.inner.begin(), ws.inner.end(), k)); }
+			while (st_in < i && (a[i].x >> 32 != a[st_in].x >> 32 || a[i].x > a[st_in].x + (uint64_t)max_inner || (int64_t)ws.inner.size() > P.cap_rmq_size)) {
+				if (st_in < i0) { const uint64_t k = inner_key(st_in); const auto it = std::lower_bound(ws.inner.begin(), ws.inner.end(), k); if (it != ws.inner.end() && *it == k) ws.inner.erase(it); }
 				++st_in;
 			}
 		int max_f = q_i, max_j = -1;
-		// lchain.c:311-315: the closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index): yi - max_dist < y < yi, or anchor 0 itself at y == yi
-		const int lo = (int)(std::upper_bound(ws.ys.begin(), ws.ys.end(), yi - max_dist) - ws.ys.begin());
-		const int hi = (int)(std::lower_bound(ws.ys.begin(), ws.ys.end(), yi) - ws.ys.begin());
-		Node best = lo < hi ? best_in(lo, hi) : Node{ 0.0, -1, 0 };
-		if ((int32_t)a[0].y == yi && st == 0 && i0 > 0) best = better(best, ws.tree[(size_t)(leaves + ws.rank_of[0])]);
-		if (best.cnt > 0) {
-			if (best.cnt > 1) ++tied;
-			const int j = ws.by_rank[(size_t)best.rank];
+		// lchain.c:311-315: the closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index)
+		const int j = tree.lowest_between(yi - max_dist, INT32_MAX, yi, 0);
+		if (j >= 0) {
 			bool exact; int width;
 			const int sc = f[j] + pair_score(a[i], a[j], P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
 			if (width <= P.bw && sc > max_f) { max_f = sc; max_j = j; }
-			if (!exact && max_inner > 0 && st_in < i0 && yi > 0) {
+			if (!exact && max_inner > 0 && !ws.inner.empty() && yi > 0) {
 				// lchain.c:320-341 at max_chn_skip = infinity: the best of the inner window's anchors with y in [yi - max_inner, yi - 1];
 				// the walk goes from the largest (y, index) down and only a strictly better score replaces the best
 				int bs = INT32_MIN, cj = -1;
@@ -143,7 +302,6 @@ int64_t rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor
 		f[i] = max_f;
 		p_rel[i] = max_j < 0 ? 0 : i - max_j;
 	}
-	return tied;
 }
 
 } // namespace
@@ -183,8 +341,7 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 			const int64_t n = offsets[r + 1] - offsets[r];
 			if (n == 0) continue;
 			f.resize((size_t)n); p.resize((size_t)n);
-			const int64_t t = rmq_fill_one(*prm, n, anchors + offsets[r], f.data(), p.data(), ws);
-			if (n_tied) n_tied[r] = (int32_t)std::min<int64_t>(t, INT32_MAX);
+			rmq_fill_one(*prm, n, anchors + offsets[r], f.data(), p.data(), ws);
 			nu_of[(size_t)r] = backtrack_compact(misc, n, anchors + offsets[r], f.data(), p.data(), libc_mem, bs, &u_of[(size_t)r], &a_of[(size_t)r]);
 			for (int c = 0; c < nu_of[(size_t)r]; ++c) na_of[(size_t)r] += (uint32_t)u_of[(size_t)r][c];
 		}

@@ -37,9 +37,8 @@ def test_reference_test_pairs_paf_identical(engine, case, tgt, qry):
 
 
 def test_simulated_long_reads_paf(engine, tmp_path):
-    """Everything a long-read run exercises: minimizers above mid_occ, reads on both strands, secondary hits, re-chaining through
-    mg_lchain_rmq's device form.  A read whose re-chaining met a priority tie (the reference breaks it by the shape of its tree,
-    DESIGN 6b) is counted by the mapper and may differ; every other line must be the reference's."""
+    """Everything a long-read run exercises: minimizers above mid_occ, reads on both strands, secondary hits, re-chaining of most reads
+    through mg_lchain_rmq (host form with the reference's tree: ties on the range-minimum priority break as they do there)."""
     meta = json.load(open(os.path.join(GOLD, "sim160.json")))
     ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
     sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
@@ -47,10 +46,8 @@ def test_simulated_long_reads_paf(engine, tmp_path):
     assert hashlib.md5(open(reads, "rb").read()).hexdigest() == meta["reads_md5"]
     paf, st = map_files(engine, ref, reads)
     want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
-    by_read = lambda text: {k: [ln for ln in text.splitlines() if ln.split("\t", 1)[0] == k] for k in {ln.split("\t", 1)[0] for ln in text.splitlines()}}
-    g, w = by_read(paf), by_read(want)
-    differing = sorted(k for k in set(g) | set(w) if g.get(k) != w.get(k))
-    assert st["n_reads"] == meta["n_reads"] and st["n_mapped"] >= 150
-    assert len(differing) <= st["n_rmq_tied"], f"{len(differing)} reads differ, {st['n_rmq_tied']} met an RMQ tie: {differing[:5]} {st}"
-    if st["n_rmq_tied"] == 0:
-        assert paf == want
+    assert st["n_reads"] == meta["n_reads"] and st["n_mapped"] >= 150 and st["n_rechained"] >= 100
+    if paf != want:
+        g, w = paf.splitlines(), want.splitlines()
+        bad = [k for k in range(min(len(g), len(w))) if g[k] != w[k]]
+        raise AssertionError(f"{len(bad)} of {len(w)} PAF lines differ (got {len(g)}); first: {g[bad[0]] if bad else None} vs {w[bad[0]] if bad else None}")

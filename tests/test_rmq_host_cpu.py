@@ -24,34 +24,63 @@ def first_pass(a):
 
 @pytest.mark.parametrize("path", CASES, ids=golden_io.case_ids(CASES))
 def test_reference_vectors(path):
+    """Every recorded call of the reference's mg_lchain_rmq, the ones whose range-minimum met ties included: this form keeps the
+    reference's tree, so its chains are the reference's."""
     g = golden_io.load_rmq(path)
     if g["prm"].max_chn_skip != orc.INT32_MAX:
         pytest.skip("recorded with a finite max_chn_skip; this form is exhaustive by contract")
-    res, tied = mm.rmq_chain_host(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]), threads=1)
-    assert int(tied[0]) == g["tied"]
-    if g["tied"] == 0:
-        assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
+    res, _ = mm.rmq_chain_host(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]), threads=1)
+    assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
 
 
-def test_batch_against_the_oracle():
-    """Reads re-chained in one call on several threads, under the parameter sets the device test uses plus the real call's (bw = bw_long
-    = 20 000, map.c:704): tie counts and chains equal the oracle's (same stated tie rule)."""
+def batch_of_reads():
     a, off = mm.synth_reads(41, 0, 24, 10_000, 90_000)
     reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(24)]
     reads.insert(7, np.zeros((0, 2), np.uint64))
     rng = np.random.default_rng(3)
-    reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(900, 1), np.zeros(900, np.int64), 1000 + rng.integers(0, 150, 900), 100 + rng.integers(0, 150, 900)))))
+    for k in range(4):   # dense clouds: many equal priorities, i.e. ties
+        reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(900, 1), np.zeros(900, np.int64), 1000 + rng.integers(0, 150 + 200 * k, 900), 100 + rng.integers(0, 150 + 100 * k, 900)))))
+    return reads
+
+
+PARAMS = (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(bw=20000, max_dist=5000, max_dist_inner=1000),
+          dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05)))
+
+
+def test_batch_against_the_oracle_where_there_is_no_tie():
+    """Reads re-chained in one call on several threads, under the parameter sets the device test uses plus the real call's (bw = bw_long
+    = 20 000, map.c:704).  The oracle scans ranges and only KNOWS the answer where the range-minimum is unique: those reads must agree."""
+    reads = batch_of_reads()
     o2 = np.zeros(len(reads) + 1, dtype=np.int64)
     o2[1:] = np.cumsum([len(x) for x in reads])
     allr = np.concatenate(reads)
-    for kw in (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(bw=20000, max_dist=5000, max_dist_inner=1000),
-               dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05))):
+    for kw in PARAMS:
         prm = orc.default_rmq_param(**kw)
-        res, tied = mm.rmq_chain_host(allr, o2, to_lib(prm), threads=4)
-        n_with_ties = 0
+        res, _ = mm.rmq_chain_host(allr, o2, to_lib(prm), threads=4)
+        untied = 0
         for r, x in enumerate(reads):
             o = orc.lchain_rmq(x, prm)
-            assert int(tied[r]) == o["n_tied"], (kw, r)
-            n_with_ties += o["n_tied"] > 0
-            assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r)
-        assert n_with_ties >= 1
+            if o["n_tied"] == 0:
+                untied += 1
+                assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r)
+        assert untied >= 10
+
+
+@pytest.mark.skipif(not orc.ref_available(), reason="needs the reference build (oracle/_ref, made where /root/reference exists)")
+def test_ties_are_broken_like_the_reference():
+    """Against the compiled reference's mg_lchain_rmq itself, on reads where many elements share the smallest priority: which one the
+    reference returns follows from the shape of its AVL tree (krmq.h); ShapeTree must be that tree."""
+    reads = batch_of_reads()
+    n_tied_reads = 0
+    for kw in PARAMS:
+        prm = orc.default_rmq_param(**kw)
+        o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+        o2[1:] = np.cumsum([len(x) for x in reads])
+        res, _ = mm.rmq_chain_host(np.concatenate(reads), o2, to_lib(prm), threads=4)
+        for r, x in enumerate(reads):
+            if len(x) == 0:
+                continue
+            ref = orc.ref_lchain_rmq(x, prm)
+            n_tied_reads += orc.lchain_rmq(x, prm)["n_tied"] > 0
+            assert np.array_equal(res[r][0], ref["u"]) and np.array_equal(res[r][1], ref["a_out"]), (kw, r)
+    assert n_tied_reads >= 8
