@@ -139,7 +139,7 @@ int  mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int6
 /* The same on host threads with the reference's own tree (csrc/rmq_host.cpp: an AVL tree with krmq.h's insertion, deletion, rotation and
  * subtree-minimum rules, on arrays): O(log n) per anchor where the kernel scans the window -- the form for the re-chaining call of
  * map.c:697-708, whose window is bw_long = 20 000 bases -- and the reference's answer for EVERY read, priority ties included (which
- * element a tie returns follows from the tree's shape).  max_chn_skip must be INT32_MAX.  n_tied (may be NULL) is set to 0s. */
+ * element a tie returns follows from the tree's shape), at any max_chn_skip.  n_tied (may be NULL) is set to 0s. */
 int  mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
                           mm2gb_chains_t *out, int32_t *n_tied);
 mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,

@@ -243,7 +243,7 @@ struct ShapeTree {
 	unsigned size() const { return root < 0 ? 0u : count[(size_t)root]; }
 };
 
-struct FillScratch { ShapeTree tree; std::vector<uint64_t> inner; };   // inner: y << 32 | index of the inner window's anchors, ascending
+struct FillScratch { ShapeTree tree; std::vector<uint64_t> inner; std::vector<int32_t> seen; };   // inner: y << 32 | index of the inner window's anchors, ascending; seen: the reference's t[] (lchain.c:333-338)
 
 // f[n], p_rel[n] (i - predecessor, 0 = none) of one read
 void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws)
@@ -255,6 +255,7 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 	ShapeTree &tree = ws.tree;
 	tree.reset(a, n);
 	ws.inner.clear();
+	ws.seen.assign((size_t)n, 0);
 	auto inner_key = [&](int j) { return (uint64_t)(uint32_t)(int32_t)a[j].y << 32 | (uint32_t)j; };   // query positions are non-negative
 	int i0 = 0, st = 0, st_in = 0;
 	for (int i = 0; i < n; ++i) {
@@ -284,19 +285,22 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 			const int sc = f[j] + pair_score(a[i], a[j], P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
 			if (width <= P.bw && sc > max_f) { max_f = sc; max_j = j; }
 			if (!exact && max_inner > 0 && !ws.inner.empty() && yi > 0) {
-				// lchain.c:320-341 at max_chn_skip = infinity: the best of the inner window's anchors with y in [yi - max_inner, yi - 1];
-				// the walk goes from the largest (y, index) down and only a strictly better score replaces the best
-				int bs = INT32_MIN, cj = -1;
+				// lchain.c:320-341: the inner window's anchors with y in [yi - max_inner, yi - 1], from the largest (y, index) down; a
+				// strictly better score replaces the best; the walk gives up after max_chn_skip anchors whose own predecessor chain
+				// this anchor has already been offered (the marks in seen[], lchain.c:333-338)
+				int n_skip = 0;
 				const auto from = std::lower_bound(ws.inner.begin(), ws.inner.end(), (uint64_t)(uint32_t)std::max(yi - max_inner, 0) << 32);
 				auto it = std::lower_bound(from, ws.inner.end(), (uint64_t)(uint32_t)yi << 32);
-				while (it != from) {                              // (y, index) descending
+				while (it != from) {
 					--it;
 					const int j2 = (int)(uint32_t)*it;
 					int w2;
 					const int s2 = f[j2] + pair_score(a[i], a[j2], P.chn_pen_gap, P.chn_pen_skip, nullptr, &w2);
-					if (w2 <= P.bw && s2 > bs) { bs = s2; cj = j2; }
+					if (w2 > P.bw) continue;
+					if (s2 > max_f) { max_f = s2; max_j = j2; if (n_skip > 0) --n_skip; }
+					else if (ws.seen[(size_t)j2] == i) { if (++n_skip > P.max_chn_skip) break; }
+					if (p_rel[j2]) ws.seen[(size_t)(j2 - p_rel[j2])] = i;
 				}
-				if (cj >= 0 && bs > max_f) { max_f = bs; max_j = cj; }
 			}
 		}
 		f[i] = max_f;
@@ -316,7 +320,6 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 {
 	if (!prm || !out || n_reads < 0 || !offsets || offsets[0] != 0) return fail("mm2gb_rmq_chain_host: offsets[0] must be 0");
 	memset(out, 0, sizeof(*out));
-	if (prm->max_chn_skip != INT32_MAX) return fail("mm2gb_rmq_chain_host: max_chn_skip must be INT32_MAX (the exhaustive scan of the GPU path's contract)");
 	for (int64_t r = 0; r < n_reads; ++r) {
 		if (offsets[r + 1] < offsets[r]) return fail("mm2gb_rmq_chain_host: offsets must be non-decreasing");
 		if (offsets[r + 1] - offsets[r] >= ((int64_t)1 << 30)) return fail("mm2gb_rmq_chain_host: a read is limited to 2^30 anchors");

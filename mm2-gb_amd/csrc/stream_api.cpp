@@ -380,7 +380,7 @@ mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int m
 	// One read at a time: the fill is a chain of n dependent steps either way.  On the host it is O(log n) per step (segment tree,
 	// csrc/rmq_host.cpp); the kernel scans the window at every step and is for batches of reads with narrow windows (MM2GB_RMQ=gpu forces it).
 	static const bool on_device = [] { const char *v = getenv("MM2GB_RMQ"); return v && strcmp(v, "gpu") == 0; }();
-	if (!on_device && max_chn_skip == INT32_MAX) {
+	if (!on_device) {
 		if (mm2gb_rmq_chain_host(&prm, 1, off, a, 1, &out, &tied)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
 	} else {
 		mm2gb_misc_t misc = {};                                               // the engine wants one; the re-chaining call carries its own thresholds
@@ -531,7 +531,7 @@ void free_stream_gpu(int n_threads)
 	g_streams.ready = false;
 	free_single_read_engines();
 	if (const char *v = getenv("MM2GB_RMQ_REPORT"))
-		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls on the device: %lld, of which handed to the host because of a tie: %lld\n",
+		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls answered by the library: %lld, of which handed to the host's own function because of a tie (device form only): %lld\n",
 		                             (long long)g_rmq_calls.load(), (long long)g_rmq_tied_calls.load());
 }
 

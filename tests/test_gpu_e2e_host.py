@@ -129,10 +129,13 @@ def test_device_post_pass_through_the_boundary(tmp_path, threads):
 
 
 @needs_host
-def test_rmq_rechaining_on_the_device_paf_diff_empty(tmp_path):
+@pytest.mark.parametrize("form", ["host_tree", "kernel"])
+def test_rmq_rechaining_through_the_library_paf_diff_empty(tmp_path, form):
     """The same host linked with -Wl,--wrap=mg_lchain_rmq (oracle/Makefile target gpuhost_rmq; sources untouched): every
-    re-chaining call of post_chaining_helper (map.c:450) lands in the library's device path; reads whose
-    range-minimum meets a tie go back to the host's own function.  Same PAF as the reference CPU path."""
+    re-chaining call of post_chaining_helper (map.c:450) lands in the library.  Default: the host form that keeps the
+    reference's tree, all 160 reads, no call goes back to the host's own function.  MM2GB_RMQ=gpu: the kernel, one read per call (one
+    workgroup walking a sequential DP with a window scan per anchor: far slower per call, so 48 reads), reads whose range-minimum meets
+    a tie go back to the host's own function.  Same PAF as the reference CPU path either way."""
     import json
     import re
     import sim_reads
@@ -142,19 +145,24 @@ def test_rmq_rechaining_on_the_device_paf_diff_empty(tmp_path):
     meta = json.load(open(os.path.join(GOLD, "sim160.json")))
     ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
     sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
-    # the first 48 reads only: a re-chaining call is one read at a time, i.e. one wave on the whole GPU walking a sequential DP --
-    # far slower than the host per call (the batch form is the one that pays); reads map independently of each other
-    recs = open(reads).read().split(">")[1:49]
+    n_take = 160 if form == "host_tree" else 48                # reads map independently of each other
+    recs = open(reads).read().split(">")[1:n_take + 1]
     some = str(tmp_path / "some.fa")
     open(some, "w").write("".join(">" + x for x in recs))
     names = {x.split()[0] for x in recs}
-    r = subprocess.run([host_rmq, "-t", "1", "--gpu-chain", "--gpu-cfg", CFG, ref, some], capture_output=True, timeout=900,
-                       env=dict(os.environ, MM2GB_RMQ_REPORT="1"))
+    env = dict(os.environ, MM2GB_RMQ_REPORT="1")
+    if form == "kernel":
+        env["MM2GB_RMQ"] = "gpu"
+    r = subprocess.run([host_rmq, "-t", "1", "--gpu-chain", "--gpu-cfg", CFG, ref, some], capture_output=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     want = "".join(l + "\n" for l in open(os.path.join(GOLD, "sim160_inf.paf")).read().splitlines() if l.split("\t")[0] in names)
-    assert want.count("\n") >= 48 and r.stdout.decode() == want
-    m = re.search(r"mg_lchain_rmq calls on the device: (\d+), of which handed to the host because of a tie: (\d+)", r.stderr.decode())
-    assert m and int(m.group(1)) > 10 and int(m.group(2)) < int(m.group(1)), r.stderr.decode()[-500:]
+    assert want.count("\n") >= n_take and r.stdout.decode() == want
+    m = re.search(r"mg_lchain_rmq calls answered by the library: (\d+), of which handed to the host's own function because of a tie \(device form only\): (\d+)", r.stderr.decode())
+    assert m and int(m.group(1)) > 10, r.stderr.decode()[-500:]
+    if form == "host_tree":
+        assert int(m.group(2)) == 0
+    else:
+        assert int(m.group(2)) < int(m.group(1))
 
 
 @needs_host

@@ -26,9 +26,7 @@ def first_pass(a):
 def test_reference_vectors(path):
     """Every recorded call of the reference's mg_lchain_rmq, the ones whose range-minimum met ties included: this form keeps the
     reference's tree, so its chains are the reference's."""
-    g = golden_io.load_rmq(path)
-    if g["prm"].max_chn_skip != orc.INT32_MAX:
-        pytest.skip("recorded with a finite max_chn_skip; this form is exhaustive by contract")
+    g = golden_io.load_rmq(path)                        # some were recorded with a finite max_chn_skip: this form honours it
     res, _ = mm.rmq_chain_host(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]), threads=1)
     assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
 
@@ -43,7 +41,7 @@ def batch_of_reads():
     return reads
 
 
-PARAMS = (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(bw=20000, max_dist=5000, max_dist_inner=1000),
+PARAMS = (dict(), dict(max_chn_skip=25), dict(max_chn_skip=3, bw=20000, max_dist=5000, max_dist_inner=1000), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(bw=20000, max_dist=5000, max_dist_inner=1000),
           dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05)))
 
 
