@@ -197,6 +197,9 @@ mm2gb_index_t *mm2gb_index_build(int k, int w, int32_t n_seq, const char *const 
 void mm2gb_index_destroy(mm2gb_index_t *ix);
 int64_t mm2gb_index_size(const mm2gb_index_t *ix, int64_t *n_occurrences);     /* distinct minimizers */
 int32_t mm2gb_index_mid_occ(const mm2gb_index_t *ix, float mid_occ_frac, int32_t min_mid_occ, int32_t max_mid_occ);
+int  mm2gb_collect_seeds_host(int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds, const int64_t *hit_off,
+                              const uint64_t *hits, const int32_t *qlen, const int32_t *q_rank, int32_t n_ref, const int32_t *ref_len,
+                              const int32_t *ref_rank, int n_threads, int64_t *anchor_off, mm2gb_anchor_t *anchors);   /* = mm2gb_collect_seeds_gpu, on host threads */
 int  mm2gb_collect_matches(const mm2gb_index_t *ix, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out);
 void mm2gb_matches_free(mm2gb_matches_t *m);
 
@@ -214,6 +217,7 @@ typedef struct {
 	float   rmq_rescue_ratio, chain_gap_scale, chain_skip_scale;
 	float   mask_level; int32_t mask_len; float pri_ratio; int32_t best_n;
 	int32_t host_threads;
+	int32_t seeds_on_device;   /* matches -> sorted anchors: 1 on the device, -1 on host threads, 0 by batch size */
 } mm2gb_map_opt_t;
 typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; double s_seed, s_anchors, s_chain, s_rechain, s_regs, s_post; } mm2gb_map_stats_t;   /* s_*: seconds per stage */
 void mm2gb_map_opt_init(mm2gb_map_opt_t *opt);

@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_collect_seeds_host"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -380,6 +380,32 @@ def _engine_gen_regs(self, chains, qlen, hashes, is_qstrand=0):
 
 Engine.sort_seeds = _engine_sort_seeds
 Engine.collect_seeds = _engine_collect_seeds
+
+
+def collect_seeds_host(flag, reads, ref_len=None, ref_rank=None, threads=4):
+    """mm2gb_collect_seeds_host: same arguments and results as Engine.collect_seeds, on host threads."""
+    L = lib()
+    L.mm2gb_collect_seeds_host.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    R = len(reads)
+    seed_off = np.zeros(R + 1, np.int64)
+    seed_off[1:] = np.cumsum([len(r["seeds"]) for r in reads])
+    seeds = np.ascontiguousarray(np.concatenate([np.asarray(r["seeds"], np.uint32).reshape(-1, 4) for r in reads]) if R else np.zeros((0, 4), np.uint32), dtype=np.uint32)
+    hit_off = np.zeros(len(seeds) + 1, np.int64)
+    np.cumsum(seeds[:, 0], out=hit_off[1:])
+    hits = np.ascontiguousarray(np.concatenate([np.asarray(r["hits"], np.uint64) for r in reads]) if R else np.zeros(0, np.uint64), dtype=np.uint64)
+    qlen = np.ascontiguousarray([r["qlen"] for r in reads], dtype=np.int32)
+    have_rank = any("q_rank" in r for r in reads)
+    q_rank = np.ascontiguousarray([r.get("q_rank", 0) for r in reads], dtype=np.int32) if have_rank else None
+    rl = np.ascontiguousarray(ref_len, dtype=np.int32) if ref_len is not None else None
+    rr = np.ascontiguousarray(ref_rank, dtype=np.int32) if ref_rank is not None else None
+    n_ref = len(rl) if rl is not None else (len(rr) if rr is not None else 0)
+    a_off = np.zeros(R + 1, np.int64)
+    out = np.zeros((max(len(hits), 1), 2), np.uint64)
+    _check(L.mm2gb_collect_seeds_host(int(flag), R, seed_off.ctypes.data, seeds.ctypes.data, hit_off.ctypes.data, hits.ctypes.data, qlen.ctypes.data,
+                                      q_rank.ctypes.data if q_rank is not None else None, n_ref, rl.ctypes.data if rl is not None else None,
+                                      rr.ctypes.data if rr is not None else None, int(threads), a_off.ctypes.data, out.ctypes.data))
+    return [out[a_off[r]:a_off[r + 1]].copy() for r in range(R)]
 Engine.gen_regs = _engine_gen_regs
 
 
@@ -621,7 +647,7 @@ class MapOpt(C.Structure):
                 ("min_cnt", C.c_int32), ("min_chain_score", C.c_int32), ("bw", C.c_int32), ("bw_long", C.c_int32), ("max_gap", C.c_int32),
                 ("max_gap_ref", C.c_int32), ("max_chain_iter", C.c_int32), ("rmq_inner_dist", C.c_int32), ("rmq_size_cap", C.c_int32),
                 ("rmq_rescue_size", C.c_int32), ("rmq_rescue_ratio", C.c_float), ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
-                ("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32), ("host_threads", C.c_int32)]
+                ("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32), ("host_threads", C.c_int32), ("seeds_on_device", C.c_int32)]
 
 
 class MapStats(C.Structure):

@@ -1,7 +1,7 @@
 // mapper.cpp -- reads in, PAF out, without the reference's sources: the host side around the device path, written
 // from scratch to give the reference's output for single-segment reads mapped without base-level alignment (no -a / -c).
 //
-//   per batch of reads:   matches (seeding.cpp, host threads)  ->  anchors, sorted (device: collect_seed_hits)  ->  chains (device:
+//   per batch of reads:   matches (seeding.cpp, host threads)  ->  anchors, sorted (collect_seed_hits: device for large batches, host threads otherwise)  ->  chains (device:
 //   chaining DP + backtrack)  ->  re-chaining of reads whose chains look broken (host threads: mg_lchain_rmq with the reference's tree, csrc/rmq_host.cpp, map.c:697-708)
 //   ->  hit records (device: mm_gen_regs)  ->  per read on the host: primary / secondary (mm_set_parent, hit.c:125-198), which
 //   secondaries stay (mm_select_sub, hit.c:272-295, mm_sync_regs hit.c:247-270), divergence estimate (mm_est_err, esterr.c:31-64),
@@ -286,8 +286,13 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	std::vector<int32_t> qlen(lens, lens + n_reads);
 	std::vector<int64_t> a_off(R + 1, 0);
 	std::vector<mm2gb_anchor_t> anchors((size_t)std::max<int64_t>(n_hits, 1));
-	if (mm2gb_collect_seeds_gpu(eng, opt.flag, n_reads, seed_off.data(), seeds.data(), hit_off.data(), hits.data(), qlen.data(), nullptr, n_ref, nullptr, nullptr,
-	                            a_off.data(), anchors.data())) { free_matches(); return -1; }
+	// on the device for large batches (mm2gb_collect_seeds_gpu: matches up, anchors down, one wave sorts a read); below that the host
+	// threads are quicker: the largest read's sort alone is hundreds of milliseconds for one wave, milliseconds for a core
+	const bool seeds_on_device = opt.seeds_on_device > 0 || (opt.seeds_on_device == 0 && n_hits >= 400000000);
+	if (seeds_on_device ? mm2gb_collect_seeds_gpu(eng, opt.flag, n_reads, seed_off.data(), seeds.data(), hit_off.data(), hits.data(), qlen.data(), nullptr, n_ref, nullptr, nullptr,
+	                                              a_off.data(), anchors.data())
+	                    : mm2gb_collect_seeds_host(opt.flag, n_reads, seed_off.data(), seeds.data(), hit_off.data(), hits.data(), qlen.data(), nullptr, n_ref, nullptr, nullptr,
+	                                               std::max(1, opt.host_threads), a_off.data(), anchors.data())) { free_matches(); return -1; }
 	st_local.n_anchors = a_off[R];
 	lap(st_local.s_anchors);
 

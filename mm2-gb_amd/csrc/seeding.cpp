@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 #include "engine.h"
+#include "host_chain.h"
 
 namespace mm2gb {
 namespace {
@@ -300,6 +301,80 @@ int mm2gb_collect_matches(const mm2gb_index_t *ix_, const char *seq, int32_t len
 	out->rep_len = rep_len + (rep_en - rep_st);
 	out->n_hits = n_hits;
 	out->n_mini_pos = out->n_seeds;
+	return 0;
+}
+
+// collect_seed_hits (map.c:295-331) with skip_seed (map.c:205-227) on host threads: the same function as mm2gb_collect_seeds_gpu, for
+// batches small enough that the trip over the link and one wave sorting the largest read cost more than they save
+int mm2gb_collect_seeds_host(int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds, const int64_t *hit_off,
+                             const uint64_t *hits, const int32_t *qlen, const int32_t *q_rank, int32_t n_ref, const int32_t *ref_len,
+                             const int32_t *ref_rank, int n_threads, int64_t *anchor_off, mm2gb_anchor_t *anchors)
+{
+	constexpr int64_t F_NO_DIAG = 0x001, F_NO_DUAL = 0x002, F_FOR_ONLY = 0x100000, F_REV_ONLY = 0x200000, F_QSTRAND = 0x100000000LL;   // minimap.h:8-9,28-29,40
+	if (n_reads < 0 || !seed_off || !anchor_off || seed_off[0] != 0) return fail("mm2gb_collect_seeds_host: seed_off[0] must be 0");
+	anchor_off[0] = 0;
+	if (n_reads == 0) return 0;
+	const int64_t n_seeds = seed_off[n_reads];
+	if (!qlen || !hit_off || (n_seeds > 0 && !seeds) || hit_off[0] != 0) return fail("mm2gb_collect_seeds_host: null argument, or hit_off[0] is not 0");
+	const bool names = (opt_flag & (F_NO_DIAG | F_NO_DUAL)) != 0 && q_rank != nullptr;
+	if (names && (!ref_rank || n_ref <= 0)) return fail("mm2gb_collect_seeds_host: NO_DIAG / NO_DUAL need ref_rank");
+	if (((opt_flag & F_QSTRAND) || (names && (opt_flag & F_NO_DIAG))) && (!ref_len || n_ref <= 0)) return fail("mm2gb_collect_seeds_host: QSTRAND / NO_DIAG need ref_len");
+	if (hit_off[n_seeds] > 0 && (!hits || !anchors)) return fail("mm2gb_collect_seeds_host: null buffer");
+	// every read writes at its hits' offset first (an upper bound of where it ends up), sorts there, and is moved down afterwards
+	std::vector<int64_t> kept((size_t)n_reads, 0);
+	std::atomic<int64_t> next(0);
+	auto work = [&]() {
+		for (;;) {
+			const int64_t r = next.fetch_add(1);
+			if (r >= n_reads) break;
+			mm2gb_anchor_t *out = anchors + hit_off[seed_off[r]];
+			int64_t n_a = 0;
+			for (int64_t k = seed_off[r]; k < seed_off[r + 1]; ++k) {
+				const mm2gb_seed_t &q = seeds[k];
+				const uint32_t q_span = q.span_flt & 0x7fffffffu, seg_id = q.seg_tandem & 0x7fffffffu;
+				for (int64_t h = hit_off[k]; h < hit_off[k + 1]; ++h) {
+					const uint64_t rr = hits[h];
+					const int32_t rpos = (int32_t)((uint32_t)rr >> 1);
+					const bool same_strand = (rr & 1) == (q.q_pos & 1);
+					bool skip = false, is_self = false;
+					if (names) {                                                                      // map.c:208-219
+						const int32_t rid = (int32_t)(rr >> 32);
+						if ((opt_flag & F_NO_DIAG) && q_rank[r] == ref_rank[rid] && ref_len[rid] == qlen[r]) {
+							if ((uint32_t)rr >> 1 == (q.q_pos >> 1)) skip = true;
+							else if (same_strand) is_self = true;
+						}
+						if (!skip && (opt_flag & F_NO_DUAL) && q_rank[r] > ref_rank[rid]) skip = true;
+					}
+					if (!skip && (opt_flag & (F_FOR_ONLY | F_REV_ONLY))) skip = same_strand ? (opt_flag & F_REV_ONLY) != 0 : (opt_flag & F_FOR_ONLY) != 0;   // map.c:220-226
+					if (skip) continue;
+					mm2gb_anchor_t &p = out[n_a++];
+					if (same_strand) {                                                                // map.c:311-313
+						p.x = (rr & 0xffffffff00000000ULL) | (uint32_t)rpos;
+						p.y = (uint64_t)q_span << 32 | q.q_pos >> 1;
+					} else if (!(opt_flag & F_QSTRAND)) {                                             // map.c:314-316
+						p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | (uint32_t)rpos;
+						p.y = (uint64_t)q_span << 32 | (uint32_t)(qlen[r] - (int32_t)((q.q_pos >> 1) + 1 - q_span) - 1);
+					} else {                                                                          // map.c:317-321
+						p.x = 1ULL << 63 | (rr & 0xffffffff00000000ULL) | (uint32_t)(ref_len[rr >> 32] - (rpos + 1 - (int32_t)q_span) - 1);
+						p.y = (uint64_t)q_span << 32 | q.q_pos >> 1;
+					}
+					p.y |= (uint64_t)seg_id << 48;                                                     // MM_SEED_SEG_SHIFT
+					if (q.seg_tandem >> 31) p.y |= 1ULL << 42;                                         // MM_SEED_TANDEM
+					if (is_self) p.y |= 1ULL << 43;                                                    // MM_SEED_SELF
+				}
+			}
+			sort_by_x_like_host(out, out + n_a);                                                       // map.c:329
+			kept[(size_t)r] = n_a;
+		}
+	};
+	const int nt = std::max(1, n_threads);
+	if (nt == 1) work();
+	else { std::vector<std::thread> pool; for (int t = 0; t < nt; ++t) pool.emplace_back(work); for (auto &th : pool) th.join(); }
+	for (int64_t r = 0; r < n_reads; ++r) {
+		anchor_off[r + 1] = anchor_off[r] + kept[(size_t)r];
+		const int64_t from = hit_off[seed_off[r]];
+		if (from != anchor_off[r] && kept[(size_t)r] > 0) memmove(anchors + anchor_off[r], anchors + from, (size_t)kept[(size_t)r] * sizeof(mm2gb_anchor_t));
+	}
 	return 0;
 }
 

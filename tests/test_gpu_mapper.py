@@ -29,14 +29,16 @@ def map_files(engine, ref_fa, reads_fa, **opt):
         return mm.map_reads(engine, ix, [n for n, _ in refs], reads, opt=mm.map_opt(**opt))
 
 
+@pytest.mark.parametrize("seeds_on_device", [1, -1], ids=["anchors_on_device", "anchors_on_host"])
 @pytest.mark.parametrize("case,tgt,qry", [("mt", "MT-human.fa", "MT-orang.fa"), ("inv", "t-inv.fa", "q-inv.fa"), ("q2", "t2.fa", "q2.fa")])
-def test_reference_test_pairs_paf_identical(engine, case, tgt, qry):
-    paf, st = map_files(engine, os.path.join(DATA, tgt), os.path.join(DATA, qry))
+def test_reference_test_pairs_paf_identical(engine, case, tgt, qry, seeds_on_device):
+    paf, st = map_files(engine, os.path.join(DATA, tgt), os.path.join(DATA, qry), seeds_on_device=seeds_on_device)
     assert paf == open(os.path.join(GOLD, f"real_{case}_inf.paf")).read()
     assert st["n_rmq_tied"] == 0
 
 
-def test_simulated_long_reads_paf(engine, tmp_path):
+@pytest.mark.parametrize("seeds_on_device", [1, -1], ids=["anchors_on_device", "anchors_on_host"])
+def test_simulated_long_reads_paf(engine, tmp_path, seeds_on_device):
     """Everything a long-read run exercises: minimizers above mid_occ, reads on both strands, secondary hits, re-chaining of most reads
     through mg_lchain_rmq (host form with the reference's tree: ties on the range-minimum priority break as they do there)."""
     meta = json.load(open(os.path.join(GOLD, "sim160.json")))
@@ -44,7 +46,7 @@ def test_simulated_long_reads_paf(engine, tmp_path):
     sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
     assert hashlib.md5(open(ref, "rb").read()).hexdigest() == meta["ref_md5"], "simulator drifted: regenerate the golden"
     assert hashlib.md5(open(reads, "rb").read()).hexdigest() == meta["reads_md5"]
-    paf, st = map_files(engine, ref, reads)
+    paf, st = map_files(engine, ref, reads, seeds_on_device=seeds_on_device)
     want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
     assert st["n_reads"] == meta["n_reads"] and st["n_mapped"] >= 150 and st["n_rechained"] >= 100
     if paf != want:

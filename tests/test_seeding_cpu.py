@@ -88,3 +88,18 @@ def test_sketch_edge_cases():
     lower = mm.sketch((b"ACGTTGCATGCCATGA" * 20).lower(), 10, 15)
     upper = mm.sketch(b"ACGTTGCATGCCATGA" * 20, 10, 15)
     assert np.array_equal(lower, upper)
+
+
+def test_matches_to_anchors_on_host_threads_reference_vectors():
+    """mm2gb_collect_seeds_host = collect_seed_hits + skip_seed (map.c:205-227,295-331) on host threads: every recorded call of the
+    reference (both strands, --for-only / --rev-only, the name tests of -X), batched by option set, anchors bit-identical."""
+    cases = [golden_io.load_seeds(p) for p in golden_io.seed_cases()]
+    groups = {}
+    for g in cases:
+        groups.setdefault((g["flag"], tuple(g["ref_rank"] or ()), tuple(g["ref_len"] or ())), []).append(g)
+    assert len(groups) >= 4
+    for (flag, ref_rank, ref_len), gs in groups.items():
+        reads = [dict(seeds=g["seeds"], hits=g["hits"], qlen=g["qlen"], **({"q_rank": g["q_rank"]} if ref_rank else {})) for g in gs]
+        got = mm.collect_seeds_host(flag, reads, ref_len=list(ref_len) or None, ref_rank=list(ref_rank) or None, threads=3)
+        for g, a in zip(gs, got):
+            assert a.shape == g["a"].shape and np.array_equal(a, g["a"]), g["name"]
