@@ -303,7 +303,10 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	misc.chn_pen_gap = (float)(opt.chain_gap_scale * 0.01 * k); misc.chn_pen_skip = (float)(opt.chain_skip_scale * 0.01 * k);
 	if (mm2gb_engine_set_misc(eng, &misc)) { free_matches(); return -1; }
 	mm2gb_chains_t ch; memset(&ch, 0, sizeof ch);
-	if (mm2gb_chain_gpu(eng, n_reads, a_off.data(), anchors.data(), &ch, nullptr)) { free_matches(); return -1; }
+	// backtrack + compaction as kernels for large batches; below that on host threads, overlapped with the device: a single huge read (a
+	// tandem array) keeps one wave busy for hundreds of milliseconds where a core needs tens
+	if (a_off[R] >= 200000000 ? mm2gb_chain_gpu(eng, n_reads, a_off.data(), anchors.data(), &ch, nullptr)
+	                          : mm2gb_chain_host(eng, n_reads, a_off.data(), anchors.data(), std::max(1, opt.host_threads), &ch, nullptr)) { free_matches(); return -1; }
 
 	// 4. re-chaining of long reads whose best chain leaves much of the read uncovered (map.c:697-708): the chained anchors, sorted
 	//    again, through mg_lchain_rmq's fill
