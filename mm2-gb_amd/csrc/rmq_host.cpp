@@ -243,10 +243,42 @@ struct ShapeTree {
 	unsigned size() const { return root < 0 ? 0u : count[(size_t)root]; }
 };
 
-struct FillScratch { ShapeTree tree; std::vector<uint64_t> inner; std::vector<int32_t> seen; };   // inner: y << 32 | index of the inner window's anchors, ascending; seen: the reference's t[] (lchain.c:333-338)
+// The inner window (lchain.c:286-290, 301-310, 320-341): its anchors are only ever walked in (y, index) order over a y-range, which
+// does not depend on a tree's shape.  They are kept in buckets of 64 query positions, each a small array in (y, index) order holding
+// what scoring a pair needs -- position, span, score -- so that the walk reads memory front to back instead of chasing indices.
+struct InnerCand { int32_t y, j, x, f; int32_t span; };
+struct InnerWindow {
+	static constexpr int SHIFT = 6;
+	std::vector<std::vector<InnerCand>> bucket;
+	int y0 = 0;
+	size_t count = 0;
+	void reset(int y_min, int y_max)
+	{
+		y0 = y_min; count = 0;
+		const size_t nb = (size_t)((y_max - y_min) >> SHIFT) + 1;
+		if (bucket.size() < nb) bucket.resize(nb);
+		for (size_t b = 0; b < nb; ++b) bucket[b].clear();
+	}
+	static bool before(const InnerCand &u, int y, int j) { return u.y != y ? u.y < y : u.j < j; }
+	void insert(const InnerCand &c)
+	{
+		auto &v = bucket[(size_t)((c.y - y0) >> SHIFT)];
+		size_t at = v.size();
+		while (at > 0 && !before(v[at - 1], c.y, c.j)) --at;       // arrivals come in order of x; within a bucket that is mostly near the end
+		v.insert(v.begin() + (ptrdiff_t)at, c);
+		++count;
+	}
+	void erase(int y, int j)
+	{
+		auto &v = bucket[(size_t)((y - y0) >> SHIFT)];
+		for (size_t at = 0; at < v.size(); ++at) if (v[at].j == j) { v.erase(v.begin() + (ptrdiff_t)at); --count; return; }
+	}
+};
+struct FillScratch { ShapeTree tree; InnerWindow inner; std::vector<int32_t> seen; };   // seen: the reference's t[] (lchain.c:333-338)
 
 // f[n], p_rel[n] (i - predecessor, 0 = none) of one read
-void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws)
+// pen: (int)(gap * dd + .5 * mg_log2(dd + 1)) for dd = 0 .. bw when chn_pen_skip == 0 (the penalty then depends on dd alone), else null
+void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws, const int32_t *pen)
 {
 	const int n = (int)n64;
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                                   // lchain.c:264
@@ -254,16 +286,19 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 	const double half_gap = 0.5 * (double)P.chn_pen_gap;
 	ShapeTree &tree = ws.tree;
 	tree.reset(a, n);
-	ws.inner.clear();
 	ws.seen.assign((size_t)n, 0);
-	auto inner_key = [&](int j) { return (uint64_t)(uint32_t)(int32_t)a[j].y << 32 | (uint32_t)j; };   // query positions are non-negative
+	if (max_inner > 0 && n > 0) {
+		int y_min = INT32_MAX, y_max = INT32_MIN;
+		for (int j = 0; j < n; ++j) { const int y = (int32_t)a[j].y; y_min = std::min(y_min, y); y_max = std::max(y_max, y); }
+		ws.inner.reset(y_min, y_max);
+	} else ws.inner.count = 0;
 	int i0 = 0, st = 0, st_in = 0;
 	for (int i = 0; i < n; ++i) {
 		const int yi = (int32_t)a[i].y, q_i = (int)(a[i].y >> 32 & 0xff);
 		if (i0 < i && a[i0].x != a[i].x) {                     // lchain.c:279-292: the anchors before the run of equal x that holds i go in
 			for (int j = i0; j < i; ++j) {
 				tree.insert(j, -((double)f[j] + half_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y)));          // lchain.c:284
-				if (max_inner > 0) { const uint64_t k = inner_key(j); ws.inner.insert(std::lower_bound(ws.inner.begin(), ws.inner.end(), k), k); }
+				if (max_inner > 0) ws.inner.insert(InnerCand{ (int32_t)a[j].y, j, (int32_t)a[j].x, f[j], (int32_t)(a[j].y >> 32 & 0xff) });
 			}
 			i0 = i;
 		}
@@ -273,8 +308,8 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 			++st;
 		}
 		if (max_inner > 0)
-			while (st_in < i && (a[i].x >> 32 != a[st_in].x >> 32 || a[i].x > a[st_in].x + (uint64_t)max_inner || (int64_t)ws.inner.size() > P.cap_rmq_size)) {
-				if (st_in < i0) { const uint64_t k = inner_key(st_in); const auto it = std::lower_bound(ws.inner.begin(), ws.inner.end(), k); if (it != ws.inner.end() && *it == k) ws.inner.erase(it); }
+			while (st_in < i && (a[i].x >> 32 != a[st_in].x >> 32 || a[i].x > a[st_in].x + (uint64_t)max_inner || (int64_t)ws.inner.count > P.cap_rmq_size)) {
+				if (st_in < i0) ws.inner.erase((int32_t)a[st_in].y, st_in);
 				++st_in;
 			}
 		int max_f = q_i, max_j = -1;
@@ -284,22 +319,40 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 			bool exact; int width;
 			const int sc = f[j] + pair_score(a[i], a[j], P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
 			if (width <= P.bw && sc > max_f) { max_f = sc; max_j = j; }
-			if (!exact && max_inner > 0 && !ws.inner.empty() && yi > 0) {
+			if (!exact && max_inner > 0 && ws.inner.count > 0 && yi > 0) {
 				// lchain.c:320-341: the inner window's anchors with y in [yi - max_inner, yi - 1], from the largest (y, index) down; a
 				// strictly better score replaces the best; the walk gives up after max_chn_skip anchors whose own predecessor chain
 				// this anchor has already been offered (the marks in seen[], lchain.c:333-338)
 				int n_skip = 0;
-				const auto from = std::lower_bound(ws.inner.begin(), ws.inner.end(), (uint64_t)(uint32_t)std::max(yi - max_inner, 0) << 32);
-				auto it = std::lower_bound(from, ws.inner.end(), (uint64_t)(uint32_t)yi << 32);
-				while (it != from) {
-					--it;
-					const int j2 = (int)(uint32_t)*it;
-					int w2;
-					const int s2 = f[j2] + pair_score(a[i], a[j2], P.chn_pen_gap, P.chn_pen_skip, nullptr, &w2);
-					if (w2 > P.bw) continue;
-					if (s2 > max_f) { max_f = s2; max_j = j2; if (n_skip > 0) --n_skip; }
-					else if (ws.seen[(size_t)j2] == i) { if (++n_skip > P.max_chn_skip) break; }
-					if (p_rel[j2]) ws.seen[(size_t)(j2 - p_rel[j2])] = i;
+				const int y_top = yi - 1, y_bot = yi - max_inner;
+				const int xi = (int32_t)a[i].x;
+				const int b_top = std::min<int>((int)ws.inner.bucket.size() - 1, (std::max(y_top, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT);
+				const int b_bot = (std::max(y_bot, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT;
+				bool stop = y_top < ws.inner.y0;
+				for (int b = b_top; b >= b_bot && !stop; --b) {
+					const auto &v = ws.inner.bucket[(size_t)b];
+					for (size_t at = v.size(); at-- > 0;) {
+						const InnerCand &c = v[at];
+						if (c.y > y_top) continue;
+						if (c.y < y_bot) break;
+						// comput_sc_simple (lchain.c:232-248) on the copies
+						const int dq = yi - c.y, dr = xi - c.x, dd = dr > dq ? dr - dq : dq - dr;
+						if (dd > P.bw) continue;
+						const int dg = dr < dq ? dr : dq;
+						int sc = c.span < dg ? c.span : dg;
+						if (dd || dq > c.span) {
+							if (pen) sc -= pen[dd];
+							else {
+								const float lin = P.chn_pen_gap * (float)dd + P.chn_pen_skip * (float)dg;
+								const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
+								sc -= (int)(lin + .5f * lg);
+							}
+						}
+						const int s2 = c.f + sc;
+						if (s2 > max_f) { max_f = s2; max_j = c.j; if (n_skip > 0) --n_skip; }
+						else if (ws.seen[(size_t)c.j] == i) { if (++n_skip > P.max_chn_skip) { stop = true; break; } }
+						if (p_rel[c.j]) ws.seen[(size_t)(c.j - p_rel[c.j])] = i;
+					}
 				}
 			}
 		}
@@ -332,6 +385,16 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 	std::vector<int64_t> na_of(R, 0);
 	mm2gb_misc_t misc = {};
 	misc.min_cnt = prm->min_cnt; misc.min_score = prm->min_sc; misc.bw = prm->bw; misc.is_cdna = 0; misc.n_seg = 1;   // max_drop = bw (lchain.c:253,355)
+	// the pair penalty as a table when it depends on the diagonal distance alone (entries by the same arithmetic as pair_score)
+	std::vector<int32_t> pen;
+	if (prm->chn_pen_skip == 0.0f && prm->bw >= 0 && prm->bw < (1 << 22)) {
+		pen.resize((size_t)prm->bw + 1);
+		for (int dd = 0; dd <= prm->bw; ++dd) {
+			const float lin = prm->chn_pen_gap * (float)dd + prm->chn_pen_skip * 0.0f;
+			const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
+			pen[(size_t)dd] = (int)(lin + .5f * lg);
+		}
+	}
 	std::atomic<int64_t> next(0);
 	HostAlloc libc_mem;
 	auto work = [&]() {
@@ -344,7 +407,7 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 			const int64_t n = offsets[r + 1] - offsets[r];
 			if (n == 0) continue;
 			f.resize((size_t)n); p.resize((size_t)n);
-			rmq_fill_one(*prm, n, anchors + offsets[r], f.data(), p.data(), ws);
+			rmq_fill_one(*prm, n, anchors + offsets[r], f.data(), p.data(), ws, pen.empty() ? nullptr : pen.data());
 			nu_of[(size_t)r] = backtrack_compact(misc, n, anchors + offsets[r], f.data(), p.data(), libc_mem, bs, &u_of[(size_t)r], &a_of[(size_t)r]);
 			for (int c = 0; c < nu_of[(size_t)r]; ++c) na_of[(size_t)r] += (uint32_t)u_of[(size_t)r][c];
 		}
