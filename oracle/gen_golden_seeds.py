@@ -33,14 +33,18 @@ XRUNS = {
 }
 
 
-def run(tgt, qry, extra):
+def run(tgt, qry, extra, paf_to=None):
     exe = os.path.join(orc.REF_DIR, "minimap2_cpu")
     hook = os.path.join(orc.REF_DIR, "libcapture.so")
     with tempfile.TemporaryDirectory() as td:
         cap = os.path.join(td, "seeds.bin")
         env = dict(os.environ, LD_PRELOAD=hook, MM2GB_CAPTURE_SEEDS=cap)
         subprocess.run([exe, "-t", "1"] + extra + [tgt, qry], env=env, check=True, capture_output=True)
-        return orc.read_seed_capture(cap) if os.path.exists(cap) else []
+        recs = orc.read_seed_capture(cap) if os.path.exists(cap) else []
+    if paf_to:   # what the reference prints for this run at max-chain-skip = infinity (the GPU path's contract): for tests/test_gpu_mapper.py
+        r = subprocess.run([exe, "-t", "1", "--max-chain-skip=2147483647"] + extra + [tgt, qry], check=True, capture_output=True)
+        open(paf_to, "wb").write(r.stdout)
+    return recs
 
 
 def save(name, k, r, flag, source, **names):
@@ -54,7 +58,7 @@ if __name__ == "__main__":
         sys.exit("reference build missing: run `make -C oracle all` in a container that has /root/reference")
     os.makedirs(OUT, exist_ok=True)
     for name, (tgt, qry, extra, flag) in RUNS.items():
-        recs = run(os.path.join(REF, "test", tgt), os.path.join(REF, "test", qry), extra)
+        recs = run(os.path.join(REF, "test", tgt), os.path.join(REF, "test", qry), extra, paf_to=os.path.join(OUT, name + ".paf") if extra else None)
         for k, r in enumerate(recs):
             save(name, k, r, flag, f"{tgt} x {qry} {' '.join(extra)}".strip())
         print(f"{name}: {len(recs)} records, {sum(len(r['hits']) for r in recs)} hits, {sum(len(r['a']) for r in recs)} anchors")

@@ -53,3 +53,30 @@ def test_simulated_long_reads_paf(engine, tmp_path, seeds_on_device):
         g, w = paf.splitlines(), want.splitlines()
         bad = [k for k in range(min(len(g), len(w))) if g[k] != w[k]]
         raise AssertionError(f"{len(bad)} of {len(w)} PAF lines differ (got {len(g)}); first: {g[bad[0]] if bad else None} vs {w[bad[0]] if bad else None}")
+
+
+@pytest.mark.parametrize("name,tgt,qry,flag", [("mt_for", "MT-human.fa", "MT-orang.fa", 0x100000), ("mt_rev", "MT-human.fa", "MT-orang.fa", 0x200000),
+                                               ("inv_rev", "t-inv.fa", "q-inv.fa", 0x200000)])
+def test_strand_restricted_runs(engine, name, tgt, qry, flag):
+    """--for-only / --rev-only (MM_F_FOR_ONLY / MM_F_REV_ONLY reach skip_seed, map.c:220-226): the reference's PAF for the same run."""
+    paf, _ = map_files(engine, os.path.join(DATA, tgt), os.path.join(DATA, qry), flag=flag)
+    assert paf == open(os.path.join(GOLD, "seeds", name + ".paf")).read()
+
+
+def test_reads_that_map_nowhere_and_odd_input(engine):
+    """Empty reads, reads shorter than a k-mer, runs of N, lower case, random sequence, names with blanks cut by the caller: no line for
+    what does not map, the same line for the same sequence in either case."""
+    import numpy as np
+    refs = read_fasta(os.path.join(DATA, "MT-human.fa"))
+    good = read_fasta(os.path.join(DATA, "MT-orang.fa"))[0][1]
+    rng = np.random.default_rng(2)
+    rand = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 3000))
+    reads = [("empty", b""), ("short", b"ACGTACGTAC"), ("n_only", b"N" * 500), ("random", rand), ("upper", good), ("lower", good.lower()),
+             ("with_n", good[:8000] + b"N" * 50 + good[8050:])]
+    with mm.SeedIndex([s for _, s in refs]) as ix:
+        paf, st = mm.map_reads(engine, ix, [n for n, _ in refs], reads)
+    lines = paf.splitlines()
+    by = {ln.split("\t")[0]: ln for ln in lines}
+    assert set(by) == {"upper", "lower", "with_n"} and st["n_mapped"] == 3 and st["n_reads"] == 7
+    assert by["upper"].split("\t")[1:] == by["lower"].split("\t")[1:]
+    assert by["upper"] == open(os.path.join(GOLD, "real_mt_inf.paf")).read().strip().replace("MT_orang", "upper", 1)
