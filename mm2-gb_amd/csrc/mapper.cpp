@@ -16,11 +16,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 #include "engine.h"
 #include "host_chain.h"
+#include "trace.h"
 
 namespace mm2gb {
 namespace {
@@ -254,6 +256,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	std::vector<int32_t> ref_len_v(ref_lens, ref_lens + n_ref);
 
 	// 1. matches on host threads
+	std::unique_ptr<TraceRange> tr(new TraceRange("mm2gb:map_seed"));   // stage ranges for rocprofv3 --marker-trace / rocprof-sys
 	std::vector<mm2gb_matches_t> mt(R);
 	for (auto &m : mt) memset(&m, 0, sizeof m);
 	const mm2gb_seed_opt_t so = { opt.mid_occ, opt.max_max_occ, opt.occ_dist, opt.q_occ_frac };
@@ -269,6 +272,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	}
 	auto free_matches = [&]() { for (auto &m : mt) mm2gb_matches_free(&m); };
 	lap(st_local.s_seed);
+	tr.reset(); tr.reset(new TraceRange("mm2gb:map_anchors"));
 
 	// 2. anchors, sorted, on the device
 	std::vector<int64_t> seed_off(R + 1, 0);
@@ -295,6 +299,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	                                               std::max(1, opt.host_threads), a_off.data(), anchors.data())) { free_matches(); return -1; }
 	st_local.n_anchors = a_off[R];
 	lap(st_local.s_anchors);
+	tr.reset(); tr.reset(new TraceRange("mm2gb:map_chain"));
 
 	// 3. chains on the device; map.c:393-426 for the parameters (the GPU path chains with max-chain-skip = infinity)
 	mm2gb_misc_t misc;
@@ -315,6 +320,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	std::vector<mm2gb_anchor_t> ca(ch.a, ch.a + c_off[R]);
 	mm2gb_chains_free(&ch);
 	lap(st_local.s_chain);
+	tr.reset(); tr.reset(new TraceRange("mm2gb:map_rechain"));
 	std::vector<int32_t> redo;
 	if (opt.bw_long > opt.bw) {
 		for (size_t r = 0; r < R; ++r) {
@@ -363,6 +369,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	}
 	st_local.n_chains = u_off[R];
 	lap(st_local.s_rechain);
+	tr.reset(); tr.reset(new TraceRange("mm2gb:map_hit_records"));
 
 	// 5. hit records on the device (hit.c:52-88); the hash of map.c:660-662
 	std::vector<uint32_t> hash(R);
@@ -378,6 +385,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	}
 
 	lap(st_local.s_regs);
+	tr.reset(); tr.reset(new TraceRange("mm2gb:map_hits_to_paf"));
 	// 6. per read on the host
 	std::vector<std::string> lines(R);
 	{
@@ -413,6 +421,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	}
 	free_matches();
 	lap(st_local.s_post);
+	tr.reset();
 	size_t total = 0;
 	for (const auto &l : lines) total += l.size();
 	char *buf = (char*)malloc(total + 1);
