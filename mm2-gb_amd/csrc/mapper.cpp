@@ -252,6 +252,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	double t_mark = now();
 	auto lap = [&](double &slot) { const double t = now(); slot += t - t_mark; t_mark = t; };
 	*paf_out = nullptr; *paf_len = 0;
+	if (n_reads == 0) { *paf_out = (char*)calloc(1, 1); if (stats) *stats = st_local; return *paf_out ? 0 : fail("mm2gb_map_reads: out of memory"); }
 	const size_t R = (size_t)n_reads;
 	std::vector<int32_t> ref_len_v(ref_lens, ref_lens + n_ref);
 

@@ -75,6 +75,7 @@ def test_reads_that_map_nowhere_and_odd_input(engine):
              ("with_n", good[:8000] + b"N" * 50 + good[8050:])]
     with mm.SeedIndex([s for _, s in refs]) as ix:
         paf, st = mm.map_reads(engine, ix, [n for n, _ in refs], reads)
+        assert mm.map_reads(engine, ix, [n for n, _ in refs], [])[0] == ""
     lines = paf.splitlines()
     by = {ln.split("\t")[0]: ln for ln in lines}
     assert set(by) == {"upper", "lower", "with_n"} and st["n_mapped"] == 3 and st["n_reads"] == 7
