@@ -51,68 +51,65 @@ inline int pair_score(const mm2gb_anchor_t &ai, const mm2gb_anchor_t &aj, float 
 // kid[0] / kid[1]: left / right child (-1: none); low[v]: the node of smallest priority in v's subtree, ties as described above;
 // tilt: AVL balance factor (right height - left height); count: nodes in the subtree.
 struct ShapeTree {
-	const mm2gb_anchor_t *a = nullptr;
-	std::vector<int> kid[2], low;
-	std::vector<signed char> tilt;
-	std::vector<unsigned> count;
-	std::vector<double> pri;
+	struct Node { int kid[2], low; unsigned count; double pri; int y; signed char tilt; };   // 32 bytes: a visit touches one line, not five arrays
+	std::vector<Node> nd;
 	int root = -1, scratch = 0;
 	static constexpr int MAX_DEPTH = 64;
 
 	void reset(const mm2gb_anchor_t *anchors, int n)
 	{
-		a = anchors; root = -1; scratch = n;
-		for (auto *v : { &kid[0], &kid[1], &low }) v->assign((size_t)n + 1, -1);
-		tilt.assign((size_t)n + 1, 0); count.assign((size_t)n + 1, 0); pri.assign((size_t)n + 1, 0.0);
+		root = -1; scratch = n;
+		nd.resize((size_t)n + 1);
+		for (int v = 0; v < n; ++v) nd[(size_t)v].y = (int32_t)anchors[v].y;
 	}
 	// order of (y, index) pairs (lchain.c:225): the key of node v is (y of anchor v, v)
 	int order(int y, int64_t i, int v) const
 	{
-		const int yv = (int32_t)a[v].y;
+		const int yv = nd[(size_t)v].y;
 		return y < yv ? -1 : y > yv ? 1 : (i > v) - (i < v);
 	}
-	bool lower(int u, int v) const { return pri[(size_t)u] < pri[(size_t)v]; }              // lchain.c:226
-	unsigned below(int v, int side) const { const int c = kid[side][(size_t)v]; return c < 0 ? 0u : count[(size_t)c]; }
+	bool lower(int u, int v) const { return nd[(size_t)(u)].pri < nd[(size_t)(v)].pri; }              // lchain.c:226
+	unsigned below(int v, int side) const { const int c = nd[(size_t)(v)].kid[side]; return c < 0 ? 0u : nd[(size_t)(c)].count; }
 	// krmq.h:146-150
 	void refresh_low(int v, int first, int second)
 	{
-		int m = (first < 0 || lower(v, low[(size_t)first])) ? v : low[(size_t)first];
-		m = (second < 0 || lower(m, low[(size_t)second])) ? m : low[(size_t)second];
-		low[(size_t)v] = m;
+		int m = (first < 0 || lower(v, nd[(size_t)(first)].low)) ? v : nd[(size_t)(first)].low;
+		m = (second < 0 || lower(m, nd[(size_t)(second)].low)) ? m : nd[(size_t)(second)].low;
+		nd[(size_t)(v)].low = m;
 	}
 	// krmq.h:151-163: (a,(b,c)q)p => ((a,b)p,c)q for side == 0, mirrored for side == 1
 	int rotate_once(int p, int side)
 	{
-		const int other = 1 - side, q = kid[other][(size_t)p], keep = low[(size_t)p];
-		const unsigned was = count[(size_t)p];
-		count[(size_t)p] -= count[(size_t)q] - below(q, side);
-		count[(size_t)q] = was;
-		refresh_low(p, kid[side][(size_t)p], kid[side][(size_t)q]);
-		low[(size_t)q] = keep;
-		kid[other][(size_t)p] = kid[side][(size_t)q];
-		kid[side][(size_t)q] = p;
+		const int other = 1 - side, q = nd[(size_t)(p)].kid[other], keep = nd[(size_t)(p)].low;
+		const unsigned was = nd[(size_t)(p)].count;
+		nd[(size_t)(p)].count -= nd[(size_t)(q)].count - below(q, side);
+		nd[(size_t)(q)].count = was;
+		refresh_low(p, nd[(size_t)(p)].kid[side], nd[(size_t)(q)].kid[side]);
+		nd[(size_t)(q)].low = keep;
+		nd[(size_t)(p)].kid[other] = nd[(size_t)(q)].kid[side];
+		nd[(size_t)(q)].kid[side] = p;
 		return q;
 	}
 	// krmq.h:164-187: (a,((b,c)r,d)q)p => ((a,b)p,(c,d)q)r
 	int rotate_twice(int p, int side)
 	{
-		const int other = 1 - side, q = kid[other][(size_t)p], r = kid[side][(size_t)q], keep = low[(size_t)p];
+		const int other = 1 - side, q = nd[(size_t)(p)].kid[other], r = nd[(size_t)(q)].kid[side], keep = nd[(size_t)(p)].low;
 		const unsigned inner = below(r, side);
-		count[(size_t)r] = count[(size_t)p];
-		count[(size_t)p] -= count[(size_t)q] - inner;
-		count[(size_t)q] -= inner + 1;
-		refresh_low(p, kid[side][(size_t)p], kid[side][(size_t)r]);
-		refresh_low(q, kid[other][(size_t)q], kid[other][(size_t)r]);
-		low[(size_t)r] = keep;
-		kid[other][(size_t)p] = kid[side][(size_t)r];
-		kid[side][(size_t)r] = p;
-		kid[side][(size_t)q] = kid[other][(size_t)r];
-		kid[other][(size_t)r] = q;
+		nd[(size_t)(r)].count = nd[(size_t)(p)].count;
+		nd[(size_t)(p)].count -= nd[(size_t)(q)].count - inner;
+		nd[(size_t)(q)].count -= inner + 1;
+		refresh_low(p, nd[(size_t)(p)].kid[side], nd[(size_t)(r)].kid[side]);
+		refresh_low(q, nd[(size_t)(q)].kid[other], nd[(size_t)(r)].kid[other]);
+		nd[(size_t)(r)].low = keep;
+		nd[(size_t)(p)].kid[other] = nd[(size_t)(r)].kid[side];
+		nd[(size_t)(r)].kid[side] = p;
+		nd[(size_t)(q)].kid[side] = nd[(size_t)(r)].kid[other];
+		nd[(size_t)(r)].kid[other] = q;
 		const int lean = side == 0 ? +1 : -1;
-		if (tilt[(size_t)r] == lean) { tilt[(size_t)q] = 0; tilt[(size_t)p] = (signed char)-lean; }
-		else if (tilt[(size_t)r] == 0) tilt[(size_t)q] = tilt[(size_t)p] = 0;
-		else { tilt[(size_t)q] = (signed char)lean; tilt[(size_t)p] = 0; }
-		tilt[(size_t)r] = 0;
+		if (nd[(size_t)(r)].tilt == lean) { nd[(size_t)(q)].tilt = 0; nd[(size_t)(p)].tilt = (signed char)-lean; }
+		else if (nd[(size_t)(r)].tilt == 0) nd[(size_t)(q)].tilt = nd[(size_t)(p)].tilt = 0;
+		else { nd[(size_t)(q)].tilt = (signed char)lean; nd[(size_t)(p)].tilt = 0; }
+		nd[(size_t)(r)].tilt = 0;
 		return r;
 	}
 	// krmq.h:189-240
@@ -121,31 +118,31 @@ struct ShapeTree {
 		unsigned char turn[MAX_DEPTH];
 		int path[MAX_DEPTH];
 		int pivot = root, above_pivot = -1, p = root, q = -1, top = 0, len = 0, side = 0;
-		for (; p >= 0; q = p, p = kid[side][(size_t)p]) {
-			const int c = order((int32_t)a[x].y, x, p);
-			if (tilt[(size_t)p] != 0) { above_pivot = q; pivot = p; top = 0; }
+		for (; p >= 0; q = p, p = nd[(size_t)(p)].kid[side]) {
+			const int c = order(nd[(size_t)x].y, x, p);
+			if (nd[(size_t)(p)].tilt != 0) { above_pivot = q; pivot = p; top = 0; }
 			turn[top++] = (unsigned char)(side = c > 0);
 			path[len++] = p;
 		}
-		pri[(size_t)x] = priority;
-		tilt[(size_t)x] = 0; count[(size_t)x] = 1; kid[0][(size_t)x] = kid[1][(size_t)x] = -1; low[(size_t)x] = x;
-		if (q < 0) root = x; else kid[side][(size_t)q] = x;
+		nd[(size_t)(x)].pri = priority;
+		nd[(size_t)(x)].tilt = 0; nd[(size_t)(x)].count = 1; nd[(size_t)(x)].kid[0] = nd[(size_t)(x)].kid[1] = -1; nd[(size_t)(x)].low = x;
+		if (q < 0) root = x; else nd[(size_t)(q)].kid[side] = x;
 		if (pivot < 0) return;
-		for (int i = 0; i < len; ++i) ++count[(size_t)path[i]];
+		for (int i = 0; i < len; ++i) ++nd[(size_t)(path[i])].count;
 		for (int i = len - 1; i >= 0; --i) {
-			refresh_low(path[i], kid[0][(size_t)path[i]], kid[1][(size_t)path[i]]);
-			if (low[(size_t)path[i]] != x) break;
+			refresh_low(path[i], nd[(size_t)(path[i])].kid[0], nd[(size_t)(path[i])].kid[1]);
+			if (nd[(size_t)(path[i])].low != x) break;
 		}
 		top = 0;
-		for (p = pivot; p != x; p = kid[turn[top]][(size_t)p], ++top) tilt[(size_t)p] += turn[top] == 0 ? -1 : +1;
-		if (tilt[(size_t)pivot] > -2 && tilt[(size_t)pivot] < 2) return;
-		side = tilt[(size_t)pivot] < 0;
+		for (p = pivot; p != x; p = nd[(size_t)(p)].kid[turn[top]], ++top) nd[(size_t)(p)].tilt += turn[top] == 0 ? -1 : +1;
+		if (nd[(size_t)(pivot)].tilt > -2 && nd[(size_t)(pivot)].tilt < 2) return;
+		side = nd[(size_t)(pivot)].tilt < 0;
 		const int lean = side == 0 ? +1 : -1;
-		q = kid[1 - side][(size_t)pivot];
+		q = nd[(size_t)(pivot)].kid[1 - side];
 		int r;
-		if (tilt[(size_t)q] == lean) { r = rotate_once(pivot, side); tilt[(size_t)q] = tilt[(size_t)pivot] = 0; }
+		if (nd[(size_t)(q)].tilt == lean) { r = rotate_once(pivot, side); nd[(size_t)(q)].tilt = nd[(size_t)(pivot)].tilt = 0; }
 		else r = rotate_twice(pivot, side);
-		if (above_pivot < 0) root = r; else kid[pivot != kid[0][(size_t)above_pivot]][(size_t)above_pivot] = r;
+		if (above_pivot < 0) root = r; else nd[(size_t)(above_pivot)].kid[pivot != nd[(size_t)(above_pivot)].kid[0]] = r;
 	}
 	// krmq.h:242-325 for a node that is in the tree
 	void erase(int x)
@@ -154,61 +151,61 @@ struct ShapeTree {
 		int path[MAX_DEPTH];
 		unsigned char turn[MAX_DEPTH];
 		const int f = scratch;
-		kid[0][(size_t)f] = root; kid[1][(size_t)f] = -1; low[(size_t)f] = low[(size_t)root]; tilt[(size_t)f] = tilt[(size_t)root];
-		count[(size_t)f] = count[(size_t)root]; pri[(size_t)f] = pri[(size_t)root];
+		nd[(size_t)(f)].kid[0] = root; nd[(size_t)(f)].kid[1] = -1; nd[(size_t)(f)].low = nd[(size_t)(root)].low; nd[(size_t)(f)].tilt = nd[(size_t)(root)].tilt;
+		nd[(size_t)(f)].count = nd[(size_t)(root)].count; nd[(size_t)(f)].pri = nd[(size_t)(root)].pri;
 		int d = 0, p = f;
-		for (int c = -1; c != 0; c = order((int32_t)a[x].y, x, p)) {
+		for (int c = -1; c != 0; c = order(nd[(size_t)x].y, x, p)) {
 			const int side = c > 0;
 			turn[d] = (unsigned char)side; path[d++] = p;
-			p = kid[side][(size_t)p];
+			p = nd[(size_t)(p)].kid[side];
 			if (p < 0) return;
 		}
-		for (int i = 1; i < d; ++i) --count[(size_t)path[i]];
-		if (kid[1][(size_t)p] < 0) kid[turn[d - 1]][(size_t)path[d - 1]] = kid[0][(size_t)p];
+		for (int i = 1; i < d; ++i) --nd[(size_t)(path[i])].count;
+		if (nd[(size_t)(p)].kid[1] < 0) nd[(size_t)(path[d - 1])].kid[turn[d - 1]] = nd[(size_t)(p)].kid[0];
 		else {
-			int q = kid[1][(size_t)p];
-			if (kid[0][(size_t)q] < 0) {
-				kid[0][(size_t)q] = kid[0][(size_t)p];
-				tilt[(size_t)q] = tilt[(size_t)p];
-				kid[turn[d - 1]][(size_t)path[d - 1]] = q;
+			int q = nd[(size_t)(p)].kid[1];
+			if (nd[(size_t)(q)].kid[0] < 0) {
+				nd[(size_t)(q)].kid[0] = nd[(size_t)(p)].kid[0];
+				nd[(size_t)(q)].tilt = nd[(size_t)(p)].tilt;
+				nd[(size_t)(path[d - 1])].kid[turn[d - 1]] = q;
 				path[d] = q; turn[d++] = 1;
-				count[(size_t)q] = count[(size_t)p] - 1;
+				nd[(size_t)(q)].count = nd[(size_t)(p)].count - 1;
 			} else {
 				int r;
 				const int e = d++;
 				for (;;) {
 					turn[d] = 0; path[d++] = q;
-					r = kid[0][(size_t)q];
-					if (kid[0][(size_t)r] < 0) break;
+					r = nd[(size_t)(q)].kid[0];
+					if (nd[(size_t)(r)].kid[0] < 0) break;
 					q = r;
 				}
-				kid[0][(size_t)r] = kid[0][(size_t)p];
-				kid[0][(size_t)q] = kid[1][(size_t)r];
-				kid[1][(size_t)r] = kid[1][(size_t)p];
-				tilt[(size_t)r] = tilt[(size_t)p];
-				kid[turn[e - 1]][(size_t)path[e - 1]] = r;
+				nd[(size_t)(r)].kid[0] = nd[(size_t)(p)].kid[0];
+				nd[(size_t)(q)].kid[0] = nd[(size_t)(r)].kid[1];
+				nd[(size_t)(r)].kid[1] = nd[(size_t)(p)].kid[1];
+				nd[(size_t)(r)].tilt = nd[(size_t)(p)].tilt;
+				nd[(size_t)(path[e - 1])].kid[turn[e - 1]] = r;
 				path[e] = r; turn[e] = 1;
-				for (int i = e + 1; i < d; ++i) --count[(size_t)path[i]];
-				count[(size_t)r] = count[(size_t)p] - 1;
+				for (int i = e + 1; i < d; ++i) --nd[(size_t)(path[i])].count;
+				nd[(size_t)(r)].count = nd[(size_t)(p)].count - 1;
 			}
 		}
-		for (int i = d - 1; i >= 0; --i) refresh_low(path[i], kid[0][(size_t)path[i]], kid[1][(size_t)path[i]]);
+		for (int i = d - 1; i >= 0; --i) refresh_low(path[i], nd[(size_t)(path[i])].kid[0], nd[(size_t)(path[i])].kid[1]);
 		while (--d > 0) {
 			const int q = path[d], side = turn[d], other = 1 - side;
 			const int b1 = side ? -1 : 1, b2 = side ? -2 : 2;
-			tilt[(size_t)q] += (signed char)b1;
-			if (tilt[(size_t)q] == b1) break;
-			if (tilt[(size_t)q] == b2) {
-				const int r = kid[other][(size_t)q];
-				if (tilt[(size_t)r] == -b1) kid[turn[d - 1]][(size_t)path[d - 1]] = rotate_twice(q, side);
+			nd[(size_t)(q)].tilt += (signed char)b1;
+			if (nd[(size_t)(q)].tilt == b1) break;
+			if (nd[(size_t)(q)].tilt == b2) {
+				const int r = nd[(size_t)(q)].kid[other];
+				if (nd[(size_t)(r)].tilt == -b1) nd[(size_t)(path[d - 1])].kid[turn[d - 1]] = rotate_twice(q, side);
 				else {
-					kid[turn[d - 1]][(size_t)path[d - 1]] = rotate_once(q, side);
-					if (tilt[(size_t)r] == 0) { tilt[(size_t)r] = (signed char)-b1; tilt[(size_t)q] = (signed char)b1; break; }
-					tilt[(size_t)r] = tilt[(size_t)q] = 0;
+					nd[(size_t)(path[d - 1])].kid[turn[d - 1]] = rotate_once(q, side);
+					if (nd[(size_t)(r)].tilt == 0) { nd[(size_t)(r)].tilt = (signed char)-b1; nd[(size_t)(q)].tilt = (signed char)b1; break; }
+					nd[(size_t)(r)].tilt = nd[(size_t)(q)].tilt = 0;
 				}
 			}
 		}
-		root = kid[0][(size_t)f];
+		root = nd[(size_t)(f)].kid[0];
 	}
 	// krmq.h:108-148: the node of smallest priority among those with (y_lo, i_lo) <= key <= (y_hi, i_hi), -1 if none
 	int lowest_between(int y_lo, int64_t i_lo, int y_hi, int64_t i_hi) const
@@ -219,7 +216,7 @@ struct ShapeTree {
 			for (int p = root; p >= 0;) {
 				const int c = side == 0 ? order(y_lo, i_lo, p) : order(y_hi, i_hi, p);
 				path[side][len[side]] = p; went[side][len[side]++] = c;
-				if (c < 0) p = kid[0][(size_t)p]; else if (c > 0) p = kid[1][(size_t)p]; else break;
+				if (c < 0) p = nd[(size_t)(p)].kid[0]; else if (c > 0) p = nd[(size_t)(p)].kid[1]; else break;
 			}
 		int fork = 0;
 		for (; fork < len[0] && fork < len[1]; ++fork)
@@ -228,19 +225,19 @@ struct ShapeTree {
 		int m = path[0][fork];
 		for (int i = fork + 1; i < len[0]; ++i)
 			if (went[0][i] <= 0) {
-				const int v = path[0][i], c = kid[1][(size_t)v];
+				const int v = path[0][i], c = nd[(size_t)(v)].kid[1];
 				if (lower(v, m)) m = v;
-				if (c >= 0 && lower(low[(size_t)c], m)) m = low[(size_t)c];
+				if (c >= 0 && lower(nd[(size_t)(c)].low, m)) m = nd[(size_t)(c)].low;
 			}
 		for (int i = fork + 1; i < len[1]; ++i)
 			if (went[1][i] >= 0) {
-				const int v = path[1][i], c = kid[0][(size_t)v];
+				const int v = path[1][i], c = nd[(size_t)(v)].kid[0];
 				if (lower(v, m)) m = v;
-				if (c >= 0 && lower(low[(size_t)c], m)) m = low[(size_t)c];
+				if (c >= 0 && lower(nd[(size_t)(c)].low, m)) m = nd[(size_t)(c)].low;
 			}
 		return m;
 	}
-	unsigned size() const { return root < 0 ? 0u : count[(size_t)root]; }
+	unsigned size() const { return root < 0 ? 0u : nd[(size_t)(root)].count; }
 };
 
 // The inner window (lchain.c:286-290, 301-310, 320-341): its anchors are only ever walked in (y, index) order over a y-range, which
