@@ -247,28 +247,39 @@ struct InnerCand { int32_t y, j, x, f; int32_t span; };
 struct InnerWindow {
 	static constexpr int SHIFT = 6;
 	std::vector<std::vector<InnerCand>> bucket;
+	std::vector<int32_t> top;      // per bucket: the largest f + span in it: no pair with one of its anchors can score more (lchain.c:237: sc <= q_span)
 	int y0 = 0;
 	size_t count = 0;
 	void reset(int y_min, int y_max)
 	{
 		y0 = y_min; count = 0;
 		const size_t nb = (size_t)((y_max - y_min) >> SHIFT) + 1;
-		if (bucket.size() < nb) bucket.resize(nb);
-		for (size_t b = 0; b < nb; ++b) bucket[b].clear();
+		if (bucket.size() < nb) { bucket.resize(nb); top.resize(nb); }
+		for (size_t b = 0; b < nb; ++b) { bucket[b].clear(); top[b] = INT32_MIN; }
 	}
 	static bool before(const InnerCand &u, int y, int j) { return u.y != y ? u.y < y : u.j < j; }
 	void insert(const InnerCand &c)
 	{
-		auto &v = bucket[(size_t)((c.y - y0) >> SHIFT)];
+		const size_t b = (size_t)((c.y - y0) >> SHIFT);
+		auto &v = bucket[b];
 		size_t at = v.size();
 		while (at > 0 && !before(v[at - 1], c.y, c.j)) --at;       // arrivals come in order of x; within a bucket that is mostly near the end
 		v.insert(v.begin() + (ptrdiff_t)at, c);
+		top[b] = std::max(top[b], c.f + c.span);
 		++count;
 	}
 	void erase(int y, int j)
 	{
-		auto &v = bucket[(size_t)((y - y0) >> SHIFT)];
-		for (size_t at = 0; at < v.size(); ++at) if (v[at].j == j) { v.erase(v.begin() + (ptrdiff_t)at); --count; return; }
+		const size_t b = (size_t)((y - y0) >> SHIFT);
+		auto &v = bucket[b];
+		for (size_t at = 0; at < v.size(); ++at)
+			if (v[at].j == j) {
+				v.erase(v.begin() + (ptrdiff_t)at); --count;
+				int32_t t = INT32_MIN;
+				for (const InnerCand &c : v) t = std::max(t, c.f + c.span);
+				top[b] = t;
+				return;
+			}
 	}
 };
 struct FillScratch { ShapeTree tree; InnerWindow inner; std::vector<int32_t> seen; };   // seen: the reference's t[] (lchain.c:333-338)
@@ -321,6 +332,7 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 				// strictly better score replaces the best; the walk gives up after max_chn_skip anchors whose own predecessor chain
 				// this anchor has already been offered (the marks in seen[], lchain.c:333-338)
 				int n_skip = 0;
+				const bool exhaustive = P.max_chn_skip == INT32_MAX;
 				const int y_top = yi - 1, y_bot = yi - max_inner;
 				const int xi = (int32_t)a[i].x;
 				const int b_top = std::min<int>((int)ws.inner.bucket.size() - 1, (std::max(y_top, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT);
@@ -328,6 +340,8 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 				bool stop = y_top < ws.inner.y0;
 				for (int b = b_top; b >= b_bot && !stop; --b) {
 					const auto &v = ws.inner.bucket[(size_t)b];
+					// without a skip limit a candidate matters only if it beats the best so far, and none of this bucket can
+					if (exhaustive && ws.inner.top[(size_t)b] <= max_f) continue;
 					for (size_t at = v.size(); at-- > 0;) {
 						const InnerCand &c = v[at];
 						if (c.y > y_top) continue;
