@@ -406,6 +406,10 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 			pen[(size_t)dd] = (int)(lin + .5f * lg);
 		}
 	}
+	// largest reads first: one read is one thread's work, and a read inside a tandem array can be a hundred times the median
+	std::vector<int64_t> order((size_t)n_reads);
+	for (int64_t r = 0; r < n_reads; ++r) order[(size_t)r] = r;
+	std::sort(order.begin(), order.end(), [&](int64_t u, int64_t v) { const int64_t nu = offsets[u + 1] - offsets[u], nv = offsets[v + 1] - offsets[v]; return nu != nv ? nu > nv : u < v; });
 	std::atomic<int64_t> next(0);
 	HostAlloc libc_mem;
 	auto work = [&]() {
@@ -413,8 +417,9 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 		BacktrackScratch bs;
 		std::vector<int32_t> f, p;
 		for (;;) {
-			const int64_t r = next.fetch_add(1);
-			if (r >= n_reads) break;
+			const int64_t at = next.fetch_add(1);
+			if (at >= n_reads) break;
+			const int64_t r = order[(size_t)at];
 			const int64_t n = offsets[r + 1] - offsets[r];
 			if (n == 0) continue;
 			f.resize((size_t)n); p.resize((size_t)n);
