@@ -225,6 +225,12 @@ int  mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const 
                      const mm2gb_map_opt_t *opt, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
                      char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats);
 
+/* the same over several engines (one per device; reads shard, no exchange): contiguous runs of reads balanced by bases, one host thread per
+ * engine, PAF in read order; counts are summed, stage times are the slowest engine's */
+int  mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens,
+                           int32_t n_ref, const mm2gb_map_opt_t *opt, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
+                           char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats);
+
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host
  *      thread, nothing is exchanged between devices, results come back in read order.  devices == NULL: 0..n_devices-1;

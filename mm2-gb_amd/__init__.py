@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_collect_seeds_host"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -680,6 +680,26 @@ def map_reads(engine, index, ref_names, reads, opt=None, k=15):
     out, n, st = C.c_void_p(), C.c_int64(), MapStats()
     _check(L.mm2gb_map_reads(engine._h, index._h, k, rn, index.lens.ctypes.data, len(ref_names), C.byref(opt), len(reads), names, seqs, lens.ctypes.data,
                              C.byref(out), C.byref(n), C.byref(st)))
+    text = C.string_at(out, n.value).decode()
+    L.mm2gb_free(out)
+    return text, st.as_dict()
+
+
+def map_reads_multi(engines, index, ref_names, reads, opt=None, k=15):
+    """mm2gb_map_reads_multi: like map_reads over a list of engines (one per device): reads shard, PAF in read order."""
+    L = lib()
+    L.mm2gb_map_reads_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                        C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
+    opt = opt or map_opt()
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    rn = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    names = (C.c_char_p * len(reads))(*[n.encode() for n, _ in reads])
+    seqs_b = [bytes(s) for _, s in reads]
+    seqs = (C.c_char_p * len(reads))(*seqs_b)
+    lens = np.ascontiguousarray([len(s) for s in seqs_b], dtype=np.int32)
+    out, n, st = C.c_void_p(), C.c_int64(), MapStats()
+    _check(L.mm2gb_map_reads_multi(hs, len(engines), index._h, k, rn, index.lens.ctypes.data, len(ref_names), C.byref(opt), len(reads), names, seqs, lens.ctypes.data,
+                                   C.byref(out), C.byref(n), C.byref(st)))
     text = C.string_at(out, n.value).decode()
     L.mm2gb_free(out)
     return text, st.as_dict()

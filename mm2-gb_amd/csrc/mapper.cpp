@@ -436,4 +436,56 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	return 0;
 }
 
+// Several devices (reads shard, no exchange): the batch is cut into contiguous runs of reads balanced by bases, every engine
+// maps its run on its own host thread (the host threads of opt are shared out among them), the PAF comes back in read order.
+int mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens,
+                          int32_t n_ref, const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
+                          char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats)
+{
+	if (!engines || n_engines < 1 || !opt_in || !paf_out || !paf_len || n_reads < 0 || (n_reads > 0 && !lens)) return fail("mm2gb_map_reads_multi: null argument");
+	if (n_engines == 1) return mm2gb_map_reads(engines[0], ix, k, ref_names, ref_lens, n_ref, opt_in, n_reads, names, seqs, lens, paf_out, paf_len, stats);
+	*paf_out = nullptr; *paf_len = 0;
+	int64_t total = 0;
+	for (int32_t r = 0; r < n_reads; ++r) total += lens[r];
+	std::vector<int32_t> cut((size_t)n_engines + 1, n_reads);
+	cut[0] = 0;
+	{ int64_t acc = 0; int e = 1; for (int32_t r = 0; r < n_reads && e < n_engines; ++r) { acc += lens[r]; if (acc * n_engines >= total * e) cut[(size_t)e++] = r + 1; } }
+	mm2gb_map_opt_t opt = *opt_in;
+	opt.host_threads = std::max(1, opt_in->host_threads / n_engines);
+	if (opt.mid_occ <= 0) opt.mid_occ = mm2gb_index_mid_occ(ix, opt.mid_occ_frac, opt.min_mid_occ, opt.max_mid_occ);     // once, not per engine
+	std::vector<char*> part((size_t)n_engines, nullptr);
+	std::vector<int64_t> part_len((size_t)n_engines, 0);
+	std::vector<mm2gb_map_stats_t> st((size_t)n_engines);
+	std::vector<int> rc((size_t)n_engines, 0);
+	std::vector<std::string> err((size_t)n_engines);
+	std::vector<std::thread> pool;
+	for (int e = 0; e < n_engines; ++e)
+		pool.emplace_back([&, e]() {
+			const int32_t from = cut[(size_t)e], n = cut[(size_t)e + 1] - from;
+			rc[(size_t)e] = mm2gb_map_reads(engines[e], ix, k, ref_names, ref_lens, n_ref, &opt, n, names + from, seqs + from, lens + from, &part[(size_t)e], &part_len[(size_t)e], &st[(size_t)e]);
+			if (rc[(size_t)e]) err[(size_t)e] = mm2gb_last_error();
+		});
+	for (auto &th : pool) th.join();
+	int bad = -1;
+	for (int e = 0; e < n_engines; ++e) if (rc[(size_t)e] && bad < 0) bad = e;
+	if (bad >= 0) { for (char *p : part) free(p); return fail("mm2gb_map_reads_multi: engine " + std::to_string(bad) + ": " + err[(size_t)bad]); }
+	int64_t all = 0;
+	for (int64_t l : part_len) all += l;
+	char *buf = (char*)malloc((size_t)all + 1);
+	if (!buf) { for (char *p : part) free(p); return fail("mm2gb_map_reads_multi: out of memory"); }
+	int64_t at = 0;
+	mm2gb_map_stats_t sum; memset(&sum, 0, sizeof sum);
+	for (int e = 0; e < n_engines; ++e) {
+		memcpy(buf + at, part[(size_t)e], (size_t)part_len[(size_t)e]); at += part_len[(size_t)e]; free(part[(size_t)e]);
+		const mm2gb_map_stats_t &q = st[(size_t)e];
+		sum.n_reads += q.n_reads; sum.n_mapped += q.n_mapped; sum.n_anchors += q.n_anchors; sum.n_chains += q.n_chains; sum.n_rechained += q.n_rechained; sum.n_rmq_tied += q.n_rmq_tied;
+		sum.s_seed = std::max(sum.s_seed, q.s_seed); sum.s_anchors = std::max(sum.s_anchors, q.s_anchors); sum.s_chain = std::max(sum.s_chain, q.s_chain);
+		sum.s_rechain = std::max(sum.s_rechain, q.s_rechain); sum.s_regs = std::max(sum.s_regs, q.s_regs); sum.s_post = std::max(sum.s_post, q.s_post);
+	}
+	buf[all] = 0;
+	*paf_out = buf; *paf_len = all;
+	if (stats) *stats = sum;
+	return 0;
+}
+
 } // extern "C"

@@ -81,3 +81,16 @@ def test_reads_that_map_nowhere_and_odd_input(engine):
     assert set(by) == {"upper", "lower", "with_n"} and st["n_mapped"] == 3 and st["n_reads"] == 7
     assert by["upper"].split("\t")[1:] == by["lower"].split("\t")[1:]
     assert by["upper"] == open(os.path.join(GOLD, "real_mt_inf.paf")).read().strip().replace("MT_orang", "upper", 1)
+
+
+def test_reads_sharded_over_several_engines(engine, tmp_path):
+    """mm2gb_map_reads_multi with three engines on the one GPU (the multi-GPU path without a multi-GPU box, as tests/test_gpu_pool.py does for
+    the chaining calls): same PAF as one engine, in read order."""
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    refs, rd = read_fasta(ref), read_fasta(reads)
+    with mm.SeedIndex([s for _, s in refs]) as ix, mm.Engine() as e2, mm.Engine() as e3:
+        paf, st = mm.map_reads_multi([engine, e2, e3], ix, [n for n, _ in refs], rd, opt=mm.map_opt(host_threads=12))
+    assert paf == open(os.path.join(GOLD, "sim160_inf.paf")).read()
+    assert st["n_reads"] == meta["n_reads"]
