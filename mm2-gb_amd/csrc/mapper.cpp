@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -264,12 +265,23 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	{
 		std::atomic<int32_t> next(0);
 		std::atomic<int> bad(0);
-		auto work = [&]() { for (;;) { const int32_t r = next.fetch_add(1); if (r >= n_reads) break; if (lens[r] > 0 && mm2gb_collect_matches(ix, seqs[r], lens[r], &so, &mt[(size_t)r])) bad = 1; } };
+		std::string why;                                      // error text is per thread: carry the first one over
+		std::mutex why_lock;
+		auto work = [&]() {
+			for (;;) {
+				const int32_t r = next.fetch_add(1);
+				if (r >= n_reads) break;
+				if (lens[r] > 0 && mm2gb_collect_matches(ix, seqs[r], lens[r], &so, &mt[(size_t)r])) {
+					std::lock_guard<std::mutex> g(why_lock);
+					if (!bad.exchange(1)) why = mm2gb_last_error();
+				}
+			}
+		};
 		const int nt = std::max(1, opt.host_threads);
 		std::vector<std::thread> pool;
 		for (int t = 0; t < nt; ++t) pool.emplace_back(work);
 		for (auto &th : pool) th.join();
-		if (bad) { for (auto &m : mt) mm2gb_matches_free(&m); return -1; }
+		if (bad) { for (auto &m : mt) mm2gb_matches_free(&m); return fail(why); }
 	}
 	auto free_matches = [&]() { for (auto &m : mt) mm2gb_matches_free(&m); };
 	lap(st_local.s_seed);
