@@ -216,7 +216,7 @@ typedef struct {
 	int32_t rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
 	float   rmq_rescue_ratio, chain_gap_scale, chain_skip_scale;
 	float   mask_level; int32_t mask_len; float pri_ratio; int32_t best_n;
-	int32_t host_threads;
+	int32_t host_threads;      /* 0: every CPU the process may use, at most 32 */
 	int32_t seeds_on_device;   /* matches -> sorted anchors: 1 on the device, -1 on host threads, 0 by batch size */
 } mm2gb_map_opt_t;
 typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; double s_seed, s_anchors, s_chain, s_rechain, s_regs, s_post; } mm2gb_map_stats_t;   /* s_*: seconds per stage */

@@ -45,4 +45,7 @@ void emit_anchor_order(const BacktrackScratch &ws, int32_t *idx);
 int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t *a, const int32_t *f, const int32_t *p_rel,
                       const HostAlloc &mem, BacktrackScratch &ws, uint64_t **u_out, mm2gb_anchor_t **a_out);
 
+// CPUs this process may use at once: affinity mask and cgroup quota, whichever is smaller (stream_api.cpp)
+int usable_cpus();
+
 } // namespace mm2gb

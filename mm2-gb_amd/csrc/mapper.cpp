@@ -235,7 +235,7 @@ void mm2gb_map_opt_init(mm2gb_map_opt_t *o)       // mm_mapopt_init (options.c:1
 	o->max_chain_iter = 5000; o->rmq_inner_dist = 1000; o->rmq_size_cap = 100000; o->rmq_rescue_size = 1000; o->rmq_rescue_ratio = 0.1f;
 	o->chain_gap_scale = 0.8f; o->chain_skip_scale = 0.0f; o->max_max_occ = 4095; o->occ_dist = 500;
 	o->mask_level = 0.5f; o->mask_len = INT32_MAX; o->pri_ratio = 0.8f; o->best_n = 5;
-	o->host_threads = 8;
+	o->host_threads = 0;           // 0: as many as the process may use, at most 32
 }
 
 int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
@@ -248,6 +248,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	if (opt.flag & ~(int64_t)(0x100000 | 0x200000)) return fail("mm2gb_map_reads: of mm_mapopt_t::flag only MM_F_FOR_ONLY and MM_F_REV_ONLY are supported");
 	if (opt.mid_occ <= 0) opt.mid_occ = mm2gb_index_mid_occ(ix, opt.mid_occ_frac, opt.min_mid_occ, opt.max_mid_occ);   // options.c:78-84
 	if (opt.bw_long < opt.bw) opt.bw_long = opt.bw;
+	if (opt.host_threads <= 0) opt.host_threads = std::min(32, usable_cpus());
 	mm2gb_map_stats_t st_local; memset(&st_local, 0, sizeof st_local);
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double t_mark = now();
@@ -463,7 +464,7 @@ int mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const m
 	cut[0] = 0;
 	{ int64_t acc = 0; int e = 1; for (int32_t r = 0; r < n_reads && e < n_engines; ++r) { acc += lens[r]; if (acc * n_engines >= total * e) cut[(size_t)e++] = r + 1; } }
 	mm2gb_map_opt_t opt = *opt_in;
-	opt.host_threads = std::max(1, opt_in->host_threads / n_engines);
+	opt.host_threads = std::max(1, (opt_in->host_threads > 0 ? opt_in->host_threads : std::min(32, usable_cpus())) / n_engines);
 	if (opt.mid_occ <= 0) opt.mid_occ = mm2gb_index_mid_occ(ix, opt.mid_occ_frac, opt.min_mid_occ, opt.max_mid_occ);     // once, not per engine
 	std::vector<char*> part((size_t)n_engines, nullptr);
 	std::vector<int64_t> part_len((size_t)n_engines, 0);

@@ -284,7 +284,7 @@ static StreamSlot &slot_for(int thread_id)
 }
 
 // CPUs this process may use at once: affinity mask and cgroup quota, whichever is smaller (containers give 16 of 128 here)
-static int usable_cpus()
+int usable_cpus()
 {
 	int n = (int)std::thread::hardware_concurrency();
 	cpu_set_t set;
