@@ -218,6 +218,7 @@ typedef struct {
 	float   mask_level; int32_t mask_len; float pri_ratio; int32_t best_n;
 	int32_t host_threads;      /* 0: every CPU the process may use, at most 32 */
 	int32_t seeds_on_device;   /* matches -> sorted anchors: 1 on the device, -1 on host threads, 0 by batch size */
+	int32_t rechain_on_device; /* mg_lchain_rmq's fill: 1 on the device (reads that met a tie are redone on host threads), otherwise on host threads */
 } mm2gb_map_opt_t;
 typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; double s_seed, s_anchors, s_chain, s_rechain, s_regs, s_post; } mm2gb_map_stats_t;   /* s_*: seconds per stage */
 void mm2gb_map_opt_init(mm2gb_map_opt_t *opt);

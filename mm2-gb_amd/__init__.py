@@ -647,7 +647,7 @@ class MapOpt(C.Structure):
                 ("min_cnt", C.c_int32), ("min_chain_score", C.c_int32), ("bw", C.c_int32), ("bw_long", C.c_int32), ("max_gap", C.c_int32),
                 ("max_gap_ref", C.c_int32), ("max_chain_iter", C.c_int32), ("rmq_inner_dist", C.c_int32), ("rmq_size_cap", C.c_int32),
                 ("rmq_rescue_size", C.c_int32), ("rmq_rescue_ratio", C.c_float), ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
-                ("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32), ("host_threads", C.c_int32), ("seeds_on_device", C.c_int32)]
+                ("mask_level", C.c_float), ("mask_len", C.c_int32), ("pri_ratio", C.c_float), ("best_n", C.c_int32), ("host_threads", C.c_int32), ("seeds_on_device", C.c_int32), ("rechain_on_device", C.c_int32)]
 
 
 class MapStats(C.Structure):

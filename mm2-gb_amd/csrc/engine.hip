@@ -210,7 +210,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &reg_out,
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -446,7 +446,13 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		RmqBatch rb;
 		rb.raw = (const uint4*)s.raw.ptr; rb.offsets = (const int64_t*)s.offsets.ptr; rb.n = n; rb.n_reads = n_reads;
 		rb.f = (int32_t*)s.f.ptr; rb.p = (int32_t*)s.p.ptr; rb.key = (double*)post_z.ptr; rb.n_tied = (int32_t*)rmq_tied.ptr;
+		const size_t n_sum = (size_t)(n >> 6) + (size_t)n_reads + 1;
+		if (rmq_by_y.ensure(nn * 16) || rmq_ord.ensure(nn * 4) || rmq_meta.ensure(nn * 16) || rmq_sum.ensure(n_sum * 20)) return -1;
+		rb.by_y = (ulonglong2*)rmq_by_y.ptr; rb.ord_idx = (int32_t*)rmq_ord.ptr; rb.meta = (int4*)rmq_meta.ptr;
+		rb.l1 = (uint4*)rmq_sum.ptr; rb.bound = (int32_t*)((char*)rmq_sum.ptr + n_sum * 16);
 		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;
+		rb.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1536) : nullptr;
+		if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1536, 0, 64, stream));
 		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
 		launch_rmq_fill(rb, rp, stream);
 		MM2GB_HIP(hipGetLastError());
@@ -455,6 +461,12 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, rmq)) return -1;
 	s.used = false;                                     // nothing of this set is in flight once the call returns
 	if (sync()) return -1;
+	if (rmq && debug_phases && n > 0) {
+		long long t[8] = { 0 };
+		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
+			fprintf(stderr, "[mm2gb rmq fill] %lld steps: late entries %lld, summaries rebuilt %lld, ties looked at %lld, summary loads %lld, inner blocks read %lld, winners read from memory %lld, eviction tests %lld\n",
+			        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+	}
 	const int64_t n_u = n_reads > 0 ? h_post_totals[0] : 0, n_a = n_reads > 0 ? h_post_totals[1] : 0;
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);

@@ -336,6 +336,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	lap(st_local.s_chain);
 	tr.reset(); tr.reset(new TraceRange("mm2gb:map_rechain"));
 	std::vector<int32_t> redo;
+	const auto t_rechain = std::chrono::steady_clock::now();
 	if (opt.bw_long > opt.bw) {
 		for (size_t r = 0; r < R; ++r) {
 			if (u_off[r + 1] - u_off[r] <= 1) continue;
@@ -345,41 +346,79 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		}
 	}
 	st_local.n_rechained = (int64_t)redo.size();
+	// largest first: a read is one wave's (or one thread's) work from start to end, and the call ends with its longest read
+	std::sort(redo.begin(), redo.end(), [&](int32_t u, int32_t v) { const int64_t nu = c_off[(size_t)u + 1] - c_off[(size_t)u], nv = c_off[(size_t)v + 1] - c_off[(size_t)v]; return nu != nv ? nu > nv : u < v; });
 	if (!redo.empty()) {
 		std::vector<int64_t> ro(redo.size() + 1, 0);
 		for (size_t q = 0; q < redo.size(); ++q) ro[q + 1] = ro[q] + (c_off[(size_t)redo[q] + 1] - c_off[(size_t)redo[q]]);
 		std::vector<mm2gb_anchor_t> ra((size_t)ro.back());
-		for (size_t q = 0; q < redo.size(); ++q) {
-			const size_t r = (size_t)redo[q];
-			memcpy(ra.data() + ro[q], ca.data() + c_off[r], (size_t)(ro[q + 1] - ro[q]) * sizeof(mm2gb_anchor_t));
-			sort_by_x_like_host(ra.data() + ro[q], ra.data() + ro[q + 1]);
+		{
+			std::atomic<int64_t> next(0);
+			auto work = [&]() {
+				for (;;) {
+					const int64_t q = next.fetch_add(1);
+					if (q >= (int64_t)redo.size()) break;
+					const size_t r = (size_t)redo[(size_t)q];
+					memcpy(ra.data() + ro[(size_t)q], ca.data() + c_off[r], (size_t)(ro[(size_t)q + 1] - ro[(size_t)q]) * sizeof(mm2gb_anchor_t));
+					sort_by_x_like_host(ra.data() + ro[(size_t)q], ra.data() + ro[(size_t)q + 1]);
+				}
+			};
+			const int nt = std::max(1, std::min<int>(opt.host_threads, (int)redo.size()));
+			std::vector<std::thread> pool;
+			for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+			work();
+			for (auto &th : pool) th.join();
 		}
+		const bool verbose = getenv("MM2GB_DEBUG_PHASES") != nullptr;
+		const auto t_sorted = std::chrono::steady_clock::now();
 		const mm2gb_rmq_param_t rp = { opt.max_gap, opt.rmq_inner_dist, opt.bw_long, INT32_MAX, opt.rmq_size_cap, opt.min_cnt, opt.min_chain_score, misc.chn_pen_gap, misc.chn_pen_skip };
 		mm2gb_chains_t rc; memset(&rc, 0, sizeof rc);
+		mm2gb_chains_t rc_tie; memset(&rc_tie, 0, sizeof rc_tie);
 		std::vector<int32_t> tied(redo.size(), 0);
-		// on host threads: the window of this call is bw_long bases wide, a tree beats the kernel's window scan by orders of magnitude, and
-		// this tree breaks priority ties as the reference's does (csrc/rmq_host.cpp)
-		if (mm2gb_rmq_chain_host(&rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, tied.data())) { free_matches(); return -1; }
+		std::vector<int> tie_slot(redo.size(), -1);          // reads the device reported a tie for: their place in the host call that follows
+		// mg_lchain_rmq's fill: on host threads by default -- a tree per read, O(log n) per anchor and a tightly bounded inner scan
+		// (csrc/rmq_host.cpp), 3.4 s for 92 M anchors on 16 threads where k_rmq_fill, one wave per read and the read with the densest
+		// windows last, needs 70 s on the same reads.  On the device when asked for: reads the kernel reports a tie for -- where
+		// the reference's answer depends on the shape of its tree -- are redone by the host form, which keeps that tree.
+		if (opt.rechain_on_device > 0) {
+			if (mm2gb_rmq_chain_gpu(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), &rc, tied.data(), nullptr)) { free_matches(); return -1; }
+			std::vector<int64_t> to(1, 0);
+			std::vector<mm2gb_anchor_t> ta;
+			for (size_t q = 0; q < redo.size(); ++q)
+				if (tied[q]) {
+					tie_slot[q] = (int)to.size() - 1;
+					ta.insert(ta.end(), ra.begin() + ro[q], ra.begin() + ro[q + 1]);
+					to.push_back((int64_t)ta.size());
+				}
+			if (to.size() > 1 && mm2gb_rmq_chain_host(&rp, (int64_t)to.size() - 1, to.data(), ta.data(), std::max(1, opt.host_threads), &rc_tie, nullptr)) { mm2gb_chains_free(&rc); free_matches(); return -1; }
+		} else if (mm2gb_rmq_chain_host(&rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, tied.data())) { free_matches(); return -1; }
+		const auto t_filled = std::chrono::steady_clock::now();
 		// splice the re-chained reads back in
 		std::vector<int64_t> nu_off(R + 1, 0), nc_off(R + 1, 0);
 		std::vector<int> which(R, -1);
 		for (size_t q = 0; q < redo.size(); ++q) { which[(size_t)redo[q]] = (int)q; if (tied[q]) ++st_local.n_rmq_tied; }
 		for (size_t r = 0; r < R; ++r) {
 			const int q = which[r];
-			nu_off[r + 1] = nu_off[r] + (q < 0 ? u_off[r + 1] - u_off[r] : rc.u_off[q + 1] - rc.u_off[q]);
-			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : rc.a_off[q + 1] - rc.a_off[q]);
+			const mm2gb_chains_t &from = q >= 0 && tie_slot[(size_t)q] >= 0 ? rc_tie : rc;
+			const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
+			nu_off[r + 1] = nu_off[r] + (q < 0 ? u_off[r + 1] - u_off[r] : from.u_off[qq + 1] - from.u_off[qq]);
+			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : from.a_off[qq + 1] - from.a_off[qq]);
 		}
 		std::vector<uint64_t> nu((size_t)nu_off[R]);
 		std::vector<mm2gb_anchor_t> nc((size_t)nc_off[R]);
 		for (size_t r = 0; r < R; ++r) {
 			const int q = which[r];
-			const uint64_t *su = q < 0 ? u.data() + u_off[r] : rc.u + rc.u_off[q];
-			const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : rc.a + rc.a_off[q];
+			const mm2gb_chains_t &from = q >= 0 && tie_slot[(size_t)q] >= 0 ? rc_tie : rc;
+			const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
+			const uint64_t *su = q < 0 ? u.data() + u_off[r] : from.u + from.u_off[qq];
+			const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : from.a + from.a_off[qq];
 			if (nu_off[r + 1] > nu_off[r]) memcpy(nu.data() + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);
 			if (nc_off[r + 1] > nc_off[r]) memcpy(nc.data() + nc_off[r], sa, (size_t)(nc_off[r + 1] - nc_off[r]) * sizeof(mm2gb_anchor_t));
 		}
-		mm2gb_chains_free(&rc);
+		mm2gb_chains_free(&rc); mm2gb_chains_free(&rc_tie);
 		u.swap(nu); ca.swap(nc); u_off.swap(nu_off); c_off.swap(nc_off);
+		if (verbose) fprintf(stderr, "[mm2gb] re-chaining %zu reads (%lld redone on the host after a tie), %lld anchors: sort %.3f s, fill %.3f s, splice %.3f s\n", redo.size(), (long long)st_local.n_rmq_tied, (long long)ro.back(), std::chrono::duration<double>(t_sorted - t_rechain).count(),
+		                     std::chrono::duration<double>(t_filled - t_sorted).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_filled).count());
 	}
 	st_local.n_chains = u_off[R];
 	lap(st_local.s_rechain);

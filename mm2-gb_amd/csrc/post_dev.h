@@ -42,7 +42,13 @@ struct RmqBatch {
 	const int64_t *offsets;
 	int64_t        n, n_reads;
 	int32_t *f, *p;            // out: score, i - predecessor (0 = none)
-	double  *key;              // scratch, n: f + 0.5 * gap * (x + y), the negated priority of lchain.c:284
+	double  *key;              // scratch, n: the (negated, order-preserving) priority of lchain.c:284 by RANK in the read's (y, index) order, once the anchor is in the tree
+	ulonglong2 *by_y;          // scratch, n: (y << 32 | index, -) sorted: the (y, index) order of every read
+	int32_t *ord_idx;          // scratch, n: index of the anchor at every rank
+	int4    *meta;             // scratch, n: per anchor its rank, and the first and last rank of its range-minimum query
+	uint4   *l1;               // scratch, n / 64 + n_reads + 1: per 64 ranks the largest key (low, high), its holder | several << 31, holder's rank & 63
+	int32_t *bound;            // scratch, n / 64 + n_reads + 1: per 64 anchors (by index) the largest f + span
+	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed over reads [0] steps [1] late entries [2] summaries rebuilt [3] ties looked at [4] summary loads [5] inner blocks read [6] winners read from memory [7] eviction tests
 	int32_t *n_tied;           // out, per read: anchors whose range-minimum was shared by several elements (see post_kernels.hip)
 	int32_t *cursor;
 	int      grid_waves;

@@ -745,147 +745,388 @@ __device__ __forceinline__ int leading_out(unsigned long long stay)
 	return lo ? __builtin_ctz(lo) : hi ? 32 + __builtin_ctz(hi) : W;
 }
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+// ordered image of a double: signed 64-bit comparison of the images orders the values (no NaN here)
+__device__ __forceinline__ long long key_order(double k)
 {
-	const unsigned long long u = __double_as_longlong(v);
-	const unsigned lo = __shfl_xor((int)(unsigned)u, m), hi = __shfl_xor((int)(unsigned)(u >> 32), m);
-	return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+	const long long bits = __double_as_longlong(k);
+	return bits ^ ((bits >> 63) & 0x7fffffffffffffffLL);
+}
+
+// maximum over the wave, the same in every lane: rotations inside the four rows of 16 lanes by DPP, then the rows' values through
+// scalar registers.  Every lane must be active.
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));   // row_ror:1
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));   // row_ror:2
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));   // row_ror:4
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));   // row_ror:8
+	return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return (unsigned)wave_max_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
+__device__ __forceinline__ long long wave_max_i64(long long v)
+{
+	const int hi = wave_max_i32((int)(v >> 32));
+	const unsigned lo = wave_max_u32((int)(v >> 32) == hi ? (unsigned)v : 0u);
+	return (long long)((unsigned long long)(unsigned)hi << 32 | lo);
+}
+
+constexpr long long RMQ_NONE = LLONG_MIN;   // key of a slot nothing has been put in
+constexpr int RMQ_RING = 256;               // per wave: the most recent blocks' score bounds kept in LDS
+
+// a candidate of the range-minimum query.  rank: position in the read's (y, index) order -- among equal keys the stated rule takes the
+// largest.  check: >= 0 when the candidate stands for a block of 64 ranks whose summary says "several anchors share this key"; the
+// summary may say so after one of them has left the window, so the block is looked at before the tie is believed.
+struct RmqCand { long long ord; int j, rank, tie, check; };
+__device__ __forceinline__ void rmq_offer(RmqCand &c, bool in, long long ord, int j, int rank, int tie, int check)
+{
+	if (!in) return;
+	if (ord > c.ord) { c.ord = ord; c.j = j; c.rank = rank; c.tie = tie; c.check = check; }
+	else if (ord == c.ord) {
+		if (rank > c.rank) { c.j = j; c.rank = rank; }
+		c.tie = 1; c.check = -1;
+	}
+}
+
+// the largest key among the anchors of ranks [64 * blk, 64 * blk + 64) that are in the tree now (put in, index >= st), as a summary:
+// (key low, key high, holder's index | several holders << 31, holder's rank & 63); written back, and returned in every lane
+__device__ __forceinline__ uint4 rmq_block_summary(int blk, int n, int st, const long long *key, const int32_t *ord_idx, uint4 *l1)
+{
+	const int rk = (blk << 6) + lane();
+	long long k = RMQ_NONE;
+	int id = -1;
+	if (rk < n) { k = key[rk]; id = ord_idx[rk]; }
+	const bool act = k != RMQ_NONE && id >= st;
+	const long long top = wave_max_i64(act ? k : RMQ_NONE);
+	uint4 e = make_uint4((unsigned)top, (unsigned)((unsigned long long)top >> 32), 0x7fffffffu, 0u);
+	if (top != RMQ_NONE) {
+		const unsigned long long win = __ballot(act && k == top);
+		const int who = 63 - first_set_from_top(win);
+		e.z = (unsigned)__builtin_amdgcn_readlane(id, who) | (__popcll(win) > 1 ? 0x80000000u : 0u);
+		e.w = (unsigned)who;
+	}
+	if (lane() == 0) l1[blk] = e;
+	return e;
 }
 
 } // namespace
 
-// One WORKGROUP (4 waves) per read: the ranges a query scans hold thousands of anchors inside repeats, so 256 lanes scan them; every
-// wave keeps the (wave-uniform) state of the DP for itself -- same loads, same arithmetic -- and only the two arg-max reductions
-// cross waves, through LDS.
-__global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams P)
+// ---- preparation, one thread per anchor: the (y, index) order of every read, and what each anchor's query looks like in it ----
+__device__ __forceinline__ int64_t rmq_read_of(const int64_t *offsets, int64_t n_reads, int64_t g)
 {
-	constexpr int NW = POST_THREADS / W;
-	__shared__ double s_key[2][NW];
-	__shared__ int s_j[2][NW], s_y[2][NW], s_cnt[2][NW];
-	__shared__ int s_sc[2][NW], s_cj[2][NW], s_cy[2][NW];
-	const int l = lane(), w = uni(threadIdx.x / W), tid = threadIdx.x;
-	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
-	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;   // lchain.c:265
-	const double half_gap = 0.5 * (double)P.pen_gap;
-	for (int64_t r = blockIdx.x; r < b.n_reads; r += gridDim.x) {
+	int64_t lo = 0, hi = n_reads;                      // last r with offsets[r] <= g
+	while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (offsets[mid] <= g) lo = mid; else hi = mid; }
+	return lo;
+}
+__global__ __launch_bounds__(256) void k_rmq_prep_keys(RmqBatch b)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r = rmq_read_of(b.offsets, b.n_reads, g);
+		b.by_y[g] = make_ulonglong2((unsigned long long)b.raw[g].z << 32 | (unsigned long long)(g - b.offsets[r]), 0ULL);
+		((long long*)b.key)[g] = RMQ_NONE;
+	}
+	const int64_t nb = (b.n >> 6) + b.n_reads + 1;
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nb; g += (int64_t)gridDim.x * blockDim.x)
+		b.l1[g] = make_uint4(0u, 0x80000000u, 0x7fffffffu, 0u);   // RMQ_NONE, nobody
+}
+__global__ __launch_bounds__(256) void k_rmq_prep_ranks(RmqBatch b)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t off = b.offsets[rmq_read_of(b.offsets, b.n_reads, g)];
+		const int idx = (int)(unsigned)b.by_y[g].x;
+		b.ord_idx[g] = idx;
+		b.meta[off + idx].x = (int)(g - off);
+	}
+}
+__global__ __launch_bounds__(256) void k_rmq_prep_ranges(RmqBatch b, int max_dist)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r = rmq_read_of(b.offsets, b.n_reads, g);
 		const int64_t off = b.offsets[r];
 		const int n = (int)(b.offsets[r + 1] - off);
-		const uint4 *a = b.raw + off;
-		int32_t *f = b.f + off, *p = b.p + off;
-		double *key = b.key + off;
-		int i0 = 0, st = 0, st_in = 0, tied = 0;
-		for (int i = 0; i < n; ++i) {
-			const int par = i & 1;                                        // reduction slots alternate: one barrier per reduction
-			const uint4 ai = a[i];                                        // same address in every lane
-			const int yi = (int)ai.z, q_i = (int)(ai.w & 0xffu);
-			if (i0 < i) { const uint4 a0 = a[i0]; if (a0.x != ai.x || a0.y != ai.y) i0 = i; }               // lchain.c:279-292
-			i0 = uni(i0);
-			// eviction (lchain.c:293-310): the conditions hold for a prefix of [st, i), so 64 candidates are tested at once (by
-			// every wave for itself).  Loop control is explicitly wave-uniform and the bit scan is done on 32-bit halves: an
-			// earlier form with `for (;;) ... break` on __builtin_ctzll of the ballot hung (ROCm 7.2).
-			int adv;
-			do {
-				const int j = st + l;
-				bool out = false;
-				if (j < i) { const uint2 xj = *(const uint2*)&a[j]; out = xj.y != ai.y || ai.x > xj.x + (unsigned)max_dist || (i0 > j ? i0 - j : 0) > P.cap_rmq_size; }
-				const unsigned long long stay = ~__ballot(out);
-				adv = uni(leading_out(stay));
-				st += adv;
-			} while (adv == W);
-			if (max_inner > 0)
-				do {
-					const int j = st_in + l;
-					bool out = false;
-					if (j < i) { const uint2 xj = *(const uint2*)&a[j]; out = xj.y != ai.y || ai.x > xj.x + (unsigned)max_inner || (i0 > j ? i0 - j : 0) > P.cap_rmq_size; }
-					const unsigned long long stay = ~__ballot(out);
-					adv = uni(leading_out(stay));
-					st_in += adv;
-				} while (adv == W);
-			int max_f = q_i, max_j = -1;
-			// the range-minimum (lchain.c:311-315): closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index)
-			double bk = 0.0;
-			int bj = -1, by = 0, cnt = 0;
-			for (int j = st + tid; j < i0; j += POST_THREADS) {
-				const int yj = (int)a[j].z;
-				if (!((yj > yi - max_dist && yj < yi) || (yj == yi && j == 0))) continue;
-				const double k = key[j];
-				if (bj < 0 || k > bk) { bk = k; bj = j; by = yj; cnt = 1; }
-				else if (k == bk) { ++cnt; if (yj > by || (yj == by && j > bj)) { bj = j; by = yj; } }
-			}
-			for (int m = W / 2; m > 0; m >>= 1) {
-				const double ok = shfl_xor_f64(bk, m);
-				const int oj = __shfl_xor(bj, m), oy = __shfl_xor(by, m), oc = __shfl_xor(cnt, m);
-				if (oj >= 0) {
-					if (bj < 0 || ok > bk) { bk = ok; bj = oj; by = oy; cnt = oc; }
-					else if (ok == bk) { cnt += oc; if (oy > by || (oy == by && oj > bj)) { bj = oj; by = oy; } }
-				}
-			}
-			if (l == 0) { s_key[par][w] = bk; s_j[par][w] = bj; s_y[par][w] = by; s_cnt[par][w] = cnt; }
-			__syncthreads();
-			bk = s_key[par][0]; bj = s_j[par][0]; by = s_y[par][0]; cnt = s_cnt[par][0];
-			for (int q = 1; q < NW; ++q) {
-				const double ok = s_key[par][q];
-				const int oj = s_j[par][q], oy = s_y[par][q], oc = s_cnt[par][q];
-				if (oj >= 0) {
-					if (bj < 0 || ok > bk) { bk = ok; bj = oj; by = oy; cnt = oc; }
-					else if (ok == bk) { cnt += oc; if (oy > by || (oy == by && oj > bj)) { bj = oj; by = oy; } }
-				}
-			}
-			bj = uni(bj);
-			bool inner = false;
-			if (bj >= 0) {
-				if (uni(cnt) > 1) ++tied;
-				const uint4 aj = a[bj];
-				bool exact; int width;
-				const int sc = f[bj] + rmq_pair_score(ai.x, yi, aj.x, (int)aj.z, (int)(aj.w & 0xffu), P, exact, width);
-				if (width <= P.bw && sc > max_f) { max_f = sc; max_j = bj; }
-				inner = !exact && max_inner > 0 && st_in < i0 && yi > 0;
-			}
-			inner = uni(inner);
-			if (inner) {
-				// lchain.c:320-341: every inner-tree element with y in [yi - max_inner, yi - 1], from the largest (y, index) down;
-				// strict '>' keeps the first of equal scores, i.e. the largest (y, index)
-				int bs = INT_MIN, cj = -1, cy = 0;
-				for (int j = st_in + tid; j < i0; j += POST_THREADS) {
-					const uint4 aj2 = a[j];
-					const int yj = (int)aj2.z;
-					if (yj > yi - 1 || yj < yi - max_inner) continue;
-					bool ex2; int w2;
-					const int s2 = f[j] + rmq_pair_score(ai.x, yi, aj2.x, yj, (int)(aj2.w & 0xffu), P, ex2, w2);
-					if (w2 > P.bw) continue;
-					if (s2 > bs || (s2 == bs && (yj > cy || (yj == cy && j > cj)))) { bs = s2; cj = j; cy = yj; }
-				}
-				for (int m = W / 2; m > 0; m >>= 1) {
-					const int os = __shfl_xor(bs, m), oj = __shfl_xor(cj, m), oy = __shfl_xor(cy, m);
-					if (oj >= 0 && (cj < 0 || os > bs || (os == bs && (oy > cy || (oy == cy && oj > cj))))) { bs = os; cj = oj; cy = oy; }
-				}
-				if (l == 0) { s_sc[par][w] = bs; s_cj[par][w] = cj; s_cy[par][w] = cy; }
-				__syncthreads();
-				bs = s_sc[par][0]; cj = s_cj[par][0]; cy = s_cy[par][0];
-				for (int q = 1; q < NW; ++q) {
-					const int os = s_sc[par][q], oj = s_cj[par][q], oy = s_cy[par][q];
-					if (oj >= 0 && (cj < 0 || os > bs || (os == bs && (oy > cy || (oy == cy && oj > cj))))) { bs = os; cj = oj; cy = oy; }
-				}
-				cj = uni(cj); bs = uni(bs);
-				if (cj >= 0 && bs > max_f) { max_f = bs; max_j = cj; }
-			}
-			if (tid == 0) {                                                                            // lchain.c:346 (+ the key of lchain.c:284)
-				f[i] = max_f;
-				p[i] = max_j < 0 ? 0 : i - max_j;
-				key[i] = (double)max_f + half_gap * (double)((int)ai.x + (int)ai.z);
-			}
-			__threadfence_block();
-			__syncthreads();                                                                           // f / key of anchor i before any wave scans it
-		}
-		if (tid == 0) b.n_tied[r] = tied;
+		const ulonglong2 *z = b.by_y + off;
+		const int yi = (int)b.raw[g].z;
+		auto first_not_below = [&](long long y) {          // first rank whose y is >= y
+			int lo = 0, hi = n;
+			while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)(z[mid].x >> 32) < y) lo = mid + 1; else hi = mid; }
+			return lo;
+		};
+		// closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index) (lchain.c:311-313): y in (yi - max_dist, yi), plus anchor 0 when its y is yi
+		b.meta[g].y = first_not_below((long long)yi - max_dist + 1);
+		b.meta[g].z = first_not_below((long long)yi) - 1 + ((int)b.raw[off].z == yi ? 1 : 0);
 	}
 }
 
-void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
+// One WAVE per read, one anchor per step.  The reference's tree is ordered by (y, index) and answers "smallest priority with y in a
+// range"; here every read's anchors are ranked in that order beforehand, key[] holds the (negated) priorities by RANK -- set when an
+// anchor enters the tree -- and l1[] the largest key of every 64 consecutive ranks with its holder.  A query reads the two blocks of
+// ranks at the ends of its interval anchor by anchor and up to 64 block summaries per instruction in between.  Nothing is ever taken
+// out: an anchor that left the window is recognised by its index (< st), and a summary whose holder has left is rebuilt when a query
+// meets it.  Anchors enter one per step, some steps after they were scored; until then they are candidates straight from the
+// registers that hold the current block of 64 anchors and the one before it (one anchor per lane), so that no step waits for its
+// predecessor's stores.  The inner window's exhaustive scan (lchain.c:320-341) goes over indices, block by block, and skips a
+// block whose largest f + span cannot beat the score already found (comput_sc_simple never returns more than the span).
+__global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams P)
 {
-	if (b.n_reads <= 0) return;
-	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(b.n_reads, (int64_t)b.grid_waves / (POST_THREADS / W)));
-	hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
+	__shared__ int ring[POST_THREADS / W][RMQ_RING];       // largest f + span of the most recent finished blocks (by index)
+	const int l = lane(), w = uni(threadIdx.x / W);
+	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
+	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;   // lchain.c:265
+	const double half_gap = 0.5 * (double)P.pen_gap;
+	for (;;) {
+		int r = 0;
+		if (l == 0) r = atomicAdd(b.cursor, 1);
+		r = uni(r);
+		if (r >= b.n_reads) break;
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const uint4 *a = b.raw + off;
+		const int4 *meta = b.meta + off;
+		const int32_t *ord_idx = b.ord_idx + off;
+		int32_t *f = b.f + off, *p = b.p + off;
+		long long *key = (long long*)b.key + off;
+		uint4 *l1 = b.l1 + (off >> 6) + r;                 // n / 64 + 1 entries of this read
+		int32_t *bound = b.bound + (off >> 6) + r;
+		int i0 = 0, st = 0, st_in = 0, ins = 0, tied = 0;
+		int d_late = 0, d_stale = 0, d_check = 0, d_l1 = 0, d_inner = 0, d_far = 0, d_evict = 0;   // MM2GB_DEBUG_PHASES
+		unsigned x0_lo = 0, x0_hi = 0;                     // x of anchor i0
+		uint4 ca = make_uint4(0, 0, 0, 0), pa = ca;        // anchors of the current block and of the one before
+		int4 cm = make_int4(0, 0, 0, 0);                   // current block: rank, first and last rank of the query
+		int cf = 0, cp = 0, pf = 0, prank = 0;
+		long long ck = 0, pk = 0;
+		int hblk = -1, iblk = -1;
+		unsigned hxl = 0, hxh = 0, ixl = 0, ixh = 0;       // x of the blocks st and st_in are in
+		for (int i = 0; i < n; ++i) {
+			const int k = i & 63, B = i >> 6;
+			if (k == 0) {
+				if (i > 0) {
+					const int base = (B - 1) << 6;
+					f[base + l] = cf; p[base + l] = cp;
+					const int top = wave_max_i32(cf + (int)(ca.w & 0xffu));
+					if (l == 0) { ring[w][(B - 1) & (RMQ_RING - 1)] = top; bound[B - 1] = top; }
+					pa = ca; pf = cf; pk = ck; prank = cm.x;
+				}
+				ca = i + l < n ? a[i + l] : make_uint4(0, 0, 0, 0);
+				cm = i + l < n ? meta[i + l] : make_int4(0, 0, 0, 0);
+				cf = 0; cp = 0; ck = 0;
+			}
+			const unsigned xi_lo = (unsigned)__builtin_amdgcn_readlane((int)ca.x, k), xi_hi = (unsigned)__builtin_amdgcn_readlane((int)ca.y, k);
+			const int yi = __builtin_amdgcn_readlane((int)ca.z, k), q_i = __builtin_amdgcn_readlane((int)ca.w, k) & 0xff;
+			const int q_lo = __builtin_amdgcn_readlane(cm.y, k), q_hi = __builtin_amdgcn_readlane(cm.z, k);
+			if (i == 0) { x0_lo = xi_lo; x0_hi = xi_hi; }
+			if (i0 < i && (x0_lo != xi_lo || x0_hi != xi_hi)) { i0 = i; x0_lo = xi_lo; x0_hi = xi_hi; }     // lchain.c:279-292
+			// eviction (lchain.c:293-310): the conditions hold for a prefix of [st, i); a block of 64 candidates is tested at once
+			for (;;) {
+				const int sb = st >> 6;
+				unsigned xl, xh;
+				if (sb == B) { xl = ca.x; xh = ca.y; }
+				else if (sb == B - 1) { xl = pa.x; xh = pa.y; }
+				else {
+					if (hblk != sb) { const uint2 t = *(const uint2*)&a[(sb << 6) + l]; hxl = t.x; hxh = t.y; hblk = sb; }
+					xl = hxl; xh = hxh;
+				}
+				const int j = (sb << 6) + l;
+				++d_evict;
+				const bool out = j < st || (j < i && (xh != xi_hi || (unsigned long long)xi_lo > (unsigned long long)xl + (unsigned)max_dist || (i0 > j ? i0 - j : 0) > P.cap_rmq_size));
+				const int adv = uni(leading_out(~__ballot(out)));
+				st = (sb << 6) + adv;
+				if (adv < W) break;
+			}
+			if (max_inner > 0)
+				for (;;) {
+					const int sb = st_in >> 6;
+					unsigned xl, xh;
+					if (sb == B) { xl = ca.x; xh = ca.y; }
+					else if (sb == B - 1) { xl = pa.x; xh = pa.y; }
+					else {
+						if (iblk != sb) { const uint2 t = *(const uint2*)&a[(sb << 6) + l]; ixl = t.x; ixh = t.y; iblk = sb; }
+						xl = ixl; xh = ixh;
+					}
+					const int j = (sb << 6) + l;
+					const bool out = j < st_in || (j < i && (xh != xi_hi || (unsigned long long)xi_lo > (unsigned long long)xl + (unsigned)max_inner || (i0 > j ? i0 - j : 0) > P.cap_rmq_size));
+					const int adv = uni(leading_out(~__ballot(out)));
+					st_in = (sb << 6) + adv;
+					if (adv < W) break;
+				}
+			// anchors that wait to enter and are no longer in registers (a run of equal x longer than a block, or the block change): now, one by one
+			if (ins < i0 && ins < (B - 1) * W) wave_sync();
+			while (ins < i0 && ins < (B - 1) * W) {
+				const uint4 e = a[ins];
+				const int rank = meta[ins].x;
+				const long long kk = key_order((double)f[ins] + half_gap * (double)((int)e.x + (int)e.z));
+				if (l == 0) key[rank] = kk;
+				wave_sync();
+				rmq_block_summary(rank >> 6, n, st, key, ord_idx, l1);
+				++ins; ++d_late;
+			}
+			wave_sync();                                       // the stores of earlier steps before this step's loads
+			// the anchor that enters in this step (if any): its block's summary is read together with the query's data and rewritten after it
+			const bool enter = ins < i0;
+			int e_rank = 0;
+			long long e_key = 0;
+			uint4 e_sum = make_uint4(0, 0, 0, 0);
+			if (enter) {
+				const int src = ins & 63;
+				if ((ins >> 6) == B) { e_rank = __builtin_amdgcn_readlane(cm.x, src); e_key = (long long)readlane64((unsigned long long)ck, src); }
+				else { e_rank = __builtin_amdgcn_readlane(prank, src); e_key = (long long)readlane64((unsigned long long)pk, src); }
+				e_sum = l1[e_rank >> 6];
+			}
+			int max_f = q_i, max_j = -1;
+			RmqCand c;
+			c.ord = RMQ_NONE; c.j = -1; c.rank = -1; c.tie = 0; c.check = -1;
+			{	// not yet in the tree's arrays: straight from the registers
+				const int j = (B << 6) + l;
+				rmq_offer(c, j >= ins && j >= st && j < i0 && cm.x >= q_lo && cm.x <= q_hi, ck, j, cm.x, 0, -1);
+			}
+			if (B > 0) {
+				const int j = ((B - 1) << 6) + l;
+				rmq_offer(c, j >= ins && j >= st && j < i0 && prank >= q_lo && prank <= q_hi, pk, j, prank, 0, -1);
+			}
+			if (q_lo <= q_hi && ins > st) {
+				const int lb = q_lo >> 6, hb = q_hi >> 6;
+				{
+					const int rk = (lb << 6) + l;
+					if (rk >= q_lo && rk <= q_hi) { const long long kk = key[rk]; const int id = ord_idx[rk]; rmq_offer(c, kk != RMQ_NONE && id >= st, kk, id, rk, 0, -1); }
+				}
+				if (hb > lb) {
+					const int rk = (hb << 6) + l;
+					if (rk <= q_hi) { const long long kk = key[rk]; const int id = ord_idx[rk]; rmq_offer(c, kk != RMQ_NONE && id >= st, kk, id, rk, 0, -1); }
+				}
+				for (int bb0 = lb + 1; bb0 < hb; bb0 += W) {
+					++d_l1;
+					const int bb = bb0 + l;
+					bool stale = false;
+					if (bb < hb) {
+						const uint4 e = l1[bb];
+						const long long kk = (long long)((unsigned long long)e.y << 32 | e.x);
+						const int id = (int)(e.z & 0x7fffffffu);
+						stale = kk != RMQ_NONE && id < st;
+						rmq_offer(c, kk != RMQ_NONE && !stale, kk, id, (bb << 6) + (int)e.w, 0, (e.z >> 31) ? bb : -1);
+					}
+					unsigned long long m = __ballot(stale);
+					while (m) {                                    // the holder of a block's largest key has left the window: look at the block
+						++d_stale;
+						const int s = first_set(m);
+						m &= m - 1;
+						const uint4 e = rmq_block_summary(bb0 + s, n, st, key, ord_idx, l1);
+						const long long kk = (long long)((unsigned long long)e.y << 32 | e.x);
+						if (l == s) rmq_offer(c, kk != RMQ_NONE, kk, (int)(e.z & 0x7fffffffu), ((bb0 + s) << 6) + (int)e.w, (int)(e.z >> 31), -1);
+					}
+				}
+			}
+			if (enter) {                                       // the entering anchor's key and its block's summary, while the query is reduced
+				const long long cur = (long long)((unsigned long long)e_sum.y << 32 | e_sum.x);
+				const int holder = (int)(e_sum.z & 0x7fffffffu), r6 = e_rank & 63;
+				if (l == 0) key[e_rank] = e_key;
+				if (cur != RMQ_NONE && holder < st) {              // that summary's holder has left: rebuilt with the new anchor in it
+					wave_sync();
+					rmq_block_summary(e_rank >> 6, n, st, key, ord_idx, l1);
+				} else if (cur == RMQ_NONE || e_key > cur) {
+					if (l == 0) l1[e_rank >> 6] = make_uint4((unsigned)e_key, (unsigned)((unsigned long long)e_key >> 32), (unsigned)ins, (unsigned)r6);
+				} else if (e_key == cur) {
+					const bool later = r6 > (int)e_sum.w;
+					if (l == 0) l1[e_rank >> 6] = make_uint4(e_sum.x, e_sum.y, (unsigned)(later ? ins : holder) | 0x80000000u, (unsigned)(later ? r6 : (int)e_sum.w));
+				}
+				++ins;
+			}
+			long long top = wave_max_i64(c.ord);
+			bool inner = false;
+			if (top != RMQ_NONE) {
+				unsigned long long m = __ballot(c.ord == top && c.check >= 0);
+				if (m) wave_sync();
+				while (m) {                                        // "several holders" on a winning summary: believed after a look at the block
+					const int s = first_set(m);
+					m &= m - 1;
+					const int blk = __builtin_amdgcn_readlane(c.check, s);
+					++d_check;
+					const uint4 e = rmq_block_summary(blk, n, st, key, ord_idx, l1);
+					if (l == s) { c.j = (int)(e.z & 0x7fffffffu); c.rank = (blk << 6) + (int)e.w; c.tie = (int)(e.z >> 31); c.check = -1; }
+				}
+				unsigned long long win = __ballot(c.ord == top);
+				if (__popcll(win) > 1 || __ballot(c.ord == top && c.tie) != 0) {
+					++tied;                                        // the stated rule among equal keys: largest (y, index), i.e. largest rank
+					const int rr = wave_max_i32(c.ord == top ? c.rank : -1);
+					win = __ballot(c.ord == top && c.rank == rr);
+				}
+				const int bj = __builtin_amdgcn_readlane(c.j, first_set(win));
+				unsigned xj; int yj, sj, fj;
+				if ((bj >> 6) == B) {
+					const int s = bj & 63;
+					xj = (unsigned)__builtin_amdgcn_readlane((int)ca.x, s); yj = __builtin_amdgcn_readlane((int)ca.z, s);
+					sj = __builtin_amdgcn_readlane((int)ca.w, s) & 0xff; fj = __builtin_amdgcn_readlane(cf, s);
+				} else if ((bj >> 6) == B - 1) {
+					const int s = bj & 63;
+					xj = (unsigned)__builtin_amdgcn_readlane((int)pa.x, s); yj = __builtin_amdgcn_readlane((int)pa.z, s);
+					sj = __builtin_amdgcn_readlane((int)pa.w, s) & 0xff; fj = __builtin_amdgcn_readlane(pf, s);
+				} else {
+					++d_far;
+					const uint4 e = a[bj];
+					xj = e.x; yj = (int)e.z; sj = (int)(e.w & 0xffu); fj = f[bj];
+				}
+				bool exact; int width;
+				const int sc = fj + rmq_pair_score(xi_lo, yi, xj, yj, sj, P, exact, width);
+				if (width <= P.bw && sc > max_f) { max_f = sc; max_j = bj; }
+				max_f = uni(max_f); max_j = uni(max_j);
+				inner = uni((int)(!exact && max_inner > 0 && st_in < i0 && yi > 0)) != 0;
+			}
+			if (inner) {
+				// lchain.c:320-341: every inner-tree element with y in [yi - max_inner, yi - 1], from the largest (y, index) down; strict '>'
+				// keeps the first of equal scores, i.e. the largest (y, index), and nothing replaces the outer result without beating it
+				int bs = max_f, cj = -1, cy = 0;
+				const int y_top = yi - 1, y_bot = yi - max_inner;
+				auto offer = [&](bool in, unsigned xj, int yj, int sj, int fj, int j) {
+					if (!in || yj > y_top || yj < y_bot) return;
+					bool ex2; int w2;
+					const int s2 = fj + rmq_pair_score(xi_lo, yi, xj, yj, sj, P, ex2, w2);
+					if (w2 > P.bw) return;
+					if (s2 > bs || (s2 == bs && cj >= 0 && (yj > cy || (yj == cy && j > cj)))) { bs = s2; cj = j; cy = yj; }
+				};
+				{ const int j = (B << 6) + l; offer(j >= st_in && j < i0, ca.x, (int)ca.z, (int)(ca.w & 0xffu), cf, j); }
+				if (B > 0) { const int j = ((B - 1) << 6) + l; offer(j >= st_in && j < i0, pa.x, (int)pa.z, (int)(pa.w & 0xffu), pf, j); }
+				const int e_hi = min(i0, (B - 1) * W);
+				if (st_in < e_hi) {
+					const int b_lo = st_in >> 6, b_hi = (e_hi + 63) >> 6;        // blocks b_lo .. b_hi - 1, all finished
+					for (int bb0 = b_lo; bb0 < b_hi; bb0 += W) {
+						const int bb = bb0 + l;
+						bool look = false;
+						if (bb < b_hi) look = (bb >= B - RMQ_RING ? ring[w][bb & (RMQ_RING - 1)] : bound[bb]) > max_f;
+						unsigned long long m = __ballot(look);
+						while (m) {
+							const int s = first_set(m);
+							m &= m - 1;
+							++d_inner;
+							const int j = ((bb0 + s) << 6) + l;
+							if (j >= st_in && j < e_hi) { const uint4 e = a[j]; offer(true, e.x, (int)e.z, (int)(e.w & 0xffu), f[j], j); }
+						}
+					}
+				}
+				const int best = wave_max_i32(cj >= 0 ? bs : INT_MIN);
+				if (best != INT_MIN) {
+					unsigned long long win = __ballot(cj >= 0 && bs == best);
+					if (__popcll(win) > 1) {
+						const int yy = wave_max_i32(cj >= 0 && bs == best ? cy : INT_MIN);
+						const int jj = wave_max_i32(cj >= 0 && bs == best && cy == yy ? cj : -1);
+						win = __ballot(cj >= 0 && bs == best && cy == yy && cj == jj);
+					}
+					max_f = best; max_j = __builtin_amdgcn_readlane(cj, first_set(win));
+				}
+			}
+			if (l == k) {                                                                              // lchain.c:346 (+ the key of lchain.c:284)
+				cf = max_f;
+				cp = max_j < 0 ? 0 : i - max_j;
+				ck = key_order((double)max_f + half_gap * (double)((int)xi_lo + yi));
+			}
+		}
+		if (n > 0) {
+			const int base = ((n - 1) >> 6) << 6;
+			if (base + l < n) { f[base + l] = cf; p[base + l] = cp; }
+		}
+		if (l == 0) b.n_tied[r] = tied;
+		if (b.dbg && l == 0) {
+			const long long v[8] = { n, d_late, d_stale, d_check, d_l1, d_inner, d_far, d_evict };
+			for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
+		}
+		wave_sync();
+	}
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -1151,6 +1392,22 @@ void launch_post(const PostBatch &b, hipStream_t s)
 	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b);
 	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b);
 	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);
+}
+
+void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
+{
+	if (b.n_reads <= 0 || b.n <= 0) { if (b.n_reads > 0) (void)hipMemsetAsync(b.n_tied, 0, (size_t)b.n_reads * sizeof(int32_t), s); return; }
+	(void)hipMemsetAsync(b.cursor, 0, sizeof(int32_t), s);
+	const unsigned wide = (unsigned)std::min<int64_t>((b.n + 255) / 256, (int64_t)b.grid_waves * 4);
+	hipLaunchKernelGGL(k_rmq_prep_keys, dim3(wide), dim3(256), 0, s, b);
+	SortBatch sb;
+	sb.a = b.by_y; sb.offsets = b.offsets; sb.n_reads = b.n_reads; sb.cursor = nullptr; sb.grid_waves = b.grid_waves;
+	launch_sort_x(sb, s);
+	hipLaunchKernelGGL(k_rmq_prep_ranks, dim3(wide), dim3(256), 0, s, b);
+	hipLaunchKernelGGL(k_rmq_prep_ranges, dim3(wide), dim3(256), 0, s, b, P.max_dist < P.bw ? P.bw : P.max_dist);
+	const int per = POST_THREADS / W;
+	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, (int64_t)b.grid_waves / per));
+	hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
 }
 
 } // namespace mm2gb

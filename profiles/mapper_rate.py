@@ -31,7 +31,7 @@ with tempfile.TemporaryDirectory() as td:
     out = {"reads": n_reads, "seed": seed, "read_len": [len_lo, len_hi], "bases": bases, "index_seconds": round(t_index, 3), "map_seconds": round(best, 4), "gbp_per_s_mapping": bases / best / 1e9,
            "gbp_per_s_with_index": bases / (best + t_index) / 1e9, "paf_lines": paf.count("\n"), "stats": st, "host_threads": 16}
     host = os.path.join(ROOT, "oracle", "_ref", "minimap2_cpu")
-    if os.path.exists(host):
+    if os.path.exists(host) and not os.environ.get("MAPPER_RATE_NO_REF"):
         t0 = time.perf_counter()
         r = subprocess.run([host, "-t", "16", "--max-chain-skip=2147483647", ref, reads], capture_output=True)
         out["reference_cpu_seconds_t16"] = round(time.perf_counter() - t0, 3)

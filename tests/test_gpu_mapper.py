@@ -37,16 +37,18 @@ def test_reference_test_pairs_paf_identical(engine, case, tgt, qry, seeds_on_dev
     assert st["n_rmq_tied"] == 0
 
 
+@pytest.mark.parametrize("rechain_on_device", [1, 0], ids=["rechain_on_device", "rechain_on_host"])
 @pytest.mark.parametrize("seeds_on_device", [1, -1], ids=["anchors_on_device", "anchors_on_host"])
-def test_simulated_long_reads_paf(engine, tmp_path, seeds_on_device):
+def test_simulated_long_reads_paf(engine, tmp_path, seeds_on_device, rechain_on_device):
     """Everything a long-read run exercises: minimizers above mid_occ, reads on both strands, secondary hits, re-chaining of most reads
-    through mg_lchain_rmq (host form with the reference's tree: ties on the range-minimum priority break as they do there)."""
+    through mg_lchain_rmq: k_rmq_fill on the device, with the reads that met a tie on the range-minimum priority redone by the host form
+    (the reference's tree: ties break as they do there), or the host form for all of them."""
     meta = json.load(open(os.path.join(GOLD, "sim160.json")))
     ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
     sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
     assert hashlib.md5(open(ref, "rb").read()).hexdigest() == meta["ref_md5"], "simulator drifted: regenerate the golden"
     assert hashlib.md5(open(reads, "rb").read()).hexdigest() == meta["reads_md5"]
-    paf, st = map_files(engine, ref, reads, seeds_on_device=seeds_on_device)
+    paf, st = map_files(engine, ref, reads, seeds_on_device=seeds_on_device, rechain_on_device=rechain_on_device)
     want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
     assert st["n_reads"] == meta["n_reads"] and st["n_mapped"] >= 150 and st["n_rechained"] >= 100
     if paf != want:
