@@ -370,6 +370,13 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			for (auto &th : pool) th.join();
 		}
 		const bool verbose = getenv("MM2GB_DEBUG_PHASES") != nullptr;
+		if (const char *path = getenv("MM2GB_DUMP_RECHAIN")) {       // the re-chaining call's input, for profiling csrc/rmq_host.cpp off the box: offsets, then anchors
+			if (FILE *fp = fopen(path, "wb")) {
+				const int64_t nr = (int64_t)redo.size();
+				fwrite(&nr, 8, 1, fp); fwrite(ro.data(), 8, ro.size(), fp); fwrite(ra.data(), sizeof(mm2gb_anchor_t), ra.size(), fp);
+				fclose(fp);
+			}
+		}
 		const auto t_sorted = std::chrono::steady_clock::now();
 		const mm2gb_rmq_param_t rp = { opt.max_gap, opt.rmq_inner_dist, opt.bw_long, INT32_MAX, opt.rmq_size_cap, opt.min_cnt, opt.min_chain_score, misc.chn_pen_gap, misc.chn_pen_skip };
 		mm2gb_chains_t rc; memset(&rc, 0, sizeof rc);

@@ -243,6 +243,74 @@ struct ShapeTree {
 // The inner window (lchain.c:286-290, 301-310, 320-341): its anchors are only ever walked in (y, index) order over a y-range, which
 // does not depend on a tree's shape.  They are kept in buckets of 64 query positions, each a small array in (y, index) order holding
 // what scoring a pair needs -- position, span, score -- so that the walk reads memory front to back instead of chasing indices.
+// A tournament tree of fixed shape over the read's anchors in (y, index) order: the same answer as the reference's tree wherever ONE
+// anchor in range holds the smallest priority, at a fraction of the cost (no rebalancing, no pointers; an update stops at the first
+// ancestor it does not change).  Where several anchors share the smallest priority the reference's answer depends on the shape of its
+// tree: this one only reports the tie, and the read is done again with ShapeTree.
+struct RankTree {
+	struct Node { double pri; int who, tie; };
+	std::vector<Node> t;
+	std::vector<uint64_t> by_y;
+	std::vector<int> rank, q_lo, q_hi;
+	int base = 1;
+	unsigned held = 0;
+	static constexpr double EMPTY = 1e300;
+
+	void reset(const mm2gb_anchor_t *a, int n, int max_dist)
+	{
+		by_y.resize((size_t)n); rank.resize((size_t)n); q_lo.resize((size_t)n); q_hi.resize((size_t)n);
+		for (int j = 0; j < n; ++j) by_y[(size_t)j] = (uint64_t)(uint32_t)(int32_t)a[j].y << 32 | (uint32_t)j;
+		std::sort(by_y.begin(), by_y.end());
+		for (int r = 0; r < n; ++r) rank[(size_t)(uint32_t)by_y[(size_t)r]] = r;
+		// the closed interval [(y - max_dist, INT32_MAX), (y, 0)] of (y, index) (lchain.c:311-313) in ranks: y' in (y - max_dist, y), and
+		// anchor 0 -- the first of its y -- when its y is y
+		const int64_t y0 = n > 0 ? (int32_t)a[0].y : 0;
+		int lo = 0, hi = 0;
+		for (int r = 0; r < n; ++r) {
+			const int64_t y = (int32_t)(by_y[(size_t)r] >> 32);
+			while (lo < n && (int64_t)(int32_t)(by_y[(size_t)lo] >> 32) <= y - max_dist) ++lo;
+			while (hi < n && (int64_t)(int32_t)(by_y[(size_t)hi] >> 32) < y) ++hi;
+			const int j = (int)(uint32_t)by_y[(size_t)r];
+			q_lo[(size_t)j] = lo; q_hi[(size_t)j] = hi - 1 + (y0 == y ? 1 : 0);
+		}
+		base = 1;
+		while (base < n) base <<= 1;
+		t.assign((size_t)base * 2, Node{ EMPTY, -1, 0 });
+		held = 0;
+	}
+	static Node lower_of(const Node &u, const Node &v)
+	{
+		if (v.pri < u.pri) return v;
+		if (v.pri == u.pri && v.pri != EMPTY) return Node{ u.pri, u.who, 1 };
+		return u;
+	}
+	void settle(size_t at)
+	{
+		for (at >>= 1; at >= 1; at >>= 1) {
+			const Node now = lower_of(t[at * 2], t[at * 2 + 1]);
+			Node &was = t[at];
+			if (now.pri == was.pri && now.who == was.who && now.tie == was.tie) break;
+			was = now;
+		}
+	}
+	void insert(int j, double priority) { const size_t at = (size_t)base + (size_t)rank[(size_t)j]; t[at] = Node{ priority, j, 0 }; ++held; settle(at); }
+	void erase(int j) { const size_t at = (size_t)base + (size_t)rank[(size_t)j]; t[at] = Node{ EMPTY, -1, 0 }; --held; settle(at); }
+	unsigned size() const { return held; }
+	// the anchor of smallest priority in anchor i's interval, -1 if none; *tied when several hold it
+	int lowest_for(int i, bool *tied) const
+	{
+		size_t l = (size_t)base + (size_t)q_lo[(size_t)i], r = (size_t)base + (size_t)(q_hi[(size_t)i] + 1);
+		Node best{ EMPTY, -1, 0 };
+		if (q_lo[(size_t)i] > q_hi[(size_t)i]) return -1;
+		for (; l < r; l >>= 1, r >>= 1) {
+			if (l & 1) best = lower_of(best, t[l++]);
+			if (r & 1) best = lower_of(best, t[--r]);
+		}
+		*tied = best.tie != 0;
+		return best.who;
+	}
+};
+
 struct InnerCand { int32_t y, j, x, f; int32_t span; };
 struct InnerWindow {
 	static constexpr int SHIFT = 6;
@@ -282,18 +350,20 @@ struct InnerWindow {
 			}
 	}
 };
-struct FillScratch { ShapeTree tree; InnerWindow inner; std::vector<int32_t> seen; };   // seen: the reference's t[] (lchain.c:333-338)
+struct FillScratch { ShapeTree tree; RankTree flat; InnerWindow inner; std::vector<int32_t> seen; };   // seen: the reference's t[] (lchain.c:333-338)
 
 // f[n], p_rel[n] (i - predecessor, 0 = none) of one read
 // pen: (int)(gap * dd + .5 * mg_log2(dd + 1)) for dd = 0 .. bw when chn_pen_skip == 0 (the penalty then depends on dd alone), else null
-void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws, const int32_t *pen)
+// EXACT_SHAPE: with the reference's tree (always complete); otherwise with the tournament tree, giving up -- false -- at the first tie
+template<bool EXACT_SHAPE>
+bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t *a, int32_t *f, int32_t *p_rel, FillScratch &ws, const int32_t *pen)
 {
 	const int n = (int)n64;
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                                   // lchain.c:264
 	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;         // lchain.c:265
 	const double half_gap = 0.5 * (double)P.chn_pen_gap;
-	ShapeTree &tree = ws.tree;
-	tree.reset(a, n);
+	auto &tree = [&]() -> auto& { if constexpr (EXACT_SHAPE) return ws.tree; else return ws.flat; }();
+	if constexpr (EXACT_SHAPE) tree.reset(a, n); else tree.reset(a, n, max_dist);
 	ws.seen.assign((size_t)n, 0);
 	if (max_inner > 0 && n > 0) {
 		int y_min = INT32_MAX, y_max = INT32_MIN;
@@ -322,7 +392,9 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 			}
 		int max_f = q_i, max_j = -1;
 		// lchain.c:311-315: the closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index)
-		const int j = tree.lowest_between(yi - max_dist, INT32_MAX, yi, 0);
+		int j;
+		if constexpr (EXACT_SHAPE) j = tree.lowest_between(yi - max_dist, INT32_MAX, yi, 0);
+		else { bool tied = false; j = tree.lowest_for(i, &tied); if (tied) return false; }
 		if (j >= 0) {
 			bool exact; int width;
 			const int sc = f[j] + pair_score(a[i], a[j], P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
@@ -370,6 +442,7 @@ void rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 		f[i] = max_f;
 		p_rel[i] = max_j < 0 ? 0 : i - max_j;
 	}
+	return true;
 }
 
 } // namespace
@@ -412,6 +485,9 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 	std::sort(order.begin(), order.end(), [&](int64_t u, int64_t v) { const int64_t nu = offsets[u + 1] - offsets[u], nv = offsets[v + 1] - offsets[v]; return nu != nv ? nu > nv : u < v; });
 	std::atomic<int64_t> next(0);
 	HostAlloc libc_mem;
+	if (n_tied) for (int64_t r = 0; r < n_reads; ++r) n_tied[r] = 0;   // becomes 1 for a read that met a tie and was done with the reference's tree
+	const char *force = getenv("MM2GB_RMQ_TREE");
+	const bool exact_only = force && !strcmp(force, "avl");              // MM2GB_RMQ_TREE=avl: the reference's tree for every read
 	auto work = [&]() {
 		FillScratch ws;
 		BacktrackScratch bs;
@@ -423,12 +499,15 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 			const int64_t n = offsets[r + 1] - offsets[r];
 			if (n == 0) continue;
 			f.resize((size_t)n); p.resize((size_t)n);
-			rmq_fill_one(*prm, n, anchors + offsets[r], f.data(), p.data(), ws, pen.empty() ? nullptr : pen.data());
+			// the quick tree first; a read in which two anchors in range share the smallest priority -- few -- is done again with the reference's
+			if (exact_only || !rmq_fill_one<false>(*prm, n, anchors + offsets[r], f.data(), p.data(), ws, pen.empty() ? nullptr : pen.data())) {
+				rmq_fill_one<true>(*prm, n, anchors + offsets[r], f.data(), p.data(), ws, pen.empty() ? nullptr : pen.data());
+				if (n_tied && !exact_only) n_tied[r] = 1;
+			}
 			nu_of[(size_t)r] = backtrack_compact(misc, n, anchors + offsets[r], f.data(), p.data(), libc_mem, bs, &u_of[(size_t)r], &a_of[(size_t)r]);
 			for (int c = 0; c < nu_of[(size_t)r]; ++c) na_of[(size_t)r] += (uint32_t)u_of[(size_t)r][c];
 		}
 	};
-	if (n_tied) for (int64_t r = 0; r < n_reads; ++r) n_tied[r] = 0;
 	const int nt = std::max(1, n_threads);
 	if (nt == 1) work();
 	else { std::vector<std::thread> pool; for (int t = 0; t < nt; ++t) pool.emplace_back(work); for (auto &th : pool) th.join(); }
