@@ -128,18 +128,21 @@ int  mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_of
  *      reproduces: n_tied[r] (optional) counts the anchors of read r where that happened; the chains of a read with
  *      n_tied[r] != 0 may differ from the reference's and are for the caller to discard (mm2gb_lchain_rmq does).
  *      max_chn_skip is ignored: the device path is exhaustive (== INT32_MAX), like mm2gb_lchain_dp.
- *      mm2gb_lchain_rmq: one read, signature and ownership of mg_lchain_rmq; a read that met a tie is handed to the host's own
- *      mg_lchain_rmq when the library is linked into minimap2 (weak import), otherwise the call fails loudly. ---- */
+ *      mm2gb_lchain_rmq: one read, signature and ownership of mg_lchain_rmq; answered by the host form below (exact for every read);
+ *      with MM2GB_RMQ=gpu by the kernel, and then a read that met a tie is handed to the host's own mg_lchain_rmq when the library is
+ *      linked into minimap2 (weak import), otherwise the call fails loudly. ---- */
 typedef struct {
 	int max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc;
 	float chn_pen_gap, chn_pen_skip;
 } mm2gb_rmq_param_t;
 int  mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                          mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats);
-/* The same on host threads with the reference's own tree (csrc/rmq_host.cpp: an AVL tree with krmq.h's insertion, deletion, rotation and
- * subtree-minimum rules, on arrays): O(log n) per anchor where the kernel scans the window -- the form for the re-chaining call of
- * map.c:697-708, whose window is bw_long = 20 000 bases -- and the reference's answer for EVERY read, priority ties included (which
- * element a tie returns follows from the tree's shape), at any max_chn_skip.  n_tied (may be NULL) is set to 0s. */
+/* The same on host threads, O(log n) per anchor, the reference's answer for EVERY read at any max_chn_skip (csrc/rmq_host.cpp): a read
+ * is first done with a tournament tree of fixed shape over its anchors' (y, index) ranks, which gives the reference's answer as long as
+ * one anchor in range holds the smallest priority; at the first tie (which element the reference returns then follows from its tree's
+ * shape) the read is done again with the reference's own tree -- an AVL tree with krmq.h's insertion, deletion, rotation and
+ * subtree-minimum rules, on arrays (MM2GB_RMQ_TREE=avl: that tree for every read).  n_tied[r] (may be NULL) = 1 for a read that was
+ * done again, else 0: information only, the chains are exact either way. */
 int  mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
                           mm2gb_chains_t *out, int32_t *n_tied);
 mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,

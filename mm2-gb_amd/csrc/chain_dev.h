@@ -11,12 +11,22 @@ struct DevParams {
 	int   dq_lim;            // min(max_dist_x, max_dist_y): the single-segment fast path's dq bound
 	int   lut_last;          // last index of the penalty table: bw + 1 (the "reject" entry) when lut_clamp, else max_dist_x
 	int   lut_clamp;         // 1: the sweep clamps the table index to lut_last; 0: the table covers every index that can matter
+	int   free_sweep;        // 1 (only without lut_clamp): source blocks whose every pair has bw < dr <= dq_lim - bw are swept without range test
 	float gap, skip;
 };
 
 // bits of DevBatch::flags[0]
 enum : unsigned { FLAG_ANY_SEGID = 1u,     // some anchor carries a segment id -> MODE_GENERAL
                   FLAG_NO_LUT = 2u };      // a query position >= 2^22 or a zero q_span -> the table sweep is not exact, use MODE_FAST
+
+// MODE_LUT keeps its penalty table at the END of the workgroup's LDS, at a compile-time address (it goes into the offset field of the
+// gathers) and all the way to the last byte the hardware allocates (a multiple of every LDS granule in use: 512 and 1 280 bytes), so
+// that an index beyond the table is an address beyond the allocation, which reads as 0 = "reject" (chain_kernels.hip, sweep_block_lut).
+constexpr int LUT_LDS_TOTAL = 31 * 2560;               // 79 360 bytes: two 1024-thread workgroups per CU (160 KB LDS)
+constexpr int LUT_ENTRIES   = 5120;                    // dd = 0 .. 5119
+constexpr int LUT_LDS_BASE  = LUT_LDS_TOTAL - LUT_ENTRIES * 4;   // 58 880 < 2^16: fits the DS offset field
+// a valid entry is LUT_BIAS - 128 * penalty, a rejecting one 0; sources are staged with their score term lowered by LUT_BIAS
+constexpr int LUT_BIAS      = (1 << 30) + (1 << 16);
 
 // Planner granularity: anchors per planning block (one k_window workgroup).
 constexpr int PLAN_BLOCK = 1024;
@@ -65,7 +75,7 @@ struct DevBatch {
 	int32_t  *counters;        // [0] n_chunks [1] work cursor (wave kernel) [2] n_long [3] work cursor (long kernel) [4] n_tracked [5] n_clamped_blocks
 	int64_t  *totals;          // [0] total pairs [1] clamped windows [2] summed cost of the chunks on the big-team list
 	unsigned *flags;           // FLAG_*
-	const int32_t *lut;        // penalty by dd, lut_last + 1 entries (MODE_LUT only)
+	const int32_t *lut;        // penalty table by dd, LUT_ENTRIES entries (MODE_LUT only)
 	int64_t  *dbg;             // optional: 4 time stamps per score workgroup (MM2GB_DEBUG_PHASES), else null
 };
 enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_NMID = 6, CNT_MCURSOR = 7, CNT_WORDS = 8 };

@@ -445,7 +445,7 @@ constexpr int SWEEP_GROUP = MM2GB_SWEEP_GROUP;
 #define MM2GB_PAIR_SWEEP_GROUP 2
 #endif
 constexpr int PAIR_SWEEP_GROUP = MM2GB_PAIR_SWEEP_GROUP;   // sources per unrolled group of the two-tile sweep
-constexpr int LUT_REJECT = 1 << 30;     // in the x128 score domain of the LUT sweep: 128*(f+16) < 2^30 is guaranteed there (FLAG_NO_LUT)
+// in the x128 score domain of the LUT sweep 128*(f+16) < 2^30 is guaranteed (FLAG_NO_LUT); LUT_BIAS (chain_dev.h) lies above that
 
 __device__ __forceinline__ float log2_fit(float v)   // mmpriv.h:118-126
 {
@@ -468,8 +468,10 @@ __device__ __forceinline__ int gap_penalty(int dd, int dg, const DevParams &P)
 __global__ void k_build_lut(int *lut, DevParams P)
 {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k > P.lut_last) return;
-	lut[k] = -(k > P.bw ? LUT_REJECT : 128 * gap_penalty(k, 0, P));     // NEGATED, so that users add it; skip == 0 here: the dg term is +0.0f
+	if (k >= LUT_ENTRIES) return;
+	// LUT_BIAS - 128 * penalty, so that users ADD it to a score term that was lowered by LUT_BIAS; 0 rejects: what is left is then
+	// LUT_BIAS below anything a pair can score.  (skip == 0 here: the dg term is +0.0f)
+	lut[k] = k > P.bw || k > P.lut_last ? 0 : LUT_BIAS - 128 * gap_penalty(k, 0, P);
 }
 
 __device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
@@ -491,7 +493,7 @@ __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int
 		// accepted pairs have dr >= 0 (same strand|rid, sorted by x) and dq >= 1, so the unsigned |dr-dq| is dd
 		const unsigned dd = abs_diff_u32(dr, dq);
 		const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-		sc_out = sc + (lut[idx] >> 7);          // the table stores -128*penalty for the block sweep
+		sc_out = sc + ((lut[idx] - LUT_BIAS) >> 7);   // the table stores LUT_BIAS - 128*penalty for the block sweep, 0 = reject
 		return (unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0;
 	}
 	const int ddiff = (int)((unsigned)dr - (unsigned)dq);
@@ -591,8 +593,8 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 		for (int u = 0; u < G; ++u) {
 			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
 			const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]);
-			// the table sits at LDS address 0 (k_score checks): the byte offset IS the address, no base to add
-			pen[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (dd4 < last4 ? dd4 : last4) : dd4);
+			// the table sits at the compile-time LDS address LUT_LDS_BASE (k_score checks): it goes into the gather's offset field
+			pen[u] = *(lds_i32_ptr)(uintptr_t)((CLAMP ? (dd4 < last4 ? dd4 : last4) : dd4) + LUT_LDS_BASE);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -639,11 +641,15 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 }
 
 // MODE_LUT: a block's 64 sources go to this wave's LDS scratch once ...
-__device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
+struct BlockX { int first, last; };       // reference positions of a block's first and last source (sources are sorted by position)
+__device__ __forceinline__ BlockX stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
 {
 	const int k = lane_id(), js = jb + k;
-	stage[k] = make_int4(((sf + 1) << 7) + k + 1, (sq - 1) * 4, (int)((unsigned)b.x[js] << 2), (int)((unsigned)b.y[js] << 2));
+	const int xs = b.x[js];
+	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS, (sq - 1) * 4, (int)((unsigned)xs << 2), (int)((unsigned)b.y[js] << 2));
 	__builtin_amdgcn_wave_barrier();                        // LDS is in-order per wave; keep the compiler from reordering
+	BlockX r; r.first = first_lane(xs); r.last = bcast(xs, WAVE - 1);
+	return r;
 }
 // ... and are swept against one tile ...
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
@@ -681,8 +687,8 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
 			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
 			const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
-			pa[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (da < last4 ? da : last4) : da);
-			pb[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (db < last4 ? db : last4) : db);
+			pa[u] = *(lds_i32_ptr)(uintptr_t)((CLAMP ? (da < last4 ? da : last4) : da) + LUT_LDS_BASE);
+			pb[u] = *(lds_i32_ptr)(uintptr_t)((CLAMP ? (db < last4 ? db : last4) : db) + LUT_LDS_BASE);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -700,13 +706,50 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 		}
 	}
 }
-__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, const int4 *stage, const DevParams &P,
+// The same without any range test, for blocks in which every (source, target) pair has  bw < dr  and  dr + bw <= dq_lim  (most of a
+// window: with the defaults, the sources 500 .. 4 500 bases left of the targets).  There the penalty table alone rejects what the
+// range test would: dq <= 0 means dd = dr - dq >= dr > bw, and dq > dq_lim means dd = dq - dr > dq_lim - dr >= bw -- either way an index
+// beyond bw, which reads 0 = "reject" from the table or, beyond the table, from beyond the workgroup's LDS allocation (out-of-range
+// LDS reads return 0; the table ends where the allocation ends).  No v_cmpx, no exec juggling, and two sources share one v_max3:
+// 6.5 vector instructions per pair instead of 8.  Unclamped table only.
+__device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, int &bva, int &bvb)
+{
+	constexpr int G = 2;
+	for (int kg = 0; kg < WAVE; kg += G) {
+		int4 s4[G];
+		int dqa[G], dra[G], pa[G], dqb[G], drb[G], pb[G], va[G], vb[G];
+#pragma unroll
+		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
+			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
+			const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
+			pa[u] = *(lds_i32_ptr)(uintptr_t)(da + LUT_LDS_BASE);
+			pb[u] = *(lds_i32_ptr)(uintptr_t)(db + LUT_LDS_BASE);
+		}
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			const int ga = dra[u] < dqa[u] ? dra[u] : dqa[u], gb = drb[u] < dqb[u] ? drb[u] : dqb[u];
+			va[u] = ((s4[u].y < ga ? s4[u].y : ga) << 5) + s4[u].x;
+			asm("" : "+v"(va[u]));
+			va[u] += pa[u];
+			vb[u] = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x;
+			asm("" : "+v"(vb[u]));
+			vb[u] += pb[u];
+		}
+		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bva) : "v"(va[0]), "v"(va[1]));
+		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bvb) : "v"(vb[0]), "v"(vb[1]));
+	}
+}
+__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, bool free_block, const int4 *stage, const DevParams &P,
                                                   int &best_a, int &arg_a, int &best_b, int &arg_b)
 {
 	const int txa = (int)(((unsigned)TA.x - 1u) << 2), tya = (int)(((unsigned)TA.y - 1u) << 2);
 	const int txb = (int)(((unsigned)TB.x - 1u) << 2), tyb = (int)(((unsigned)TB.y - 1u) << 2);
 	int bva = best_a << 7, bvb = best_b << 7;
-	if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
+	if (free_block) sweep_block_lut2_free(txa, tya, txb, tyb, stage, bva, bvb);
+	else if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	else sweep_block_lut2<false>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	const int wa = bva & 127, wb = bvb & 127;
 	arg_a = wa ? jb + wa - 1 : arg_a; best_a = bva >> 7;
@@ -720,7 +763,7 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		stage_block_lut(b, jb, sf, sq, stage);
+		(void)stage_block_lut(b, jb, sf, sq, stage);
 		const TileXY xy = { T.x, T.y, T.st };
 		sweep_staged_lut(xy, jb, k_from, no_check, stage, P, best, arg);
 		__builtin_amdgcn_wave_barrier();
@@ -778,10 +821,10 @@ __device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
 	const int4 s4 = tl.stage[t];
 	const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
 	const unsigned dd4 = abs_diff_u32(drm, dqm);
-	const int pen = *(lds_i32_ptr)(uintptr_t)(dd4 < tl.last4 ? dd4 : tl.last4);   // always clamped here: one code path, one instruction more
+	const int pen = *(lds_i32_ptr)(uintptr_t)((dd4 < tl.last4 ? dd4 : tl.last4) + LUT_LDS_BASE);   // always clamped here: one code path, one instruction more
 	const int dg = drm < dqm ? drm : dqm;
 	StepPre pre;
-	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) + pen;          // one shift-add: the table holds negated penalties
+	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) + pen;          // one shift-add: the table holds LUT_BIAS - 128*penalty
 	const unsigned long long above = t < WAVE - 1 ? ~0ull << (t + 1) : 0ull;
 	pre.ok = __ballot((unsigned)dqm < tl.lim4) & above;
 	if (tl.edges) pre.ok &= __ballot(drm != -4) & __ballot(tl.lo <= t);   // wave-uniform: most tiles of wide-window chunks skip both
@@ -790,7 +833,7 @@ __device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
 
 __device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, int &bestv)
 {
-	const int fx = (s_bv | 127) + t + 2;                    // 128(f_t + 1) + (t + 1), scalar
+	const int fx = (s_bv | 127) + (t + 2 - LUT_BIAS);       // 128(f_t + 1) + (t + 1) - LUT_BIAS, scalar
 	const int v = pre.basev + fx;
 	// one select under the combined mask (making the mask the execution mask of a v_max instead measured slower here: the
 	// scalar write of exec sits in the dependent chain)
@@ -868,7 +911,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			const int dg = dr < dq ? dr : dq;
 			const unsigned dd = abs_diff_u32(dr, dq);
 			const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-			const int sc = (span < dg ? span : dg) + (*(lds_i32_ptr)(uintptr_t)(idx << 2) >> 7);
+			const int sc = (span < dg ? span : dg) + ((*(lds_i32_ptr)(uintptr_t)((idx << 2) + LUT_LDS_BASE) - LUT_BIAS) >> 7);
 			extra = __ballot((unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && keep0 < T.st - 1);
 			extra_v = (sc + keep.f) << 7;
 		}
@@ -1062,6 +1105,7 @@ struct TilePair {
 	TileXY A, B;
 	int n_a, n_b;            // live anchors (n_b = 0: the chunk ends within A)
 	int lo_a, hi_a, lo_b, hi_b;   // smallest / largest window start of each tile
+	int x_first, x_last;          // reference position of the pair's first and last live anchor
 	int best_a, arg_a, best_b, arg_b;
 };
 
@@ -1086,17 +1130,20 @@ __device__ __forceinline__ TilePair load_pair(const DevBatch &b, int i0, int ce)
 	t.B = load_xy(b, t.n_b ? i0 + WAVE : i0, ce, t.best_b);
 	t.lo_a = first_lane(t.A.st); t.hi_a = bcast(t.A.st, t.n_a - 1);
 	t.lo_b = t.n_b ? first_lane(t.B.st) : INT_MAX; t.hi_b = t.n_b ? bcast(t.B.st, t.n_b - 1) : INT_MAX;
+	t.x_first = first_lane(t.A.x); t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : bcast(t.A.x, t.n_a - 1);   // (dead lanes repeat the last live one)
 	t.arg_a = -1; t.arg_b = -1;
 	return t;
 }
 
 // one staged block of sources before tile A against the pair
-__device__ __forceinline__ void sweep_pair_block(TilePair &t, int jb, int eq_lo, const int4 *stage, const DevParams &P)
+__device__ __forceinline__ void sweep_pair_block(TilePair &t, int jb, int eq_lo, const BlockX &bx, const int4 *stage, const DevParams &P)
 {
 	const bool nc_a = jb >= t.hi_a && jb + WAVE <= eq_lo;
 	const bool use_b = t.n_b > 0 && jb + WAVE > t.lo_b;                      // the block reaches into B's windows
 	const bool nc_b = use_b && jb >= t.hi_b && jb + WAVE <= eq_lo;           // (sources left of A are left of B, or share A's first x)
-	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
+	// every pair of this block has bw < dr and dr + bw <= dq_lim: the table rejects by itself (sweep_block_lut2_free)
+	const bool free_block = P.free_sweep && t.x_first - bx.last > P.bw && t.x_last - bx.first <= P.dq_lim - P.bw;
+	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
 		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, stage, P, t.best_a, t.arg_a);
 		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, stage, P, t.best_b, t.arg_b);
@@ -1108,7 +1155,7 @@ __device__ __forceinline__ void sweep_pair_block(TilePair &t, int jb, int eq_lo,
 __device__ __forceinline__ void sweep_a_into_b(const DevBatch &b, TilePair &t, int cs, int i0, int f_a, int q_a, int4 *stage, const DevParams &P)
 {
 	if (i0 + WAVE <= t.lo_b) return;                                           // no window of B reaches into A
-	stage_block_lut(b, i0, f_a, q_a, stage);
+	(void)stage_block_lut(b, i0, f_a, q_a, stage);
 	const int eq_lo = equal_x_run_start(b, cs, i0 + WAVE, first_lane(t.B.x));
 	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, i0 >= t.hi_b && i0 + WAVE <= eq_lo, stage, P, t.best_b, t.arg_b);
 	__builtin_amdgcn_wave_barrier();
@@ -1130,8 +1177,8 @@ __device__ __forceinline__ void run_chunk_pairs(const DevBatch &b, const DevPara
 				// next block's scores are requested before this block is consumed
 				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
 				const int nf = b.f[jn], nq = b.tag[jn] & 0xff;
-				stage_block_lut(b, jb, sf, sq, stage);
-				sweep_pair_block(t, jb, eq_lo, stage, P);
+				const BlockX bx = stage_block_lut(b, jb, sf, sq, stage);
+				sweep_pair_block(t, jb, eq_lo, bx, stage, P);
 				sf = nf; sq = nq;
 			}
 		}
@@ -1256,8 +1303,8 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 			wait_done((jb - cs) / WAVE + 1);                       // that tile's scores are in the ring
 			const int sf = ring[slot * WAVE + lane];
 			slot = slot + 1 == n_slots ? 0 : slot + 1;
-			stage_block_lut(b, jb, sf, sq, stage);
-			sweep_pair_block(t, jb, eq_lo, stage, P);
+			const BlockX bx = stage_block_lut(b, jb, sf, sq, stage);
+			sweep_pair_block(t, jb, eq_lo, bx, stage, P);
 		}
 		const int slot_a = (int)((unsigned)ta % (unsigned)n_slots), slot_b = slot_a + 1 == n_slots ? 0 : slot_a + 1;
 		wait_done(ta);                                               // every earlier tile is final
@@ -1337,7 +1384,8 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 // chunks on its own.  All lists most expensive first; a team enters the next phase as soon as its list is empty.
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_window).
-// LDS layout (dynamic): [ lut : lut_last+1 ints ][ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 7 ]
+// LDS layout (dynamic): [ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 7 ] and, MODE_LUT only, the penalty
+// table from LUT_LDS_BASE to the end of the allocation, LUT_LDS_TOTAL (chain_dev.h)
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE>
@@ -1347,14 +1395,15 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	const unsigned fl = b.flags[0];
 	const int mode = (fl & FLAG_ANY_SEGID) ? MODE_GENERAL : (host_mode == MODE_LUT && (fl & FLAG_NO_LUT)) ? MODE_FAST : host_mode;
 	if (mode != MODE) return;
-	int *lut = smem;
-	// the table sweep addresses the penalty table by raw LDS offset: it must be the first thing in LDS
-	if (MODE == MODE_LUT && (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)smem != 0u) __builtin_trap();
-	const int lut_words = MODE == MODE_LUT ? ((P.lut_last + 1 + 3) & ~3) : 0;
-	int *ring = smem + lut_words;
+	int *lut = smem + LUT_LDS_BASE / 4;
+	// the table sweep addresses the penalty table by raw LDS offset: the dynamic allocation must start at LDS address 0, and what
+	// comes before the table must end before it
+	if (MODE == MODE_LUT && ((unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)smem != 0u ||
+	                         (size_t)ring_slots * WAVE * 4 + SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) > (size_t)LUT_LDS_BASE)) __builtin_trap();
+	int *ring = smem;
 	int4 *stage = (int4*)(ring + ring_slots * WAVE) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
 	CoopShared *teams = (CoopShared*)((int4*)(ring + ring_slots * WAVE) + SCORE_THREADS);   // N_SMALL_TEAMS of them
-	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];
+	if (MODE == MODE_LUT) for (int k = threadIdx.x; k < LUT_ENTRIES; k += SCORE_THREADS) lut[k] = b.lut[k];   // zeros (= reject) from lut_last + 1 on
 	if (threadIdx.x < N_TEAM_RECORDS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
 	__syncthreads();
 
@@ -1431,13 +1480,14 @@ void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s)
 
 void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_build_lut, dim3((P.lut_last + 256) / 256), dim3(256), 0, s, d_lut, P);
+	hipLaunchKernelGGL(k_build_lut, dim3((LUT_ENTRIES + 255) / 256), dim3(256), 0, s, d_lut, P);
 }
 
 size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots)
 {
-	const size_t lut_words = host_mode == MODE_LUT ? (size_t)((P.lut_last + 1 + 3) & ~3) : 0;
-	return (lut_words + (size_t)ring_slots * WAVE) * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) + 16;
+	const size_t front = (size_t)ring_slots * WAVE * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) + 16;
+	if (host_mode != MODE_LUT) return front;
+	return front <= (size_t)LUT_LDS_BASE ? (size_t)LUT_LDS_TOTAL : (size_t)1 << 30;     // the table's place is fixed: what does not fit before it does not fit
 }
 
 int score_set_lds_limit(size_t bytes)

@@ -77,7 +77,7 @@ static DevParams make_params(const mm2gb_misc_t &m)
 	if (P.max_dist_y < P.bw && !m.is_cdna) P.max_dist_y = P.bw;        // lchain.c:161
 	P.max_iter = m.max_iter; P.n_seg = m.n_seg; P.is_cdna = m.is_cdna;
 	P.dq_lim = std::min(P.max_dist_x, P.max_dist_y);
-	P.lut_last = P.bw + 1; P.lut_clamp = 1;
+	P.lut_last = P.bw + 1; P.lut_clamp = 1; P.free_sweep = 0;
 	P.gap = m.chn_pen_gap; P.skip = m.chn_pen_skip;
 	return P;
 }
@@ -99,14 +99,14 @@ int Engine::configure_score()
 {
 	MM2GB_HIP(hipSetDevice(device));                    // kernel attributes and the table build below belong to this engine's device
 	const bool single = !params.is_cdna && params.n_seg == 1;
-	constexpr int LUT_MAX = 8192;                       // entries; bw above this falls back to per-pair arithmetic
+	constexpr int LUT_MAX = LUT_ENTRIES;                // entries (chain_dev.h: the table's place in LDS is fixed); bw above this falls back to per-pair arithmetic
 	constexpr int LUT_MAX_DIST = 1 << 28;
 	if (!single) launch.host_mode = SCORE_MODE_GENERAL;
 	// the table sweep keeps coordinates x4 (and compares (unsigned)dq_lim << 2): exact only while every distance a pair can pass
 	// the range tests with stays below 2^28; a larger max_dist (user -g / -r) runs the per-pair build
 	else if (params.skip == 0.0f && params.lut_last + 1 <= LUT_MAX && params.max_dist_x < LUT_MAX_DIST && params.max_dist_y < LUT_MAX_DIST) launch.host_mode = SCORE_MODE_LUT;
 	else launch.host_mode = SCORE_MODE_FAST;
-	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS)
+	constexpr size_t LDS_BUDGET = 80 * 1024 - 256;      // two 1024-thread workgroups per CU (160 KB LDS); MODE_LUT takes LUT_LDS_TOTAL
 	// Team modes: a team's share of the LDS ring holds the scores of the most recent tiles of its chunk and must cover the
 	// chunk's widest predecessor window plus the tile being written (64 scores per slot).  The ring takes whatever the
 	// LDS budget of two workgroups per CU leaves; the planner sends a chunk to a team only if its widest window fits
@@ -121,15 +121,16 @@ int Engine::configure_score()
 		while (slots > 0 && score_lds_bytes(prm, launch.host_mode, (int)slots) > LDS_BUDGET) slots -= 4;   // four small teams share it evenly
 		return slots;
 	};
-	// Penalty table: bw+2 entries with a clamped index, or -- one instruction less per pair -- max_dist_x+1 entries and no
-	// clamp, if that still leaves a big team room for windows of max_iter.
-	params.lut_last = params.bw + 1; params.lut_clamp = 1;
-	if (launch.host_mode == SCORE_MODE_LUT && !getenv("MM2GB_LUT_CLAMP")) {
-		DevParams wide = params;
-		wide.lut_last = std::max(params.max_dist_x, params.bw + 1); wide.lut_clamp = 0;
-		const int64_t want_big = ((int64_t)std::min(params.max_iter, 1 << 20) + 63) / 64 + 1;
-		if (fit_slots(wide) / n_big >= std::min<int64_t>(want_big, fit_slots(params) / n_big)) params = wide;
+	// Penalty table (LUT_ENTRIES entries at the end of LDS, chain_dev.h): bw+2 entries used with a clamped index, or -- one
+	// instruction less per pair -- max_dist_x+1 entries and no clamp when they fit.  Without the clamp, source blocks far enough
+	// inside a window are swept without any range test (MM2GB_FREE_SWEEP=0 turns that off, for A/B runs).
+	params.lut_last = params.bw + 1; params.lut_clamp = 1; params.free_sweep = 0;
+	if (launch.host_mode == SCORE_MODE_LUT && !getenv("MM2GB_LUT_CLAMP") && std::max(params.max_dist_x, params.bw + 1) + 1 <= LUT_ENTRIES) {
+		params.lut_last = std::max(params.max_dist_x, params.bw + 1); params.lut_clamp = 0;
+		const char *v = getenv("MM2GB_FREE_SWEEP");
+		params.free_sweep = !(v && atoi(v) == 0) && params.dq_lim > 2 * params.bw;
 	}
+	(void)n_big;
 	int64_t slots = fit_slots(params);
 	if (slots < 8) slots = 0;                                        // less than two tiles of window per small team: not worth it
 	launch.ring_slots = coop_disabled ? 0 : (int)slots;
@@ -140,7 +141,7 @@ int Engine::configure_score()
 		// the table is shared by both compute streams: nothing that reads the old one may be in flight, and the new one must be
 		// complete before either stream launches again (parameters change between runs, not between batches)
 		for (WorkSet &w : work) MM2GB_HIP(hipStreamSynchronize(w.stream));
-		if (lut.ensure((size_t)(params.lut_last + 1) * 4)) return -1;
+		if (lut.ensure((size_t)LUT_ENTRIES * 4)) return -1;
 		launch_build_lut((int*)lut.ptr, params, stream);
 		MM2GB_HIP(hipGetLastError());
 		MM2GB_HIP(hipStreamSynchronize(stream));

@@ -381,7 +381,8 @@ mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int m
 	// csrc/rmq_host.cpp); the kernel scans the window at every step and is for batches of reads with narrow windows (MM2GB_RMQ=gpu forces it).
 	static const bool on_device = [] { const char *v = getenv("MM2GB_RMQ"); return v && strcmp(v, "gpu") == 0; }();
 	if (!on_device) {
-		if (mm2gb_rmq_chain_host(&prm, 1, off, a, 1, &out, &tied)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
+		// exact for every read: a read that meets a tie is done again with the reference's tree inside the call, nothing goes back to the host
+		if (mm2gb_rmq_chain_host(&prm, 1, off, a, 1, &out, nullptr)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
 	} else {
 		mm2gb_misc_t misc = {};                                               // the engine wants one; the re-chaining call carries its own thresholds
 		misc.max_iter = 5000; misc.max_dist_x = max_dist; misc.max_dist_y = max_dist; misc.max_skip = max_chn_skip; misc.bw = std::min(bw, 8000);

@@ -20,7 +20,7 @@ with tempfile.TemporaryDirectory() as td:
         t0 = time.perf_counter()
         ix = mm.SeedIndex([s for _, s in refs], threads=16)
         t_index = time.perf_counter() - t0
-        opt = mm.map_opt(host_threads=16)
+        opt = mm.map_opt(host_threads=16, rechain_on_device=int(os.environ.get("MAPPER_RATE_RECHAIN_DEVICE", "0")))
         mm.map_reads(e, ix, [n for n, _ in refs], rd[:8], opt=opt)              # warm-up: arenas, first kernel launches
         best = 1e9
         for rep in range(3):
@@ -29,7 +29,7 @@ with tempfile.TemporaryDirectory() as td:
             best = min(best, time.perf_counter() - t0)
         ix.close()
     out = {"reads": n_reads, "seed": seed, "read_len": [len_lo, len_hi], "bases": bases, "index_seconds": round(t_index, 3), "map_seconds": round(best, 4), "gbp_per_s_mapping": bases / best / 1e9,
-           "gbp_per_s_with_index": bases / (best + t_index) / 1e9, "paf_lines": paf.count("\n"), "stats": st, "host_threads": 16}
+           "gbp_per_s_with_index": bases / (best + t_index) / 1e9, "paf_lines": paf.count("\n"), "stats": st, "host_threads": 16, "rechain_on_device": int(os.environ.get("MAPPER_RATE_RECHAIN_DEVICE", "0"))}
     host = os.path.join(ROOT, "oracle", "_ref", "minimap2_cpu")
     if os.path.exists(host) and not os.environ.get("MAPPER_RATE_NO_REF"):
         t0 = time.perf_counter()
