@@ -481,6 +481,19 @@ __device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
 	return r;
 }
 
+// LDS address of the penalty table's entry for a pair, unclamped sweeps: LUT_LDS_BASE + |a - b| with a, b taken as UNSIGNED and the sum
+// saturating at 2^32 - 1 (integer clamp).  For dq >= 1 (b >= 0) that is the entry of dd = |dr - dq|, or an address beyond the table =
+// beyond the workgroup's LDS, which reads 0 = "reject".  For dq <= 0, b is "huge": |a - b| = 2^32 - (dr - dq)*4, and with the base added
+// the sum would wrap around into LDS again -- the clamp keeps it at the top of the address space, beyond LDS: such a pair reads 0 too,
+// and lanes that read beyond LDS cost the pipe no bank cycles (why the table at the END of LDS, with the address formed here rather than
+// in the gather's offset field: with the base in the offset field the wrapped addresses fell on the ring and scratch, 4 ms per 500 M anchors).
+__device__ __forceinline__ unsigned lut_address(int a, int b)
+{
+	unsigned r;
+	asm("v_sad_u32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "s"((unsigned)LUT_LDS_BASE));
+	return r;
+}
+
 template <int MODE>
 __device__ __forceinline__ bool pair_score(int xi, int yi, int segi, int xj, int yj, int tagj, const DevParams &P, const int *lut, int &sc_out)
 {
@@ -592,9 +605,9 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
 			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
-			const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]);
-			// the table sits at the compile-time LDS address LUT_LDS_BASE (k_score checks): it goes into the gather's offset field
-			pen[u] = *(lds_i32_ptr)(uintptr_t)((CLAMP ? (dd4 < last4 ? dd4 : last4) : dd4) + LUT_LDS_BASE);
+			// the table sits at the compile-time LDS address LUT_LDS_BASE (k_score checks)
+			if (CLAMP) { const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]); pen[u] = *(lds_i32_ptr)(uintptr_t)((dd4 < last4 ? dd4 : last4) + LUT_LDS_BASE); }
+			else pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u]);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -641,15 +654,16 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 }
 
 // MODE_LUT: a block's 64 sources go to this wave's LDS scratch once ...
-struct BlockX { int first, last; };       // reference positions of a block's first and last source (sources are sorted by position)
-__device__ __forceinline__ BlockX stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
+__device__ __forceinline__ void stage_block_lut(int xs, int ys, int sf, int sq, int4 *stage)
 {
-	const int k = lane_id(), js = jb + k;
-	const int xs = b.x[js];
-	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS, (sq - 1) * 4, (int)((unsigned)xs << 2), (int)((unsigned)b.y[js] << 2));
+	const int k = lane_id();
+	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS, (sq - 1) * 4, (int)((unsigned)xs << 2), (int)((unsigned)ys << 2));
 	__builtin_amdgcn_wave_barrier();                        // LDS is in-order per wave; keep the compiler from reordering
-	BlockX r; r.first = first_lane(xs); r.last = bcast(xs, WAVE - 1);
-	return r;
+}
+__device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
+{
+	const int js = jb + lane_id();
+	stage_block_lut(b.x[js], b.y[js], sf, sq, stage);
 }
 // ... and are swept against one tile ...
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
@@ -686,9 +700,14 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 		for (int u = 0; u < G; ++u) {
 			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
 			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
-			const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
-			pa[u] = *(lds_i32_ptr)(uintptr_t)((CLAMP ? (da < last4 ? da : last4) : da) + LUT_LDS_BASE);
-			pb[u] = *(lds_i32_ptr)(uintptr_t)((CLAMP ? (db < last4 ? db : last4) : db) + LUT_LDS_BASE);
+			if (CLAMP) {
+				const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
+				pa[u] = *(lds_i32_ptr)(uintptr_t)((da < last4 ? da : last4) + LUT_LDS_BASE);
+				pb[u] = *(lds_i32_ptr)(uintptr_t)((db < last4 ? db : last4) + LUT_LDS_BASE);
+			} else {
+				pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u]);
+				pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u]);
+			}
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -710,8 +729,8 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 // window: with the defaults, the sources 500 .. 4 500 bases left of the targets).  There the penalty table alone rejects what the
 // range test would: dq <= 0 means dd = dr - dq >= dr > bw, and dq > dq_lim means dd = dq - dr > dq_lim - dr >= bw -- either way an index
 // beyond bw, which reads 0 = "reject" from the table or, beyond the table, from beyond the workgroup's LDS allocation (out-of-range
-// LDS reads return 0; the table ends where the allocation ends).  No v_cmpx, no exec juggling, and two sources share one v_max3:
-// 6.5 vector instructions per pair instead of 8.  Unclamped table only.
+// LDS reads return 0, profiles/ubench/lds_oob.hip; the table ends where the allocation ends; lut_address for dq <= 0).  No v_cmpx, no
+// exec juggling, and two sources share one v_max3: 6.5 vector instructions per pair instead of 8.  Unclamped table only.
 __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, int &bva, int &bvb)
 {
 	constexpr int G = 2;
@@ -724,9 +743,8 @@ __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb,
 		for (int u = 0; u < G; ++u) {
 			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
 			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
-			const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
-			pa[u] = *(lds_i32_ptr)(uintptr_t)(da + LUT_LDS_BASE);
-			pb[u] = *(lds_i32_ptr)(uintptr_t)(db + LUT_LDS_BASE);
+			pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u]);
+			pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u]);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -751,9 +769,11 @@ __device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY
 	if (free_block) sweep_block_lut2_free(txa, tya, txb, tyb, stage, bva, bvb);
 	else if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	else sweep_block_lut2<false>(txa, tya, txb, tyb, stage, P, bva, bvb);
+	// (k+1 of the winner is 1..64 for any input the caller's contract allows; anchors that are not sorted by position can make the
+	// unchecked sweep read outside the table, and whatever comes back must not become an index outside the block)
 	const int wa = bva & 127, wb = bvb & 127;
-	arg_a = wa ? jb + wa - 1 : arg_a; best_a = bva >> 7;
-	arg_b = wb ? jb + wb - 1 : arg_b; best_b = bvb >> 7;
+	arg_a = (unsigned)(wa - 1) < (unsigned)WAVE ? jb + wa - 1 : arg_a; best_a = bva >> 7;
+	arg_b = (unsigned)(wb - 1) < (unsigned)WAVE ? jb + wb - 1 : arg_b; best_b = bvb >> 7;
 }
 
 // Sweep of one full source block for either build.  `stage` is this wave's 64-entry LDS scratch (MODE_LUT only).
@@ -763,7 +783,7 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		(void)stage_block_lut(b, jb, sf, sq, stage);
+		stage_block_lut(b, jb, sf, sq, stage);
 		const TileXY xy = { T.x, T.y, T.st };
 		sweep_staged_lut(xy, jb, k_from, no_check, stage, P, best, arg);
 		__builtin_amdgcn_wave_barrier();
@@ -1135,14 +1155,17 @@ __device__ __forceinline__ TilePair load_pair(const DevBatch &b, int i0, int ce)
 	return t;
 }
 
-// one staged block of sources before tile A against the pair
-__device__ __forceinline__ void sweep_pair_block(TilePair &t, int jb, int eq_lo, const BlockX &bx, const int4 *stage, const DevParams &P)
+// one block of sources before tile A (scores sf, spans sq, one per lane): staged, then swept against the pair
+__device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t, int jb, int eq_lo, int sf, int sq, int4 *stage, const DevParams &P)
 {
 	const bool nc_a = jb >= t.hi_a && jb + WAVE <= eq_lo;
 	const bool use_b = t.n_b > 0 && jb + WAVE > t.lo_b;                      // the block reaches into B's windows
 	const bool nc_b = use_b && jb >= t.hi_b && jb + WAVE <= eq_lo;           // (sources left of A are left of B, or share A's first x)
-	// every pair of this block has bw < dr and dr + bw <= dq_lim: the table rejects by itself (sweep_block_lut2_free)
-	const bool free_block = P.free_sweep && t.x_first - bx.last > P.bw && t.x_last - bx.first <= P.dq_lim - P.bw;
+	const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
+	// every pair of this block has bw < dr and dr + bw <= dq_lim (sources are sorted by position: the block's last and first source
+	// give the smallest and the largest dr): the table rejects by itself (sweep_block_lut2_free)
+	const bool free_block = P.free_sweep && nc_a && nc_b && t.x_first - bcast(xs, WAVE - 1) > P.bw && t.x_last - first_lane(xs) <= P.dq_lim - P.bw;
+	stage_block_lut(xs, ys, sf, sq, stage);
 	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
 		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, stage, P, t.best_a, t.arg_a);
@@ -1155,7 +1178,7 @@ __device__ __forceinline__ void sweep_pair_block(TilePair &t, int jb, int eq_lo,
 __device__ __forceinline__ void sweep_a_into_b(const DevBatch &b, TilePair &t, int cs, int i0, int f_a, int q_a, int4 *stage, const DevParams &P)
 {
 	if (i0 + WAVE <= t.lo_b) return;                                           // no window of B reaches into A
-	(void)stage_block_lut(b, i0, f_a, q_a, stage);
+	stage_block_lut(b, i0, f_a, q_a, stage);
 	const int eq_lo = equal_x_run_start(b, cs, i0 + WAVE, first_lane(t.B.x));
 	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, i0 >= t.hi_b && i0 + WAVE <= eq_lo, stage, P, t.best_b, t.arg_b);
 	__builtin_amdgcn_wave_barrier();
@@ -1177,8 +1200,7 @@ __device__ __forceinline__ void run_chunk_pairs(const DevBatch &b, const DevPara
 				// next block's scores are requested before this block is consumed
 				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
 				const int nf = b.f[jn], nq = b.tag[jn] & 0xff;
-				const BlockX bx = stage_block_lut(b, jb, sf, sq, stage);
-				sweep_pair_block(t, jb, eq_lo, bx, stage, P);
+				sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
 				sf = nf; sq = nq;
 			}
 		}
@@ -1303,8 +1325,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 			wait_done((jb - cs) / WAVE + 1);                       // that tile's scores are in the ring
 			const int sf = ring[slot * WAVE + lane];
 			slot = slot + 1 == n_slots ? 0 : slot + 1;
-			const BlockX bx = stage_block_lut(b, jb, sf, sq, stage);
-			sweep_pair_block(t, jb, eq_lo, bx, stage, P);
+			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
 		}
 		const int slot_a = (int)((unsigned)ta % (unsigned)n_slots), slot_b = slot_a + 1 == n_slots ? 0 : slot_a + 1;
 		wait_done(ta);                                               // every earlier tile is final
