@@ -667,12 +667,38 @@ __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int s
 }
 // ... and are swept against one tile ...
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
-__device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, const int4 *stage, const DevParams &P,
+// one tile, a whole block, no test at all: sweep_block_lut2_free (below) explains when and why
+__device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int4 *stage, int &bestv)
+{
+	constexpr int G = 4;
+	for (int kg = 0; kg < WAVE; kg += G) {
+		int4 s4[G];
+		int dqm[G], drm[G], pen[G], v[G];
+#pragma unroll
+		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
+			pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
+			v[u] = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x;
+			asm("" : "+v"(v[u]));
+			v[u] += pen[u];
+		}
+		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bestv) : "v"(v[0]), "v"(v[1]));
+		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bestv) : "v"(v[2]), "v"(v[3]));
+	}
+}
+__device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, bool free_block, const int4 *stage, const DevParams &P,
                                                  int &best, int &arg)
 {
 	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
 	int bestv = best << 7;
-	if (P.lut_clamp) {
+	if (free_block) sweep_block_lut_free(tx4, ty4, stage, bestv);
+	else if (P.lut_clamp) {
 		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 	} else {
@@ -680,7 +706,7 @@ __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_
 		else sweep_block_lut<true, false>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 	}
 	const int won = bestv & 127;                            // k+1 of the source that holds the best, 0 = none of this block
-	arg = won ? jb + won - 1 : arg;
+	arg = (unsigned)(won - 1) < (unsigned)WAVE ? jb + won - 1 : arg;   // (1..64 by construction; see sweep_staged_lut2 for the test)
 	best = bestv >> 7;
 }
 // ... or against two tiles at once: one LDS broadcast read per source serves 128 targets (the LDS pipe, one per CU, is as
@@ -725,12 +751,12 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 		}
 	}
 }
-// The same without any range test, for blocks in which every (source, target) pair has  bw < dr  and  dr + bw <= dq_lim  (most of a
-// window: with the defaults, the sources 500 .. 4 500 bases left of the targets).  There the penalty table alone rejects what the
-// range test would: dq <= 0 means dd = dr - dq >= dr > bw, and dq > dq_lim means dd = dq - dr > dq_lim - dr >= bw -- either way an index
-// beyond bw, which reads 0 = "reject" from the table or, beyond the table, from beyond the workgroup's LDS allocation (out-of-range
-// LDS reads return 0, profiles/ubench/lds_oob.hip; the table ends where the allocation ends; lut_address for dq <= 0).  No v_cmpx, no
-// exec juggling, and two sources share one v_max3: 6.5 vector instructions per pair instead of 8.  Unclamped table only.
+// The same without any range test, for blocks in which every (source, target) pair has  dr + bw <= dq_lim  (most of a window: with the
+// defaults, all sources but those more than 4 500 bases left of the targets).  There the gather alone rejects what the range test
+// would: dq > dq_lim means dd = dq - dr > dq_lim - dr >= bw, an index beyond bw, which reads 0 = "reject" from the table or, beyond the
+// table, from beyond the workgroup's LDS allocation (out-of-range LDS reads return 0, profiles/ubench/lds_oob.hip; the table ends where
+// the allocation ends); and dq <= 0 makes lut_address saturate, which reads 0 as well.  No v_cmpx, no exec juggling, and two sources
+// share one v_max3: 6.5 vector instructions per pair instead of 8.  Unclamped table only; dr >= 1 is the caller's (no_check blocks).
 __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, int &bva, int &bvb)
 {
 	constexpr int G = 2;
@@ -783,9 +809,12 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		stage_block_lut(b, jb, sf, sq, stage);
+		const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
+		stage_block_lut(xs, ys, sf, sq, stage);
 		const TileXY xy = { T.x, T.y, T.st };
-		sweep_staged_lut(xy, jb, k_from, no_check, stage, P, best, arg);
+		// (dead lanes of a tile repeat its last live anchor; sweep_block_lut2_free for the condition)
+		const bool free_block = no_check && P.free_sweep && bcast(T.x, WAVE - 1) - first_lane(xs) <= P.dq_lim - P.bw;
+		sweep_staged_lut(xy, jb, k_from, no_check, free_block, stage, P, best, arg);
 		__builtin_amdgcn_wave_barrier();
 	} else {
 		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
@@ -1125,7 +1154,7 @@ struct TilePair {
 	TileXY A, B;
 	int n_a, n_b;            // live anchors (n_b = 0: the chunk ends within A)
 	int lo_a, hi_a, lo_b, hi_b;   // smallest / largest window start of each tile
-	int x_first, x_last;          // reference position of the pair's first and last live anchor
+	int x_last;                   // reference position of the pair's last live anchor
 	int best_a, arg_a, best_b, arg_b;
 };
 
@@ -1150,7 +1179,7 @@ __device__ __forceinline__ TilePair load_pair(const DevBatch &b, int i0, int ce)
 	t.B = load_xy(b, t.n_b ? i0 + WAVE : i0, ce, t.best_b);
 	t.lo_a = first_lane(t.A.st); t.hi_a = bcast(t.A.st, t.n_a - 1);
 	t.lo_b = t.n_b ? first_lane(t.B.st) : INT_MAX; t.hi_b = t.n_b ? bcast(t.B.st, t.n_b - 1) : INT_MAX;
-	t.x_first = first_lane(t.A.x); t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : bcast(t.A.x, t.n_a - 1);   // (dead lanes repeat the last live one)
+	t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : bcast(t.A.x, t.n_a - 1);   // (dead lanes repeat the last live one)
 	t.arg_a = -1; t.arg_b = -1;
 	return t;
 }
@@ -1162,14 +1191,14 @@ __device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t,
 	const bool use_b = t.n_b > 0 && jb + WAVE > t.lo_b;                      // the block reaches into B's windows
 	const bool nc_b = use_b && jb >= t.hi_b && jb + WAVE <= eq_lo;           // (sources left of A are left of B, or share A's first x)
 	const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
-	// every pair of this block has bw < dr and dr + bw <= dq_lim (sources are sorted by position: the block's last and first source
-	// give the smallest and the largest dr): the table rejects by itself (sweep_block_lut2_free)
-	const bool free_block = P.free_sweep && nc_a && nc_b && t.x_first - bcast(xs, WAVE - 1) > P.bw && t.x_last - first_lane(xs) <= P.dq_lim - P.bw;
+	// every pair of this block has dr + bw <= dq_lim (sources are sorted by position: the block's first source and the pair's last
+	// anchor give the largest dr): the gather rejects by itself (sweep_block_lut2_free)
+	const bool free_block = P.free_sweep && t.x_last - first_lane(xs) <= P.dq_lim - P.bw;
 	stage_block_lut(xs, ys, sf, sq, stage);
 	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
-		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, stage, P, t.best_a, t.arg_a);
-		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, stage, P, t.best_b, t.arg_b);
+		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_block, stage, P, t.best_a, t.arg_a);
+		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, nc_b && free_block, stage, P, t.best_b, t.arg_b);
 	}
 	__builtin_amdgcn_wave_barrier();
 }
@@ -1180,7 +1209,7 @@ __device__ __forceinline__ void sweep_a_into_b(const DevBatch &b, TilePair &t, i
 	if (i0 + WAVE <= t.lo_b) return;                                           // no window of B reaches into A
 	stage_block_lut(b, i0, f_a, q_a, stage);
 	const int eq_lo = equal_x_run_start(b, cs, i0 + WAVE, first_lane(t.B.x));
-	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, i0 >= t.hi_b && i0 + WAVE <= eq_lo, stage, P, t.best_b, t.arg_b);
+	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, i0 >= t.hi_b && i0 + WAVE <= eq_lo, false, stage, P, t.best_b, t.arg_b);
 	__builtin_amdgcn_wave_barrier();
 }
 
