@@ -102,6 +102,7 @@ struct Engine {
 
 	mm2gb_stats_t last = {};
 	bool misc_valid = false, coop_disabled = false, debug_phases = false, one_compute_stream = false;
+	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)
 	int64_t dual_stream_max_n = 16 * 1000 * 1000;   // micro-batches up to this many anchors alternate between the two compute streams
 
 	int  init(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);

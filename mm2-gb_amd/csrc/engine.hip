@@ -3,6 +3,7 @@
 // plchain_cal_score_async (plchain.cu:292-464) with a design that never leaves the stream between stages:
 // split -> window(+planner reductions) -> plan -> score are all enqueued back to back, no host sort, no hipMalloc per batch.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -94,6 +95,43 @@ int Engine::set_misc(const mm2gb_misc_t *m)
 	return configure_score();
 }
 
+// What the unclamped table sweeps of k_score take for granted about the hardware (chain_kernels.hip, lut_address / sweep_block_lut2_free),
+// checked on the device itself before they are used: an LDS read beyond the workgroup's allocation returns 0, the allocation of
+// LUT_LDS_TOTAL bytes ends exactly where the penalty table ends (no rounded-up tail with stale contents), and v_sad_u32 with the integer
+// clamp saturates instead of wrapping.  Every workgroup fills all of its LDS with a pattern, then reads at the addresses the sweep
+// would form for: dq <= 0 (two sizes), a distance beyond the table, the table's last entry, the first word after it.
+__global__ __launch_bounds__(1024) void k_probe_lds_contract(int *bad)
+{
+	extern __shared__ unsigned probe_lds[];
+	for (unsigned k = threadIdx.x; k < (unsigned)LUT_LDS_TOTAL / 4; k += blockDim.x) probe_lds[k] = 0x7f7f7f7fu;
+	__syncthreads();
+	if (threadIdx.x < 5) {
+		const int a[5] = { 4 * 10, 0, 4 * 100, 4 * 100, 4 * 100 };
+		const int b[5] = { -4, -4 * 20000, 4 * 6000, 4 * (100 + LUT_ENTRIES - 1), 4 * (100 + LUT_ENTRIES) };
+		unsigned addr, v;
+		asm volatile("v_sad_u32 %0, %1, %2, %3 clamp" : "=v"(addr) : "v"(a[threadIdx.x]), "v"(b[threadIdx.x]), "s"((unsigned)LUT_LDS_BASE));
+		asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+		const unsigned want = threadIdx.x == 3 ? 0x7f7f7f7fu : 0u;
+		if (v != want) atomicOr(bad, 1 << threadIdx.x);
+	}
+}
+
+static bool probe_lds_contract(int n_cu, hipStream_t s)
+{
+	int *d_bad = nullptr, bad = -1;
+	if (hipMalloc(&d_bad, sizeof(int)) != hipSuccess) return false;
+	bool ok = hipMemsetAsync(d_bad, 0, sizeof(int), s) == hipSuccess &&
+	          hipFuncSetAttribute((const void*)k_probe_lds_contract, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_LDS_TOTAL) == hipSuccess;
+	if (ok) {
+		hipLaunchKernelGGL(k_probe_lds_contract, dim3((unsigned)n_cu * 4), dim3(1024), LUT_LDS_TOTAL, s, d_bad);   // two resident per CU, twice over
+		ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+	}
+	(void)hipFree(d_bad);
+	if (ok && bad != 0) fprintf(stderr, "[mm2gb] this device does not read 0 beyond a workgroup's LDS / saturate v_sad_u32 clamp (probe mask %#x): "
+	                                    "the score kernel keeps its range tests and the clamped penalty table\n", bad);
+	return ok && bad == 0;
+}
+
 // Pick the scoring build and the LDS budget for these parameters; (re)build the penalty table on the device.
 int Engine::configure_score()
 {
@@ -125,7 +163,7 @@ int Engine::configure_score()
 	// instruction less per pair -- max_dist_x+1 entries and no clamp when they fit.  Without the clamp, source blocks far enough
 	// inside a window are swept without any range test (MM2GB_FREE_SWEEP=0 turns that off, for A/B runs).
 	params.lut_last = params.bw + 1; params.lut_clamp = 1; params.free_sweep = 0;
-	if (launch.host_mode == SCORE_MODE_LUT && !getenv("MM2GB_LUT_CLAMP") && std::max(params.max_dist_x, params.bw + 1) + 1 <= LUT_ENTRIES) {
+	if (launch.host_mode == SCORE_MODE_LUT && lds_contract_ok && !getenv("MM2GB_LUT_CLAMP") && std::max(params.max_dist_x, params.bw + 1) + 1 <= LUT_ENTRIES) {
 		params.lut_last = std::max(params.max_dist_x, params.bw + 1); params.lut_clamp = 0;
 		const char *v = getenv("MM2GB_FREE_SWEEP");
 		params.free_sweep = !(v && atoi(v) == 0) && params.dq_lim > 2 * params.bw;
@@ -193,6 +231,16 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	MM2GB_HIP(hipHostMalloc((void**)&h_counters, (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
 	MM2GB_HIP(hipHostMalloc((void**)&h_totals, (size_t)MAX_SLOTS * 2 * sizeof(int64_t), hipHostMallocDefault));
 	for (WorkSet &w : work) if (w.counters.ensure(CNT_WORDS * sizeof(int32_t)) || w.totals.ensure(4 * sizeof(int64_t)) || w.flags.ensure(4 * sizeof(unsigned))) return -1;
+	{
+		// once per device and process (MM2GB_LDS_PROBE=0: take the contract as broken, i.e. clamped table and every range test)
+		static std::mutex probe_lock;
+		static int probed[64];                               // 0 not yet, 1 holds, 2 does not
+		std::lock_guard<std::mutex> g(probe_lock);
+		const char *v = getenv("MM2GB_LDS_PROBE");
+		int &state = probed[device & 63];
+		if (v && atoi(v) == 0) lds_contract_ok = false;
+		else { if (!state) state = probe_lds_contract(n_cu, stream) ? 1 : 2; lds_contract_ok = state == 1; }
+	}
 	if (set_misc(m)) return -1;
 	return 0;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How the score kernel's tile-blocks (64 sources x 64 targets) split over its sweep builds, on the bench's synthetic reads: needs the
-instrumented library (variants/libcount.so, built from a patched chain_kernels.hip; see profiles/README.md).  Prints JSON."""
+instrumented library (variants/libcount.so = chain_kernels.hip + profiles/experiments/r02x_block_kinds_instrumentation.patch).  Prints JSON."""
 import ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["MM2GB_LIB_PATH"] = os.path.join(ROOT, "mm2-gb_amd", "variants", "libcount.so")
@@ -17,7 +17,7 @@ for name, lo, hi, n_reads in (("100-300kb", 100_000, 300_000, 1800), ("10-100kb"
         f, p, st = e.score(a, off)
         mm.lib().mm2gb_debug_block_counts(cnt, 1)
     c = list(cnt)
-    tot = c[0] + c[1] + c[2] + c[3] + c[5]
-    out[name] = {"anchors": int(len(a)), "pairs": int(st["n_pairs"]), "tile_blocks": {"pair_free": c[0], "pair_range_test": c[1], "single_no_check": c[2], "single_checked": c[3],
-                 "of_single_no_check_would_be_free": c[4], "in_tile_phases": c[5]}, "share": {k: round(v / tot, 4) for k, v in (("pair_free", c[0]), ("pair_range_test", c[1]), ("single_no_check", c[2]), ("single_checked", c[3]), ("in_tile", c[5]))}}
+    names = ("two_tiles_unchecked", "two_tiles_range_test", "one_tile_unchecked", "one_tile_range_test", "one_tile_window_tests", "in_tile_phases")
+    tot = sum(c[:6])
+    out[name] = {"anchors": int(len(a)), "pairs": int(st["n_pairs"]), "tile_blocks": dict(zip(names, c[:6])), "share": {k: round(v / tot, 4) for k, v in zip(names, c[:6])}}
 print(json.dumps(out))

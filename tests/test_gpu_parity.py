@@ -475,6 +475,57 @@ def test_config2_size_batch_properties():
         assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
 
 
+def band_cloud(n, seed, xwin, jitter, r0=3_000_000, q0=20_000):
+    """Dense cloud around one diagonal: reference positions uniform in a window, query position = the diagonal +- jitter.  Among the
+    pairs inside a window every case the range test exists for occurs in numbers: dq <= 0 with |dr - dq| <= bw (sources just left of a
+    target but above it on the query), dq > max_dist_y with dr far out, and dq > 0 with |dr - dq| beyond the penalty table."""
+    rng = np.random.default_rng(seed)
+    x = r0 + rng.integers(0, xwin, n)
+    y = q0 + (x - r0) + rng.integers(-jitter, jitter + 1, n)
+    return sc.sort_by_x(sc.pack(np.full(n, 5), np.zeros(n, np.int64), x, y))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_dist_y=3000), dict(max_dist_x=3000, max_dist_y=4500), dict(bw=2000), dict(bw=2400, max_dist_y=4900),
+                                dict(max_dist_x=1200, max_dist_y=1200, bw=100), dict(max_iter=900)],
+                         ids=["defaults", "dist_y_3000", "dist_x_3000", "bw_2000", "bw_near_half_dist", "dist_1200", "iter_900"])
+def test_unchecked_sweep_rejects_what_the_range_test_would(monkeypatch, kw):
+    """The table sweep leaves out the test 0 < dq <= min(max_dist_x, max_dist_y) for source blocks at most dq_lim - bw bases left of
+    their targets: there a gather beyond the penalty table (= beyond the workgroup's LDS, which reads 0) or a saturated table address
+    (dq <= 0) rejects the pair instead (chain_kernels.hip, sweep_block_lut2_free).  Dense clouds where such pairs abound, under
+    parameter sets that move every bound; with the unchecked build switched off (MM2GB_FREE_SWEEP=0) the results are the same."""
+    parts = [band_cloud(9000, 301, xwin=9000, jitter=700), band_cloud(7000, 302, xwin=3500, jitter=6500, r0=5_000_000),
+             band_cloud(6000, 303, xwin=12000, jitter=250, r0=7_000_000), sc.read_like(9000, 304),
+             sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 305), sc.colinear(600, 306)]))]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    prm = orc.default_param(**kw)
+    with mm.Engine() as e:
+        st = check_batch(e, a, off, prm)
+        assert st["n_long_chunks"] + st["n_mid_chunks"] >= 1          # team modes (two tiles per wave) took part
+        f1, p1, _ = e.score(a, off)
+    monkeypatch.setenv("MM2GB_FREE_SWEEP", "0")
+    with mm.Engine() as e:
+        check_batch(e, a, off, prm)
+        f0, p0, _ = e.score(a, off)
+    assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
+    monkeypatch.delenv("MM2GB_FREE_SWEEP")
+    monkeypatch.setenv("MM2GB_NO_COOP", "1")                          # every chunk by one wave
+    with mm.Engine() as e:
+        check_batch(e, a, off, prm)
+
+
+def test_without_the_lds_contract_the_checked_builds_run(monkeypatch):
+    """Engine::init probes what the unchecked sweeps rely on (reads beyond a workgroup's LDS return 0, v_sad_u32 clamp saturates).
+    MM2GB_LDS_PROBE=0 stands for a device where the probe fails: clamped table, every range test, same results."""
+    monkeypatch.setenv("MM2GB_LDS_PROBE", "0")
+    parts = [band_cloud(8000, 311, xwin=8000, jitter=900), sc.read_like(7000, 312)]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    with mm.Engine() as e:
+        check_batch(e, np.concatenate(parts), off, orc.default_param())
+
+
 def test_clamped_penalty_table_build(monkeypatch):
     """MM2GB_LUT_CLAMP=1: the bw+2-entry penalty table with a clamped index (no LDS read ever leaves the table) instead of
     the wide unclamped one.  Same results on saturated windows, ties, the rescue, team and wave modes."""
