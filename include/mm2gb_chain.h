@@ -76,6 +76,10 @@ mm2gb_engine_t *mm2gb_engine_create(const mm2gb_config_t *cfg, const mm2gb_misc_
 void mm2gb_engine_destroy(mm2gb_engine_t *eng);
 int  mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc);
 int  mm2gb_engine_device(const mm2gb_engine_t *eng);
+/* of the engine's last completed call: heavy chunks that were scored strip by strip with the help of idle workgroups (micro-batches of
+ * up to MM2GB_SPLIT_MAX_ANCHORS anchors; 0 = never, the default: the build is exact but measured slower), and the items
+ * of such chunks that workgroups other than the owner took */
+void mm2gb_engine_split_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64_t *helped_items);
 /* make sure arenas can take a micro-batch of this size (grows, never shrinks) */
 int  mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads);
 

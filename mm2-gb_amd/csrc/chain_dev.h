@@ -37,6 +37,21 @@ constexpr int PLAN_THREADS = MM2GB_PLAN_THREADS;   // k_window: each thread owns
 // cost charged per anchor on top of its pairs when ordering chunks (tile bookkeeping is not free)
 constexpr int COST_PER_ANCHOR = 16;
 
+// A heavy chunk scored by its owner workgroup strip by strip (16 tiles = 1 024 anchors), the sweeps over the sources BEFORE the strip
+// cut into items that any idle workgroup may take (chain_kernels.hip, split_chunk).  Every word is accessed with agent-scope atomics.
+struct SplitSlot {
+	unsigned long long word;   // total items of the open strip << 32 | next item to hand out (0: nothing open)
+	int done;                  // items of the open strip that are finished
+	int cs, ce, i_s;           // the chunk, the strip's first anchor
+	int blocks_per_item;
+	int jbs[8];                // per tile pair of the strip: first source block of its window
+	int base[9];               // per tile pair: its first item; base[8] = total
+	int pad_[8];
+};
+static_assert(sizeof(SplitSlot) == 128, "one slot per 128-byte line");
+constexpr int SPLIT_MAX_ITEMS = 128;                   // per strip: 8 tile pairs x at most 16 items
+constexpr int SPLIT_STRIP_TILES = 16;                  // = waves of a score workgroup
+
 // Everything one micro-batch needs in HBM.  SoA: one array per field, anchors of all reads concatenated.
 struct DevBatch {
 	// inputs
@@ -77,8 +92,17 @@ struct DevBatch {
 	unsigned *flags;           // FLAG_*
 	const int32_t *lut;        // penalty table by dd, LUT_ENTRIES entries (MODE_LUT only)
 	int64_t  *dbg;             // optional: 4 time stamps per score workgroup (MM2GB_DEBUG_PHASES), else null
+	// one chunk on several workgroups (k_score's SPLIT build): a slot per score workgroup, zeroed before every launch, and room
+	// for the partial results of one strip's items per workgroup; null when the build is not used
+	SplitSlot          *split_slots;
+	unsigned long long *split_part;
 };
-enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_NMID = 6, CNT_MCURSOR = 7, CNT_WORDS = 8 };
+enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_NMID = 6, CNT_MCURSOR = 7,
+       CNT_SPLIT_OPEN = 8,      // score workgroups that have started and not yet left the whole-workgroup phase
+       CNT_NSPLIT = 9,          // chunks scored strip by strip with other workgroups' help
+       CNT_HELPED = 10,         // items of such chunks that a workgroup other than the chunk's owner took
+       CNT_SPLIT_ANY = 11,      // strips that are open for items right now (what idle waves poll)
+       CNT_WORDS = 12 };
 
 struct LaunchCfg {
 	int score_grid;          // persistent 1024-thread workgroups of k_score
@@ -86,6 +110,7 @@ struct LaunchCfg {
 	int ring_slots;          // LDS ring of the team modes: slots of 64 scores, shared out among the teams of a phase; 0 = team modes off
 	int big_team;            // waves per team in the first phase: 16 (one team per workgroup) or 8 (two)
 	int whole_wg_pct;        // a big-team chunk costing more than this % of a workgroup's fair share of that list gets all 16 waves; 0 = never
+	int split;               // 1: launch the SPLIT build (such chunks strip by strip, idle workgroups help); the host's choice by batch size
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode
 	int     wide_window;     // mean window from which a big team pays; narrower heavy chunks get 4-wave teams

@@ -595,7 +595,12 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
-	const unsigned long long all_lanes = __builtin_amdgcn_read_exec();   // the execution mask the v_cmpx statements put back
+	// The v_cmpx statements put the execution mask back to ALL lanes (-1): every sweep of this kernel runs in wave-uniform control flow
+	// (dead lanes are handled by their data), so that is the mask on entry.  It is not read from the register: a copy taken "at this
+	// point" (the builtin, or a volatile s_mov) has no data dependence that keeps it here, and in the SPLIT build the compiler placed it
+	// in the wave-uniform code after split_claim's one-lane atomic, which it runs under that ONE-lane mask -- the sweep then put a
+	// one-lane mask back and finished with 63 lanes off (found with a build without helpers, profiles/split_soak.py: wrong from the
+	// first strip that has a range-tested block, in exactly the items that contain one).
 	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
 		const int j0 = jb + kg;
 		int dqm[G], drm[G], pen[G];
@@ -617,9 +622,9 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 			v += pen[u];
 			if (!CHECK) {
 				// "bestv = max(bestv, v) in the lanes whose dq is in range": the range test goes straight into the execution
-				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement (from all_lanes, read once)
-				asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
-				             : [b] "+v"(bestv) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
+				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement
+				asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, -1"
+				             : [b] "+v"(bestv) : [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
 			} else {
 				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
 				const bool take = ((unsigned)dqm[u] < lim4) & (v > bestv) & (drm[u] != -4) & (j0 + u >= t_st);
@@ -715,8 +720,7 @@ template <bool CLAMP>
 __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int tyb, const int4 *stage, const DevParams &P, int &bva, int &bvb)
 {
 	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
-	const unsigned long long all_lanes = __builtin_amdgcn_read_exec();
-	constexpr int G = PAIR_SWEEP_GROUP;
+	constexpr int G = PAIR_SWEEP_GROUP;                         // (execution mask: see sweep_block_lut)
 	for (int kg = 0; kg < WAVE; kg += G) {
 		int4 s4[G];
 		int dqa[G], dra[G], pa[G], dqb[G], drb[G], pb[G];
@@ -744,10 +748,10 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 			int vb = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x;
 			asm("" : "+v"(vb));
 			vb += pb[u];
-			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
-			             : [b] "+v"(bva) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqa[u]), [v] "v"(va) : "vcc");
-			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
-			             : [b] "+v"(bvb) : [sv] "s"(all_lanes), [lim] "s"(lim4), [dq] "v"(dqb[u]), [v] "v"(vb) : "vcc");
+			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, -1"
+			             : [b] "+v"(bva) : [lim] "s"(lim4), [dq] "v"(dqa[u]), [v] "v"(va) : "vcc");
+			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, -1"
+			             : [b] "+v"(bvb) : [lim] "s"(lim4), [dq] "v"(dqb[u]), [v] "v"(vb) : "vcc");
 		}
 	}
 }
@@ -1390,14 +1394,238 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 	}
 }
 
+
+// ---- one chunk on several workgroups (SPLIT build) ------------------------------------------------------------------------
+// A team is bounded by one CU; the largest chunks of a batch that cannot fill the machine decide when it ends.  Such a chunk (one that
+// the planner gives a whole workgroup, its OWNER) is scored strip by strip, a strip being 16 tiles, one per wave.  For every strip:
+//   phase A  the sweeps over the sources BEFORE the strip -- all final -- are cut into items (a tile pair x some source blocks) in a
+//            slot in global memory; the owner's waves take items, and so does every wave of the launch that has nothing else left to
+//            do (help_split_chunks, at the end of the kernel).  An item leaves per target the best score and its source;
+//   phase B  wave w combines tile w's items in source order (a later source wins ties, as everywhere), then goes through the tiles
+//            of its own strip that precede it -- scores through the LDS ring -- and the in-tile phase, as a team does (coop_chunk).
+// Nothing waits for a workgroup that may not be running: the owner takes items itself and only waits for items somebody HAS taken,
+// i.e. for waves that are executing them; helpers leave when no workgroup is in the whole-workgroup phase any more.
+// What crosses workgroups: the chunk's scores (owner -> whoever takes an item) and the items' partial results (-> owner).  Both are
+// PLAIN stores, drained by every storing wave, then ONE agent-scope release by the lane that signals (owner: before it opens a strip;
+// item: before it counts itself done) and an agent-scope acquire on the reading side before its plain loads -- the form
+// cdna_hip_programming.md Guideline 16 gives as always valid.  Write-through (sc1) stores with no release were tried first: the
+// OWNER's own reads of scores it had stored that way microseconds earlier came back stale, with sc1 and with plain loads alike
+// (profiles/split_soak.py with a build without helpers: every run wrong from the first strip whose sources are that fresh), while
+// other CUs read them correctly.  The slot's words are agent-scope atomics.  x, y, tag, st are not written in this launch.
+#define MM2GB_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ int  gload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, MM2GB_AGENT); }
+__device__ __forceinline__ void gstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, MM2GB_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+	return (unsigned long long)(unsigned)first_lane((int)(v >> 32)) << 32 | (unsigned)first_lane((int)v);
+}
+
+// Item `it` of workgroup `wg`'s open strip.  Any wave of the launch, whole-wave (uniform) control flow only.
+__device__ __forceinline__ void split_do_item(const DevBatch &b, const DevParams &P, int4 *stage, const int wg, const int it)
+{
+	SplitSlot *slot = b.split_slots + wg;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the scores the owner released when it opened this strip
+	// the slot's fields belong to this strip until every item that was handed out is done
+	// (plain loads behind the acquire, like the scores: the owner wrote them with plain stores before its release)
+	const volatile SplitSlot *vs = slot;
+	const int cs = first_lane(vs->cs), ce = first_lane(vs->ce), i_s = first_lane(vs->i_s), per = first_lane(vs->blocks_per_item);
+	int p = 0;
+	for (int q = 1; q < 8; ++q) if (it >= first_lane(vs->base[q])) p = q;
+	const int k = it - first_lane(vs->base[p]);
+	const int jb0 = first_lane(vs->jbs[p]) + k * per * WAVE, jb1 = min(i_s, jb0 + per * WAVE);
+	const int i0 = i_s + p * 2 * WAVE;
+	TilePair t = load_pair(b, i0, ce);
+	const int eq_lo = equal_x_run_start(b, cs, i0, first_lane(t.A.x));
+	for (int jb = jb0; jb < jb1; jb += WAVE) {
+		const int sf = b.f[jb + lane_id()], sq = b.tag[jb + lane_id()] & 0xff;
+		sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
+	}
+	unsigned long long *part = b.split_part + ((size_t)wg * SPLIT_MAX_ITEMS + it) * 2 * WAVE;
+	part[lane_id()] = (unsigned long long)(unsigned)t.best_a << 32 | (unsigned)t.arg_a;
+	part[WAVE + lane_id()] = (unsigned long long)(unsigned)t.best_b << 32 | (unsigned)t.arg_b;
+	drain_stores();
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	drain_stores();
+	if (lane_id() == 0) {
+		__hip_atomic_fetch_add(&slot->done, 1, __ATOMIC_RELAXED, MM2GB_AGENT);
+		if (wg != (int)blockIdx.x) atomicAdd(&b.counters[CNT_HELPED], 1);
+	}
+}
+// The same for the owner's own waves, as a function of its own.  Inlined into split_chunk the item code was miscompiled (ROCm 7.2): items
+// that contain a range-tested block came out with lanes missing -- every run of profiles/split_soak.py with a build without helpers
+// wrong from the first such strip on, whatever the memory protocol -- while the copy inlined into help_split_chunks and this
+// out-of-line copy give the oracle's results.  The call costs the owner little: with helpers around it takes few items itself.
+__device__ __attribute__((noinline)) void split_do_item_owner(const DevBatch &b, const DevParams &P, int4 *stage, const int it)
+{
+	split_do_item(b, P, stage, (int)blockIdx.x, it);
+}
+// Take the next item of workgroup `wg`'s open strip: its number, or -1 when none is left.  (The same shape as the work cursors of
+// k_score: one lane adds, the value is made wave-uniform.  A peek with a conditional add nested in the one-lane branch, and an early
+// return out of it, made the compiler run later items of the same wave with lanes missing.)
+__device__ __forceinline__ int split_claim(const DevBatch &b, const int wg)
+{
+	unsigned long long w = 0;
+	if (lane_id() == 0) w = __hip_atomic_fetch_add(&b.split_slots[wg].word, 1ull, __ATOMIC_RELAXED, MM2GB_AGENT);
+	w = uni64(w);
+	const int it = (int)(unsigned)w, total = (int)(w >> 32);
+	return it < total ? it : -1;
+}
+
+// A wave with nothing else to do: items of any workgroup's open strip, until no workgroup is in the whole-workgroup phase any more.
+__device__ __forceinline__ void help_split_chunks(const DevBatch &b, const DevParams &P, int4 *stage)
+{
+	unsigned idle = 0;
+	for (;;) {
+		const int open = first_lane(gload(&b.counters[CNT_SPLIT_OPEN]));       // read BEFORE the look at the slots
+		bool any = false;
+		// one word says whether any strip is open at all: that is all an idle wave reads, every few microseconds
+		if (first_lane(gload(&b.counters[CNT_SPLIT_ANY])) > 0)
+		for (int base = 0; base < (int)gridDim.x; base += WAVE) {
+			const int wg = base + lane_id();
+			unsigned long long w = 0;
+			if (wg < (int)gridDim.x) w = __hip_atomic_load(&b.split_slots[wg].word, __ATOMIC_RELAXED, MM2GB_AGENT);
+			unsigned long long has = __ballot((unsigned)w < (unsigned)(w >> 32));
+			while (has) {
+				const int sel = base + __builtin_ctzll(has);
+				const int it = split_claim(b, sel);
+				if (it >= 0) { split_do_item(b, P, stage, sel, it); any = true; }
+				else has &= has - 1;
+			}
+		}
+		if (!any) {
+			if (open <= 0 || ++idle > (1u << 22)) return;             // (the bound: seconds; helping is optional, hanging is not)
+			__builtin_amdgcn_s_sleep(64);
+		}
+	}
+}
+
+// The owner: all 16 waves of the workgroup, chunk [cs, ce).  tab: 24 ints of LDS.
+template <bool TRACK>
+__device__ __forceinline__ void split_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, CoopShared *sh, int *tab,
+                                            const int cs, const int ce, const int wave)
+{
+	constexpr int S = SPLIT_STRIP_TILES;
+	const int lane = lane_id();
+	SplitSlot *slot = b.split_slots + blockIdx.x;
+	const unsigned long long *part = b.split_part + (size_t)blockIdx.x * SPLIT_MAX_ITEMS * 2 * WAVE;
+	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
+	auto wait_done = [&](int need) {
+		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(32);
+	};
+	if (wave == 0 && lane == 0) atomicAdd(&b.counters[CNT_NSPLIT], 1);
+	for (int s0 = 0; s0 < n_tiles; s0 += S) {
+		const int i_s = cs + s0 * WAVE;
+		// ---- phase A: the sources before the strip ----
+		if (wave < 8 && lane == 0) {
+			const int i0 = i_s + wave * 2 * WAVE;
+			int jbs = i_s, nblk = 0;
+			if (s0 > 0 && i0 < ce) {
+				const int lo = b.st[i0];                           // window starts are monotone: the pair's first anchor has the smallest
+				jbs = cs + ((lo - cs) & ~(WAVE - 1));
+				nblk = jbs < i_s ? (i_s - jbs) / WAVE : 0;
+			}
+			tab[wave] = jbs; tab[8 + wave] = nblk;
+		}
+		if (wave == 0 && lane == 0) __hip_atomic_store(&sh->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		team_barrier(sh, S);
+		int total = 0, per = 8;
+		{
+			int widest = 0;
+			for (int q = 0; q < 8; ++q) widest = max(widest, first_lane(tab[8 + q]));
+			per = max(8, (widest + 15) / 16);                       // at most 16 items per pair
+			for (int q = 0; q < 8; ++q) total += (first_lane(tab[8 + q]) + per - 1) / per;
+		}
+		if (total > 0) {
+			if (wave == 0 && lane == 0) {
+				volatile SplitSlot *vs = slot;
+				vs->cs = cs; vs->ce = ce; vs->i_s = i_s; vs->blocks_per_item = per; gstore(&slot->done, 0);
+				int acc = 0;
+				for (int q = 0; q < 8; ++q) { vs->jbs[q] = tab[q]; vs->base[q] = acc; acc += (tab[8 + q] + per - 1) / per; }
+				vs->base[8] = acc;
+				drain_stores();
+				// the scores of the strips before this one: every wave drained its stores before the barrier above
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				drain_stores();
+				__hip_atomic_store(&slot->word, (unsigned long long)total << 32, __ATOMIC_RELAXED, MM2GB_AGENT);    // open
+				atomicAdd(&b.counters[CNT_SPLIT_ANY], 1);
+			}
+			team_barrier(sh, S);
+			for (;;) {
+				const int it = split_claim(b, (int)blockIdx.x);
+				if (it < 0) break;
+				split_do_item_owner(b, P, stage, it);
+			}
+			// every item is handed out; wait for the ones still being worked on (by waves that are running: no wait for anybody's turn)
+			if (lane == 0) {
+				unsigned spins = 0;
+				while (__hip_atomic_load(&slot->done, __ATOMIC_RELAXED, MM2GB_AGENT) < total) {
+					__builtin_amdgcn_s_sleep(8);
+					if (++spins > (1u << 26)) __builtin_trap();       // minutes: something is broken; fail loudly rather than hang
+				}
+			}
+			team_barrier(sh, S);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the partial results (every wave reads some)
+			if (wave == 0 && lane == 0) { __hip_atomic_store(&slot->word, 0ull, __ATOMIC_RELAXED, MM2GB_AGENT); atomicAdd(&b.counters[CNT_SPLIT_ANY], -1); }   // closed
+		}
+		// ---- phase B: the strip itself, wave w its tile w ----
+		const int tix = s0 + wave;
+		if (tix < n_tiles) {
+			const int i0 = cs + tix * WAVE;
+			const Target T = load_target(b, i0, ce, TRACK);
+			const int n_here = min(WAVE, ce - i0);
+			int best = T.q + 1, arg = -1;
+			if (total > 0) {
+				const int q = wave >> 1, side = wave & 1;
+				int first = 0;
+				for (int r = 0; r < q; ++r) first += (first_lane(tab[8 + r]) + per - 1) / per;
+				const int n_it = (first_lane(tab[8 + q]) + per - 1) / per;
+				for (int k = 0; k < n_it; ++k) {                     // ascending sources: a later one wins ties
+					const unsigned long long v = part[((size_t)(first + k) * 2 + side) * WAVE + lane];
+					const int pb = (int)(unsigned)(v >> 32), pa = (int)(unsigned)v;
+					if (pa >= 0 && pb >= best) { best = pb; arg = pa; }
+				}
+			}
+			const int tile_lo = first_lane(T.st), st_hi = bcast(T.st, n_here - 1);
+			int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
+			if (jb < i_s) jb = i_s;
+			const int eq_lo = jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(T.x)) : i0;
+			for (; jb < i0; jb += WAVE) {
+				const int src = (jb - i_s) / WAVE;                  // tile of this strip, one of the waves before this one
+				const int sq = b.tag[jb + lane] & 0xff;
+				wait_done(src + 1);
+				const int sf = ring[src * WAVE + lane];
+				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
+				sweep_any<MODE_LUT>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);
+			}
+			wait_done(wave);                                         // every earlier tile of the strip is final (earlier strips: the barrier)
+			Keep keep;
+			if (TRACK) { keep.idx = first_lane(sh->keep[0]); keep.x = first_lane(sh->keep[1]); keep.hi = first_lane(sh->keep[2]); keep.y = first_lane(sh->keep[3]); keep.tag = first_lane(sh->keep[4]); keep.f = first_lane(sh->keep[5]); }
+			else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
+			in_tile<MODE_LUT, TRACK>(b, T, i0, n_here, P, lut, stage, best, arg, keep, [&](int jj) { return b.f[jj]; });
+			const int i = i0 + lane;
+			const int fi = arg < 0 ? T.q : best;
+			if (T.live) {
+				ring[wave * WAVE + lane] = fi;
+				b.f[i] = fi;                                          // other workgroups read it in later strips' items (released when a strip opens)
+				b.p[i] = arg < 0 ? 0 : i - arg;
+			}
+			if (TRACK && lane == 0) { sh->keep[0] = keep.idx; sh->keep[1] = keep.x; sh->keep[2] = keep.hi; sh->keep[3] = keep.y; sh->keep[4] = keep.tag; sh->keep[5] = keep.f; }
+			drain_stores();
+			if (lane == 0) __hip_atomic_store(&sh->done, wave + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		team_barrier(sh, S);
+	}
+}
+
 // One phase of team work: the workgroup's waves form teams of team_size (4, 8 or 16) that pull chunks from `list`.
 // first: a chunk (position in the list) already pulled for team 0 by the previous phase, or -1.
 // min_cost: a chunk cheaper than this ends the phase for the team that pulled it; its position is returned (else -1) so
 // that the next phase can start with it.  Only meaningful for a one-team phase (whole workgroup).
-template <int MODE>
+template <int MODE, bool SPLIT>
 __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
                           const int32_t *list, const int n_list, const int cursor, const int wave, const int team_size,
-                          int first = -1, const long long min_cost = 0)
+                          int first = -1, const long long min_cost = 0, int *split_tab = nullptr)
 {
 	const int n_teams = SCORE_THREADS / WAVE / team_size;
 	const int team = wave / team_size, team_wave = wave - team * team_size;
@@ -1416,7 +1644,10 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
 		// whole-workgroup teams keep one tile per wave: with two, 32 tiles of one chunk would be in flight and the largest
 		// chunks -- the ones that decide when a small batch ends -- ran 6 % slower
-		if (MODE == MODE_LUT && team_size < SCORE_THREADS / WAVE) {
+		if (SPLIT && MODE == MODE_LUT && team_size == SCORE_THREADS / WAVE) {
+			if (b.chunk_track[ci] & 1) split_chunk<true>(b, P, lut, stage, my_ring, sh, split_tab, cs, ce, team_wave);
+			else split_chunk<false>(b, P, lut, stage, my_ring, sh, split_tab, cs, ce, team_wave);
+		} else if (MODE == MODE_LUT && team_size < SCORE_THREADS / WAVE) {
 			if (b.chunk_track[ci] & 1) coop_chunk_pairs<true>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
 			else coop_chunk_pairs<false>(b, P, lut, stage, my_ring, slots, sh, cs, ce, team_wave, team_size);
 		} else {
@@ -1438,7 +1669,7 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 // table from LUT_LDS_BASE to the end of the allocation, LUT_LDS_TOTAL (chain_dev.h)
 // --------------------------------------------------------------------------------------------------------------
 
-template <int MODE>
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_slots, int big_team, int whole_wg_pct)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -1455,6 +1686,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	CoopShared *teams = (CoopShared*)((int4*)(ring + ring_slots * WAVE) + SCORE_THREADS);   // N_SMALL_TEAMS of them
 	if (MODE == MODE_LUT) for (int k = threadIdx.x; k < LUT_ENTRIES; k += SCORE_THREADS) lut[k] = b.lut[k];   // zeros (= reject) from lut_last + 1 on
 	if (threadIdx.x < N_TEAM_RECORDS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
+	int *split_tab = (int*)(teams + N_TEAM_RECORDS);           // 24 ints between the team records and the table (SPLIT build)
+	if (SPLIT && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], 1);   // this workgroup is in the whole-workgroup phase
 	__syncthreads();
 
 	const int n_long = first_lane(b.counters[CNT_NLONG]), n_mid = first_lane(b.counters[CNT_NMID]);
@@ -1474,16 +1707,18 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 		int first = -1;
 		for (int phase = 0; phase < 3; ++phase) {
 			const bool whole = phase == 0, small = phase == 2;
-			if (whole && !(big_team < SCORE_THREADS / WAVE && whole_wg_pct > 0)) continue;
+			if (whole && !(big_team < SCORE_THREADS / WAVE && whole_wg_pct > 0)) { if (SPLIT && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], -1); continue; }
 			const long long share = whole ? max(1ll, (long long)(b.totals[2] / gridDim.x * whole_wg_pct / 100)) : 0;
 			CoopShared *records = small ? teams : whole ? teams + N_SMALL_TEAMS + 2 : teams + N_SMALL_TEAMS;
-			const int got = team_phase<MODE>(b, P, lut, stage, ring, ring_slots, records, small ? b.mid_list : b.long_list, small ? n_mid : n_long,
-			                                 small ? CNT_MCURSOR : CNT_LCURSOR, wave, small ? SMALL_TEAM : whole ? SCORE_THREADS / WAVE : big_team,
-			                                 whole || small ? -1 : first, share);
+			const int got = team_phase<MODE, SPLIT>(b, P, lut, stage, ring, ring_slots, records, small ? b.mid_list : b.long_list, small ? n_mid : n_long,
+			                                        small ? CNT_MCURSOR : CNT_LCURSOR, wave, small ? SMALL_TEAM : whole ? SCORE_THREADS / WAVE : big_team,
+			                                        whole || small ? -1 : first, share, split_tab);
 			if (whole) first = got;
+			if (SPLIT && whole && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], -1);   // (all 16 waves return together: the team's barrier)
 			if (phase == 1 && b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 		}
 	}
+	else if (SPLIT && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], -1);
 	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 	// phase 2: one wave per chunk
 	const int n_chunks = b.counters[CNT_NCHUNK] - n_long - n_mid;
@@ -1502,6 +1737,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			else run_chunk<MODE, false>(b, P, lut, stage, cs, ce);
 		}
 	}
+	// nothing left of its own: items of chunks that other workgroups score strip by strip
+	if (SPLIT && MODE == MODE_LUT) help_split_chunks(b, P, stage);
 	if (b.dbg && lane_id() == 0) atomicMax((unsigned long long*)&b.dbg[blockIdx.x * 4 + 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -1542,9 +1779,10 @@ size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots)
 
 int score_set_lds_limit(size_t bytes)
 {
-	hipError_t e = hipFuncSetAttribute((const void*)k_score<MODE_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_GENERAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	hipError_t e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_FAST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_GENERAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 	return e == hipSuccess ? 0 : -1;
 }
 
@@ -1553,9 +1791,12 @@ void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, h
 	if (b.n <= 0) return;
 	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_slots);
 	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_slots);
-	if (cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_LUT>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
-	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL(k_score<MODE_FAST>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
-	hipLaunchKernelGGL(k_score<MODE_GENERAL>, dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	if (cfg.host_mode == MODE_LUT) {
+		if (cfg.split && b.split_slots) hipLaunchKernelGGL((k_score<MODE_LUT, true>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+		else hipLaunchKernelGGL((k_score<MODE_LUT, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	}
+	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL((k_score<MODE_FAST, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	hipLaunchKernelGGL((k_score<MODE_GENERAL, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
 }
 
 } // namespace mm2gb

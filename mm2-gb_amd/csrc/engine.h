@@ -71,8 +71,9 @@ struct Engine {
 		DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
 		DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
 		DevBuf counters, totals, flags;
+		DevBuf split_slots, split_part;       // one chunk on several workgroups (k_score's SPLIT build): allocated when first used
 		std::vector<DevBuf*> all() { return { &x, &y, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_wmax, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
-		                                      &chunk_track, &order, &long_list, &mid_list, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins, &counters, &totals, &flags }; }
+		                                      &chunk_track, &order, &long_list, &mid_list, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins, &counters, &totals, &flags, &split_slots, &split_part }; }
 	};
 	WorkSet work[2];
 	DevBuf lut, dbg;
@@ -102,6 +103,8 @@ struct Engine {
 
 	mm2gb_stats_t last = {};
 	bool misc_valid = false, coop_disabled = false, debug_phases = false, one_compute_stream = false;
+	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)
+	int64_t last_split_chunks = 0, last_helped_items = 0;   // of the last call: chunks scored strip by strip, items other workgroups took
 	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)
 	int64_t dual_stream_max_n = 16 * 1000 * 1000;   // micro-batches up to this many anchors alternate between the two compute streams
 

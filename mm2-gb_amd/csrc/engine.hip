@@ -217,6 +217,8 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_WIDE_WINDOW")) launch.wide_window = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_LONG_MIN_COST")) launch.long_min_cost = std::max<int64_t>(1, atoll(v));
 	if (const char *v = getenv("MM2GB_DEBUG_PHASES")) debug_phases = *v && *v != '0';
+	split_max_n = 0;                                           // off: measured slower at every batch size (profiles/r02y_split_rate.json)
+	if (const char *v = getenv("MM2GB_SPLIT_MAX_ANCHORS")) split_max_n = std::max<int64_t>(0, atoll(v));
 	if (debug_phases && dbg.ensure((size_t)launch.score_grid * 32)) return -1;
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
@@ -306,6 +308,7 @@ int Engine::begin_call()
 	if (n_slots > 0 && sync()) return -1;     // a previous call was never collected
 	n_slots = 0;
 	last = mm2gb_stats_t();
+	last_split_chunks = last_helped_items = 0;
 	return 0;
 }
 
@@ -337,6 +340,16 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	b.lut = (const int32_t*)lut.ptr;
 	b.dbg = debug_phases ? (int64_t*)dbg.ptr : nullptr;
 	if (debug_phases) MM2GB_HIP(hipMemsetAsync(dbg.ptr, 0, (size_t)launch.score_grid * 32, stream));
+	// A batch that cannot fill the machine ends with its largest chunks: the SPLIT build scores those strip by strip with the help of
+	// the workgroups that have run out of work (chain_kernels.hip, split_chunk).  Large batches keep the plain build.
+	LaunchCfg cfg_now = launch;
+	cfg_now.split = launch.host_mode == SCORE_MODE_LUT && launch.ring_slots > 0 && n > 0 && n <= split_max_n;
+	b.split_slots = nullptr; b.split_part = nullptr;
+	if (cfg_now.split) {
+		if (w.split_slots.ensure((size_t)launch.score_grid * sizeof(SplitSlot)) || w.split_part.ensure((size_t)launch.score_grid * SPLIT_MAX_ITEMS * 2 * 64 * 8)) return -1;
+		b.split_slots = (SplitSlot*)w.split_slots.ptr; b.split_part = (unsigned long long*)w.split_part.ptr;
+		MM2GB_HIP(hipMemsetAsync(w.split_slots.ptr, 0, (size_t)launch.score_grid * sizeof(SplitSlot), stream));
+	}
 
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
 	MM2GB_HIP(hipMemsetAsync(totals.ptr, 0, 4 * sizeof(int64_t), stream));
@@ -344,10 +357,10 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	if (want_stats) MM2GB_HIP(hipEventRecord(bs.prep0, stream));
 	if (n > 0) {
 		launch_window(b, params, stream);
-		launch_plan(b, launch, stream);
+		launch_plan(b, cfg_now, stream);
 	}
 	if (want_stats) MM2GB_HIP(hipEventRecord(bs.prep1, stream));
-	if (n > 0) launch_score(b, params, launch, stream);
+	if (n > 0) launch_score(b, params, cfg_now, stream);
 	if (want_stats) {
 		MM2GB_HIP(hipEventRecord(bs.score1, stream));
 		MM2GB_HIP(hipMemcpyAsync(h_counters + (size_t)slot * CNT_WORDS, counters.ptr, CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -718,6 +731,7 @@ int Engine::collect_stats()
 		last.n_mid_chunks += c[CNT_NMID];
 		last.n_tracked_chunks += c[CNT_NTRACK];
 		last.n_clamped_blocks += c[CNT_NCLAMP];
+		last_split_chunks += c[CNT_NSPLIT]; last_helped_items += c[CNT_HELPED];
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, slots[k].prep0, slots[k].prep1) == hipSuccess) last.ms_prep += ms;
 		if (hipEventElapsedTime(&ms, slots[k].prep1, slots[k].score1) == hipSuccess) last.ms_score += ms;
@@ -801,6 +815,13 @@ using namespace mm2gb;
 extern "C" {
 
 const char *mm2gb_last_error(void) { return last_error_cstr(); }
+// of the engine's last completed call: chunks scored strip by strip (k_score's SPLIT build) and the items of such chunks that
+// workgroups other than the owner took
+void mm2gb_engine_split_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64_t *helped_items)
+{
+	if (chunks) *chunks = eng ? eng->e.last_split_chunks : 0;
+	if (helped_items) *helped_items = eng ? eng->e.last_helped_items : 0;
+}
 const char *mm2gb_version(void) { return MM2GB_VERSION; }
 
 int mm2gb_device_count(void)

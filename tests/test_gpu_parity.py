@@ -526,6 +526,46 @@ def test_without_the_lds_contract_the_checked_builds_run(monkeypatch):
         check_batch(e, np.concatenate(parts), off, orc.default_param())
 
 
+@pytest.mark.timeout(300)
+def test_one_chunk_on_several_workgroups(monkeypatch):
+    """A batch too small to fill the GPU ends with its largest chunk, which one workgroup scores at the pace of one CU.  In micro-batches
+    of up to MM2GB_SPLIT_MAX_ANCHORS anchors (0 = never, the default: the build is exact but measured slower) such chunks
+    are scored strip by strip (1 024 anchors), the sweeps over the sources before a strip cut into items that idle workgroups take
+    (chain_kernels.hip, split_chunk).  Heavy chunks of every kind -- windows cut by max_iter (the rescue state machine runs), wide and
+    narrow windows, a chunk that ends inside a strip, several owners at once -- against the oracle, every chunk of the big-team list
+    split (MM2GB_WHOLE_WG_PCT=1), and against the same batch with the build switched off."""
+    monkeypatch.setenv("MM2GB_SPLIT_MAX_ANCHORS", "200000000")
+    parts = [sc.sort_by_x(np.concatenate([sc.repeat_block(23000, 401, xwin=4500, ywin=7000), sc.colinear(900, 402)])),
+             sc.sort_by_x(sc.repeat_block(9000, 403, xwin=9000, ywin=9000, r0=4_000_000)),
+             band_cloud(12345, 404, xwin=11000, jitter=800), sc.read_like(9000, 405),
+             sc.rescue_case(n_noise=9000, n_chain=60, seed=23),
+             sc.sort_by_x(sc.repeat_block(17000 + 64 * 3 + 7, 406, xwin=3000, ywin=4000, r0=6_000_000))]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    prm = orc.default_param()
+    with mm.Engine() as e:
+        st = check_batch(e, a, off, prm)
+        f1, p1, _ = e.score(a, off)
+        chunks, helped = e.split_counts()
+        assert chunks >= 3 and helped > 0, (chunks, helped, st)
+        for _ in range(5):                                            # who takes which item changes from run to run; the results must not
+            f2, p2, _ = e.score(a, off)
+            assert np.array_equal(f1, f2) and np.array_equal(p1, p2)
+        check_batch(e, a, off, orc.default_param(max_iter=700))
+        check_batch(e, a, off, orc.default_param(max_dist_x=2000, max_dist_y=2000, bw=300))
+    monkeypatch.setenv("MM2GB_WHOLE_WG_PCT", "1")
+    with mm.Engine() as e:
+        for _ in range(3):
+            check_batch(e, a, off, prm)
+    monkeypatch.delenv("MM2GB_WHOLE_WG_PCT")
+    monkeypatch.delenv("MM2GB_SPLIT_MAX_ANCHORS")
+    with mm.Engine() as e:
+        f0, p0, _ = e.score(a, off)
+        assert e.split_counts() == (0, 0)
+    assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
+
+
 def test_clamped_penalty_table_build(monkeypatch):
     """MM2GB_LUT_CLAMP=1: the bw+2-entry penalty table with a clamped index (no LDS read ever leaves the table) instead of
     the wide unclamped one.  Same results on saturated windows, ties, the rescue, team and wave modes."""
