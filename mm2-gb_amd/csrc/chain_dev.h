@@ -9,8 +9,9 @@ namespace mm2gb {
 struct DevParams {
 	int   max_dist_x, max_dist_y, bw, max_iter, n_seg, is_cdna;
 	int   dq_lim;            // min(max_dist_x, max_dist_y): the single-segment fast path's dq bound
-	int   lut_last;          // last index of the penalty table: bw + 1 (the "reject" entry) when lut_clamp, else max_dist_x
-	int   lut_clamp;         // 1: the sweep clamps the table index to lut_last; 0: the table covers every index that can matter
+	int   lut_last;          // last index of the penalty table: bw + 1, the "reject" entry (what a clamped index ends at)
+	int   lut_base;          // LDS byte address of the table's entry 0: LUT_LDS_TOTAL - 4 * (lut_last + 1), so that it ends where LDS ends
+	int   lut_clamp;         // 1: the sweeps clamp the table index to lut_last; 0: an index beyond it reads beyond LDS, i.e. 0 = reject
 	int   free_sweep;        // 1 (only without lut_clamp): source blocks whose every pair has bw < dr <= dq_lim - bw are swept without range test
 	float gap, skip;
 };
@@ -19,12 +20,13 @@ struct DevParams {
 enum : unsigned { FLAG_ANY_SEGID = 1u,     // some anchor carries a segment id -> MODE_GENERAL
                   FLAG_NO_LUT = 2u };      // a query position >= 2^22 or a zero q_span -> the table sweep is not exact, use MODE_FAST
 
-// MODE_LUT keeps its penalty table at the END of the workgroup's LDS, at a compile-time address (it goes into the offset field of the
-// gathers) and all the way to the last byte the hardware allocates (a multiple of every LDS granule in use: 512 and 1 280 bytes), so
-// that an index beyond the table is an address beyond the allocation, which reads as 0 = "reject" (chain_kernels.hip, sweep_block_lut).
+// MODE_LUT keeps its penalty table -- entries 0 .. bw and one rejecting entry -- at the very END of the workgroup's LDS, up to the last
+// byte the hardware allocates (LUT_LDS_TOTAL is a multiple of every LDS granule in use: 512 and 1 280 bytes), so that an index beyond
+// the table is an address beyond the allocation, which reads as 0 = "reject" and costs the LDS pipe no bank cycles
+// (chain_kernels.hip, lut_address / sweep_block_lut2_free).  Where the table starts depends on bw (DevParams::lut_base).
 constexpr int LUT_LDS_TOTAL = 31 * 2560;               // 79 360 bytes: two 1024-thread workgroups per CU (160 KB LDS)
-constexpr int LUT_ENTRIES   = 5120;                    // dd = 0 .. 5119
-constexpr int LUT_LDS_BASE  = LUT_LDS_TOTAL - LUT_ENTRIES * 4;   // 58 880 < 2^16: fits the DS offset field
+constexpr int LUT_ENTRIES   = 5120;                    // the most the table may have (bw + 2 <= LUT_ENTRIES), what the global copy holds
+constexpr int LUT_LDS_BASE  = LUT_LDS_TOTAL - LUT_ENTRIES * 4;   // 58 880: the lowest address the table can start at; ring, scratch and team records end below it
 // a valid entry is LUT_BIAS - 128 * penalty, a rejecting one 0; sources are staged with their score term lowered by LUT_BIAS
 constexpr int LUT_BIAS      = (1 << 30) + (1 << 16);
 

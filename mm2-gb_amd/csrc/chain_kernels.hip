@@ -481,16 +481,16 @@ __device__ __forceinline__ unsigned abs_diff_u32(int a, int b)
 	return r;
 }
 
-// LDS address of the penalty table's entry for a pair, unclamped sweeps: LUT_LDS_BASE + |a - b| with a, b taken as UNSIGNED and the sum
+// LDS address of the penalty table's entry for a pair, unclamped sweeps: base + |a - b| with a, b taken as UNSIGNED and the sum
 // saturating at 2^32 - 1 (integer clamp).  For dq >= 1 (b >= 0) that is the entry of dd = |dr - dq|, or an address beyond the table =
 // beyond the workgroup's LDS, which reads 0 = "reject".  For dq <= 0, b is "huge": |a - b| = 2^32 - (dr - dq)*4, and with the base added
 // the sum would wrap around into LDS again -- the clamp keeps it at the top of the address space, beyond LDS: such a pair reads 0 too,
 // and lanes that read beyond LDS cost the pipe no bank cycles (why the table at the END of LDS, with the address formed here rather than
 // in the gather's offset field: with the base in the offset field the wrapped addresses fell on the ring and scratch, 4 ms per 500 M anchors).
-__device__ __forceinline__ unsigned lut_address(int a, int b)
+__device__ __forceinline__ unsigned lut_address(int a, int b, unsigned base)
 {
 	unsigned r;
-	asm("v_sad_u32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "s"((unsigned)LUT_LDS_BASE));
+	asm("v_sad_u32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "s"(base));
 	return r;
 }
 
@@ -593,7 +593,7 @@ template <bool CHECK, bool CLAMP>
 __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage,
                                                 const DevParams &P, int &bestv)
 {
-	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
+	const unsigned base = (unsigned)P.lut_base, last_at = base + ((unsigned)P.lut_last << 2), lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
 	// The v_cmpx statements put the execution mask back to ALL lanes (-1): every sweep of this kernel runs in wave-uniform control flow
 	// (dead lanes are handled by their data), so that is the mask on entry.  It is not read from the register: a copy taken "at this
@@ -610,9 +610,9 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
 			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
-			// the table sits at the compile-time LDS address LUT_LDS_BASE (k_score checks)
-			if (CLAMP) { const unsigned dd4 = abs_diff_u32(drm[u], dqm[u]); pen[u] = *(lds_i32_ptr)(uintptr_t)((dd4 < last4 ? dd4 : last4) + LUT_LDS_BASE); }
-			else pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u]);
+			// CLAMP: the saturated address of a pair with dq <= 0 ends at the rejecting entry like any distance beyond bw
+			const unsigned at = lut_address(drm[u], dqm[u], base);
+			pen[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (at < last_at ? at : last_at) : at);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -673,7 +673,7 @@ __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int s
 // ... and are swept against one tile ...
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
 // one tile, a whole block, no test at all: sweep_block_lut2_free (below) explains when and why
-__device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int4 *stage, int &bestv)
+__device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int4 *stage, const unsigned base, int &bestv)
 {
 	constexpr int G = 4;
 	for (int kg = 0; kg < WAVE; kg += G) {
@@ -684,7 +684,7 @@ __device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
 			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
-			pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u]);
+			pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u], base);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -702,7 +702,7 @@ __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_
 {
 	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
 	int bestv = best << 7;
-	if (free_block) sweep_block_lut_free(tx4, ty4, stage, bestv);
+	if (free_block) sweep_block_lut_free(tx4, ty4, stage, (unsigned)P.lut_base, bestv);
 	else if (P.lut_clamp) {
 		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
@@ -719,7 +719,7 @@ __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_
 template <bool CLAMP>
 __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int tyb, const int4 *stage, const DevParams &P, int &bva, int &bvb)
 {
-	const unsigned last4 = (unsigned)P.lut_last << 2, lim4 = (unsigned)P.dq_lim << 2;
+	const unsigned base = (unsigned)P.lut_base, last_at = base + ((unsigned)P.lut_last << 2), lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = PAIR_SWEEP_GROUP;                         // (execution mask: see sweep_block_lut)
 	for (int kg = 0; kg < WAVE; kg += G) {
 		int4 s4[G];
@@ -730,14 +730,9 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 		for (int u = 0; u < G; ++u) {
 			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
 			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
-			if (CLAMP) {
-				const unsigned da = abs_diff_u32(dra[u], dqa[u]), db = abs_diff_u32(drb[u], dqb[u]);
-				pa[u] = *(lds_i32_ptr)(uintptr_t)((da < last4 ? da : last4) + LUT_LDS_BASE);
-				pb[u] = *(lds_i32_ptr)(uintptr_t)((db < last4 ? db : last4) + LUT_LDS_BASE);
-			} else {
-				pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u]);
-				pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u]);
-			}
+			const unsigned aa = lut_address(dra[u], dqa[u], base), ab = lut_address(drb[u], dqb[u], base);
+			pa[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (aa < last_at ? aa : last_at) : aa);
+			pb[u] = *(lds_i32_ptr)(uintptr_t)(CLAMP ? (ab < last_at ? ab : last_at) : ab);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -761,7 +756,7 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 // table, from beyond the workgroup's LDS allocation (out-of-range LDS reads return 0, profiles/ubench/lds_oob.hip; the table ends where
 // the allocation ends); and dq <= 0 makes lut_address saturate, which reads 0 as well.  No v_cmpx, no exec juggling, and two sources
 // share one v_max3: 6.5 vector instructions per pair instead of 8.  Unclamped table only; dr >= 1 is the caller's (no_check blocks).
-__device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, int &bva, int &bvb)
+__device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, const unsigned base, int &bva, int &bvb)
 {
 	constexpr int G = 2;
 	for (int kg = 0; kg < WAVE; kg += G) {
@@ -773,8 +768,8 @@ __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb,
 		for (int u = 0; u < G; ++u) {
 			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
 			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
-			pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u]);
-			pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u]);
+			pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u], base);
+			pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u], base);
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -796,7 +791,7 @@ __device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY
 	const int txa = (int)(((unsigned)TA.x - 1u) << 2), tya = (int)(((unsigned)TA.y - 1u) << 2);
 	const int txb = (int)(((unsigned)TB.x - 1u) << 2), tyb = (int)(((unsigned)TB.y - 1u) << 2);
 	int bva = best_a << 7, bvb = best_b << 7;
-	if (free_block) sweep_block_lut2_free(txa, tya, txb, tyb, stage, bva, bvb);
+	if (free_block) sweep_block_lut2_free(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, bva, bvb);
 	else if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	else sweep_block_lut2<false>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	// (k+1 of the winner is 1..64 for any input the caller's contract allows; anchors that are not sorted by position can make the
@@ -858,7 +853,7 @@ __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce,
 // The acceptance tests are ballots combined on the scalar side with "lane > t", and one v_cndmask takes the mask.
 struct TileLut {
 	int tx4, ty4, lo;
-	unsigned lim4, last4;
+	unsigned lim4, base, last_at;   // table: address of entry 0, of the rejecting entry
 	const int4 *stage;
 	bool edges;              // some window starts inside the tile, or two of its anchors share a reference position
 };
@@ -873,8 +868,8 @@ __device__ __forceinline__ StepPre tile_pre(const TileLut &tl, int t)
 {
 	const int4 s4 = tl.stage[t];
 	const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
-	const unsigned dd4 = abs_diff_u32(drm, dqm);
-	const int pen = *(lds_i32_ptr)(uintptr_t)((dd4 < tl.last4 ? dd4 : tl.last4) + LUT_LDS_BASE);   // always clamped here: one code path, one instruction more
+	const unsigned at = lut_address(drm, dqm, tl.base);
+	const int pen = *(lds_i32_ptr)(uintptr_t)(at < tl.last_at ? at : tl.last_at);   // always clamped here: one code path, one instruction more
 	const int dg = drm < dqm ? drm : dqm;
 	StepPre pre;
 	pre.basev = ((s4.y < dg ? s4.y : dg) << 5) + pen;          // one shift-add: the table holds LUT_BIAS - 128*penalty
@@ -917,7 +912,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	TileLut tl;
 	tl.tx4 = (int)(((unsigned)T.x - 1u) << 2); tl.ty4 = (int)(((unsigned)T.y - 1u) << 2);
 	tl.lo = T.live ? (T.st > i0 ? T.st - i0 : 0) : WAVE;    // first in-tile source inside this lane's window
-	tl.lim4 = (unsigned)P.dq_lim << 2; tl.last4 = (unsigned)P.lut_last << 2;
+	tl.lim4 = (unsigned)P.dq_lim << 2; tl.base = (unsigned)P.lut_base; tl.last_at = tl.base + ((unsigned)P.lut_last << 2);
 	tl.stage = stage;
 	// "source inside this lane's window" and "dr != 0" (lchain.c:120) cannot fail when every window starts before the tile
 	// (then all its anchors share strand|rid and are sorted by position, so equal positions are neighbours) and no two
@@ -964,7 +959,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			const int dg = dr < dq ? dr : dq;
 			const unsigned dd = abs_diff_u32(dr, dq);
 			const unsigned idx = dd < (unsigned)P.lut_last ? dd : (unsigned)P.lut_last;
-			const int sc = (span < dg ? span : dg) + ((*(lds_i32_ptr)(uintptr_t)((idx << 2) + LUT_LDS_BASE) - LUT_BIAS) >> 7);
+			const int sc = (span < dg ? span : dg) + ((*(lds_i32_ptr)(uintptr_t)((idx << 2) + (unsigned)P.lut_base) - LUT_BIAS) >> 7);
 			extra = __ballot((unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && keep0 < T.st - 1);
 			extra_v = (sc + keep.f) << 7;
 		}
@@ -1666,7 +1661,7 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 // Exactly one MODE instance does the work of a batch (mode_sel picks it from the host's parameters and the
 // "some anchor carries a segment id" flag found on the device by k_window).
 // LDS layout (dynamic): [ ring : ring_slots x 64 ints ][ stage : 16 waves x 64 x int4 ][ CoopShared x 7 ] and, MODE_LUT only, the penalty
-// table from LUT_LDS_BASE to the end of the allocation, LUT_LDS_TOTAL (chain_dev.h)
+// table (bw + 2 entries) from P.lut_base to the end of the allocation, LUT_LDS_TOTAL (chain_dev.h)
 // --------------------------------------------------------------------------------------------------------------
 
 template <int MODE, bool SPLIT>
@@ -1676,15 +1671,16 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	const unsigned fl = b.flags[0];
 	const int mode = (fl & FLAG_ANY_SEGID) ? MODE_GENERAL : (host_mode == MODE_LUT && (fl & FLAG_NO_LUT)) ? MODE_FAST : host_mode;
 	if (mode != MODE) return;
-	int *lut = smem + LUT_LDS_BASE / 4;
+	int *lut = smem + (MODE == MODE_LUT ? P.lut_base / 4 : 0);
 	// the table sweep addresses the penalty table by raw LDS offset: the dynamic allocation must start at LDS address 0, and what
 	// comes before the table must end before it
 	if (MODE == MODE_LUT && ((unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)smem != 0u ||
-	                         (size_t)ring_slots * WAVE * 4 + SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) > (size_t)LUT_LDS_BASE)) __builtin_trap();
+	                         (size_t)ring_slots * WAVE * 4 + SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) > (size_t)LUT_LDS_BASE ||
+	                         P.lut_base < LUT_LDS_BASE || P.lut_base + 4 * (P.lut_last + 1) != LUT_LDS_TOTAL)) __builtin_trap();
 	int *ring = smem;
 	int4 *stage = (int4*)(ring + ring_slots * WAVE) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
 	CoopShared *teams = (CoopShared*)((int4*)(ring + ring_slots * WAVE) + SCORE_THREADS);   // N_SMALL_TEAMS of them
-	if (MODE == MODE_LUT) for (int k = threadIdx.x; k < LUT_ENTRIES; k += SCORE_THREADS) lut[k] = b.lut[k];   // zeros (= reject) from lut_last + 1 on
+	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];    // entry lut_last = bw + 1 is 0: reject
 	if (threadIdx.x < N_TEAM_RECORDS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
 	int *split_tab = (int*)(teams + N_TEAM_RECORDS);           // 24 ints between the team records and the table (SPLIT build)
 	if (SPLIT && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], 1);   // this workgroup is in the whole-workgroup phase
