@@ -596,11 +596,9 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 	const unsigned base = (unsigned)P.lut_base, last_at = base + ((unsigned)P.lut_last << 2), lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
 	// The v_cmpx statements put the execution mask back to ALL lanes (-1): every sweep of this kernel runs in wave-uniform control flow
-	// (dead lanes are handled by their data), so that is the mask on entry.  It is not read from the register: a copy taken "at this
-	// point" (the builtin, or a volatile s_mov) has no data dependence that keeps it here, and in the SPLIT build the compiler placed it
-	// in the wave-uniform code after split_claim's one-lane atomic, which it runs under that ONE-lane mask -- the sweep then put a
-	// one-lane mask back and finished with 63 lanes off (found with a build without helpers, profiles/split_soak.py: wrong from the
-	// first strip that has a range-tested block, in exactly the items that contain one).
+	// (dead lanes are handled by their data), so that is the mask on entry.  It is not read from the register any more: a copy taken
+	// "at this point" (the builtin, or a volatile s_mov) has no data dependence that keeps it at this point, and the compiler runs
+	// wave-uniform code under whatever mask is at hand (in the SPLIT build: the one lane of split_claim's atomic).
 	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
 		const int j0 = jb + kg;
 		int dqm[G], drm[G], pen[G];
@@ -659,10 +657,11 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 }
 
 // MODE_LUT: a block's 64 sources go to this wave's LDS scratch once ...
-__device__ __forceinline__ void stage_block_lut(int xs, int ys, int sf, int sq, int4 *stage)
+// far: the block goes through the FAR build of the unchecked sweep only, which wants the span term folded into the score term
+__device__ __forceinline__ void stage_block_lut(int xs, int ys, int sf, int sq, int4 *stage, bool far = false)
 {
 	const int k = lane_id();
-	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS, (sq - 1) * 4, (int)((unsigned)xs << 2), (int)((unsigned)ys << 2));
+	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS + (far ? (sq - 1) << 7 : 0), (sq - 1) * 4, (int)((unsigned)xs << 2), (int)((unsigned)ys << 2));
 	__builtin_amdgcn_wave_barrier();                        // LDS is in-order per wave; keep the compiler from reordering
 }
 __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
@@ -672,7 +671,8 @@ __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int s
 }
 // ... and are swept against one tile ...
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
-// one tile, a whole block, no test at all: sweep_block_lut2_free (below) explains when and why
+// one tile, a whole block, no test at all: sweep_block_lut2_free (below) explains when and why, and what FAR is
+template <bool FAR>
 __device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int4 *stage, const unsigned base, int &bestv)
 {
 	constexpr int G = 4;
@@ -688,21 +688,25 @@ __device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
-			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
-			v[u] = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x;
-			asm("" : "+v"(v[u]));
-			v[u] += pen[u];
+			if (FAR) v[u] = s4[u].x + pen[u];
+			else {
+				const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
+				v[u] = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x;
+				asm("" : "+v"(v[u]));
+				v[u] += pen[u];
+			}
 		}
 		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bestv) : "v"(v[0]), "v"(v[1]));
 		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bestv) : "v"(v[2]), "v"(v[3]));
 	}
 }
 __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, bool free_block, const int4 *stage, const DevParams &P,
-                                                 int &best, int &arg)
+                                                 int &best, int &arg, bool far_block = false)
 {
 	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
 	int bestv = best << 7;
-	if (free_block) sweep_block_lut_free(tx4, ty4, stage, (unsigned)P.lut_base, bestv);
+	if (far_block) sweep_block_lut_free<true>(tx4, ty4, stage, (unsigned)P.lut_base, bestv);
+	else if (free_block) sweep_block_lut_free<false>(tx4, ty4, stage, (unsigned)P.lut_base, bestv);
 	else if (P.lut_clamp) {
 		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
@@ -756,6 +760,11 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 // table, from beyond the workgroup's LDS allocation (out-of-range LDS reads return 0, profiles/ubench/lds_oob.hip; the table ends where
 // the allocation ends); and dq <= 0 makes lut_address saturate, which reads 0 as well.  No v_cmpx, no exec juggling, and two sources
 // share one v_max3: 6.5 vector instructions per pair instead of 8.  Unclamped table only; dr >= 1 is the caller's (no_check blocks).
+// FAR: every pair of the block also has dr > bw + 255.  A pair that survives the gather has |dr - dq| <= bw, so dq > 255 too: both
+// distances exceed any q_span (8 bits), min(q_span, dr, dq) IS the source's q_span, and the block was staged with 128 * (q_span - 1)
+// already in the score term (stage_block_lut) -- no v_min3, no shift-add: 2 sub, sad, add per pair and one v_max3 per two sources,
+// 4.5 vector instructions per pair.  (A pair the gather rejects keeps its LUT_BIAS-low value whatever the span term.)
+template <bool FAR>
 __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, const unsigned base, int &bva, int &bvb)
 {
 	constexpr int G = 2;
@@ -773,25 +782,29 @@ __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb,
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
-			const int ga = dra[u] < dqa[u] ? dra[u] : dqa[u], gb = drb[u] < dqb[u] ? drb[u] : dqb[u];
-			va[u] = ((s4[u].y < ga ? s4[u].y : ga) << 5) + s4[u].x;
-			asm("" : "+v"(va[u]));
-			va[u] += pa[u];
-			vb[u] = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x;
-			asm("" : "+v"(vb[u]));
-			vb[u] += pb[u];
+			if (FAR) { va[u] = s4[u].x + pa[u]; vb[u] = s4[u].x + pb[u]; }
+			else {
+				const int ga = dra[u] < dqa[u] ? dra[u] : dqa[u], gb = drb[u] < dqb[u] ? drb[u] : dqb[u];
+				va[u] = ((s4[u].y < ga ? s4[u].y : ga) << 5) + s4[u].x;
+				asm("" : "+v"(va[u]));
+				va[u] += pa[u];
+				vb[u] = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x;
+				asm("" : "+v"(vb[u]));
+				vb[u] += pb[u];
+			}
 		}
 		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bva) : "v"(va[0]), "v"(va[1]));
 		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bvb) : "v"(vb[0]), "v"(vb[1]));
 	}
 }
-__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, bool free_block, const int4 *stage, const DevParams &P,
+__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, bool free_block, bool far_block, const int4 *stage, const DevParams &P,
                                                   int &best_a, int &arg_a, int &best_b, int &arg_b)
 {
 	const int txa = (int)(((unsigned)TA.x - 1u) << 2), tya = (int)(((unsigned)TA.y - 1u) << 2);
 	const int txb = (int)(((unsigned)TB.x - 1u) << 2), tyb = (int)(((unsigned)TB.y - 1u) << 2);
 	int bva = best_a << 7, bvb = best_b << 7;
-	if (free_block) sweep_block_lut2_free(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, bva, bvb);
+	if (far_block) sweep_block_lut2_free<true>(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, bva, bvb);
+	else if (free_block) sweep_block_lut2_free<false>(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, bva, bvb);
 	else if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	else sweep_block_lut2<false>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	// (k+1 of the winner is 1..64 for any input the caller's contract allows; anchors that are not sorted by position can make the
@@ -809,11 +822,12 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
 {
 	if (MODE == MODE_LUT) {
 		const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
-		stage_block_lut(xs, ys, sf, sq, stage);
 		const TileXY xy = { T.x, T.y, T.st };
-		// (dead lanes of a tile repeat its last live anchor; sweep_block_lut2_free for the condition)
+		// (dead lanes of a tile repeat its last live anchor; sweep_block_lut2_free for the conditions)
 		const bool free_block = no_check && P.free_sweep && bcast(T.x, WAVE - 1) - first_lane(xs) <= P.dq_lim - P.bw;
-		sweep_staged_lut(xy, jb, k_from, no_check, free_block, stage, P, best, arg);
+		const bool far_block = free_block && first_lane(T.x) - bcast(xs, WAVE - 1) > P.bw + 255;
+		stage_block_lut(xs, ys, sf, sq, stage, far_block);
+		sweep_staged_lut(xy, jb, k_from, no_check, free_block, stage, P, best, arg, far_block);
 		__builtin_amdgcn_wave_barrier();
 	} else {
 		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
@@ -1153,7 +1167,7 @@ struct TilePair {
 	TileXY A, B;
 	int n_a, n_b;            // live anchors (n_b = 0: the chunk ends within A)
 	int lo_a, hi_a, lo_b, hi_b;   // smallest / largest window start of each tile
-	int x_last;                   // reference position of the pair's last live anchor
+	int x_first, x_last;          // reference position of the pair's first and last live anchor
 	int best_a, arg_a, best_b, arg_b;
 };
 
@@ -1178,7 +1192,7 @@ __device__ __forceinline__ TilePair load_pair(const DevBatch &b, int i0, int ce)
 	t.B = load_xy(b, t.n_b ? i0 + WAVE : i0, ce, t.best_b);
 	t.lo_a = first_lane(t.A.st); t.hi_a = bcast(t.A.st, t.n_a - 1);
 	t.lo_b = t.n_b ? first_lane(t.B.st) : INT_MAX; t.hi_b = t.n_b ? bcast(t.B.st, t.n_b - 1) : INT_MAX;
-	t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : bcast(t.A.x, t.n_a - 1);   // (dead lanes repeat the last live one)
+	t.x_first = first_lane(t.A.x); t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : bcast(t.A.x, t.n_a - 1);   // (dead lanes repeat the last live one)
 	t.arg_a = -1; t.arg_b = -1;
 	return t;
 }
@@ -1193,8 +1207,11 @@ __device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t,
 	// every pair of this block has dr + bw <= dq_lim (sources are sorted by position: the block's first source and the pair's last
 	// anchor give the largest dr): the gather rejects by itself (sweep_block_lut2_free)
 	const bool free_block = P.free_sweep && t.x_last - first_lane(xs) <= P.dq_lim - P.bw;
-	stage_block_lut(xs, ys, sf, sq, stage);
-	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
+	// ... and dr > bw + 255 too (the block's last source and the pair's first anchor give the smallest dr): the FAR build, for which
+	// the block is staged differently -- so only where both tiles take it
+	const bool far_block = free_block && nc_a && nc_b && t.x_first - bcast(xs, WAVE - 1) > P.bw + 255;
+	stage_block_lut(xs, ys, sf, sq, stage, far_block);
+	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, far_block, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
 		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_block, stage, P, t.best_a, t.arg_a);
 		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, nc_b && free_block, stage, P, t.best_b, t.arg_b);
@@ -1403,10 +1420,10 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 // What crosses workgroups: the chunk's scores (owner -> whoever takes an item) and the items' partial results (-> owner).  Both are
 // PLAIN stores, drained by every storing wave, then ONE agent-scope release by the lane that signals (owner: before it opens a strip;
 // item: before it counts itself done) and an agent-scope acquire on the reading side before its plain loads -- the form
-// cdna_hip_programming.md Guideline 16 gives as always valid.  Write-through (sc1) stores with no release were tried first: the
-// OWNER's own reads of scores it had stored that way microseconds earlier came back stale, with sc1 and with plain loads alike
-// (profiles/split_soak.py with a build without helpers: every run wrong from the first strip whose sources are that fresh), while
-// other CUs read them correctly.  The slot's words are agent-scope atomics.  x, y, tag, st are not written in this launch.
+// cdna_hip_programming.md Guideline 16 gives as always valid.  (A cheaper form, write-through sc1 stores and sc1 loads with no
+// fences, was what the first build used; it was replaced while chasing wrong results that turned out to be the compiler problem noted at
+// split_do_item_owner, and has not been tried again since.)  The slot's words are agent-scope atomics.  x, y, tag, st are not written
+// in this launch.
 #define MM2GB_AGENT __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ int  gload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, MM2GB_AGENT); }
 __device__ __forceinline__ void gstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, MM2GB_AGENT); }
@@ -1456,8 +1473,7 @@ __device__ __attribute__((noinline)) void split_do_item_owner(const DevBatch &b,
 	split_do_item(b, P, stage, (int)blockIdx.x, it);
 }
 // Take the next item of workgroup `wg`'s open strip: its number, or -1 when none is left.  (The same shape as the work cursors of
-// k_score: one lane adds, the value is made wave-uniform.  A peek with a conditional add nested in the one-lane branch, and an early
-// return out of it, made the compiler run later items of the same wave with lanes missing.)
+// k_score: one lane adds, the value is made wave-uniform.)
 __device__ __forceinline__ int split_claim(const DevBatch &b, const int wg)
 {
 	unsigned long long w = 0;
