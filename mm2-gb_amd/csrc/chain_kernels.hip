@@ -657,11 +657,14 @@ __device__ __forceinline__ void sweep_block(const DevBatch &b, const Target &T, 
 }
 
 // MODE_LUT: a block's 64 sources go to this wave's LDS scratch once ...
-// far: the block goes through the FAR build of the unchecked sweep only, which wants the span term folded into the score term
-__device__ __forceinline__ void stage_block_lut(int xs, int ys, int sf, int sq, int4 *stage, bool far = false)
+// far: the block goes through the FAR build of the unchecked sweep only, which wants the span term folded into the score term and, in
+// place of the span, the source's DIAGONAL 4 * ((x - x0) - (y - y0)) with the top bit flipped (d0 = 4 * (x0 - y0), x0 / y0 the block's
+// first source: small numbers whatever the positions; the flipped bit makes their unsigned order the signed one, for v_sad_u32)
+__device__ __forceinline__ void stage_block_lut(int xs, int ys, int sf, int sq, int4 *stage, bool far = false, int d0 = 0)
 {
 	const int k = lane_id();
-	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS + (far ? (sq - 1) << 7 : 0), (sq - 1) * 4, (int)((unsigned)xs << 2), (int)((unsigned)ys << 2));
+	const int x4 = (int)((unsigned)xs << 2), y4 = (int)((unsigned)ys << 2);
+	stage[k] = make_int4(((sf + 1) << 7) + k + 1 - LUT_BIAS + (far ? (sq - 1) << 7 : 0), far ? (int)((unsigned)(x4 - y4 - d0) ^ 0x80000000u) : (sq - 1) * 4, x4, y4);
 	__builtin_amdgcn_wave_barrier();                        // LDS is in-order per wave; keep the compiler from reordering
 }
 __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
@@ -673,18 +676,25 @@ __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int s
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
 // one tile, a whole block, no test at all: sweep_block_lut2_free (below) explains when and why, and what FAR is
 template <bool FAR>
-__device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int4 *stage, const unsigned base, int &bestv)
+__device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int4 *stage, const unsigned base, const int d0, int &bestv)
 {
 	constexpr int G = 4;
+	const int td = (int)((unsigned)(tx4 - ty4 - d0) ^ 0x80000000u);   // FAR: the target's diagonal, like the staged ones
 	for (int kg = 0; kg < WAVE; kg += G) {
 		int4 s4[G];
 		int dqm[G], drm[G], pen[G], v[G];
 #pragma unroll
-		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+		for (int u = 0; u < G; ++u) {
+			if (FAR) { const int2 h = *(const int2*)&stage[kg + u]; s4[u].x = h.x; s4[u].y = h.y; }
+			else s4[u] = stage[kg + u];
+		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
-			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
-			pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u], base);
+			if (FAR) pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(td, s4[u].y, base);
+			else {
+				dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
+				pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u], base);
+			}
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -701,12 +711,12 @@ __device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int
 	}
 }
 __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, bool free_block, const int4 *stage, const DevParams &P,
-                                                 int &best, int &arg, bool far_block = false)
+                                                 int &best, int &arg, bool far_block = false, int d0 = 0)
 {
 	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
 	int bestv = best << 7;
-	if (far_block) sweep_block_lut_free<true>(tx4, ty4, stage, (unsigned)P.lut_base, bestv);
-	else if (free_block) sweep_block_lut_free<false>(tx4, ty4, stage, (unsigned)P.lut_base, bestv);
+	if (far_block) sweep_block_lut_free<true>(tx4, ty4, stage, (unsigned)P.lut_base, d0, bestv);
+	else if (free_block) sweep_block_lut_free<false>(tx4, ty4, stage, (unsigned)P.lut_base, 0, bestv);
 	else if (P.lut_clamp) {
 		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
@@ -760,25 +770,38 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 // table, from beyond the workgroup's LDS allocation (out-of-range LDS reads return 0, profiles/ubench/lds_oob.hip; the table ends where
 // the allocation ends); and dq <= 0 makes lut_address saturate, which reads 0 as well.  No v_cmpx, no exec juggling, and two sources
 // share one v_max3: 6.5 vector instructions per pair instead of 8.  Unclamped table only; dr >= 1 is the caller's (no_check blocks).
-// FAR: every pair of the block also has dr > bw + 255.  A pair that survives the gather has |dr - dq| <= bw, so dq > 255 too: both
-// distances exceed any q_span (8 bits), min(q_span, dr, dq) IS the source's q_span, and the block was staged with 128 * (q_span - 1)
-// already in the score term (stage_block_lut) -- no v_min3, no shift-add: 2 sub, sad, add per pair and one v_max3 per two sources,
-// 4.5 vector instructions per pair.  (A pair the gather rejects keeps its LUT_BIAS-low value whatever the span term.)
+// FAR: every pair of the block also has dr >= bw + q_span of its source.  A pair that survives the gather has |dr - dq| <= bw, so
+// dq >= q_span too: min(q_span, dr, dq) IS the source's q_span, and the block was staged with 128 * (q_span - 1) already in the score
+// term (stage_block_lut) -- no v_min3, no shift-add.  And dq <= 0 needs no saturation trick there: it means dd = dr - dq >= dr > bw,
+// which the TRUE |dr - dq| rejects by itself -- so the table address comes from the two diagonals, |dr - dq| = |(x_i - y_i) - (x_j -
+// y_j)|, staged per source and formed once per tile and block: ONE v_sad_u32 per pair, no subtractions.  sad, add per pair and one
+// v_max3 per two sources: 2.5 vector instructions per pair.  (A pair the gather rejects keeps its LUT_BIAS-low value whatever the
+// span term.)
 template <bool FAR>
-__device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, const unsigned base, int &bva, int &bvb)
+__device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb, int tyb, const int4 *stage, const unsigned base, const int d0, int &bva, int &bvb)
 {
 	constexpr int G = 2;
+	const int tda = (int)((unsigned)(txa - tya - d0) ^ 0x80000000u), tdb = (int)((unsigned)(txb - tyb - d0) ^ 0x80000000u);   // FAR
 	for (int kg = 0; kg < WAVE; kg += G) {
 		int4 s4[G];
 		int dqa[G], dra[G], pa[G], dqb[G], drb[G], pb[G], va[G], vb[G];
 #pragma unroll
-		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+		for (int u = 0; u < G; ++u) {
+			// FAR needs the score term and the diagonal only: an 8-byte broadcast costs the LDS pipe half of a 16-byte one
+			if (FAR) { const int2 h = *(const int2*)&stage[kg + u]; s4[u].x = h.x; s4[u].y = h.y; }
+			else s4[u] = stage[kg + u];
+		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
-			dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
-			dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
-			pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u], base);
-			pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u], base);
+			if (FAR) {
+				pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(tda, s4[u].y, base);
+				pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(tdb, s4[u].y, base);
+			} else {
+				dqa[u] = tya - s4[u].w; dra[u] = txa - s4[u].z;
+				dqb[u] = tyb - s4[u].w; drb[u] = txb - s4[u].z;
+				pa[u] = *(lds_i32_ptr)(uintptr_t)lut_address(dra[u], dqa[u], base);
+				pb[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drb[u], dqb[u], base);
+			}
 		}
 #pragma unroll
 		for (int u = 0; u < G; ++u) {
@@ -797,14 +820,14 @@ __device__ __forceinline__ void sweep_block_lut2_free(int txa, int tya, int txb,
 		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bvb) : "v"(vb[0]), "v"(vb[1]));
 	}
 }
-__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, bool free_block, bool far_block, const int4 *stage, const DevParams &P,
+__device__ __forceinline__ void sweep_staged_lut2(const TileXY &TA, const TileXY &TB, int jb, bool free_block, bool far_block, int d0, const int4 *stage, const DevParams &P,
                                                   int &best_a, int &arg_a, int &best_b, int &arg_b)
 {
 	const int txa = (int)(((unsigned)TA.x - 1u) << 2), tya = (int)(((unsigned)TA.y - 1u) << 2);
 	const int txb = (int)(((unsigned)TB.x - 1u) << 2), tyb = (int)(((unsigned)TB.y - 1u) << 2);
 	int bva = best_a << 7, bvb = best_b << 7;
-	if (far_block) sweep_block_lut2_free<true>(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, bva, bvb);
-	else if (free_block) sweep_block_lut2_free<false>(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, bva, bvb);
+	if (far_block) sweep_block_lut2_free<true>(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, d0, bva, bvb);
+	else if (free_block) sweep_block_lut2_free<false>(txa, tya, txb, tyb, stage, (unsigned)P.lut_base, 0, bva, bvb);
 	else if (P.lut_clamp) sweep_block_lut2<true>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	else sweep_block_lut2<false>(txa, tya, txb, tyb, stage, P, bva, bvb);
 	// (k+1 of the winner is 1..64 for any input the caller's contract allows; anchors that are not sorted by position can make the
@@ -825,9 +848,11 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
 		const TileXY xy = { T.x, T.y, T.st };
 		// (dead lanes of a tile repeat its last live anchor; sweep_block_lut2_free for the conditions)
 		const bool free_block = no_check && P.free_sweep && bcast(T.x, WAVE - 1) - first_lane(xs) <= P.dq_lim - P.bw;
-		const bool far_block = free_block && first_lane(T.x) - bcast(xs, WAVE - 1) > P.bw + 255;
-		stage_block_lut(xs, ys, sf, sq, stage, far_block);
-		sweep_staged_lut(xy, jb, k_from, no_check, free_block, stage, P, best, arg, far_block);
+		// FAR: dr >= bw + q_span for every source of the block (its last source and the tile's first anchor give the smallest dr)
+		const bool far_block = free_block && __ballot(sq + P.bw > first_lane(T.x) - bcast(xs, WAVE - 1)) == 0;
+		const int d0 = (first_lane(xs) - first_lane(ys)) * 4;
+		stage_block_lut(xs, ys, sf, sq, stage, far_block, d0);
+		sweep_staged_lut(xy, jb, k_from, no_check, free_block, stage, P, best, arg, far_block, d0);
 		__builtin_amdgcn_wave_barrier();
 	} else {
 		// pair_score tests dr != 0 itself; only the window start needs the CHECK build
@@ -1207,11 +1232,12 @@ __device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t,
 	// every pair of this block has dr + bw <= dq_lim (sources are sorted by position: the block's first source and the pair's last
 	// anchor give the largest dr): the gather rejects by itself (sweep_block_lut2_free)
 	const bool free_block = P.free_sweep && t.x_last - first_lane(xs) <= P.dq_lim - P.bw;
-	// ... and dr > bw + 255 too (the block's last source and the pair's first anchor give the smallest dr): the FAR build, for which
-	// the block is staged differently -- so only where both tiles take it
-	const bool far_block = free_block && nc_a && nc_b && t.x_first - bcast(xs, WAVE - 1) > P.bw + 255;
-	stage_block_lut(xs, ys, sf, sq, stage, far_block);
-	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, far_block, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
+	// ... and dr >= bw + q_span for every source too (the block's last source and the pair's first anchor give the smallest dr): the FAR
+	// build, for which the block is staged differently -- so only where both tiles take it
+	const bool far_block = free_block && nc_a && nc_b && __ballot(sq + P.bw > t.x_first - bcast(xs, WAVE - 1)) == 0;
+	const int d0 = (first_lane(xs) - first_lane(ys)) * 4;
+	stage_block_lut(xs, ys, sf, sq, stage, far_block, d0);
+	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, far_block, d0, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
 		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_block, stage, P, t.best_a, t.arg_a);
 		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, nc_b && free_block, stage, P, t.best_b, t.arg_b);
