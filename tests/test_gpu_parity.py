@@ -475,14 +475,15 @@ def test_config2_size_batch_properties():
         assert np.array_equal(f[off[r]:off[r + 1]], fo) and np.array_equal(p[off[r]:off[r + 1]], rel(po)), f"read {r}"
 
 
-def band_cloud(n, seed, xwin, jitter, r0=3_000_000, q0=20_000):
+def band_cloud(n, seed, xwin, jitter, r0=3_000_000, q0=20_000, spans=None):
     """Dense cloud around one diagonal: reference positions uniform in a window, query position = the diagonal +- jitter.  Among the
     pairs inside a window every case the range test exists for occurs in numbers: dq <= 0 with |dr - dq| <= bw (sources just left of a
     target but above it on the query), dq > max_dist_y with dr far out, and dq > 0 with |dr - dq| beyond the penalty table."""
     rng = np.random.default_rng(seed)
     x = r0 + rng.integers(0, xwin, n)
     y = q0 + (x - r0) + rng.integers(-jitter, jitter + 1, n)
-    return sc.sort_by_x(sc.pack(np.full(n, 5), np.zeros(n, np.int64), x, y))
+    qspan = 15 if spans is None else rng.choice(np.asarray(spans), n)
+    return sc.sort_by_x(sc.pack(np.full(n, 5), np.zeros(n, np.int64), x, y, qspan=qspan))
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(max_dist_y=3000), dict(max_dist_x=3000, max_dist_y=4500), dict(bw=2000), dict(bw=2400, max_dist_y=4900),
@@ -495,6 +496,10 @@ def test_unchecked_sweep_rejects_what_the_range_test_would(monkeypatch, kw):
     parameter sets that move every bound; with the unchecked build switched off (MM2GB_FREE_SWEEP=0) the results are the same."""
     parts = [band_cloud(9000, 301, xwin=9000, jitter=700), band_cloud(7000, 302, xwin=3500, jitter=6500, r0=5_000_000),
              band_cloud(6000, 303, xwin=12000, jitter=250, r0=7_000_000), sc.read_like(9000, 304),
+             # spans of every size (the FAR build of the unchecked sweep takes min(q_span, dr, dq) = q_span where dr >= bw + q_span), and
+             # query positions far above the reference positions (negative diagonals in its table address)
+             band_cloud(9000, 307, xwin=10000, jitter=600, r0=9_000_000, spans=[1, 10, 15, 19, 60, 200, 255]),
+             band_cloud(8000, 308, xwin=9000, jitter=900, r0=20_000, q0=3_000_000, spans=[15, 21, 128]),
              sc.sort_by_x(np.concatenate([sc.repeat_block(7000, 305), sc.colinear(600, 306)]))]
     off = np.zeros(len(parts) + 1, dtype=np.int64)
     off[1:] = np.cumsum([len(x) for x in parts])
