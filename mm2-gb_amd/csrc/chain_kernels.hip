@@ -437,6 +437,9 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 // --------------------------------------------------------------------------------------------------------------
 enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
 constexpr int SCORE_THREADS = 1024;
+#ifndef MM2GB_INTILE_PRIO
+#define MM2GB_INTILE_PRIO 3
+#endif
 #ifndef MM2GB_SWEEP_GROUP
 #define MM2GB_SWEEP_GROUP 4
 #endif
@@ -946,6 +949,9 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
                                             int &best, int &arg, Keep &keep, FOld f_old)
 {
 	const int lane = lane_id(), i = i0 + lane;
+	// The in-tile phase is a chain of dependent instructions, and in a team every other wave's next tile waits for it: while it lasts
+	// this wave goes first among the 8 waves of its SIMD (the sweeping ones have independent work to fill the slots it leaves).
+	__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
 	stage[lane] = make_int4(0, (T.q - 1) * 4, (int)((unsigned)T.x << 2), (int)((unsigned)T.y << 2));
 	__builtin_amdgcn_wave_barrier();
 	TileLut tl;
@@ -1072,6 +1078,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	arg = (unsigned)(won - 1) < (unsigned)WAVE ? i0 + won - 1 : arg;
 	best = (bestv + 1) >> 7;
 	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_s_setprio(0);
 }
 
 // Predecessors inside the tile: lane t becomes final at step t and is pushed to the lanes above it.
