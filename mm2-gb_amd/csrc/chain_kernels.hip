@@ -1412,6 +1412,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 		else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
 		const Target TA = load_target(b, i0, ce, TRACK);
 		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);
+		__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);                 // still on the team's critical path: publish A, A into B, B, publish B
 		const int f_a = t.arg_a < 0 ? TA.q : t.best_a;
 		if (TA.live) {
 			const int i = i0 + lane;
@@ -1425,6 +1426,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);
 			const Target TB = load_target(b, i0 + WAVE, ce, TRACK);
 			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);
+			__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
 			if (TB.live) {
 				const int i = i0 + WAVE + lane;
 				const int f_b = t.arg_b < 0 ? TB.q : t.best_b;
@@ -1436,6 +1438,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 		if (TRACK && lane == 0) { sh->keep[0] = keep.idx; sh->keep[1] = keep.x; sh->keep[2] = keep.hi; sh->keep[3] = keep.y; sh->keep[4] = keep.tag; sh->keep[5] = keep.f; }
 		// publish: ring + keep writes above are ordered before the counter by the release
 		if (lane == 0) __hip_atomic_store(&sh->done, ta + (t.n_b > 0 ? 2 : 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__builtin_amdgcn_s_setprio(0);
 	}
 }
 
