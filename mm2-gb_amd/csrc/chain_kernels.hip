@@ -437,6 +437,9 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 // --------------------------------------------------------------------------------------------------------------
 enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
 constexpr int SCORE_THREADS = 1024;
+#ifndef MM2GB_POLL_SLEEP
+#define MM2GB_POLL_SLEEP 32            // x 64 cycles between two looks at a team's tile counter
+#endif
 #ifndef MM2GB_INTILE_PRIO
 #define MM2GB_INTILE_PRIO 3
 #endif
@@ -1338,7 +1341,7 @@ __device__ __forceinline__ void coop_chunk(const DevBatch &b, const DevParams &P
 	auto wait_done = [&](int need) {
 		// a waiting wave must not steal issue slots from the waves it waits for: poll rarely (s_sleep 32 = 2048 cycles,
 		// a few percent of the shortest tile)
-		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(32);
+		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP);
 	};
 	for (int t = wave; t < n_tiles; t += n_waves) {
 		const int i0 = cs + t * WAVE;
@@ -1389,7 +1392,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 	const int lane = lane_id();
 	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
 	auto wait_done = [&](int need) {
-		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(32);
+		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP);
 	};
 	auto f_old = [&](int jj) { const unsigned d = (unsigned)(jj - cs); return ring[(d / WAVE) % (unsigned)n_slots * WAVE + d % WAVE]; };
 	for (int pr = wave; 2 * pr < n_tiles; pr += n_waves) {
@@ -1558,7 +1561,7 @@ __device__ __forceinline__ void split_chunk(const DevBatch &b, const DevParams &
 	const unsigned long long *part = b.split_part + (size_t)blockIdx.x * SPLIT_MAX_ITEMS * 2 * WAVE;
 	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
 	auto wait_done = [&](int need) {
-		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(32);
+		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP);
 	};
 	if (wave == 0 && lane == 0) atomicAdd(&b.counters[CNT_NSPLIT], 1);
 	for (int s0 = 0; s0 < n_tiles; s0 += S) {
