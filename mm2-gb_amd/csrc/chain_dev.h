@@ -112,6 +112,9 @@ struct LaunchCfg {
 	int ring_slots;          // LDS ring of the team modes: slots of 64 scores, shared out among the teams of a phase; 0 = team modes off
 	int big_team;            // waves per team in the first phase: 16 (one team per workgroup) or 8 (two)
 	int whole_wg_pct;        // a big-team chunk costing more than this % of a workgroup's fair share of that list gets all 16 waves; 0 = never
+	int team4_all;           // 1: every heavy chunk of the table build goes to a 4-wave team, whatever its widest window (for A/B runs)
+	int team4_share_pct;     // a wide-window heavy chunk goes to a 4-wave team unless it costs more than this % of a 4-wave team's fair share
+	                         // of the batch's pairs (then: a big team); 0 = wide windows always go to big teams
 	int split;               // 1: launch the SPLIT build (such chunks strip by strip, idle workgroups help); the host's choice by batch size
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode

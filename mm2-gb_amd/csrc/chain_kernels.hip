@@ -251,6 +251,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 //   plan_scatter     per chunk: slot in its list
 // --------------------------------------------------------------------------------------------------------------
 constexpr int PLANNER_THREADS = 1024;
+constexpr int N_SMALL_TEAMS_PLAN = 4;                  // 4-wave teams per score workgroup (k_score: 16 waves)
 constexpr int COST_BINS = 256;
 enum { LIST_WAVE = 0, LIST_BIG = 1, LIST_TEAM4 = 2, N_LISTS = 3 };
 
@@ -368,8 +369,15 @@ __global__ __launch_bounds__(256) void plan_finish(DevBatch b, LaunchCfg cfg)
 			// a team's share of the LDS ring must hold the tiles its widest window reaches back to, plus the one being written
 			const int need_slots = (wmax + WAVE - 1) / WAVE + 1;
 			const int big_slots = cfg.ring_slots / (16 / cfg.big_team), small_slots = cfg.ring_slots / 4;   // k_score: 16 waves, four small teams
+			// A team is bounded by the chain of its chunk's in-tile phases, which keeps four waves busy but not eight: wide windows go to
+			// 4-wave teams too (table build only: its teams take the scores their ring share no longer holds from global memory) unless
+			// the chunk is so large that on four waves it alone would outlast the batch -- more than team4_share_pct % of what each of the
+			// launch's 4-wave teams gets of all pairs.  Such chunks, and every wide-window chunk of a small batch, keep the big team.
+			const bool lut_build = cfg.host_mode == SCORE_MODE_LUT && !(b.flags[0] & (FLAG_ANY_SEGID | FLAG_NO_LUT));
+			const bool small_share = lut_build && (cfg.team4_all || (cfg.team4_share_pct > 0 &&
+			                         cost * 100 * cfg.score_grid * N_SMALL_TEAMS_PLAN <= (long long)cfg.team4_share_pct * b.totals[0]));
 			if (len * cfg.wide_window > cost && need_slots <= small_slots) list = LIST_TEAM4;
-			else if (need_slots <= big_slots) list = LIST_BIG;   // else: window wider than the ring can hold -> one wave
+			else if (need_slots <= big_slots) list = small_share ? LIST_TEAM4 : LIST_BIG;   // else: window wider than the ring can hold -> one wave
 		}
 		b.chunk_end[c] = end;
 		b.chunk_cost[c] = cost;
@@ -1394,17 +1402,34 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 	auto wait_done = [&](int need) {
 		while (first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP);
 	};
-	auto f_old = [&](int jj) { const unsigned d = (unsigned)(jj - cs); return ring[(d / WAVE) % (unsigned)n_slots * WAVE + d % WAVE]; };
+	// The ring holds the team's most recent n_slots tiles (tile k in slot k mod n_slots; nothing newer than the tile being worked on can
+	// have been written: a tile is final only after all before it).  A window that reaches further back takes the older scores from
+	// global memory, where every final score goes as well -- written by waves of this workgroup before they published the tile, read
+	// behind the acquire of that publication, one block ahead of its use.
+	int cur = 0;                                                 // the tile whose in-tile phase is running (for f_old)
+	auto f_old = [&](int jj) {
+		const unsigned d = (unsigned)(jj - cs);
+		const int k = (int)(d / WAVE);
+		return k >= cur - n_slots ? ring[(unsigned)k % (unsigned)n_slots * WAVE + d % WAVE] : b.f[jj];
+	};
 	for (int pr = wave; 2 * pr < n_tiles; pr += n_waves) {
 		const int ta = 2 * pr, i0 = cs + ta * WAVE;              // tile A = tile ta of the chunk, tile B = ta + 1
 		TilePair t = load_pair(b, i0, ce);
 		int jb = cs + ((t.lo_a - cs) & ~(WAVE - 1));
 		const int eq_lo = jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(t.A.x)) : i0;
 		int slot = (int)((unsigned)((jb - cs) / WAVE) % (unsigned)n_slots);
+		const int first_in_ring = ta - n_slots;                      // tiles from this one on are in the ring
+		int nf = 0;
+		if (jb < i0 && (jb - cs) / WAVE < first_in_ring) { wait_done((jb - cs) / WAVE + 1); nf = b.f[jb + lane]; }
 		for (; jb < i0; jb += WAVE) {
 			const int sq = b.tag[jb + lane] & 0xff;
-			wait_done((jb - cs) / WAVE + 1);                       // that tile's scores are in the ring
-			const int sf = ring[slot * WAVE + lane];
+			const int k = (jb - cs) / WAVE;
+			wait_done(k + 1);                                          // that tile's scores are final (and in the ring, if recent)
+			int sf;
+			if (k < first_in_ring) {
+				sf = nf;
+				if (k + 1 < first_in_ring) { wait_done(k + 2); nf = b.f[jb + WAVE + lane]; }
+			} else sf = ring[slot * WAVE + lane];
 			slot = slot + 1 == n_slots ? 0 : slot + 1;
 			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
 		}
@@ -1414,6 +1439,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 		if (TRACK) { keep.idx = first_lane(sh->keep[0]); keep.x = first_lane(sh->keep[1]); keep.hi = first_lane(sh->keep[2]); keep.y = first_lane(sh->keep[3]); keep.tag = first_lane(sh->keep[4]); keep.f = first_lane(sh->keep[5]); }
 		else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
 		const Target TA = load_target(b, i0, ce, TRACK);
+		cur = ta;
 		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);
 		__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);                 // still on the team's critical path: publish A, A into B, B, publish B
 		const int f_a = t.arg_a < 0 ? TA.q : t.best_a;
@@ -1428,6 +1454,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 			if (lane == 0) __hip_atomic_store(&sh->done, ta + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);
 			const Target TB = load_target(b, i0 + WAVE, ce, TRACK);
+			cur = ta + 1;
 			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);
 			__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
 			if (TB.live) {

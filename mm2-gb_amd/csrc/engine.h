@@ -103,6 +103,7 @@ struct Engine {
 
 	mm2gb_stats_t last = {};
 	bool misc_valid = false, coop_disabled = false, debug_phases = false, one_compute_stream = false;
+	int64_t team4_min_n = 0;        // micro-batches from this many anchors on send wide-window heavy chunks to 4-wave teams (launch.team4_share_pct)
 	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)
 	int64_t last_split_chunks = 0, last_helped_items = 0;   // of the last call: chunks scored strip by strip, items other workgroups took
 	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)

@@ -216,6 +216,13 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_LONG_MIN_WINDOW")) launch.long_min_window = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_WIDE_WINDOW")) launch.wide_window = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_LONG_MIN_COST")) launch.long_min_cost = std::max<int64_t>(1, atoll(v));
+	// Wide-window heavy chunks on 4-wave teams (chain_kernels.hip, plan_finish): pays once a micro-batch keeps the machine full for
+	// long -- 500 M anchors: 59.3 -> 47.6 ms, 300 M: 39.2 -> 36.2 -- and costs a few per cent where the largest chunks decide when the
+	// batch ends (200 M: 27.1 -> 28.5 ms), so it is tied to the batch size (profiles/r02w_ab.txt)
+	launch.team4_all = 0; launch.team4_share_pct = 150; team4_min_n = 250000000;
+	if (const char *v = getenv("MM2GB_TEAM4_ALL")) launch.team4_all = atoi(v) != 0;
+	if (const char *v = getenv("MM2GB_TEAM4_SHARE_PCT")) launch.team4_share_pct = std::max(0, atoi(v));
+	if (const char *v = getenv("MM2GB_TEAM4_MIN_ANCHORS")) team4_min_n = std::max<int64_t>(0, atoll(v));
 	if (const char *v = getenv("MM2GB_DEBUG_PHASES")) debug_phases = *v && *v != '0';
 	split_max_n = 0;                                           // off: measured slower at every batch size (profiles/r02y_split_rate.json)
 	if (const char *v = getenv("MM2GB_SPLIT_MAX_ANCHORS")) split_max_n = std::max<int64_t>(0, atoll(v));
@@ -343,6 +350,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	// A batch that cannot fill the machine ends with its largest chunks: the SPLIT build scores those strip by strip with the help of
 	// the workgroups that have run out of work (chain_kernels.hip, split_chunk).  Large batches keep the plain build.
 	LaunchCfg cfg_now = launch;
+	if (n < team4_min_n) cfg_now.team4_share_pct = 0;
 	cfg_now.split = launch.host_mode == SCORE_MODE_LUT && launch.ring_slots > 0 && n > 0 && n <= split_max_n;
 	b.split_slots = nullptr; b.split_part = nullptr;
 	if (cfg_now.split) {

@@ -386,7 +386,10 @@ def test_large_batch_properties_and_mode_agreement(monkeypatch):
     # a predecessor's score plus at most q_span reaches the successor's score: f[i] <= f[j] + span[j]
     assert np.all(f[has] <= f[j[has]] + span[j[has]])
     ck = (int(f.astype(np.int64).sum()), int(p.astype(np.int64).sum()), int((f.astype(np.int64) * (idx % 1009)).sum()))
-    for env in ({"MM2GB_NO_COOP": "1"}, {"MM2GB_WIDE_WINDOW": "100000000"}, {"MM2GB_LONG_MIN_COST": "50000000"}):
+    # (the last two: wide-window chunks on 4-wave teams, which take the scores their ring share no longer holds from global memory --
+    # the rule of batches from 250 M anchors on, here for all chunks but the dominant ones and for all chunks)
+    for env in ({"MM2GB_NO_COOP": "1"}, {"MM2GB_WIDE_WINDOW": "100000000"}, {"MM2GB_LONG_MIN_COST": "50000000"},
+                {"MM2GB_TEAM4_MIN_ANCHORS": "0"}, {"MM2GB_TEAM4_ALL": "1"}):
         f2, p2, st2 = run(env)
         assert st2["n_pairs"] == st["n_pairs"]
         ck2 = (int(f2.astype(np.int64).sum()), int(p2.astype(np.int64).sum()), int((f2.astype(np.int64) * (idx % 1009)).sum()))
