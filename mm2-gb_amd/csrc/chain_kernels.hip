@@ -861,9 +861,9 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
 		const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
 		const TileXY xy = { T.x, T.y, T.st };
 		// (dead lanes of a tile repeat its last live anchor; sweep_block_lut2_free for the conditions)
-		const bool free_block = no_check && P.free_sweep && bcast(T.x, WAVE - 1) - first_lane(xs) <= P.dq_lim - P.bw;
+		const bool free_block = no_check && P.free_sweep && (unsigned)(bcast(T.x, WAVE - 1) - first_lane(xs)) <= (unsigned)(P.dq_lim - P.bw);
 		// FAR: dr >= bw + q_span for every source of the block (its last source and the tile's first anchor give the smallest dr)
-		const bool far_block = free_block && __ballot(sq + P.bw > first_lane(T.x) - bcast(xs, WAVE - 1)) == 0;
+		const bool far_block = free_block && first_lane(T.x) > bcast(xs, WAVE - 1) && __ballot(sq + P.bw > first_lane(T.x) - bcast(xs, WAVE - 1)) == 0;
 		const int d0 = (first_lane(xs) - first_lane(ys)) * 4;
 		stage_block_lut(xs, ys, sf, sq, stage, far_block, d0);
 		sweep_staged_lut(xy, jb, k_from, no_check, free_block, stage, P, best, arg, far_block, d0);
@@ -1210,7 +1210,7 @@ struct TilePair {
 	TileXY A, B;
 	int n_a, n_b;            // live anchors (n_b = 0: the chunk ends within A)
 	int lo_a, hi_a, lo_b, hi_b;   // smallest / largest window start of each tile
-	int x_first, x_last;          // reference position of the pair's first and last live anchor
+	int x_first, x_last_a, x_last;   // reference position of the pair's first anchor, of tile A's last live one, of the pair's last live one
 	int best_a, arg_a, best_b, arg_b;
 };
 
@@ -1235,7 +1235,8 @@ __device__ __forceinline__ TilePair load_pair(const DevBatch &b, int i0, int ce)
 	t.B = load_xy(b, t.n_b ? i0 + WAVE : i0, ce, t.best_b);
 	t.lo_a = first_lane(t.A.st); t.hi_a = bcast(t.A.st, t.n_a - 1);
 	t.lo_b = t.n_b ? first_lane(t.B.st) : INT_MAX; t.hi_b = t.n_b ? bcast(t.B.st, t.n_b - 1) : INT_MAX;
-	t.x_first = first_lane(t.A.x); t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : bcast(t.A.x, t.n_a - 1);   // (dead lanes repeat the last live one)
+	t.x_first = first_lane(t.A.x); t.x_last_a = bcast(t.A.x, t.n_a - 1);
+	t.x_last = t.n_b ? bcast(t.B.x, t.n_b - 1) : t.x_last_a;            // (dead lanes repeat the last live one)
 	t.arg_a = -1; t.arg_b = -1;
 	return t;
 }
@@ -1249,15 +1250,20 @@ __device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t,
 	const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
 	// every pair of this block has dr + bw <= dq_lim (sources are sorted by position: the block's first source and the pair's last
 	// anchor give the largest dr): the gather rejects by itself (sweep_block_lut2_free)
-	const bool free_block = P.free_sweep && t.x_last - first_lane(xs) <= P.dq_lim - P.bw;
+	// A chunk may hold several runs of anchors (reads, strands): positions are only comparable between a block and the tiles whose
+	// windows it lies in, so a tile that takes the block alone is judged by its own last anchor, and a difference that is not a
+	// distance (negative) never passes (unsigned compare).  found by tests/fuzz_soak.py: tests/golden/regress/fuzz_tiny_dist_y.npz
+	const unsigned free_span = (unsigned)(P.dq_lim - P.bw);
+	const bool free_block = P.free_sweep && (unsigned)(t.x_last - first_lane(xs)) <= free_span;
+	const bool free_a = P.free_sweep && (unsigned)(t.x_last_a - first_lane(xs)) <= free_span;
 	// ... and dr >= bw + q_span for every source too (the block's last source and the pair's first anchor give the smallest dr): the FAR
 	// build, for which the block is staged differently -- so only where both tiles take it
-	const bool far_block = free_block && nc_a && nc_b && __ballot(sq + P.bw > t.x_first - bcast(xs, WAVE - 1)) == 0;
+	const bool far_block = free_block && nc_a && nc_b && t.x_first > bcast(xs, WAVE - 1) && __ballot(sq + P.bw > t.x_first - bcast(xs, WAVE - 1)) == 0;
 	const int d0 = (first_lane(xs) - first_lane(ys)) * 4;
 	stage_block_lut(xs, ys, sf, sq, stage, far_block, d0);
 	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, far_block, d0, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
-		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_block, stage, P, t.best_a, t.arg_a);
+		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_a, stage, P, t.best_a, t.arg_a);
 		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, nc_b && free_block, stage, P, t.best_b, t.arg_b);
 	}
 	__builtin_amdgcn_wave_barrier();

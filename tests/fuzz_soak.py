@@ -52,6 +52,8 @@ if args.teams:
     engines.append(("team8", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "0"})))
     engines.append(("team16", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "1"})))
     engines.append(("team4", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "100000000"})))
+    # every heavy chunk on a 4-wave team, also with windows wider than the team's share of the ring (older scores from global memory)
+    engines.append(("team4all", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_TEAM4_ALL": "1", "MM2GB_WHOLE_WG_PCT": "0"})))
 seen = {name: [0, 0] for name, _ in engines}
 for seed in args.seeds:
     rng = np.random.default_rng(seed)

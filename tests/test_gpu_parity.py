@@ -135,6 +135,30 @@ def test_rescue_state_restarts_at_every_read(engine):
         assert st["n_tracked_chunks"] >= 1
 
 
+def test_unchecked_sweep_and_tiles_that_span_reads(engine):
+    """A chunk may hold several reads; a tile pair whose second tile reaches into the next read has a 'last anchor' whose position says
+    nothing about the first tile's distances.  A seeded fuzz run found it (max_dist_y = 10, bw = 1: a source 32 bases left of its
+    targets was accepted by the unchecked sweep of the first tile).  Then the same shape made on purpose: short reads over one region,
+    read boundaries at every offset inside tile pairs, bounds that make almost every pair fail the range test."""
+    import json, os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "fuzz_tiny_dist_y.npz"), allow_pickle=True)
+    kw = json.loads(str(z["kw"]))
+    prm = orc.default_param(**{k: (np.float32(v) if k.startswith("pen") else int(v)) for k, v in kw.items()})
+    check_batch(engine, z["a"], z["off"], prm)
+    rng = np.random.default_rng(77)
+    reads = []
+    for r in range(40):
+        n = int(rng.integers(30, 260))
+        x = 1_000_000 + np.sort(rng.integers(0, 6000, n)) + int(rng.integers(-40000, 40000)) * (r % 3 == 0)
+        y = 500 + (x - x.min()) + rng.integers(-12, 13, n)
+        reads.append(sc.sort_by_x(sc.pack(np.full(n, 2), np.full(n, r & 1), x, y)))
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in reads])
+    a = np.concatenate(reads)
+    for kw in (dict(max_dist_y=10, bw=1, max_dist_x=20000, max_iter=200), dict(max_dist_y=40, bw=8, max_iter=500), dict(max_dist_y=300, bw=100), dict()):
+        check_batch(engine, a, off, orc.default_param(**kw))
+
+
 @pytest.mark.parametrize("env", [{}, {"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "0"},
                                  {"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_WHOLE_WG_PCT": "1"},
                                  {"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "100000000"}],
