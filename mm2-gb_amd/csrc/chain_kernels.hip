@@ -609,10 +609,10 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 {
 	const unsigned base = (unsigned)P.lut_base, last_at = base + ((unsigned)P.lut_last << 2), lim4 = (unsigned)P.dq_lim << 2;
 	constexpr int G = SWEEP_GROUP;                          // sources per unrolled group: G broadcasts + G gathers in flight
-	// The v_cmpx statements put the execution mask back to ALL lanes (-1): every sweep of this kernel runs in wave-uniform control flow
-	// (dead lanes are handled by their data), so that is the mask on entry.  It is not read from the register any more: a copy taken
-	// "at this point" (the builtin, or a volatile s_mov) has no data dependence that keeps it at this point, and the compiler runs
-	// wave-uniform code under whatever mask is at hand (in the SPLIT build: the one lane of split_claim's atomic).
+	// The v_cmpx statements save the execution mask and put it back INSIDE the same asm statement (s_mov to a scalar pair the
+	// statement owns), so they are correct under whatever mask the caller runs with and the compiler never sees exec change.  (An
+	// earlier build restored -1, which is only right while every caller is wave-uniform; a copy read in a SEPARATE statement has no
+	// data dependence that keeps it in place, and the compiler runs wave-uniform code under whatever mask is at hand.)
 	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
 		const int j0 = jb + kg;
 		int dqm[G], drm[G], pen[G];
@@ -635,8 +635,9 @@ __device__ __forceinline__ void sweep_block_lut(int t_st, int tx4, int ty4, int 
 			if (!CHECK) {
 				// "bestv = max(bestv, v) in the lanes whose dq is in range": the range test goes straight into the execution
 				// mask (v_cmpx), so no select is needed; the mask is put back within the same statement
-				asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, -1"
-				             : [b] "+v"(bestv) : [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
+				unsigned long long saved;
+				asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
+				             : [b] "+v"(bestv), [sv] "=&s"(saved) : [lim] "s"(lim4), [dq] "v"(dqm[u]), [v] "v"(v) : "vcc");
 			} else {
 				// bitwise on purpose: short-circuit '&&' makes the compiler fork the wave on the first test
 				const bool take = ((unsigned)dqm[u] < lim4) & (v > bestv) & (drm[u] != -4) & (j0 + u >= t_st);
@@ -771,10 +772,12 @@ __device__ __forceinline__ void sweep_block_lut2(int txa, int tya, int txb, int 
 			int vb = ((s4[u].y < gb ? s4[u].y : gb) << 5) + s4[u].x;
 			asm("" : "+v"(vb));
 			vb += pb[u];
-			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, -1"
-			             : [b] "+v"(bva) : [lim] "s"(lim4), [dq] "v"(dqa[u]), [v] "v"(va) : "vcc");
-			asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, -1"
-			             : [b] "+v"(bvb) : [lim] "s"(lim4), [dq] "v"(dqb[u]), [v] "v"(vb) : "vcc");
+			// one statement for both tiles: the mask on entry is saved and put back INSIDE the statement, so it is whatever the caller
+			// runs under (every caller today: all 64 lanes) and the compiler never sees a changed mask
+			unsigned long long saved;
+			asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[dqa]\n\tv_max_i32_e32 %[ba], %[va], %[ba]\n\ts_mov_b64 exec, %[sv]\n\t"
+			             "v_cmpx_gt_u32_e32 vcc, %[lim], %[dqb]\n\tv_max_i32_e32 %[bb], %[vb], %[bb]\n\ts_mov_b64 exec, %[sv]"
+			             : [ba] "+v"(bva), [bb] "+v"(bvb), [sv] "=&s"(saved) : [lim] "s"(lim4), [dqa] "v"(dqa[u]), [va] "v"(va), [dqb] "v"(dqb[u]), [vb] "v"(vb) : "vcc");
 		}
 	}
 }

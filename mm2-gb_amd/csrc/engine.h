@@ -125,7 +125,8 @@ struct Engine {
 	// backtrack + compaction of a scored micro-batch on the device (all pointers device pointers; d_f / d_p as enqueue() left
 	// them); enqueued on the compute stream.  Results stay in post_uoff / post_aoff / post_uout / post_aout; totals land in
 	// h_post_totals once the stream has been synchronised.
-	int  reserve_post(int64_t n_anchors, int64_t n_reads);
+	int  reserve_post(int64_t n_anchors, int64_t n_reads);                 // work arrays of the post kernels (shared by both result sets)
+	int  reserve_post_out(int set, int64_t n_anchors, int64_t n_reads);    // result buffers of one set; never touches the other
 	int  enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
 	                  const mm2gb_rmq_param_t *rmq = nullptr, int out_set = 0);   // rmq given: thresholds of the re-chaining call (lchain.c:355) instead of misc's
 	// the boundary's device post-pass: host anchors in (page-locked), H2D + score kernels + post kernels enqueued, nothing waited

@@ -193,8 +193,17 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	// multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and streams that share a queue run one after the
 	// other: next to a framework's own streams the engine's copies and kernels then serialise (200 M anchors through
 	// mm2gb_score_host: 146 ms instead of 92 ms, profiles/README.md).  Only effective before the runtime starts, so hosts
-	// that initialise HIP first (PyTorch) should export it themselves; bench.py does.
-	if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	// export it themselves before their first HIP call; bench.py and tests/conftest.py do.
+	// The library does not touch the environment here (setenv races with getenv in threaded hosts, and is too late once the runtime
+	// runs): it says so once when the variable is missing.  INTEGRATION.md documents it; init_stream_gpu, the one entry point that IS
+	// the process's first HIP call and runs before the host starts threads, still exports it for the C host.
+	{
+		static std::once_flag warned;
+		const char *q = getenv("GPU_MAX_HW_QUEUES");
+		if (!q || atoi(q) < 8)
+			std::call_once(warned, [] { fprintf(stderr, "[mm2gb] GPU_MAX_HW_QUEUES is unset or below 8: the engine's copy and compute streams may share a hardware queue and "
+			                                            "serialise (export GPU_MAX_HW_QUEUES=8 before the process starts HIP)\n"); });
+	}
 	int n_dev = 0;
 	MM2GB_HIP(hipGetDeviceCount(&n_dev));
 	if (dev < 0 || dev >= n_dev) return fail("mm2gb: device " + std::to_string(dev) + " not present (" + std::to_string(n_dev) + " visible)");
@@ -388,34 +397,44 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	}
 	for (hipEvent_t *e : { &post0, &post1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
 	if (n <= cap_post_n && n_reads <= cap_post_reads) return 0;
+	// Only the WORK arrays of the post kernels live here: they are dead once the kernels of the batch that used them have run, so
+	// waiting for the compute stream is all it takes to move them.  What a batch leaves for the host (PostOut) is sized by
+	// reserve_post_out for the one set that is about to be written: the other set may hold a batch that has not been fetched yet
+	// (the boundary launches batch k+1 before it fetches batch k), and a buffer that grows is a new, uninitialised buffer.
 	MM2GB_HIP(hipStreamSynchronize(stream));
 	const int64_t nn = std::max<int64_t>(std::max(n, cap_post_n), 1024), nr = std::max<int64_t>(std::max(n_reads, cap_post_reads), 16);
-	const int64_t had_n = cap_post_n;
-	(void)had_n;
 	cap_post_n = cap_post_reads = 0;                    // as in reserve(): only restored when every buffer has its size
 	// per-chain arrays are sized for min_cnt = 1 (a chain per anchor): min_cnt is a per-call parameter and may drop
 	const size_t chains = (size_t)(nn + nr);
 	if (post_z.ensure((size_t)nn * 8) || post_mark.ensure((size_t)nn) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
-	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_uoff.ensure((size_t)(nr + 1) * 8) ||
-	    post_aoff.ensure((size_t)(nr + 1) * 8) || post_uout.ensure(chains * 8) || post_aout.ensure((size_t)nn * 16) || post_misc.ensure(2048) || post_order.ensure((size_t)nr * 4) ||
+	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_misc.ensure(2048) || post_order.ensure((size_t)nr * 4) ||
 	    post_up4.ensure((size_t)nn * 4) || post_up16.ensure((size_t)nn * 4)) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
+	return 0;
+}
+
+// Result buffers of ONE post set, for a batch of n anchors / n_reads reads that is about to be written into it.  The caller's
+// contract (boundary: stage k <-> set k, a stage is finished before it is launched again) is that the set's previous results have
+// been fetched; the other set is never touched.  Growth waits for the compute stream (kernels that wrote the set) and the D2H
+// stream (a fetch of it that is still copying).
+int Engine::reserve_post_out(int set, int64_t n, int64_t n_reads)
+{
+	PostOut &po = post_out[set];
+	const int64_t nn = std::max<int64_t>(n, 1024), nr = std::max<int64_t>(n_reads, 16);
+	const size_t need_off = (size_t)(nr + 1) * 8, need_u = (size_t)(nn + nr) * 8, need_a = (size_t)nn * 16;
+	if (po.u_off.bytes >= need_off && po.a_off.bytes >= need_off && po.u_out.bytes >= need_u && po.a_out.bytes >= need_a) return 0;
+	MM2GB_HIP(hipStreamSynchronize(stream));
+	MM2GB_HIP(hipStreamSynchronize(s_out));
+	if (po.u_off.ensure(need_off) || po.a_off.ensure(need_off) || po.u_out.ensure(need_u) || po.a_out.ensure(need_a)) return -1;
 	return 0;
 }
 
 int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
                          const mm2gb_rmq_param_t *rmq, int out_set)
 {
-	if (reserve_post(n, n_reads)) return -1;
+	if (out_set < 0 || out_set > 1) return fail("mm2gb: post set out of range");
+	if (reserve_post(n, n_reads) || reserve_post_out(out_set, n, n_reads)) return -1;
 	PostOut &po = post_out[out_set];
-	if (out_set != 0) {                                                  // set 0 is sized by reserve_post
-		const size_t need_off = (size_t)(cap_post_reads + 1) * 8, need_u = (size_t)(cap_post_n + cap_post_reads) * 8, need_a = (size_t)cap_post_n * 16;
-		if (po.u_off.bytes < need_off || po.a_off.bytes < need_off || po.u_out.bytes < need_u || po.a_out.bytes < need_a) {
-			MM2GB_HIP(hipStreamSynchronize(stream));
-			MM2GB_HIP(hipStreamSynchronize(s_out));
-			if (po.u_off.ensure(need_off) || po.a_off.ensure(need_off) || po.u_out.ensure(need_u) || po.a_out.ensure(need_a)) return -1;
-		}
-	}
 	PostBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads; b.f = d_f; b.p = d_p;
 	b.z = (unsigned long long*)post_z.ptr; b.mark = (uint8_t*)post_mark.ptr; b.picked = (int32_t*)post_picked.ptr;
@@ -457,6 +476,9 @@ int Engine::enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const
 	if (n > 0) MM2GB_HIP(hipMemcpyAsync(s.raw.ptr, h_anchors, (size_t)n * 16, hipMemcpyHostToDevice, s_in));
 	MM2GB_HIP(hipEventRecord(s.in_done, s_in));
 	MM2GB_HIP(hipStreamWaitEvent(stream, s.in_done, 0));
+	// the score kernels overwrite s.f / s.p: a batch that went through enqueue_host (several micro-batches) may still be copying
+	// them out of this set on the D2H stream, and its kernels may have run on the other compute stream
+	if (s.used) { MM2GB_HIP(hipStreamWaitEvent(stream, s.out_done, 0)); MM2GB_HIP(hipStreamWaitEvent(stream, s.comp_done, 0)); }
 	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, false, 0)) return -1;
 	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, nullptr, out_set)) return -1;
 	MM2GB_HIP(hipEventRecord(s.comp_done, stream));
@@ -644,7 +666,7 @@ int Engine::gen_regs(int64_t n_reads, const mm2gb_chains_t *ch, const int32_t *q
 	if (!regs || !ch->u || !ch->a) return fail("mm2gb_gen_regs_gpu: null buffer");
 	static_assert(sizeof(RegRecord) == sizeof(mm2gb_reg_t) && sizeof(mm2gb_reg_t) == 72, "hit record layout");
 	MM2GB_HIP(hipSetDevice(device));
-	if (reserve_post(std::max<int64_t>(n_a, n_u), n_reads) || reg_out.ensure((size_t)n_u * sizeof(RegRecord))) return -1;
+	if (reserve_post(std::max<int64_t>(n_a, n_u), n_reads) || reserve_post_out(0, std::max<int64_t>(n_a, n_u), n_reads) || reg_out.ensure((size_t)n_u * sizeof(RegRecord))) return -1;
 	MM2GB_HIP(hipStreamSynchronize(stream));
 	MM2GB_HIP(hipMemcpyAsync(post_uoff.ptr, ch->u_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
 	MM2GB_HIP(hipMemcpyAsync(post_aoff.ptr, ch->a_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, stream));

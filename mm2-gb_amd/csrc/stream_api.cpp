@@ -4,6 +4,7 @@
 //     same deferred hand-back protocol (launch batch k, return batch k-1 finished), one engine per stream/thread id.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cstddef>
 #include <cstdio>
@@ -24,11 +25,6 @@
 extern "C" {
 mm2gb_Misc build_misc(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, const int64_t qlen_sum, const int n_seg) __attribute__((weak));
 void post_chaining_helper(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *read, mm2gb_Misc misc, void *km) __attribute__((weak));
-// the host's own re-chaining (lchain.c:250): takes the reads whose range-minimum met a tie (include/mm2gb_chain.h).  Two names: the
-// plain one when the library is simply linked next to lchain.c, the __real_ one when the host was linked with
-// -Wl,--wrap=mg_lchain_rmq so that its calls land in __wrap_mg_lchain_rmq below.
-mm2gb_anchor_t *mg_lchain_rmq(int, int, int, int, int, int, int, float, float, int64_t, mm2gb_anchor_t*, int*, uint64_t**, void*) __attribute__((weak));
-mm2gb_anchor_t *__real_mg_lchain_rmq(int, int, int, int, int, int, int, float, float, int64_t, mm2gb_anchor_t*, int*, uint64_t**, void*) __attribute__((weak));
 }
 
 // Layout of the records shared with the host, as a C compiler lays out gpu/plutils.h:19-73 on x86-64 (checked against the
@@ -298,28 +294,56 @@ int usable_cpus()
 	return std::max(1, n);
 }
 
-// Engines of the synchronous single-read surface (mm2gb_lchain_dp): one per calling host thread, dealt round-robin over the
-// visible devices (MM2GB_DEVICES), so a threaded host neither queues on one mutex nor piles onto device 0.
+// Engines of the synchronous single-read surface (mm2gb_lchain_dp / mm2gb_lchain_rmq): a bounded pool, leased per CALL.  A caller
+// takes a free engine (one is created while the pool is below its bound, dealt round-robin over the visible devices, MM2GB_DEVICES),
+// or waits for one; the lease's destructor hands it back.  So a host with many or short-lived threads holds at most
+// MM2GB_SINGLE_ENGINES engines (default: 2 per device, at most the CPUs the process may use) instead of one per thread id ever seen
+// -- each is 4 streams, pinned staging and two work arenas -- and a recycled thread id can never share an engine with a live thread.
 static std::mutex g_single_mu;
-static std::map<std::thread::id, mm2gb_engine_t*> g_single_engines;
+static std::condition_variable g_single_cv;
+static std::vector<mm2gb_engine_t*> g_single_free;
+static int g_single_made = 0, g_single_max = 0;
 
-static mm2gb_engine_t *single_read_engine(const mm2gb_misc_t &misc)
-{
-	std::lock_guard<std::mutex> lock(g_single_mu);
-	auto it = g_single_engines.find(std::this_thread::get_id());
-	if (it != g_single_engines.end()) return it->second;
-	std::vector<int> devs;
-	if (devices_for_streams(devs)) return nullptr;
-	mm2gb_engine_t *e = mm2gb_engine_create(nullptr, &misc, devs[g_single_engines.size() % devs.size()]);
-	if (e) g_single_engines[std::this_thread::get_id()] = e;
-	return e;
-}
+struct EngineLease {
+	mm2gb_engine_t *eng = nullptr;
+	explicit EngineLease(const mm2gb_misc_t &misc)
+	{
+		std::unique_lock<std::mutex> lock(g_single_mu);
+		for (;;) {
+			if (!g_single_free.empty()) { eng = g_single_free.back(); g_single_free.pop_back(); return; }
+			std::vector<int> devs;
+			if (devices_for_streams(devs)) return;
+			if (g_single_max == 0) {
+				g_single_max = std::max(1, std::min(2 * (int)devs.size(), usable_cpus()));
+				if (const char *v = getenv("MM2GB_SINGLE_ENGINES")) g_single_max = std::max(1, atoi(v));
+			}
+			if (g_single_made < g_single_max) {
+				const int dev = devs[(size_t)g_single_made % devs.size()];
+				++g_single_made;                               // reserved; creation happens outside the lock (it takes ~0.1 s)
+				lock.unlock();
+				eng = mm2gb_engine_create(nullptr, &misc, dev);
+				if (!eng) { lock.lock(); --g_single_made; g_single_cv.notify_one(); }
+				return;
+			}
+			g_single_cv.wait(lock);
+		}
+	}
+	~EngineLease()
+	{
+		if (!eng) return;
+		{ std::lock_guard<std::mutex> lock(g_single_mu); g_single_free.push_back(eng); }
+		g_single_cv.notify_one();
+	}
+	EngineLease(const EngineLease&) = delete;
+	EngineLease &operator=(const EngineLease&) = delete;
+};
 
 static void free_single_read_engines()
 {
 	std::lock_guard<std::mutex> lock(g_single_mu);
-	for (auto &kv : g_single_engines) mm2gb_engine_destroy(kv.second);
-	g_single_engines.clear();
+	for (mm2gb_engine_t *e : g_single_free) mm2gb_engine_destroy(e);   // (engines on lease belong to calls still running: theirs to return)
+	g_single_made -= (int)g_single_free.size();
+	g_single_free.clear();
 }
 
 } // namespace mm2gb
@@ -346,7 +370,8 @@ mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_
 	misc.max_iter = max_iter; misc.max_dist_x = max_dist_x; misc.max_dist_y = max_dist_y; misc.max_skip = max_skip; misc.bw = bw;
 	misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.is_cdna = is_cdna; misc.n_seg = n_seg;
 	misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
-	mm2gb_engine_t *eng = single_read_engine(misc);        // this thread's own engine: no lock held while the GPU works
+	EngineLease lease(misc);                               // an engine of the pool for this call: no lock held while the GPU works
+	mm2gb_engine_t *eng = lease.eng;
 	if (!eng) { fprintf(stderr, "[Error] mm2gb_lchain_dp: %s\n", mm2gb_last_error()); exit(1); }
 	const int64_t off[2] = { 0, n };
 	std::vector<int32_t> f((size_t)n), p((size_t)n);
@@ -387,22 +412,18 @@ mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int m
 		mm2gb_misc_t misc = {};                                               // the engine wants one; the re-chaining call carries its own thresholds
 		misc.max_iter = 5000; misc.max_dist_x = max_dist; misc.max_dist_y = max_dist; misc.max_skip = max_chn_skip; misc.bw = std::min(bw, 8000);
 		misc.min_cnt = min_cnt; misc.min_score = min_sc; misc.n_seg = 1; misc.chn_pen_gap = chn_pen_gap; misc.chn_pen_skip = chn_pen_skip;
-		mm2gb_engine_t *eng = single_read_engine(misc);
+		EngineLease lease(misc);
+		mm2gb_engine_t *eng = lease.eng;
 		if (!eng) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
 		if (mm2gb_rmq_chain_gpu(eng, &prm, 1, off, a, &out, &tied, nullptr)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
 	}
 	g_rmq_calls.fetch_add(1);
 	if (tied != 0) {
-		// the reference's answer depends on the shape of its tree here: ask the reference (it consumes a[] like we would)
+		// the reference's answer depends on the shape of its tree here (krmq.h:110-147): the read is done again by the library's own
+		// exact host form (csrc/rmq_host.cpp: the reference's tree rules on index arrays).  Nothing is ever handed to the host program.
 		mm2gb_chains_free(&out);
 		g_rmq_tied_calls.fetch_add(1);
-		auto host_fn = __real_mg_lchain_rmq ? __real_mg_lchain_rmq : mg_lchain_rmq;
-		if (!host_fn) {
-			fprintf(stderr, "[Error] mm2gb_lchain_rmq: %d anchors of this read tie on the range-minimum priority; the reference breaks such ties by the shape of its "
-			                "AVL tree (krmq.h), so the read needs the host's mg_lchain_rmq, which is not linked\n", tied);
-			exit(1);
-		}
-		return host_fn(max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip, n, a, n_u_, _u, km);
+		if (mm2gb_rmq_chain_host(&prm, 1, off, a, 1, &out, nullptr)) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: %s\n", mm2gb_last_error()); exit(1); }
 	}
 	const int n_u = (int)out.u_off[1];
 	uint64_t *u = nullptr; mm2gb_anchor_t *res = nullptr;
@@ -424,7 +445,7 @@ mm2gb_anchor_t *__wrap_mg_lchain_rmq(int max_dist, int max_dist_inner, int bw, i
 	return mm2gb_lchain_rmq(max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip, n, a, n_u_, _u, km);
 }
 
-// how many single-read re-chaining calls there were, and how many of them went to the host because of a tie
+// how many single-read re-chaining calls there were, and how many of them (device form only) met a tie and were redone by the exact host form
 void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls)
 {
 	if (calls) *calls = g_rmq_calls.load();
@@ -532,7 +553,7 @@ void free_stream_gpu(int n_threads)
 	g_streams.ready = false;
 	free_single_read_engines();
 	if (const char *v = getenv("MM2GB_RMQ_REPORT"))
-		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls answered by the library: %lld, of which handed to the host's own function because of a tie (device form only): %lld\n",
+		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls answered by the library: %lld, of which redone by the library's exact host form because of a tie (device form only): %lld; handed to the host program: 0\n",
 		                             (long long)g_rmq_calls.load(), (long long)g_rmq_tied_calls.load());
 }
 

@@ -133,9 +133,10 @@ def test_device_post_pass_through_the_boundary(tmp_path, threads):
 def test_rmq_rechaining_through_the_library_paf_diff_empty(tmp_path, form):
     """The same host linked with -Wl,--wrap=mg_lchain_rmq (oracle/Makefile target gpuhost_rmq; sources untouched): every
     re-chaining call of post_chaining_helper (map.c:450) lands in the library.  Default: the host form that keeps the
-    reference's tree, all 160 reads, no call goes back to the host's own function.  MM2GB_RMQ=gpu: the kernel, one read per call (one
-    workgroup walking a sequential DP with a window scan per anchor: far slower per call, so 48 reads), reads whose range-minimum meets
-    a tie go back to the host's own function.  Same PAF as the reference CPU path either way."""
+    reference's tree rules, all 160 reads.  MM2GB_RMQ=gpu: the kernel, one read per call (far slower per call, so 48 reads); a read whose
+    range-minimum meets a tie is redone by the library's own exact host form.  Neither form ever calls the host program's
+    mg_lchain_rmq: the library does not import it (tests/test_host_cpu.py checks the symbol table), and the report line says so.
+    Same PAF as the reference CPU path either way."""
     import json
     import re
     import sim_reads
@@ -157,12 +158,14 @@ def test_rmq_rechaining_through_the_library_paf_diff_empty(tmp_path, form):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     want = "".join(l + "\n" for l in open(os.path.join(GOLD, "sim160_inf.paf")).read().splitlines() if l.split("\t")[0] in names)
     assert want.count("\n") >= n_take and r.stdout.decode() == want
-    m = re.search(r"mg_lchain_rmq calls answered by the library: (\d+), of which handed to the host's own function because of a tie \(device form only\): (\d+)", r.stderr.decode())
+    m = re.search(r"mg_lchain_rmq calls answered by the library: (\d+), of which redone by the library's exact host form because of a tie \(device form only\): (\d+); "
+                  r"handed to the host program: (\d+)", r.stderr.decode())
     assert m and int(m.group(1)) > 10, r.stderr.decode()[-500:]
+    assert int(m.group(3)) == 0
     if form == "host_tree":
         assert int(m.group(2)) == 0
-    else:
-        assert int(m.group(2)) < int(m.group(1))
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "mm2-gb_amd", "libmm2gb_chain.so")], capture_output=True, text=True).stdout
+    assert "mg_lchain_rmq" not in undefined
 
 
 @needs_host

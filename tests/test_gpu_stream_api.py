@@ -119,6 +119,75 @@ def test_batched_deferred_protocol(tmp_path, max_total_n, micro_batch):
         assert np.array_equal(u, expect[i]["u"]) and np.array_equal(a, expect[i]["a_out"]), f"read {i}"
 
 
+def drive_boundary(tmp_path, batches, cfg_edit=None, env=None):
+    """Push `batches` (lists of anchor arrays) through init / chain / finish / free_stream_gpu on stream id 0 and check every read's
+    chains against the oracle."""
+    L = mm.lib()
+    cfg = json.load(open(os.path.join(ROOT, "mm2-gb_amd", "mi355x_config.json")))
+    cfg.update(cfg_edit or {})
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    prm = orc.default_param()
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        mt, mr, mn = C.c_size_t(0), C.c_int(0), C.c_int(0)
+        L.init_stream_gpu.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, mm.Misc]
+        L.chain_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+        L.finish_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+        L.free_stream_gpu.argtypes = [C.c_int]
+        L.init_stream_gpu(C.byref(mt), C.byref(mr), C.byref(mn), str(path).encode(), mm.default_misc())
+        expect, done, keep_alive, base = {}, [], [], 0
+        for b in batches:
+            arr = make_batch(b)
+            for k in range(len(b)):
+                arr[k].seq.i = base + k
+                expect[base + k] = orc.lchain_dp(b[k], prm, want_fp=False) if len(b[k]) else dict(u=np.zeros(0, np.uint64), a_out=np.zeros((0, 2), np.uint64))
+            base += len(b)
+            keep_alive.append(arr)
+            ptr, n = C.c_void_p(C.addressof(arr)), C.c_int(len(b))
+            L.chain_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+            if len(keep_alive) > 1:
+                assert ptr.value == C.addressof(keep_alive[-2]) and n.value == len(keep_alive[-2])
+                done += collect(ptr.value, n.value)
+        ptr, n = C.c_void_p(0), C.c_int(0)
+        L.finish_stream_gpu(None, None, C.byref(ptr), C.byref(n), 0, None)
+        done += collect(ptr.value, n.value)
+        L.free_stream_gpu(1)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert sorted(i for i, _, _ in done) == list(range(base))
+    for i, u, a in done:
+        assert np.array_equal(u, expect[i]["u"]) and np.array_equal(a, expect[i]["a_out"]), f"read {i}"
+
+
+def test_device_post_pass_with_growing_batches(tmp_path):
+    """MM2GB_POST=gpu, every batch much larger than all before it: batch k+1 is launched -- and sizes its result
+    set -- while batch k's chains still wait, unfetched, in the other set.  Growing the arenas for k+1 must not free or move k's
+    results (they did: set 0's buffers were re-allocated by every growth)."""
+    anchors, off = mm.synth_reads(77, 0, 63, 4_000, 30_000)
+    reads = [anchors[off[r]:off[r + 1]] for r in range(63)]
+    batches = [reads[0:1], reads[1:3], reads[3:7], reads[7:15], reads[15:31], reads[31:63]]
+    sizes = [sum(len(a) for a in b) for b in batches]
+    assert all(sizes[k + 1] > 1.5 * sizes[k] for k in range(len(sizes) - 1))
+    drive_boundary(tmp_path, batches, env={"MM2GB_POST": "gpu"})
+
+
+def test_device_post_pass_mixed_with_multi_micro_batch_batches(tmp_path):
+    """MM2GB_POST=gpu with a small max_total_n: batches that need several micro-batches take the host post-pass (scores copied out
+    of the two staging sets on the D2H stream), single-micro-batch ones the device post-pass, which writes scores into the same
+    staging sets (the kernels must wait for the earlier copy-out of the set they reuse)."""
+    anchors, off = mm.synth_reads(78, 0, 40, 4_000, 30_000)
+    reads = [anchors[off[r]:off[r + 1]] for r in range(40)]
+    cap = max(len(a) for a in reads) + 1
+    batches = [reads[0:9], reads[9:10], reads[10:20], reads[20:21], reads[21:22], reads[22:33], reads[33:34], reads[34:40]]
+    drive_boundary(tmp_path, batches, cfg_edit={"max_total_n": cap, "max_read": 1000}, env={"MM2GB_POST": "gpu"})
+
+
 def test_auto_sized_batch_limits(tmp_path):
     """A config without max_total_n / max_read (only avg_read_n, plmem.cu:497-539): limits are derived from the device's
     memory and this engine's per-anchor footprint."""

@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol():
     assert L.mm2gb_version().decode().startswith("0.")
 
 
+def test_library_imports_nothing_of_the_reference_or_the_oracle():
+    """The product may call back into the host only through the four callbacks of the boundary (build_misc,
+    post_chaining_helper, kmalloc, kfree -- weak, so it also loads without a host).  In particular it imports neither the oracle nor
+    the reference's chaining functions: a read whose range-minimum ties (N3) is redone by the library's own exact host form, never
+    by the host program's mg_lchain_rmq."""
+    import subprocess
+    so = os.path.join(ROOT, "mm2-gb_amd", "libmm2gb_chain.so")
+    out = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1].split("@")[0] for l in out.splitlines() if l.strip()}
+    banned = {n for n in names if re.search(r"^(__real_|__wrap_)?(mg_|mm_|orc_|krmq|radix_sort|compact_a|ks_)", n)}
+    assert not banned, banned
+    host_callbacks = {n for n in names if n in ("build_misc", "post_chaining_helper", "kmalloc", "kfree", "kcalloc", "krealloc")}
+    assert host_callbacks <= {"build_misc", "post_chaining_helper", "kmalloc", "kfree"}
+
+
 def test_misc_layout_matches_reference_struct():
     # Misc (gpu/plutils.h:33-37): 9 ints then 2 floats = 44 bytes, passed by value across the boundary
     assert C.sizeof(mm.Misc) == 44
