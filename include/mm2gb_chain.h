@@ -80,6 +80,7 @@ int  mm2gb_engine_device(const mm2gb_engine_t *eng);
  * up to MM2GB_SPLIT_MAX_ANCHORS anchors; 0 = never, the default: the build is exact but measured slower), and the items
  * of such chunks that workgroups other than the owner took */
 void mm2gb_engine_split_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64_t *helped_items);
+int  mm2gb_has_split_build(void);   /* 1 if the library was built with `make SPLIT=1` (k_score's one-chunk-on-several-workgroups build; MM2GB_SPLIT_MAX_ANCHORS is ignored otherwise) */
 /* make sure arenas can take a micro-batch of this size (grows, never shrinks) */
 int  mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads);
 

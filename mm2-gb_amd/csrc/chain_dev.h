@@ -127,6 +127,7 @@ void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, h
 void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s);
 size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots);
 int  score_set_lds_limit(size_t bytes);     // hipFuncSetAttribute on every k_score instance
+bool score_has_split_build();               // compiled with -DMM2GB_WITH_SPLIT (make SPLIT=1)
 enum { SCORE_MODE_LUT = 0, SCORE_MODE_FAST = 1, SCORE_MODE_GENERAL = 2 };
 
 } // namespace mm2gb

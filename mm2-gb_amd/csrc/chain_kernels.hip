@@ -1864,10 +1864,20 @@ size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots)
 	return front <= (size_t)LUT_LDS_BASE ? (size_t)LUT_LDS_TOTAL : (size_t)1 << 30;     // the table's place is fixed: what does not fit before it does not fit
 }
 
+// The SPLIT instantiation of k_score (one chunk on several workgroups: exact, and measured slower at every batch size)
+// is only compiled into builds that ask for it (make SPLIT=1): it is the heaviest instantiation of the kernel (hundreds of spilled
+// registers) and nothing selects it by default.
+#ifdef MM2GB_WITH_SPLIT
+constexpr bool HAVE_SPLIT = true;
+#else
+constexpr bool HAVE_SPLIT = false;
+#endif
+bool score_has_split_build() { return HAVE_SPLIT; }
+
 int score_set_lds_limit(size_t bytes)
 {
 	hipError_t e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if constexpr (HAVE_SPLIT) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, HAVE_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_FAST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_GENERAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 	return e == hipSuccess ? 0 : -1;
@@ -1879,7 +1889,7 @@ void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, h
 	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_slots);
 	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_slots);
 	if (cfg.host_mode == MODE_LUT) {
-		if (cfg.split && b.split_slots) hipLaunchKernelGGL((k_score<MODE_LUT, true>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+		if (HAVE_SPLIT && cfg.split && b.split_slots) hipLaunchKernelGGL((k_score<MODE_LUT, HAVE_SPLIT>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
 		else hipLaunchKernelGGL((k_score<MODE_LUT, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
 	}
 	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL((k_score<MODE_FAST, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);

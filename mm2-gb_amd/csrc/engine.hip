@@ -360,7 +360,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	// the workgroups that have run out of work (chain_kernels.hip, split_chunk).  Large batches keep the plain build.
 	LaunchCfg cfg_now = launch;
 	if (n < team4_min_n) cfg_now.team4_share_pct = 0;
-	cfg_now.split = launch.host_mode == SCORE_MODE_LUT && launch.ring_slots > 0 && n > 0 && n <= split_max_n;
+	cfg_now.split = score_has_split_build() && launch.host_mode == SCORE_MODE_LUT && launch.ring_slots > 0 && n > 0 && n <= split_max_n;
 	b.split_slots = nullptr; b.split_part = nullptr;
 	if (cfg_now.split) {
 		if (w.split_slots.ensure((size_t)launch.score_grid * sizeof(SplitSlot)) || w.split_part.ensure((size_t)launch.score_grid * SPLIT_MAX_ITEMS * 2 * 64 * 8)) return -1;
@@ -853,6 +853,7 @@ void mm2gb_engine_split_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64
 	if (helped_items) *helped_items = eng ? eng->e.last_helped_items : 0;
 }
 const char *mm2gb_version(void) { return MM2GB_VERSION; }
+int mm2gb_has_split_build(void) { return score_has_split_build() ? 1 : 0; }
 
 int mm2gb_device_count(void)
 {
