@@ -133,15 +133,22 @@ int  mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_of
  *      reproduces: n_tied[r] (optional) counts the anchors of read r where that happened; the chains of a read with
  *      n_tied[r] != 0 may differ from the reference's and are for the caller to discard (mm2gb_lchain_rmq does).
  *      max_chn_skip is ignored: the device path is exhaustive (== INT32_MAX), like mm2gb_lchain_dp.
+ *      mm2gb_rmq_chain: the batch call that is exact for EVERY read with the device carrying the load (csrc/rmq_hybrid.cpp): reads are
+ *      dealt between the kernel form and the host form by estimated cost so that both finish together (a read inside a tandem array is
+ *      a hundred times the median and would be one wave's alone), both run at the same time, and reads the kernel reports a tie for
+ *      are redone by the host form.  where[r] (optional): 0 device, 1 host threads (cost), 2 host threads (tie).
  *      mm2gb_lchain_rmq: one read, signature and ownership of mg_lchain_rmq; answered by the host form below (exact for every read);
- *      with MM2GB_RMQ=gpu by the kernel, and then a read that met a tie is handed to the host's own mg_lchain_rmq when the library is
- *      linked into minimap2 (weak import), otherwise the call fails loudly. ---- */
+ *      with MM2GB_RMQ=gpu by the kernel, and then a read that met a tie is redone by the host form.  The host PROGRAM's mg_lchain_rmq
+ *      is never called: the library does not import it. ---- */
 typedef struct {
 	int max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc;
 	float chn_pen_gap, chn_pen_skip;
 } mm2gb_rmq_param_t;
 int  mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                          mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats);
+typedef struct { int64_t n_device, n_host_cost, n_host_tie; double est_device_s, est_host_s, device_s, host_s, tie_s, total_s; } mm2gb_rmq_deal_t;
+int  mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                     int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal);
 /* The same on host threads, O(log n) per anchor, the reference's answer for EVERY read at any max_chn_skip (csrc/rmq_host.cpp): a read
  * is first done with a tournament tree of fixed shape over its anchors' (y, index) ranks, which gives the reference's answer as long as
  * one anchor in range holds the smallest priority; at the first tie (which element the reference returns then follows from its tree's
@@ -226,7 +233,7 @@ typedef struct {
 	float   mask_level; int32_t mask_len; float pri_ratio; int32_t best_n;
 	int32_t host_threads;      /* 0: every CPU the process may use, at most 32 */
 	int32_t seeds_on_device;   /* matches -> sorted anchors: 1 on the device, -1 on host threads, 0 by batch size */
-	int32_t rechain_on_device; /* mg_lchain_rmq's fill: 1 on the device (reads that met a tie are redone on host threads), otherwise on host threads */
+	int32_t rechain_on_device; /* mg_lchain_rmq's fill: 0 (default) mm2gb_rmq_chain -- device and host threads at the same time, reads dealt by cost, ties redone on the host; 1 every read on the device first (ties redone on host threads); -1 host threads only */
 } mm2gb_map_opt_t;
 typedef struct { int64_t n_reads, n_mapped, n_anchors, n_chains, n_rechained, n_rmq_tied; double s_seed, s_anchors, s_chain, s_rechain, s_regs, s_post; } mm2gb_map_stats_t;   /* s_*: seconds per stage */
 void mm2gb_map_opt_init(mm2gb_map_opt_t *opt);

@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_rmq_chain", "mm2gb_has_split_build", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -322,6 +322,32 @@ def _engine_rmq_chain(self, anchors, offsets, prm):
 
 
 Engine.rmq_chain = _engine_rmq_chain
+
+
+class RmqDeal(C.Structure):
+    _fields_ = [("n_device", C.c_int64), ("n_host_cost", C.c_int64), ("n_host_tie", C.c_int64), ("est_device_s", C.c_double), ("est_host_s", C.c_double),
+                ("device_s", C.c_double), ("host_s", C.c_double), ("tie_s", C.c_double), ("total_s", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def _engine_rmq_chain_exact(self, anchors, offsets, prm, threads=4):
+    """mm2gb_rmq_chain: device and host threads at the same time, exact for every read: list of (u, a_out) per read, where each read was
+    done (0 device, 1 host by cost, 2 host after a tie), the deal."""
+    L = lib()
+    L.mm2gb_rmq_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    a = np.ascontiguousarray(anchors, dtype=np.uint64)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    R = len(off) - 1
+    out = Chains()
+    where = np.zeros(max(R, 1), dtype=np.int32)
+    deal = RmqDeal()
+    _check(L.mm2gb_rmq_chain(self._h, C.byref(prm), R, off.ctypes.data, a.ctypes.data, int(threads), C.byref(out), where.ctypes.data, C.byref(deal)))
+    return _take_chains(out, R), where[:R], deal.as_dict()
+
+
+Engine.rmq_chain_exact = _engine_rmq_chain_exact
 
 
 def rmq_chain_host(anchors, offsets, prm, threads=4):

@@ -383,11 +383,18 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		mm2gb_chains_t rc_tie; memset(&rc_tie, 0, sizeof rc_tie);
 		std::vector<int32_t> tied(redo.size(), 0);
 		std::vector<int> tie_slot(redo.size(), -1);          // reads the device reported a tie for: their place in the host call that follows
-		// mg_lchain_rmq's fill: on host threads by default -- a tree per read, O(log n) per anchor and a tightly bounded inner scan
-		// (csrc/rmq_host.cpp), 3.4 s for 92 M anchors on 16 threads where k_rmq_fill, one wave per read and the read with the densest
-		// windows last, needs 70 s on the same reads.  On the device when asked for: reads the kernel reports a tie for -- where
-		// the reference's answer depends on the shape of its tree -- are redone by the host form, which keeps that tree.
-		if (opt.rechain_on_device > 0) {
+		// mg_lchain_rmq's fill.  Default: mm2gb_rmq_chain (csrc/rmq_hybrid.cpp) -- the kernel form takes the bulk of the reads, the host
+		// threads, at the same time, the few whose windows are so dense that one wave would still be on them long after the rest of the
+		// batch is done, and afterwards the reads the kernel reported a tie for (where the reference's answer follows from the shape of
+		// its tree; the host form keeps that tree's rules).  rechain_on_device = 1: every read on the device first; -1: host threads only.
+		if (opt.rechain_on_device == 0) {
+			std::vector<int32_t> where(redo.size(), 0);
+			mm2gb_rmq_deal_t deal;
+			if (mm2gb_rmq_chain(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, where.data(), &deal)) { free_matches(); return -1; }
+			for (size_t q = 0; q < redo.size(); ++q) tied[q] = where[q] == 2;
+			if (verbose) fprintf(stderr, "[mm2gb] re-chaining deal: %lld reads on the device (%.3f s, estimated %.3f), %lld on host threads by cost (%.3f s, estimated %.3f), %lld redone after a tie (%.3f s)\n",
+			                     (long long)deal.n_device, deal.device_s, deal.est_device_s, (long long)deal.n_host_cost, deal.host_s, deal.est_host_s, (long long)deal.n_host_tie, deal.tie_s);
+		} else if (opt.rechain_on_device > 0) {
 			if (mm2gb_rmq_chain_gpu(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), &rc, tied.data(), nullptr)) { free_matches(); return -1; }
 			std::vector<int64_t> to(1, 0);
 			std::vector<mm2gb_anchor_t> ta;

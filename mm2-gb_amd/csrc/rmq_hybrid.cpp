@@ -1,0 +1,213 @@
+// rmq_hybrid.cpp -- mg_lchain_rmq (lchain.c:250-369) for a batch of reads, exact for every read, with the DEVICE carrying the load:
+// mm2gb_rmq_chain deals the reads between the kernel form (k_rmq_fill, one wave per read, thousands of reads at once) and the host
+// form (csrc/rmq_host.cpp, one thread per read) so that both finish together, runs them AT THE SAME TIME, and has the reads for which
+// the kernel reports a tie on the range-minimum priority (where the reference's answer follows from the shape of its tree,
+// krmq.h:110-147) redone by the host form, which keeps that tree's rules.  Nothing is handed back to a caller to redo.
+//
+// Why a deal at all: the fill is a chain of n dependent steps per read.  A wave takes microseconds per step where a CPU core takes a
+// fraction of one, and wins by running thousands of reads side by side -- so a batch is as slow as its slowest read, and a read inside a
+// tandem array (hundreds of thousands of kept anchors within bw_long of each other, hundreds of inner candidates per anchor) is a
+// hundred times the median.  Those few go to the host threads, which would otherwise idle while the device works.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "engine.h"
+#include "host_chain.h"
+
+namespace mm2gb {
+namespace {
+
+// What a read costs either side, in seconds, from three sums that take one pass over its anchors (sorted by x):
+//   n      steps
+//   s_in   sum over anchors of ceil(anchors within max_dist_inner before it on the reference / 64): blocks of the kernel's inner scan
+//   s_out  sum over anchors of ceil(anchors within max_dist before it / 4096): iterations over block summaries of the kernel's query
+// The constants are measured rates (profiles/r03_rmq_rate.json: counters of k_rmq_fill under MM2GB_DEBUG_PHASES against its time on
+// the read that ends a batch; rmq_host.cpp's thread-seconds per anchor); they only steer the deal, never a result.
+struct ReadCost { double dev, host; };
+
+ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n)
+{
+	const int64_t max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;
+	const int64_t max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;
+	double s_in = 0, s_out = 0;
+	int64_t lo_in = 0, lo_out = 0;
+	// every 16th anchor stands for its neighbours: windows change slowly along a read
+	constexpr int64_t STRIDE = 16;
+	for (int64_t i = 0; i < n; i += STRIDE) {
+		const uint64_t xi = a[i].x;
+		while (lo_out < i && (a[lo_out].x >> 32 != xi >> 32 || xi > a[lo_out].x + (uint64_t)max_dist)) ++lo_out;
+		if (lo_in < lo_out) lo_in = lo_out;
+		while (lo_in < i && xi > a[lo_in].x + (uint64_t)max_inner) ++lo_in;
+		const int64_t w_out = std::min<int64_t>(i - lo_out, P.cap_rmq_size > 0 ? P.cap_rmq_size : i - lo_out);
+		const int64_t w_in = max_inner > 0 ? std::min<int64_t>(i - lo_in, P.cap_rmq_size > 0 ? P.cap_rmq_size : i - lo_in) : 0;
+		s_in += (double)((w_in + 63) / 64) * STRIDE;
+		s_out += (double)((w_out + 4095) / 4096) * STRIDE;
+	}
+	ReadCost c;
+	c.dev = 2.5e-6 * (double)n + 0.26e-6 * (s_in + s_out);
+	c.host = 0.45e-6 * (double)n + 0.012e-6 * s_in * 64.0 / 8.0;     // the host's inner scan visits the candidates of one y-range, not the window
+	return c;
+}
+
+void append(mm2gb_chains_t &dst, size_t r, const mm2gb_chains_t &src, size_t q)
+{
+	const int64_t nu = src.u_off[q + 1] - src.u_off[q], na = src.a_off[q + 1] - src.a_off[q];
+	dst.u_off[r + 1] = nu; dst.a_off[r + 1] = na;                     // counts for now; turned into offsets by the caller
+}
+
+} // namespace
+} // namespace mm2gb
+
+using namespace mm2gb;
+
+extern "C" {
+
+int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                    int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal)
+{
+	if (!eng || !prm || !out || n_reads < 0 || !offsets || offsets[0] != 0) return fail("mm2gb_rmq_chain: null argument, or offsets[0] is not 0");
+	memset(out, 0, sizeof(*out));
+	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_rmq_chain: offsets must be non-decreasing");
+	if (offsets[n_reads] > 0 && !anchors) return fail("mm2gb_rmq_chain: null buffer");
+	const size_t R = (size_t)n_reads;
+	const int nt = std::max(1, n_threads);
+	const auto t0 = std::chrono::steady_clock::now();
+	auto seconds_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+
+	// ---- the deal ----
+	std::vector<ReadCost> cost(R);
+	{
+		std::atomic<int64_t> next(0);
+		auto work = [&]() { for (;;) { const int64_t r = next.fetch_add(1); if (r >= n_reads) break; cost[(size_t)r] = estimate(*prm, anchors + offsets[r], offsets[r + 1] - offsets[r]); } };
+		std::vector<std::thread> pool;
+		for (int t = 1; t < std::min<int>(nt, (int)std::max<int64_t>(1, n_reads)); ++t) pool.emplace_back(work);
+		work();
+		for (auto &th : pool) th.join();
+	}
+	std::vector<int64_t> by_dev(R);
+	for (size_t r = 0; r < R; ++r) by_dev[r] = (int64_t)r;
+	std::sort(by_dev.begin(), by_dev.end(), [&](int64_t u, int64_t v) { return cost[(size_t)u].dev != cost[(size_t)v].dev ? cost[(size_t)u].dev > cost[(size_t)v].dev : u < v; });
+	const double slots = std::max(64.0, (double)eng->e.n_cu * 12.0);     // waves k_rmq_fill keeps resident (LDS-bound)
+	double dev_sum = 0, host_sum = 0, host_max = 0;
+	for (size_t r = 0; r < R; ++r) dev_sum += cost[r].dev;
+	size_t n_host = 0;                                                   // the first n_host reads of by_dev go to the host threads
+	int policy = 0;                                                      // MM2GB_RMQ_DEAL=device / host: everything one side (A/B runs, tests)
+	if (const char *v = getenv("MM2GB_RMQ_DEAL")) policy = !strcmp(v, "device") ? 1 : !strcmp(v, "host") ? 2 : 0;
+	const double launch_s = 1.5e-3;                                      // what a device call costs before its first step (copies, sort by y, ranks)
+	if (policy == 2) n_host = R;
+	else if (policy == 0)
+		while (n_host < R) {
+			const ReadCost &c = cost[(size_t)by_dev[n_host]];
+			const double dev_now = launch_s + std::max(c.dev, dev_sum / slots);                       // with this read still on the device
+			const double host_then = std::max(std::max(host_max, c.host), (host_sum + c.host) / nt);  // with it on the host threads
+			if (host_then >= dev_now) break;
+			host_sum += c.host; host_max = std::max(host_max, c.host); dev_sum -= c.dev;
+			++n_host;
+		}
+	if (deal) { memset(deal, 0, sizeof(*deal)); deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
+
+	// ---- both sides at once ----
+	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, std::vector<mm2gb_anchor_t> &buf) {
+		off.assign(1, 0);
+		int64_t total = 0;
+		for (size_t q = from; q < to; ++q) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
+		buf.resize((size_t)std::max<int64_t>(total, 1));
+		for (size_t q = from; q < to; ++q) {
+			const int64_t r = by_dev[q], n = offsets[r + 1] - offsets[r];
+			if (n) memcpy(buf.data() + off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
+			off.push_back(off.back() + n);
+		}
+	};
+	std::vector<int64_t> h_off, d_off, t_off;
+	std::vector<mm2gb_anchor_t> h_a, d_a, t_a;
+	mm2gb_chains_t h_out, d_out, t_out;
+	memset(&h_out, 0, sizeof h_out); memset(&d_out, 0, sizeof d_out); memset(&t_out, 0, sizeof t_out);
+	int h_rc = 0;
+	std::string h_err;
+	double h_seconds = 0;
+	std::thread host_side;
+	if (n_host > 0) {
+		gather(0, n_host, h_off, h_a);
+		// the host side leaves one thread to the device call's own host work when it shares the machine with it
+		const int h_threads = n_host < R ? std::max(1, nt - 1) : nt;
+		host_side = std::thread([&, h_threads]() {
+			const auto th = std::chrono::steady_clock::now();
+			h_rc = mm2gb_rmq_chain_host(prm, (int64_t)n_host, h_off.data(), h_a.data(), h_threads, &h_out, nullptr);
+			if (h_rc) h_err = mm2gb_last_error();
+			h_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - th).count();
+		});
+	}
+	std::vector<int32_t> tied(R - n_host + 1, 0);
+	int d_rc = 0;
+	double d_seconds = 0;
+	if (n_host < R) {
+		gather(n_host, R, d_off, d_a);                                   // most expensive first: a wave takes reads in this order
+		const auto td = std::chrono::steady_clock::now();
+		d_rc = mm2gb_rmq_chain_gpu(eng, prm, (int64_t)(R - n_host), d_off.data(), d_a.data(), &d_out, tied.data(), nullptr);
+		d_seconds = seconds_since(td);
+	}
+	const std::string d_err = d_rc ? mm2gb_last_error() : "";
+	if (host_side.joinable()) host_side.join();
+	auto give_up = [&](const std::string &why) { mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out); return fail(why); };
+	if (d_rc) return give_up(d_err);
+	if (h_rc) return give_up(h_err);
+
+	// ---- reads that met a tie on the device: the host form, which keeps the reference's tree ----
+	std::vector<int64_t> tie_slot(R, -1);
+	double t_seconds = 0;
+	{
+		std::vector<size_t> redo;
+		for (size_t q = n_host; q < R; ++q) if (tied[q - n_host]) { tie_slot[q] = (int64_t)redo.size(); redo.push_back(q); }
+		if (!redo.empty()) {
+			t_off.assign(1, 0);
+			int64_t total = 0;
+			for (size_t q : redo) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
+			t_a.resize((size_t)total);
+			for (size_t q : redo) {
+				const int64_t r = by_dev[q], n = offsets[r + 1] - offsets[r];
+				memcpy(t_a.data() + t_off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
+				t_off.push_back(t_off.back() + n);
+			}
+			const auto tt = std::chrono::steady_clock::now();
+			if (mm2gb_rmq_chain_host(prm, (int64_t)redo.size(), t_off.data(), t_a.data(), nt, &t_out, nullptr)) return give_up(mm2gb_last_error());
+			t_seconds = seconds_since(tt);
+		}
+		if (deal) deal->n_host_tie = (int64_t)redo.size();
+	}
+
+	// ---- one result, in the caller's read order ----
+	out->u_off = (int64_t*)malloc((R + 1) * 8);
+	out->a_off = (int64_t*)malloc((R + 1) * 8);
+	if (!out->u_off || !out->a_off) { mm2gb_chains_free(out); return give_up("mm2gb_rmq_chain: out of memory"); }
+	out->u_off[0] = out->a_off[0] = 0;
+	struct Src { const mm2gb_chains_t *c; size_t q; };
+	std::vector<Src> src(R);
+	for (size_t q = 0; q < R; ++q) {
+		const size_t r = (size_t)by_dev[q];
+		if (q < n_host) src[r] = { &h_out, q };
+		else if (tie_slot[q] >= 0) src[r] = { &t_out, (size_t)tie_slot[q] };
+		else src[r] = { &d_out, q - n_host };
+		if (where) where[r] = q < n_host ? 1 : tie_slot[q] >= 0 ? 2 : 0;
+	}
+	for (size_t r = 0; r < R; ++r) append(*out, r, *src[r].c, src[r].q);
+	for (size_t r = 0; r < R; ++r) { out->u_off[r + 1] += out->u_off[r]; out->a_off[r + 1] += out->a_off[r]; }
+	out->u = (uint64_t*)malloc(((size_t)out->u_off[R] + 1) * 8);
+	out->a = (mm2gb_anchor_t*)malloc(((size_t)out->a_off[R] + 1) * 16);
+	if (!out->u || !out->a) { mm2gb_chains_free(out); return give_up("mm2gb_rmq_chain: out of memory"); }
+	for (size_t r = 0; r < R; ++r) {
+		const mm2gb_chains_t &c = *src[r].c;
+		const size_t q = src[r].q;
+		const int64_t nu = c.u_off[q + 1] - c.u_off[q], na = c.a_off[q + 1] - c.a_off[q];
+		if (nu) memcpy(out->u + out->u_off[r], c.u + c.u_off[q], (size_t)nu * 8);
+		if (na) memcpy(out->a + out->a_off[r], c.a + c.a_off[q], (size_t)na * 16);
+	}
+	mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out);
+	if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
+	return 0;
+}
+
+} // extern "C"

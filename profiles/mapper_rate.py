@@ -23,7 +23,7 @@ with tempfile.TemporaryDirectory() as td:
         opt = mm.map_opt(host_threads=16, rechain_on_device=int(os.environ.get("MAPPER_RATE_RECHAIN_DEVICE", "0")))
         mm.map_reads(e, ix, [n for n, _ in refs], rd[:8], opt=opt)              # warm-up: arenas, first kernel launches
         best = 1e9
-        for rep in range(3):
+        for rep in range(int(os.environ.get("MAPPER_RATE_REPS", "3"))):
             t0 = time.perf_counter()
             paf, st = mm.map_reads(e, ix, [n for n, _ in refs], rd, opt=opt)
             best = min(best, time.perf_counter() - t0)

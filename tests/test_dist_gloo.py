@@ -74,3 +74,24 @@ def test_bench_main_routes_on_world_size(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     bench.main()
     assert calls == ["spawn", "rank", "rank"]
+
+
+def test_pool_leg_tiles_rank0_reads_once_per_device():
+    """The one-process leg of bench.py's host_path: rank 0's reads repeated once per device, offsets consistent,
+    the total capped."""
+    import numpy as np
+    import bench
+    rng = np.random.default_rng(5)
+    lens = rng.integers(1, 50, 20)
+    off = np.zeros(21, np.int64); off[1:] = np.cumsum(lens)
+    anchors = rng.integers(0, 1 << 62, (int(off[-1]), 2)).astype(np.uint64)
+    per_dev, n = bench.pool_leg_reads(off, 20, 4)
+    assert (per_dev, n) == (20, int(off[-1]))
+    out = np.zeros((4 * n, 2), np.int64)
+    p_off = bench.tile_reads(anchors, off, per_dev, 4, out)
+    assert len(p_off) == 81 and p_off[-1] == 4 * n and (np.diff(p_off) == np.tile(lens, 4)).all()
+    for k in range(4):
+        assert (out[k * n:(k + 1) * n].view(np.uint64) == anchors).all()
+    per_dev, n = bench.pool_leg_reads(off, 20, 8, cap_anchors=4 * int(off[-1]))       # 8 copies must fit a cap of 4: half the reads each
+    assert per_dev == 10 and n == int(off[10])
+    assert bench.pool_leg_reads(off, 20, 1) == (20, int(off[-1]))

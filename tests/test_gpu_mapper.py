@@ -37,7 +37,7 @@ def test_reference_test_pairs_paf_identical(engine, case, tgt, qry, seeds_on_dev
     assert st["n_rmq_tied"] == 0
 
 
-@pytest.mark.parametrize("rechain_on_device", [1, 0], ids=["rechain_on_device", "rechain_on_host"])
+@pytest.mark.parametrize("rechain_on_device", [1, 0, -1], ids=["rechain_on_device", "rechain_dealt_device_and_host", "rechain_on_host"])
 @pytest.mark.parametrize("seeds_on_device", [1, -1], ids=["anchors_on_device", "anchors_on_host"])
 def test_simulated_long_reads_paf(engine, tmp_path, seeds_on_device, rechain_on_device):
     """Everything a long-read run exercises: minimizers above mid_occ, reads on both strands, secondary hits, re-chaining of most reads

@@ -90,3 +90,34 @@ def test_single_read_entry_with_the_reference_signature(engine):
     calls, tied = C.c_int64(0), C.c_int64(0)
     L.mm2gb_lchain_rmq_counts(C.byref(calls), C.byref(tied))
     assert calls.value >= 1 and tied.value == 0
+
+
+@pytest.mark.parametrize("deal", ["auto", "device", "host"])
+def test_batch_call_that_is_exact_for_every_read(engine, monkeypatch, deal):
+    """mm2gb_rmq_chain (csrc/rmq_hybrid.cpp): kernel form and host form at the same time, reads dealt by estimated cost, reads the kernel
+    reports a tie for redone by the host form -- the chains of EVERY read equal the host form's (which tests/test_rmq_host_cpu.py pins to
+    the reference's vectors and to the compiled reference on tied reads), whatever the deal: the estimate's, everything on the device
+    first, everything on the host."""
+    a, off = mm.synth_reads(43, 0, 48, 10_000, 120_000)
+    reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(48)]
+    reads.insert(5, np.zeros((0, 2), np.uint64))
+    rng = np.random.default_rng(7)
+    # dense clouds: ties on the range-minimum priority are certain, and the windows are full of inner candidates
+    for k, n in enumerate((900, 20_000)):
+        reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(n, 1), np.zeros(n, np.int64), 1000 + rng.integers(0, 150 + 400 * k, n), 100 + rng.integers(0, 150 + 400 * k, n)))))
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    if deal != "auto":
+        monkeypatch.setenv("MM2GB_RMQ_DEAL", deal)
+    for kw in (dict(), dict(bw=300, max_dist=1500, max_dist_inner=200)):
+        prm = to_lib(orc.default_rmq_param(**kw))
+        want, _ = mm.rmq_chain_host(allr, o2, prm, threads=8)
+        got, where, d = engine.rmq_chain_exact(allr, o2, prm, threads=8)
+        for r in range(len(reads)):
+            assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), (deal, kw, r, int(where[r]))
+        assert d["n_device"] + d["n_host_cost"] == len(reads) and d["n_host_tie"] == int((where == 2).sum())
+        if deal == "device":
+            assert d["n_host_cost"] == 0 and d["n_host_tie"] >= 1          # the clouds tie: found on the device, redone on the host
+        if deal == "host":
+            assert d["n_device"] == 0 and (where == 1).all()
