@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_rmq_chain", "mm2gb_has_split_build", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_rmq_chain", "mm2gb_has_split_build", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi", "mm2gb_map_reads_stream"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -531,14 +531,20 @@ def plan_batches(n_anchors, max_total_n, max_read, min_n):
 class Batcher:
     """mm2gb_batcher_t: feed reads one at a time, get every read's chains back (dict read_id -> (u, a_out))."""
 
-    def __init__(self, devices=None, misc=None, config=None, post_threads=2):
+    def __init__(self, devices=None, misc=None, config=None, post_threads=2, keep_results=True):
         L = lib()
         self.misc = misc if misc is not None else default_misc()
         self.config = config if config is not None else default_config()
         self.results = {}
         self.order = []
+        self.n_chains = 0
+        self.n_kept = 0
 
         def on_done(_user, read_id, n_u, u, n_a, a):
+            if not keep_results:                     # rate measurements: count, do not copy
+                self.n_chains += n_u
+                self.n_kept += n_a
+                return
             uu = np.ctypeslib.as_array(u, shape=(n_u,)).copy() if n_u else np.zeros(0, np.uint64)
             aa = (np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint64)), shape=(n_a, 2)).copy() if n_a else np.zeros((0, 2), np.uint64))
             self.results[read_id] = (uu, aa)
@@ -734,6 +740,28 @@ def map_reads_multi(engines, index, ref_names, reads, opt=None, k=15):
     out, n, st = C.c_void_p(), C.c_int64(), MapStats()
     _check(L.mm2gb_map_reads_multi(hs, len(engines), index._h, k, rn, index.lens.ctypes.data, len(ref_names), C.byref(opt), len(reads), names, seqs, lens.ctypes.data,
                                    C.byref(out), C.byref(n), C.byref(st)))
+    text = C.string_at(out, n.value).decode()
+    L.mm2gb_free(out)
+    return text, st.as_dict()
+
+
+def map_reads_stream(engines, index, ref_names, reads, opt=None, k=15, chunk_bases=0):
+    """mm2gb_map_reads_stream: a run of any size as a stream of chunks of about chunk_bases bases; every engine (several per device overlap
+    host stages with kernels, engines on several devices shard the reads) takes the next chunk.  Returns (PAF text in read order, stats:
+    counts summed, s_* summed over chunks)."""
+    L = lib()
+    L.mm2gb_map_reads_stream.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
+    opt = opt or map_opt()
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    rn = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    names = (C.c_char_p * len(reads))(*[n.encode() for n, _ in reads])
+    seqs_b = [s if isinstance(s, bytes) else bytes(s) for _, s in reads]
+    seqs = (C.c_char_p * len(reads))(*seqs_b)
+    lens = np.ascontiguousarray([len(s) for s in seqs_b], dtype=np.int32)
+    out, n, st = C.c_void_p(), C.c_int64(), MapStats()
+    _check(L.mm2gb_map_reads_stream(hs, len(engines), index._h, k, rn, index.lens.ctypes.data, len(ref_names), C.byref(opt), len(reads), names, seqs, lens.ctypes.data,
+                                    int(chunk_bases), C.byref(out), C.byref(n), C.byref(st)))
     text = C.string_at(out, n.value).decode()
     L.mm2gb_free(out)
     return text, st.as_dict()

@@ -69,6 +69,7 @@ struct Batch {
 	GrowPinned anchors;
 	std::vector<int64_t> offsets, ids;
 	int lane = LANE_BIG;
+	int writers = 0;                               // producers that have reserved a place in `anchors` and are still copying into it (guarded by the batcher's mutex)
 	int64_t count() const { return (int64_t)ids.size(); }
 	int64_t total() const { return offsets.empty() ? 0 : offsets.back(); }
 	void clear() { offsets.assign(1, 0); ids.clear(); }
@@ -88,7 +89,7 @@ struct mm2gb_batcher {
 	std::vector<mm2gb_engine_t*> engines;
 	std::vector<std::thread> workers;
 	std::mutex mu;                                 // accumulators, queues, counters
-	std::condition_variable cv_ready, cv_free, cv_idle;
+	std::condition_variable cv_ready, cv_free, cv_idle, cv_copy;   // cv_copy: some batch's last writer has finished
 	std::vector<std::unique_ptr<Batch>> all;
 	std::deque<Batch*> free_list, ready;
 	Batch *acc[N_LANES] = { nullptr, nullptr };
@@ -127,6 +128,7 @@ struct mm2gb_batcher {
 				if (ready.empty()) return;
 				b = ready.front(); ready.pop_front();
 				++in_flight;
+				cv_copy.wait(lk, [&] { return b->writers == 0; });   // a batch can be closed while producers are still copying their reads into it
 			}
 			mm2gb_chains_t out;
 			int rc;
@@ -212,13 +214,29 @@ int mm2gb_batcher_add(mm2gb_batcher_t *b, int64_t read_id, const mm2gb_anchor_t 
 		if (b->acc[lane]) { b->free_list.push_back(fresh); b->cv_free.notify_one(); continue; }   // another producer opened the lane's batch first
 		b->acc[lane] = fresh;
 	}
+	for (;;) {                                                // room for this read: the buffer grows only while no producer is copying into it
+		Batch *cur = b->acc[lane];
+		if (!cur || b->rule.closes(cur->count(), cur->total(), n)) { lk.unlock(); return mm2gb_batcher_add(b, read_id, a, n); }   // closed under our feet while we waited: start over
+		const size_t need = (size_t)(cur->total() + n) * 16;
+		if (need <= cur->anchors.bytes) break;
+		if (cur->writers > 0) { b->cv_copy.wait(lk); continue; }
+		if (cur->anchors.reserve_keep(need, (size_t)cur->total() * 16)) return -1;
+		break;
+	}
+	// A place in the batch is reserved under the lock; the read is copied into it OUTSIDE the lock, so producers copy side by side
+	// (with the copy inside, three producer threads fed the batcher no faster than one).  The buffer may only move while nobody copies.
 	Batch &acc = *b->acc[lane];
 	const int64_t at = acc.total();
-	if (acc.anchors.reserve_keep((size_t)(at + n) * 16, (size_t)at * 16)) return -1;
-	if (n) memcpy((mm2gb_anchor_t*)acc.anchors.ptr + at, a, (size_t)n * 16);
 	acc.offsets.push_back(at + n);
 	acc.ids.push_back(read_id);
 	b->stats.reads += 1; b->stats.anchors += n; b->stats.reads_per_lane[lane] += 1;
+	if (n == 0) return 0;
+	mm2gb_anchor_t *dst = (mm2gb_anchor_t*)acc.anchors.ptr + at;
+	++acc.writers;
+	lk.unlock();
+	memcpy(dst, a, (size_t)n * 16);
+	lk.lock();
+	if (--acc.writers == 0) b->cv_copy.notify_all();
 	return 0;
 }
 

@@ -277,7 +277,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &reg_out,
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -407,7 +407,7 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	// per-chain arrays are sized for min_cnt = 1 (a chain per anchor): min_cnt is a per-call parameter and may drop
 	const size_t chains = (size_t)(nn + nr);
 	if (post_z.ensure((size_t)nn * 8) || post_mark.ensure((size_t)nn) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
-	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_misc.ensure(2048) || post_order.ensure((size_t)nr * 4) ||
+	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_misc.ensure(2048) || post_bins.ensure(2 * N_SIZE_CLASSES * 4) || post_order.ensure((size_t)nr * 4) ||
 	    post_up4.ensure((size_t)nn * 4) || post_up16.ensure((size_t)nn * 4)) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
 	return 0;
@@ -443,7 +443,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)po.u_off.ptr; b.a_off = (int64_t*)po.a_off.ptr;
 	b.u_out = (unsigned long long*)po.u_out.ptr; b.a_out = (uint4*)po.a_out.ptr;
 	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 16);
-	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)((char*)post_misc.ptr + 128);
+	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)post_bins.ptr;
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
 	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream));
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
@@ -452,6 +452,13 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	// one read per wave at a time: as many waves as the chip holds (latency-bound pointer chases; parallelism is across reads)
 	b.grid_waves = n_cu * 32;
 	if (const char *v = getenv("MM2GB_POST_WAVES")) b.grid_waves = std::max(4, atoi(v));
+	// Whole workgroups start on the largest reads together (k_post_chains: collection and the buckets of the sort's top pass shared by the
+	// four waves) only in batches that leave the chip idle anyway -- at most one read per workgroup the chip holds at a time (3 per CU by
+	// the kernel's LDS).  There a batch ends with its largest read and the helpers have nothing else to do.  In a batch that fills the
+	// chip the helpers' wait for the serial top pass costs as many wave slots as the sharing saves: measured at 500 M anchors / 9 016
+	// reads, k_post_chains + lift + emit 58.9 ms with no teams, 59.3 / 62.6 / 65.3 ms with 64 / 256 / 640 (profiles/r03_post_teams.txt).
+	b.team_reads = n_reads <= (int64_t)n_cu * 3 ? (int)n_reads : 0;
+	if (const char *v = getenv("MM2GB_POST_TEAM_READS")) b.team_reads = std::max(0, atoi(v));
 	MM2GB_HIP(hipEventRecord(post0, stream));
 	launch_post(b, stream);
 	MM2GB_HIP(hipEventRecord(post1, stream));

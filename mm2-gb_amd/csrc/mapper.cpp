@@ -554,4 +554,72 @@ int mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const m
 	return 0;
 }
 
+// A run of any size as a stream of batches (role of the batch rotation of worker_for, map.c:924-1153: seed batch k+1 while batch k is
+// chained and batch k-1 is finished): the reads are cut into consecutive chunks of about chunk_bases bases, and every engine -- several
+// per device are the point: each has its own streams and arenas -- has a host thread that takes the next chunk and maps it from
+// seeding to PAF.  A chunk's stages alternate between host threads and the device, so with two or three engines on a GPU one chunk is
+// being seeded or post-processed while another one's kernels run; with engines on several GPUs the reads shard (no
+// exchange).  The host threads of opt are shared out with some over-subscription, because a chunk's threads idle while its kernels run.
+// PAF in read order; stats: counts summed, s_* = seconds of each stage SUMMED over chunks (they overlap: not wall time).
+int mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens,
+                           int32_t n_ref, const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
+                           int64_t chunk_bases, char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats)
+{
+	if (!engines || n_engines < 1 || !opt_in || !paf_out || !paf_len || n_reads < 0 || (n_reads > 0 && !lens)) return fail("mm2gb_map_reads_stream: null argument");
+	*paf_out = nullptr; *paf_len = 0;
+	if (chunk_bases <= 0) chunk_bases = 48 * 1000 * 1000;
+	std::vector<int32_t> cut(1, 0);
+	{ int64_t acc = 0; for (int32_t r = 0; r < n_reads; ++r) { acc += lens[r]; if (acc >= chunk_bases && r + 1 < n_reads) { cut.push_back(r + 1); acc = 0; } } }
+	cut.push_back(n_reads);
+	const size_t n_chunks = cut.size() - 1;
+	mm2gb_map_opt_t opt = *opt_in;
+	const int all_threads = opt_in->host_threads > 0 ? opt_in->host_threads : std::min(32, usable_cpus());
+	const int workers = (int)std::min<size_t>((size_t)n_engines, std::max<size_t>(1, n_chunks));
+	opt.host_threads = std::max(1, workers == 1 ? all_threads : (all_threads * 3 / 2 + workers - 1) / workers);
+	if (opt.mid_occ <= 0) opt.mid_occ = mm2gb_index_mid_occ(ix, opt.mid_occ_frac, opt.min_mid_occ, opt.max_mid_occ);     // once, not per chunk
+	std::vector<char*> part(n_chunks, nullptr);
+	std::vector<int64_t> part_len(n_chunks, 0);
+	std::vector<mm2gb_map_stats_t> st(n_chunks);
+	std::atomic<size_t> next(0);
+	std::atomic<int> failed(0);
+	std::string why;
+	std::mutex why_lock;
+	auto work = [&](int e) {
+		for (;;) {
+			const size_t c = next.fetch_add(1);
+			if (c >= n_chunks || failed.load()) break;
+			const int32_t from = cut[c], n = cut[c + 1] - from;
+			memset(&st[c], 0, sizeof(st[c]));
+			if (mm2gb_map_reads(engines[e], ix, k, ref_names, ref_lens, n_ref, &opt, n, names + from, seqs + from, lens + from, &part[c], &part_len[c], &st[c])) {
+				std::lock_guard<std::mutex> g(why_lock);
+				if (!failed.exchange(1)) why = "chunk " + std::to_string(c) + " on engine " + std::to_string(e) + ": " + mm2gb_last_error();
+			}
+		}
+	};
+	{
+		std::vector<std::thread> pool;
+		for (int e = 1; e < workers; ++e) pool.emplace_back(work, e);
+		work(0);
+		for (auto &th : pool) th.join();
+	}
+	if (failed.load()) { for (char *p : part) free(p); return fail("mm2gb_map_reads_stream: " + why); }
+	int64_t all = 0;
+	for (int64_t l : part_len) all += l;
+	char *buf = (char*)malloc((size_t)all + 1);
+	if (!buf) { for (char *p : part) free(p); return fail("mm2gb_map_reads_stream: out of memory"); }
+	int64_t at = 0;
+	mm2gb_map_stats_t sum; memset(&sum, 0, sizeof sum);
+	for (size_t c = 0; c < n_chunks; ++c) {
+		if (part_len[c]) memcpy(buf + at, part[c], (size_t)part_len[c]);
+		at += part_len[c]; free(part[c]);
+		const mm2gb_map_stats_t &q = st[c];
+		sum.n_reads += q.n_reads; sum.n_mapped += q.n_mapped; sum.n_anchors += q.n_anchors; sum.n_chains += q.n_chains; sum.n_rechained += q.n_rechained; sum.n_rmq_tied += q.n_rmq_tied;
+		sum.s_seed += q.s_seed; sum.s_anchors += q.s_anchors; sum.s_chain += q.s_chain; sum.s_rechain += q.s_rechain; sum.s_regs += q.s_regs; sum.s_post += q.s_post;
+	}
+	buf[all] = 0;
+	*paf_out = buf; *paf_len = all;
+	if (stats) *stats = sum;
+	return 0;
+}
+
 } // extern "C"

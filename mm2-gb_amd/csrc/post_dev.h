@@ -10,6 +10,7 @@ namespace mm2gb {
 // Everything the device post-pass (post_kernels.hip: backtrack + compaction, lchain.c:9-111) needs for one micro-batch.
 // Chains of a read hold at least mc = max(1, min_cnt) anchors, so read r has at most n_r / mc of them: the per-chain arrays
 // (u_tmp, heads) give read r the slots from offsets[r] / mc + r on.
+constexpr int N_SIZE_CLASSES = 512;
 struct PostBatch {
 	const uint4   *raw;        // anchors (mm128_t)
 	const int64_t *offsets;    // n_reads + 1
@@ -28,9 +29,10 @@ struct PostBatch {
 	int64_t  *totals;          // [0] chains [1] anchors kept
 	int32_t  *cursor;          // two work cursors
 	int32_t  *order;           // n_reads: reads, largest first (the kernel ends with its longest read: start those first)
-	int32_t  *size_bins;       // 2 x 64: reads per power-of-two size class, and the fill counters of the scatter
+	int32_t  *size_bins;       // 2 x N_SIZE_CLASSES: reads per size class (eight classes per power of two), and the fill cursors of the scatter
 	int       min_cnt, min_sc, max_drop;
 	int       grid_waves;      // waves to launch (one read per wave at a time)
+	int       team_reads;      // the largest reads of the batch that a whole workgroup starts on together (k_post_chains)
 	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed 100 MHz ticks of [0] candidate collection [1] sort [2] chain walks [3] emit
 };
 void launch_post(const PostBatch &b, hipStream_t s);

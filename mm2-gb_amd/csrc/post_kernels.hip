@@ -356,9 +356,17 @@ __device__ __forceinline__ int64_t chain_slot(int64_t off_r, int64_t r, int mc) 
 } // namespace
 
 // --------------------------------------------------------------------------------------------------------------
-// reads by size class, largest first (order inside a class is arbitrary: reads are independent, results do not depend on it)
+// reads by size, largest first: N_SIZE_CLASSES classes, eight per power of two, so reads of one class differ by at most an eighth (order
+// inside a class is arbitrary: reads are independent, results do not depend on it).  The kernel ends with its largest reads: they start
+// first, and the very largest are the ones whole workgroups start on (k_post_chains).
 // --------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int size_class(int64_t n) { return n <= 0 ? 0 : 64 - __clzll((unsigned long long)n); }   // 0..63
+__device__ __forceinline__ int size_class(int64_t n)
+{
+	if (n <= 0) return 0;
+	const int msb = 63 - __clzll((unsigned long long)n);                      // 0..62
+	const int frac = msb >= 3 ? (int)((n >> (msb - 3)) & 7) : (int)((n << (3 - msb)) & 7);
+	return min(N_SIZE_CLASSES - 1, 1 + msb * 8 + frac);
+}
 
 __global__ __launch_bounds__(256) void k_post_size_count(PostBatch b)
 {
@@ -366,14 +374,20 @@ __global__ __launch_bounds__(256) void k_post_size_count(PostBatch b)
 	if (r < b.n_reads) atomicAdd(&b.size_bins[size_class(b.offsets[r + 1] - b.offsets[r])], 1);
 }
 
+// counts -> first slot of every class (largest class first), one wave
+__global__ __launch_bounds__(64) void k_post_size_bases(PostBatch b)
+{
+	if (threadIdx.x != 0) return;
+	int acc = 0;
+	for (int k = N_SIZE_CLASSES - 1; k >= 0; --k) { const int c = b.size_bins[k]; b.size_bins[N_SIZE_CLASSES + k] = acc; acc += c; }
+}
+
 __global__ __launch_bounds__(256) void k_post_size_scatter(PostBatch b)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= b.n_reads) return;
 	const int c = size_class(b.offsets[r + 1] - b.offsets[r]);
-	int base = 0;
-	for (int k = 63; k > c; --k) base += b.size_bins[k];
-	b.order[base + atomicAdd(&b.size_bins[64 + c], 1)] = (int)r;
+	b.order[atomicAdd(&b.size_bins[N_SIZE_CLASSES + c], 1)] = (int)r;
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -394,66 +408,49 @@ __global__ __launch_bounds__(256) void k_post_lift(PostBatch b, int level)
 // --------------------------------------------------------------------------------------------------------------
 // per read: candidates, host order, chain walks (lchain.c:27-76)
 // --------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
+namespace {
+
+struct WalkDbg { long long load = 0, longt = 0, groups = 0, open = 0, nlong = 0; };
+
+// The chain walks of one read (lchain.c:44-74) over its sorted candidates z[0, n_z): one wave.
+__device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t off, const int n_z, const unsigned long long *z, const int32_t *f, const int32_t *p,
+                                               uint8_t *mark, int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd)
 {
-	__shared__ PassLds lds[POST_THREADS / W];
-	PassLds &L = lds[threadIdx.x / W];
 	const int l = lane();
-	const int mc = b.min_cnt > 1 ? b.min_cnt : 1;
-	for (;;) {
-		int r = 0;
-		if (l == 0) r = atomicAdd(b.cursor, 1);
-		r = uni(r);
-		if (r >= b.n_reads) break;
-		r = uni(b.order[r]);
-		const int64_t off = b.offsets[r];
-		const int n = (int)(b.offsets[r + 1] - off);
-		const int32_t *f = b.f + off, *p = b.p + off;
-		unsigned long long *z = b.z + off;
-		uint8_t *mark = b.mark + off;
-		int32_t *picked = b.picked + off;
-		unsigned long long *u_tmp = b.u_tmp + chain_slot(off, r, mc);
-		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-		// candidates in index order (lchain.c:35-41) and cleared marks (lchain.c:43)
-		int n_z = 0;
-		for (int base = 0; base < n; base += W) {
-			const int i = base + l;
-			const bool in = i < n;
-			const int fi = in ? f[i] : INT_MIN;
-			if (in) mark[i] = 0;
-			const bool take = in && fi >= b.min_sc;
-			const unsigned long long m = __ballot(take);
-			if (take) z[n_z + __popcll(m & ((1ull << l) - 1))] = (unsigned long long)(unsigned)fi << 32 | (unsigned)i;
-			n_z += __popcll(m);
-		}
-		wave_sync();
-		const long long t1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-		sort_like_host<ZElem>(z, n_z, L, b.dbg);
-		const long long t2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-		// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
-		// A walk (mg_chain_bk_end, lchain.c:9-25: back from the chain end until an anchor that is taken, the start of the path, or an
-		// X-drop of more than max_drop below the best prefix) is a chain of dependent loads, one memory round trip per anchor, and
-		// walks depend on each other through the marks.  Candidates are handled 64 at a time, in the host's order.
-		const int32_t *up4 = b.up4 + off, *up16 = b.up16 + off;
-		int n_u = 0, n_v = 0;
-		long long dbg_load = 0, dbg_longt = 0, dbg_groups = 0, dbg_open = 0, dbg_long = 0;
-		for (int kb = n_z - 1; kb >= 0; kb -= W) {
-			const int k_l = kb - l;
-			const unsigned long long z_l = k_l >= 0 ? z[k_l] : 0;
-			const int n0 = (int)(unsigned)z_l, top_l = (int)(z_l >> 32);
-			unsigned long long pending = __ballot(k_l >= 0);
-			while (pending) {
-				// Every pending candidate that is still free takes the first SPEC steps of its own walk, all lanes at once: SPEC + 1 memory
-				// round trips for the group instead of for each candidate.  Scores and links never change; marks only ever get set, which
-				// can only end a walk earlier -- so a lane may stop loading where its walk would end with the marks it sees now.
-				wave_sync();
-				const long long ta = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-				int m0 = 1, nx[SPEC], sx[SPEC], mx[SPEC];
-				int own_kept = 0, own_best = 0, own_ended = 0, touched = 0;   // the lane's own walk as far as it can tell now
+	long long &dbg_load = wd.load, &dbg_longt = wd.longt, &dbg_groups = wd.groups, &dbg_open = wd.open, &dbg_long = wd.nlong;
+	// best-scoring end first; every anchor walked is consumed even if its chain is dropped (lchain.c:59-71)
+	// A walk (mg_chain_bk_end, lchain.c:9-25: back from the chain end until an anchor that is taken, the start of the path, or an
+	// X-drop of more than max_drop below the best prefix) is a chain of dependent loads, one memory round trip per anchor, and
+	// walks depend on each other through the marks.  Candidates are handled 64 at a time, in the host's order.
+	const int32_t *up4 = b.up4 + off, *up16 = b.up16 + off;
+	int n_u = 0, n_v = 0;
+	for (int kb = n_z - 1; kb >= 0; kb -= W) {
+		const int k_l = kb - l;
+		const unsigned long long z_l = k_l >= 0 ? z[k_l] : 0;
+		const int n0 = (int)(unsigned)z_l, top_l = (int)(z_l >> 32);
+		unsigned long long pending = __ballot(k_l >= 0);
+		int nx[SPEC], sx[SPEC];                                 // the group's look-ahead: anchors SPEC steps down every candidate's path, and their score drops
+		bool fresh = true;
+		while (pending) {
+			// Every pending candidate that is still free takes the first SPEC steps of its own walk, all lanes at once: SPEC + 1 memory
+			// round trips for the group instead of for each candidate.  Scores and links never change; marks only ever get set, which
+			// can only end a walk earlier -- so a lane may stop loading where its walk would end with the marks it sees now.
+			// After a long walk of the group the lanes that are left look again: the paths are the same, only marks can have
+			// changed (a walk can only END earlier than it did), so the second look reads the marks of the anchors it already
+			// knows -- one round trip of independent loads instead of SPEC + 1 dependent ones.
+			wave_sync();
+			const long long ta = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+			int m0 = 1, mx[SPEC];
+			int own_kept = 0, own_best = 0, own_ended = 0, touched = 0;   // the lane's own walk as far as it can tell now
 #pragma unroll
-				for (int j = 0; j < SPEC; ++j) { nx[j] = -1; sx[j] = top_l; mx[j] = 1; }
-				if ((pending >> l) & 1) {
-					m0 = mark[n0];
+			for (int j = 0; j < SPEC; ++j) mx[j] = 1;
+			if (fresh) {
+#pragma unroll
+				for (int j = 0; j < SPEC; ++j) { nx[j] = -1; sx[j] = top_l; }
+			}
+			if ((pending >> l) & 1) {
+				m0 = mark[n0];
+				if (fresh) {
 					int pc = p[n0];
 					if (m0 == 0) {
 						int cur = n0, best = 0, kept = 0;
@@ -472,123 +469,285 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 						}
 						own_kept = kept; own_best = best; own_ended = ended;
 					}
+				} else {
+#pragma unroll
+					for (int j = 0; j < SPEC; ++j) if (nx[j] >= 0) mx[j] = mark[nx[j]];
+					if (m0 == 0) {
+						int best = 0, kept = 0;
+						bool ended = false;
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							if (!ended) {
+								if (sx[j] > best) { best = sx[j]; kept = j + 1; }
+								else if (best - sx[j] > b.max_drop) ended = true;
+								if (mx[j] != 0) ended = true;
+							}
+						}
+						own_kept = kept; own_best = best; own_ended = ended;
+					}
 				}
-				// The candidates in order, on wave-uniform copies of their lane's values -- no memory round trip for a walk that ends
-				// within SPEC steps.  What an earlier walk of the group takes is set in the later lanes' copies of the marks.
-				unsigned long long open = __ballot(m0 == 0);
-				bool stale = false;
-				if (b.dbg) { dbg_load += (long long)__builtin_amdgcn_s_memrealtime() - ta; ++dbg_groups; dbg_open += __popcll(open); }
-				while (open != 0 && !stale) {
-					const int src = first_set(open);                 // lowest lane = highest k
-					open &= open - 1;
-					if (__builtin_amdgcn_readlane(m0, src) != 0) continue;   // taken by an earlier walk of this group
-					const int c0 = __builtin_amdgcn_readlane(n0, src);
-					if (__builtin_amdgcn_readlane(own_ended, src) != 0 && __builtin_amdgcn_readlane(touched, src) == 0) {
-						// no earlier walk of the group took any anchor this lane looked at: its own evaluation stands (most candidates:
-						// one or two anchors, then an anchor that was taken long ago)
-						const int kept = __builtin_amdgcn_readlane(own_kept, src), best = __builtin_amdgcn_readlane(own_best, src);
-#pragma unroll
-						for (int j = 0; j < SPEC; ++j) {
-							if (j < kept) {
-								const int v = j == 0 ? c0 : __builtin_amdgcn_readlane(nx[j > 0 ? j - 1 : 0], src);
-								if (l == 0) { picked[n_v + j] = v; mark[v] = 1; }
-								const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
-								touched |= hit;
-								m0 |= n0 == v;
-#pragma unroll
-								for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
-							}
-						}
-						if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
-							if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
-							++n_u; n_v += kept;
-						}
-						continue;
-					}
-					const int top = __builtin_amdgcn_readlane(top_l, src);
-					int cn[SPEC], cs[SPEC], cm[SPEC];
+			}
+			fresh = false;
+			// The candidates in order, on wave-uniform copies of their lane's values -- no memory round trip for a walk that ends
+			// within SPEC steps.  What an earlier walk of the group takes is set in the later lanes' copies of the marks.
+			unsigned long long open = __ballot(m0 == 0);
+			bool stale = false;
+			if (b.dbg) { dbg_load += (long long)__builtin_amdgcn_s_memrealtime() - ta; ++dbg_groups; dbg_open += __popcll(open); }
+			while (open != 0 && !stale) {
+				const int src = first_set(open);                 // lowest lane = highest k
+				open &= open - 1;
+				if (__builtin_amdgcn_readlane(m0, src) != 0) continue;   // taken by an earlier walk of this group
+				const int c0 = __builtin_amdgcn_readlane(n0, src);
+				if (__builtin_amdgcn_readlane(own_ended, src) != 0 && __builtin_amdgcn_readlane(touched, src) == 0) {
+					// no earlier walk of the group took any anchor this lane looked at: its own evaluation stands (most candidates:
+					// one or two anchors, then an anchor that was taken long ago)
+					const int kept = __builtin_amdgcn_readlane(own_kept, src), best = __builtin_amdgcn_readlane(own_best, src);
 #pragma unroll
 					for (int j = 0; j < SPEC; ++j) {
-						cn[j] = __builtin_amdgcn_readlane(nx[j], src); cs[j] = __builtin_amdgcn_readlane(sx[j], src); cm[j] = __builtin_amdgcn_readlane(mx[j], src);
-					}
-					// `kept` is how many of the visited anchors lie before the one the best prefix stops at
-					int cur = c0, kept = 0, visited = 0, best = 0;
-					bool ended = false;
+						if (j < kept) {
+							const int v = j == 0 ? c0 : __builtin_amdgcn_readlane(nx[j > 0 ? j - 1 : 0], src);
+							if (l == 0) { picked[n_v + j] = v; mark[v] = 1; }
+							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
+							touched |= hit;
+							m0 |= n0 == v;
 #pragma unroll
-					for (int j = 0; j < SPEC; ++j) {
-						if (!ended) {
-							if (l == 0) picked[n_v + visited] = cur;
-							++visited;
-							if (cs[j] > best) { best = cs[j]; kept = visited; }
-							else if (best - cs[j] > b.max_drop) ended = true;
-							if (cm[j] != 0) ended = true;
-							cur = cn[j];
+							for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
 						}
 					}
-					if (ended) {
-						// at most SPEC anchors taken: marked from the registers, and noted in the lanes that come later
-#pragma unroll
-						for (int j = 0; j < SPEC; ++j) {
-							if (j < kept) {
-								const int v = j == 0 ? c0 : cn[j - 1];
-								if (l == 0) mark[v] = 1;
-								const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
-								touched |= hit;
-								m0 |= n0 == v;
-#pragma unroll
-								for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
-							}
-						}
-					} else {
-						// a walk that goes on: 64 anchors at a time, lane j finds the j-th anchor down the path through the lifting tables
-						// (p, p^4, p^16: at most 9 dependent loads instead of j); what the sequential loop decides step by step -- the running
-						// best prefix, the first step that ends the walk -- becomes a prefix maximum and a ballot over the wave.  It may take
-						// anchors the other lanes have looked at: they look again afterwards.
-						stale = true;
-						wave_sync();
-						const long long tl = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-						++dbg_long;
-						while (!ended) {
-							int t = cur;
-							for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
-							for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
-							for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = p[t]; t = rj ? t - rj : -1; }
-							const bool valid = t >= 0;
-							const int pt = valid ? p[t] : 0, next = pt ? t - pt : -1;
-							int s = top, m = 1;
-							if (next >= 0) { s = top - f[next]; m = mark[next]; }
-							// best prefix BEFORE this lane's step
-							int inc = valid ? s : INT_MIN;
-							for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
-							int before = __shfl_up(inc, 1);
-							before = l == 0 ? best : max(best, before);
-							const bool newmax = valid && s > before;
-							const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
-							const unsigned long long endm = __ballot(ends);
-							const int jb = endm ? first_set(endm) : W;             // the step that ends the walk (all of it is still taken)
-							if (valid && l <= jb) picked[n_v + visited + l] = t;
-							const unsigned long long nm = __ballot(newmax && l <= jb);
-							if (nm) {
-								const int last = 63 - first_set_from_top(nm);
-								best = __shfl(s, last);
-								kept = visited + last + 1;
-							}
-							if (jb < W) { visited += jb + 1; ended = true; }
-							else { visited += W; cur = __shfl(next, W - 1); }
-						}
-						wave_sync();
-						for (int q = l; q < kept; q += W) mark[picked[n_v + q]] = 1;
-						if (b.dbg) dbg_longt += (long long)__builtin_amdgcn_s_memrealtime() - tl;
-					}
-					// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
 					if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
 						if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
 						++n_u; n_v += kept;
 					}
+					continue;
 				}
-				pending = stale ? open : 0;
+				const int top = __builtin_amdgcn_readlane(top_l, src);
+				int cn[SPEC], cs[SPEC], cm[SPEC];
+#pragma unroll
+				for (int j = 0; j < SPEC; ++j) {
+					cn[j] = __builtin_amdgcn_readlane(nx[j], src); cs[j] = __builtin_amdgcn_readlane(sx[j], src); cm[j] = __builtin_amdgcn_readlane(mx[j], src);
+				}
+				// `kept` is how many of the visited anchors lie before the one the best prefix stops at
+				int cur = c0, kept = 0, visited = 0, best = 0;
+				bool ended = false;
+#pragma unroll
+				for (int j = 0; j < SPEC; ++j) {
+					if (!ended) {
+						if (l == 0) picked[n_v + visited] = cur;
+						++visited;
+						if (cs[j] > best) { best = cs[j]; kept = visited; }
+						else if (best - cs[j] > b.max_drop) ended = true;
+						if (cm[j] != 0) ended = true;
+						cur = cn[j];
+					}
+				}
+				if (ended) {
+					// at most SPEC anchors taken: marked from the registers, and noted in the lanes that come later
+#pragma unroll
+					for (int j = 0; j < SPEC; ++j) {
+						if (j < kept) {
+							const int v = j == 0 ? c0 : cn[j - 1];
+							if (l == 0) mark[v] = 1;
+							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
+							touched |= hit;
+							m0 |= n0 == v;
+#pragma unroll
+							for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
+						}
+					}
+				} else {
+					// a walk that goes on: 64 anchors at a time, lane j finds the j-th anchor down the path through the lifting tables
+					// (p, p^4, p^16: at most 9 dependent loads instead of j); what the sequential loop decides step by step -- the running
+					// best prefix, the first step that ends the walk -- becomes a prefix maximum and a ballot over the wave.  It may take
+					// anchors the other lanes have looked at: they look again afterwards.
+					stale = true;
+					wave_sync();
+					const long long tl = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+					++dbg_long;
+					while (!ended) {
+						int t = cur;
+						for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
+						for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
+						for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = p[t]; t = rj ? t - rj : -1; }
+						const bool valid = t >= 0;
+						const int pt = valid ? p[t] : 0, next = pt ? t - pt : -1;
+						int s = top, m = 1;
+						if (next >= 0) { s = top - f[next]; m = mark[next]; }
+						// best prefix BEFORE this lane's step
+						int inc = valid ? s : INT_MIN;
+						for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
+						int before = __shfl_up(inc, 1);
+						before = l == 0 ? best : max(best, before);
+						const bool newmax = valid && s > before;
+						const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
+						const unsigned long long endm = __ballot(ends);
+						const int jb = endm ? first_set(endm) : W;             // the step that ends the walk (all of it is still taken)
+						if (valid && l <= jb) picked[n_v + visited + l] = t;
+						const unsigned long long nm = __ballot(newmax && l <= jb);
+						if (nm) {
+							const int last = 63 - first_set_from_top(nm);
+							best = __shfl(s, last);
+							kept = visited + last + 1;
+						}
+						if (jb < W) { visited += jb + 1; ended = true; }
+						else { visited += W; cur = __shfl(next, W - 1); }
+					}
+					wave_sync();
+					for (int q = l; q < kept; q += W) mark[picked[n_v + q]] = 1;
+					if (b.dbg) dbg_longt += (long long)__builtin_amdgcn_s_memrealtime() - tl;
+				}
+				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
+				if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
+					if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
+					++n_u; n_v += kept;
+				}
 			}
+			pending = stale ? open : 0;
 		}
+	}
+	n_u_out = n_u; n_v_out = n_v;
+}
+
+// candidates of anchors [i_lo, i_hi) of a read, in index order (lchain.c:35-41), appended at z[at...]; marks cleared (lchain.c:43).
+// Returns how many; any / all: OR and AND of their keys (which key bytes differ at all).
+__device__ __forceinline__ int post_collect(const PostBatch &b, const int32_t *f, uint8_t *mark, unsigned long long *z, int i_lo, int i_hi, int at, bool write,
+                                            unsigned &any, unsigned &all)
+{
+	const int l = lane();
+	int n_z = 0;
+	for (int base = i_lo; base < i_hi; base += W) {
+		const int i = base + l;
+		const bool in = i < i_hi;
+		const int fi = in ? f[i] : INT_MIN;
+		if (in && write) mark[i] = 0;
+		const bool take = in && fi >= b.min_sc;
+		const unsigned long long m = __ballot(take);
+		if (take) { any |= (unsigned)fi; all &= (unsigned)fi; }
+		if (take && write) z[at + n_z + __popcll(m & ((1ull << l) - 1))] = (unsigned long long)(unsigned)fi << 32 | (unsigned)i;
+		n_z += __popcll(m);
+	}
+	return n_z;
+}
+
+} // namespace
+
+// One wave per read, except at the very start of the launch: reads come largest first, and the kernel ends with the largest ones -- a
+// read is one wave's serial work (the sort's cycle walks, the chain walks), ~0.45 us per anchor, while most of the chip has long run out of
+// reads.  So the FIRST read a workgroup takes (the `team_reads` largest of the batch) is shared by its four waves as far as the
+// reference's algorithm allows: candidates are collected by all four (each a quarter of the anchors), the top radix pass -- one token walk
+// through 256 bucket heads, inherently serial (ksort.h:116-146) -- is wave 0's, and its buckets, which the host sorts independently of each
+// other (rs_sort's recursion, ksort.h:140-145), are dealt to the four waves, largest first.  The chain walks are wave 0's again (they
+// depend on each other through the marks); the other three waves go on to reads of their own.
+__global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b, int team_reads)
+{
+	__shared__ PassLds lds[POST_THREADS / W];
+	__shared__ int s_team[8];                                // [0] the team's read (position in the order), [1..4] candidates per wave, [5] next task
+	__shared__ unsigned s_bits[2 * (POST_THREADS / W)];      // per wave: OR / AND of its candidates' keys
+	__shared__ int s_bound[257];                             // ends of the top pass's buckets
+	__shared__ int s_task[256];                              // buckets worth a task, largest first
+	PassLds &L = lds[threadIdx.x / W];
+	const int l = lane(), w = uni(threadIdx.x / W);
+	const int mc = b.min_cnt > 1 ? b.min_cnt : 1;
+	// ---- the team's read ----
+	bool walker = false;                                     // wave 0 of a team: sorted candidates wait for its walks
+	int team_r = -1, team_nz = 0, solo_q = -1;
+	if (team_reads > 0) {
+		if (threadIdx.x == 0) s_team[0] = atomicAdd(b.cursor, 1);
+		__syncthreads();
+		const int q = uni(s_team[0]);
+		if (q < team_reads && q < b.n_reads) {
+			const int r = uni(b.order[q]);
+			const int64_t off = b.offsets[r];
+			const int n = (int)(b.offsets[r + 1] - off);
+			const int32_t *f = b.f + off;
+			unsigned long long *z = b.z + off;
+			uint8_t *mark = b.mark + off;
+			// candidates: every wave a quarter of the anchors (whole groups of 64), counted first, then written behind the earlier quarters'
+			const int per = ((n + 4 * W - 1) / (4 * W)) * W;
+			const int i_lo = min(n, w * per), i_hi = min(n, (w + 1) * per);
+			unsigned any = 0, all = ~0u;
+			const int mine = post_collect(b, f, mark, z, i_lo, i_hi, 0, false, any, all);
+			for (int o = W / 2; o > 0; o >>= 1) { any |= __shfl_xor(any, o); all &= __shfl_xor(all, o); }
+			if (l == 0) { s_team[1 + w] = mine; s_bits[2 * w] = any; s_bits[2 * w + 1] = all; }
+			__syncthreads();
+			int at = 0, n_z = 0;
+			for (int k = 0; k < POST_THREADS / W; ++k) { const int c = uni(s_team[1 + k]); if (k < w) at += c; n_z += c; any |= s_bits[2 * k]; all &= s_bits[2 * k + 1]; }
+			{ unsigned a2 = 0, b2 = ~0u; post_collect(b, f, mark, z, i_lo, i_hi, at, true, a2, b2); }
+			__threadfence_block();
+			__syncthreads();
+			// the top pass: the highest key byte in which any two candidates differ (sort_like_host), wave 0 alone
+			const unsigned diff = uni((int)(any ^ all));
+			int n_tasks = 0;
+			if (n_z > SMALL_RUN && diff != 0) {
+				int top = 24;                                      // of the key = the score: byte 3 .. 0 (sort_like_host's `top`)
+				while (top > 0 && ((diff >> top) & 255u) == 0) top -= 8;
+				if (w == 0) {
+					radix_pass<ZElem>(z, 0, n_z, top, L, b.dbg ? b.dbg + 24 : nullptr);
+					for (int k = l; k < 256; k += W) s_bound[k + 1] = L.tail[k];
+					if (l == 0) s_bound[0] = 0;
+					wave_sync();
+					// buckets of more than one element are tasks, largest first (a few hold nearly everything: the scores of a read span two
+					// to four values of the top byte): rank of every bucket by (size, number), all 256 against all 256
+					int sz[4], rank[4] = { 0, 0, 0, 0 }, tasks = 0;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { sz[q] = s_bound[4 * l + q + 1] - s_bound[4 * l + q]; tasks += sz[q] > 1; }
+					for (int k = 0; k < 256; ++k) {
+						const int other = uni(s_bound[k + 1]) - uni(s_bound[k]);
+#pragma unroll
+						for (int q = 0; q < 4; ++q) rank[q] += (other > sz[q]) | ((other == sz[q]) & (k < 4 * l + q));
+					}
+#pragma unroll
+					for (int q = 0; q < 4; ++q) s_task[rank[q]] = 4 * l + q;
+					for (int o = W / 2; o > 0; o >>= 1) tasks += __shfl_xor(tasks, o);
+					if (l == 0) { s_team[6] = tasks; s_team[5] = 0; }
+				}
+				__threadfence_block();
+				__syncthreads();
+				n_tasks = uni(s_team[6]);
+				for (;;) {
+					int t = 0;
+					if (l == 0) t = atomicAdd(&s_team[5], 1);
+					t = uni(t);
+					if (t >= n_tasks) break;
+					const int k = uni(s_task[t]);
+					const int lo = uni(s_bound[k]), hi = uni(s_bound[k + 1]);
+					sort_like_host<ZElem>(z + lo, hi - lo, L, b.dbg);
+				}
+				__threadfence_block();
+				__syncthreads();
+			} else if (w == 0) sort_like_host<ZElem>(z, n_z, L, b.dbg);
+			if (w == 0) { walker = true; team_r = r; team_nz = n_z; }
+		} else if (w == 0) solo_q = q;                       // not a team read (any more): wave 0's first read, on its own
+	}
+	for (bool first = true;; first = false) {
+		int r = 0, n_z = 0;
+		const bool team = first && walker;
+		if (team) { r = team_r; n_z = team_nz; }
+		else {
+			if (first && solo_q >= 0) r = solo_q;
+			else { if (l == 0) r = atomicAdd(b.cursor, 1); r = uni(r); }
+			if (r >= b.n_reads) break;
+			r = uni(b.order[r]);
+		}
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const int32_t *f = b.f + off, *p = b.p + off;
+		unsigned long long *z = b.z + off;
+		uint8_t *mark = b.mark + off;
+		int32_t *picked = b.picked + off;
+		unsigned long long *u_tmp = b.u_tmp + chain_slot(off, r, mc);
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		long long t1 = t0, t2 = t0;
+		if (!team) {
+			unsigned any = 0, all = ~0u;
+			n_z = post_collect(b, f, mark, z, 0, n, 0, true, any, all);
+			wave_sync();
+			t1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+			sort_like_host<ZElem>(z, n_z, L, b.dbg);
+			t2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		}
+		int n_u = 0, n_v = 0;
+		WalkDbg wd;
+		post_walk_read(b, off, n_z, z, f, p, mark, picked, u_tmp, n_u, n_v, wd);
 		wave_sync();
 		if (l == 0) {
 			b.n_u[r] = n_u;
@@ -601,11 +760,11 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b)
 				atomicMax((unsigned long long*)&b.dbg[4], (unsigned long long)(t2 - t1));
 				atomicMax((unsigned long long*)&b.dbg[5], (unsigned long long)(t3 - t2));
 				atomicMax((unsigned long long*)&b.dbg[6], (unsigned long long)(t3 - t0));
-				atomicAdd((unsigned long long*)&b.dbg[7], (unsigned long long)dbg_load);
-				atomicAdd((unsigned long long*)&b.dbg[8], (unsigned long long)dbg_longt);
-				atomicAdd((unsigned long long*)&b.dbg[9], (unsigned long long)dbg_groups);
-				atomicAdd((unsigned long long*)&b.dbg[10], (unsigned long long)dbg_open);
-				atomicAdd((unsigned long long*)&b.dbg[11], (unsigned long long)dbg_long);
+				atomicAdd((unsigned long long*)&b.dbg[7], (unsigned long long)wd.load);
+				atomicAdd((unsigned long long*)&b.dbg[8], (unsigned long long)wd.longt);
+				atomicAdd((unsigned long long*)&b.dbg[9], (unsigned long long)wd.groups);
+				atomicAdd((unsigned long long*)&b.dbg[10], (unsigned long long)wd.open);
+				atomicAdd((unsigned long long*)&b.dbg[11], (unsigned long long)wd.nlong);
 				atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z);
 			}
 		}
@@ -1091,11 +1250,23 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 						if (bb < b_hi) look = (bb >= B - RMQ_RING ? ring[w][bb & (RMQ_RING - 1)] : bound[bb]) > max_f;
 						unsigned long long m = __ballot(look);
 						while (m) {
-							const int s = first_set(m);
-							m &= m - 1;
-							++d_inner;
-							const int j = ((bb0 + s) << 6) + l;
-							if (j >= st_in && j < e_hi) { const uint4 e = a[j]; offer(true, e.x, (int)e.z, (int)(e.w & 0xffu), f[j], j); }
+							// up to four blocks at a time: their loads are issued together (one round trip), then scored
+							int jj[4];
+							uint4 ee[4];
+							int ff[4];
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {
+								jj[u] = -1;
+								if (m) { jj[u] = ((bb0 + first_set(m)) << 6) + l; m &= m - 1; ++d_inner; }
+							}
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {
+								const bool in = jj[u] >= st_in && jj[u] < e_hi;        // (jj = -1: no block)
+								ee[u] = in ? a[jj[u]] : make_uint4(0, 0, 0, 0);
+								ff[u] = in ? f[jj[u]] : 0;
+							}
+#pragma unroll
+							for (int u = 0; u < 4; ++u) offer(jj[u] >= st_in && jj[u] < e_hi, ee[u].x, (int)ee[u].z, (int)(ee[u].w & 0xffu), ff[u], jj[u]);
 						}
 					}
 				}
@@ -1380,16 +1551,18 @@ void launch_post(const PostBatch &b, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;
 	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
-	(void)hipMemsetAsync(b.size_bins, 0, 128 * sizeof(int32_t), s);
+	(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
 	const unsigned rgrid = (unsigned)((b.n_reads + 255) / 256);
 	hipLaunchKernelGGL(k_post_size_count, dim3(rgrid), dim3(256), 0, s, b);
+	hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b);
 	hipLaunchKernelGGL(k_post_size_scatter, dim3(rgrid), dim3(256), 0, s, b);
 	const int64_t waves = (int64_t)b.grid_waves;
-	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
+	unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
+	if (b.team_reads > 0) grid = (unsigned)std::max<int64_t>(grid, std::min<int64_t>(b.team_reads, (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));   // a workgroup per team read
 	const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n + 255) / 256, 256 * 64));
 	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0);
 	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1);
-	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b);
+	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads);
 	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b);
 	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);
 }

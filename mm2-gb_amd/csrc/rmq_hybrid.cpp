@@ -48,8 +48,12 @@ ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n
 		s_out += (double)((w_out + 4095) / 4096) * STRIDE;
 	}
 	ReadCost c;
-	c.dev = 2.5e-6 * (double)n + 0.26e-6 * (s_in + s_out);
-	c.host = 0.45e-6 * (double)n + 0.012e-6 * s_in * 64.0 / 8.0;     // the host's inner scan visits the candidates of one y-range, not the window
+	// measured (profiles/r03c_*): the kernel's estimate summed to 20.3 s where the call took 30.4 s, and 0.136 s for 0.246 s on reads
+	// with narrow windows: the rates below are the first guesses times 1.6.  The host form took 0.40 us per anchor of reads with
+	// narrow windows, 0.59 us on the mapper's reads, 0.9 us on a read inside a tandem array (its inner scan visits the candidates
+	// of one y-range, not the window: a few hundred at worst).
+	c.dev = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);
+	c.host = (double)n * (0.40e-6 + 0.5e-6 * std::min(1.0, s_in / ((double)std::max<int64_t>(n, 1) * 100.0)));
 	return c;
 }
 

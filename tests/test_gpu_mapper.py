@@ -96,3 +96,21 @@ def test_reads_sharded_over_several_engines(engine, tmp_path):
         paf, st = mm.map_reads_multi([engine, e2, e3], ix, [n for n, _ in refs], rd, opt=mm.map_opt(host_threads=12))
     assert paf == open(os.path.join(GOLD, "sim160_inf.paf")).read()
     assert st["n_reads"] == meta["n_reads"]
+
+
+def test_a_run_as_a_stream_of_chunks(engine, tmp_path):
+    """mm2gb_map_reads_stream: the run cut into chunks of ~600 kb of reads (about 15 of them), three engines on the one GPU taking chunks as
+    they become free -- one chunk's host stages overlap another's kernels (role of worker_for's batch rotation,
+    map.c:924-1153).  Same PAF as one batch, in read order; counts add up."""
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    refs, rd = read_fasta(ref), read_fasta(reads)
+    want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
+    with mm.SeedIndex([s for _, s in refs]) as ix, mm.Engine() as e2, mm.Engine() as e3:
+        paf, st = mm.map_reads_stream([engine, e2, e3], ix, [n for n, _ in refs], rd, opt=mm.map_opt(host_threads=12), chunk_bases=600_000)
+        assert paf == want
+        assert st["n_reads"] == meta["n_reads"] and st["n_rechained"] >= 100
+        paf1, _ = mm.map_reads_stream([engine], ix, [n for n, _ in refs], rd, opt=mm.map_opt(host_threads=8), chunk_bases=10**12)   # one chunk, one engine
+        assert paf1 == want
+        assert mm.map_reads_stream([engine, e2], ix, [n for n, _ in refs], [])[0] == ""
