@@ -294,6 +294,8 @@ typedef struct {
 mm2gb_batcher_t *mm2gb_batcher_create(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int n_devices, const int *devices,
                                       int post_threads, mm2gb_read_done_fn done, void *user);
 int  mm2gb_batcher_add(mm2gb_batcher_t *b, int64_t read_id, const mm2gb_anchor_t *a, int64_t n);
+/* the reads of a packed batch added one at a time by n_producers threads of the library (read r gets the id first_id + r) */
+int  mm2gb_batcher_feed(mm2gb_batcher_t *b, int64_t n_reads, int64_t first_id, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_producers);
 int  mm2gb_batcher_flush(mm2gb_batcher_t *b);                     /* close the partial batches, wait until every read is delivered */
 int  mm2gb_batcher_stats(mm2gb_batcher_t *b, mm2gb_batcher_stats_t *out);
 void mm2gb_batcher_destroy(mm2gb_batcher_t *b);

@@ -82,7 +82,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
                 "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
-                "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
+                "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_feed", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
                 "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_rmq_chain_host", "mm2gb_rmq_chain", "mm2gb_has_split_build", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi", "mm2gb_map_reads_stream"]
@@ -219,6 +219,7 @@ class Engine:
         L = lib()
         self.misc = misc if misc is not None else default_misc()
         self.config = config if config is not None else default_config()
+        self.device = int(device)
         self._h = L.mm2gb_engine_create(C.byref(self.config), C.byref(self.misc), device)
         if not self._h:
             raise Mm2gbError(L.mm2gb_last_error().decode())
@@ -560,6 +561,14 @@ class Batcher:
     def add(self, read_id, anchors):
         a = np.ascontiguousarray(anchors, dtype=np.uint64)
         _check(lib().mm2gb_batcher_add(self._h, read_id, a.ctypes.data, len(a)))
+
+    def feed(self, first_id, anchors, offsets, producers=1):
+        """mm2gb_batcher_feed: the reads of a packed batch added one at a time by `producers` native threads (read r gets id first_id + r)."""
+        a = np.ascontiguousarray(anchors, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        L = lib()
+        L.mm2gb_batcher_feed.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        _check(L.mm2gb_batcher_feed(self._h, len(off) - 1, int(first_id), off.ctypes.data, a.ctypes.data, int(producers)))
 
     def flush(self):
         _check(lib().mm2gb_batcher_flush(self._h))

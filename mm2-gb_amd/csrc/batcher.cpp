@@ -240,6 +240,32 @@ int mm2gb_batcher_add(mm2gb_batcher_t *b, int64_t read_id, const mm2gb_anchor_t 
 	return 0;
 }
 
+// The reads of a packed batch (offsets[n_reads + 1] into anchors), added one at a time by n_producers threads that deal the reads among
+// themselves: what a multi-threaded host's seeding threads do, from one call (read r gets the id first_id + r).
+int mm2gb_batcher_feed(mm2gb_batcher_t *b, int64_t n_reads, int64_t first_id, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_producers)
+{
+	if (!b || n_reads < 0 || !offsets) return fail("mm2gb_batcher_feed: bad argument");
+	std::atomic<int64_t> next(0);
+	std::atomic<int> bad(0);
+	std::string why;
+	std::mutex why_lock;
+	auto work = [&]() {
+		for (;;) {
+			const int64_t r = next.fetch_add(1);
+			if (r >= n_reads || bad.load()) break;
+			if (mm2gb_batcher_add(b, first_id + r, anchors + offsets[r], offsets[r + 1] - offsets[r])) {
+				std::lock_guard<std::mutex> g(why_lock);
+				if (!bad.exchange(1)) why = mm2gb_last_error();
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < std::max(1, n_producers); ++t) pool.emplace_back(work);
+	work();
+	for (auto &th : pool) th.join();
+	return bad.load() ? fail(why) : 0;
+}
+
 int mm2gb_batcher_flush(mm2gb_batcher_t *b)
 {
 	if (!b) return fail("mm2gb_batcher_flush: null argument");

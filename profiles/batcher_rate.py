@@ -12,7 +12,7 @@ import bench, mm2gb_amd as mm
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=4000)
-ap.add_argument("--producers", type=int, nargs="+", default=[1, 4])
+ap.add_argument("--producers", type=int, nargs="+", default=[1, 4, 8])
 ap.add_argument("--engines", type=int, nargs="+", default=[1, 2])
 ap.add_argument("--max-total-n", type=int, default=40_000_000)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "batcher_rate.json"))
@@ -30,14 +30,9 @@ for post_threads, label in ((max(1, threads - 4), "host post-pass"), (0, "device
     for n_eng in args.engines:
         for prod in args.producers:
             with mm.Batcher(devices=[0] * n_eng, config=cfg, post_threads=post_threads, keep_results=False) as b:
-                def feed(k):
-                    for r in range(k, args.reads, prod):
-                        b.add(r, reads[r])
                 for rep in range(2):                              # the first round grows the page-locked batch buffers
                     t0 = time.perf_counter()
-                    th = [threading.Thread(target=feed, args=(k,)) for k in range(prod)]
-                    for t in th: t.start()
-                    for t in th: t.join()
+                    b.feed(0, a, off, producers=prod)             # native producer threads (a Python loop would measure the interpreter)
                     t_fed = time.perf_counter() - t0
                     b.flush()
                     dt = time.perf_counter() - t0

@@ -74,3 +74,21 @@ def test_several_producer_threads_and_a_read_larger_than_the_limit():
         assert b.stats()["batches"][0] == 24
         for r in range(24):
             assert np.array_equal(b.results[r][0], want[r]["u"]) and np.array_equal(b.results[r][1], want[r]["a_out"]), f"read {r}"
+
+
+@pytest.mark.parametrize("post_threads", [2, 0], ids=["host-post-pass", "device-post-pass"])
+def test_native_producers_copy_side_by_side(post_threads):
+    """mm2gb_batcher_feed: six producer threads of the library add the reads of a packed batch one at a time; a read's place in the open
+    batch is reserved under the batcher's lock and the read is copied OUTSIDE it, batches close under the producers'
+    feet and their buffers grow while others copy.  Every read's chains equal the oracle's, twice over on the same batcher."""
+    a, off, want = reads_and_oracle(91, 60, 2_000, 30_000)
+    with mm.Batcher(devices=[0, 0], config=small_config(90_000, 7, 0), post_threads=post_threads) as b:
+        for rnd in range(2):
+            b.results.clear()
+            b.feed(1000 * rnd, a, off, producers=6)
+            b.flush()
+            assert len(b.results) == 60
+            for r in range(60):
+                u, ao = b.results[1000 * rnd + r]
+                assert np.array_equal(u, want[r]["u"]) and np.array_equal(ao, want[r]["a_out"]), f"round {rnd} read {r}"
+        assert b.stats()["reads"] == 120
