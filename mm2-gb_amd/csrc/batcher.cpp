@@ -10,6 +10,7 @@
 //   * closed batches are dealt to the devices' workers (one engine, one host thread each) as they become free; a worker chains
 //     its batch -- scores on the GPU, post-pass on host threads overlapped with the device, or (post_threads == 0) on the device
 //     too -- and hands every read's chains to the caller's callback.  Reads never move between devices: no collective.
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -45,12 +46,14 @@ struct Grouping {
 // Page-locked buffer that grows keeping its contents.
 struct GrowPinned {
 	void *ptr = nullptr;
-	size_t bytes = 0;
+	size_t bytes = 0, first = 0;                   // first: size of the first allocation
 	int reserve_keep(size_t need, size_t used)
 	{
 		if (need <= bytes) return 0;
-		size_t want = bytes ? bytes : ((size_t)1 << 20);
-		while (want < need) want += want / 2 + 4096;
+		// page-locking costs ~0.4 s per GB and a grown buffer is a new one: the first allocation is already `first` bytes (the batch limit, up to
+		// 256 MB), later ones double -- growing from 1 MB by halves re-pinned and re-copied a 640 MB batch sixteen times (1 s per batch)
+		size_t want = bytes ? bytes : std::max<size_t>(first, (size_t)1 << 20);
+		while (want < need) want += want;
 		void *fresh = nullptr;
 		if (hipHostMalloc(&fresh, want, hipHostMallocDefault) != hipSuccess) {
 			(void)hipGetLastError();
@@ -193,7 +196,11 @@ mm2gb_batcher_t *mm2gb_batcher_create(const mm2gb_config_t *cfg, const mm2gb_mis
 		b->engines.push_back(e);
 	}
 	// two batches per worker (one on the device, one being filled / waiting) and one per lane on top
-	for (int k = 0; k < 2 * n_devices + N_LANES; ++k) { b->all.emplace_back(new Batch()); b->free_list.push_back(b->all.back().get()); }
+	for (int k = 0; k < 2 * n_devices + N_LANES; ++k) {
+		b->all.emplace_back(new Batch());
+		b->all.back()->anchors.first = (size_t)std::min<int64_t>(b->rule.max_total_n > 0 ? b->rule.max_total_n : (int64_t)1 << 24, (int64_t)1 << 24) * 16;
+		b->free_list.push_back(b->all.back().get());
+	}
 	for (int k = 0; k < n_devices; ++k) b->workers.emplace_back([p = b.get(), k] { p->work(k); });
 	return b.release();
 }

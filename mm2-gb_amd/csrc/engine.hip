@@ -277,7 +277,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &reg_out,
+	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -549,6 +549,15 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		if (rmq_by_y.ensure(nn * 16) || rmq_ord.ensure(nn * 4) || rmq_meta.ensure(nn * 16) || rmq_sum.ensure(n_sum * 20)) return -1;
 		rb.by_y = (ulonglong2*)rmq_by_y.ptr; rb.ord_idx = (int32_t*)rmq_ord.ptr; rb.meta = (int4*)rmq_meta.ptr;
 		rb.l1 = (uint4*)rmq_sum.ptr; rb.bound = (int32_t*)((char*)rmq_sum.ptr + n_sum * 16);
+		rb.win = nullptr; rb.tree = nullptr;
+		{
+			// tile form (k_rmq_fill_tiles) unless MM2GB_RMQ_KERNEL=steps asks for the one-anchor-per-step kernel (A/B runs, tests)
+			const char *v = getenv("MM2GB_RMQ_KERNEL");
+			if (!(v && !strcmp(v, "steps"))) {
+				if (rmq_win.ensure(nn * 16) || rmq_tree.ensure(nn * 32)) return -1;
+				rb.win = (int4*)rmq_win.ptr; rb.tree = (uint4*)rmq_tree.ptr;
+			}
+		}
 		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;
 		rb.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1536) : nullptr;
 		if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1536, 0, 64, stream));
@@ -563,7 +572,8 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (rmq && debug_phases && n > 0) {
 		long long t[8] = { 0 };
 		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
-			fprintf(stderr, "[mm2gb rmq fill] %lld steps: late entries %lld, summaries rebuilt %lld, ties looked at %lld, summary loads %lld, inner blocks read %lld, winners read from memory %lld, eviction tests %lld\n",
+			fprintf(stderr, rmq_tree.ptr && !(getenv("MM2GB_RMQ_KERNEL") && !strcmp(getenv("MM2GB_RMQ_KERNEL"), "steps")) ? "[mm2gb rmq fill, tiles] %lld anchors: tiles %lld, tree leaves changed %lld, levels walked %lld, query rounds %lld, anchors broadcast %lld (%lld %lld)\n" :
+			        "[mm2gb rmq fill] %lld steps: late entries %lld, summaries rebuilt %lld, ties looked at %lld, summary loads %lld, inner blocks read %lld, winners read from memory %lld, eviction tests %lld\n",
 			        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
 	}
 	const int64_t n_u = n_reads > 0 ? h_post_totals[0] : 0, n_a = n_reads > 0 ? h_post_totals[1] : 0;

@@ -921,6 +921,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
 	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));   // row_ror:8
 	return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+__device__ __forceinline__ int wave_sum_i32(int v) { for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return (unsigned)wave_max_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
 __device__ __forceinline__ long long wave_max_i64(long long v)
 {
@@ -1301,6 +1302,266 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 }
 
 // --------------------------------------------------------------------------------------------------------------
+// RMQ re-chaining, tile form (round 3).  k_rmq_fill above takes one anchor per step: a chain of dependent memory round trips per
+// anchor (query the summaries, fetch the winner, scan the inner window), microseconds each.  Here a wave takes 64 consecutive anchors
+// per step -- a TILE, one anchor per lane -- the way the chaining DP does (chain_kernels.hip):
+//   * what every anchor of the tile may look at splits into (1) anchors that are settled for the whole tile -- in reach of every
+//     lane, evicted for none: index in [lo, hi), lo = the LAST lane's window start, hi = the first lane's i0 -- which live in a binary
+//     tournament tree over the read's (y, index) ranks in global memory (key = the negated priority of lchain.c:284, a node = the best
+//     key below it, its rank, "shared by several"): every lane asks it for the best key in its own rank interval, O(log n) INDEPENDENT
+//     loads, all 64 queries side by side; (2) the few anchors around the edges -- leaving the window during the tile, [st of lane 0,
+//     lo), or waiting to enter, [hi, tile start) -- and every anchor of the inner window (lchain.c:320-341 scores ALL of them): these
+//     are read 64 at a time, coalesced, and broadcast one by one to all lanes, each lane testing its own window, rank interval and
+//     query range; (3) the tile's own anchors, which depend on each other: 64 serial steps, all in registers -- lane t's result is
+//     final at step t and is broadcast to the lanes above it.
+//   * the tree is kept exact by batches: before a tile's queries, the leaves of the anchors that left [lo, hi) are emptied and those
+//     that entered are set, one leaf per lane, and the lanes walk up to the root together, each recomputing the nodes on its path from
+//     their children; a lane that is a level behind another on a common path rewrites it with final children, so the last write of
+//     every node is right.
+// Same definition of the result as k_rmq_fill and the oracle (orc_rmq_fill), incl. the stated tie rule and the count of tied anchors.
+// --------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ uint4 tnode_none() { return make_uint4(0u, 0x80000000u, 0u, 0u); }      // key = RMQ_NONE
+__device__ __forceinline__ long long tnode_key(const uint4 &e) { return (long long)((unsigned long long)e.y << 32 | e.x); }
+__device__ __forceinline__ uint4 tnode_comb(const uint4 &a, const uint4 &b)
+{
+	const long long ka = tnode_key(a), kb = tnode_key(b);
+	if (ka > kb) return a;
+	if (kb > ka) return b;
+	if (ka == RMQ_NONE) return a;                          // both empty
+	const unsigned ra = a.z & 0x7fffffffu, rb = b.z & 0x7fffffffu;
+	return make_uint4(a.x, a.y, (ra > rb ? ra : rb) | 0x80000000u, 0u);   // equal keys: the larger (y, index) rank, and "several share it"
+}
+
+// the best candidate of the outer query a lane has seen so far, with what scoring it needs (lchain.c:316-318)
+struct TileCand { long long key; int rank, tie, j; unsigned x; int y, span, f; };
+__device__ __forceinline__ void tile_offer(TileCand &c, bool in, long long key, int rank, int tie, int j, unsigned x, int y, int span, int f)
+{
+	if (!in) return;
+	if (key > c.key) { c.key = key; c.rank = rank; c.tie = tie; c.j = j; c.x = x; c.y = y; c.span = span; c.f = f; }
+	else if (key == c.key) {
+		c.tie = 1;
+		if (rank > c.rank) { c.rank = rank; c.j = j; c.x = x; c.y = y; c.span = span; c.f = f; }
+	}
+}
+// the best of the inner window (lchain.c:328-341 with max_chn_skip = infinity): largest score, then largest (y, index)
+struct TileInner { int s, y, j; };
+__device__ __forceinline__ void tile_offer_inner(TileInner &c, bool in, int s2, int yj, int j)
+{
+	if (!in) return;
+	if (c.j < 0 || s2 > c.s || (s2 == c.s && (yj > c.y || (yj == c.y && j > c.j)))) { c.s = s2; c.y = yj; c.j = j; }
+}
+
+} // namespace
+
+// per anchor: its window starts and the start of its run of equal x, closed forms of the carried values of lchain.c:279-310 (the
+// conditions of the eviction loops hold for a prefix of the anchors before i, so the loops end at the largest of the three bounds)
+__global__ __launch_bounds__(256) void k_rmq_prep_windows(RmqBatch b, int max_dist, int max_inner, int cap)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r = rmq_read_of(b.offsets, b.n_reads, g);
+		const int64_t off = b.offsets[r];
+		const uint4 *a = b.raw + off;
+		const int i = (int)(g - off);
+		const unsigned xl = a[i].x, xh = a[i].y;
+		// first index of the run of equal x that holds i (anchors are sorted by x)
+		int lo = 0, hi = i;
+		while (lo < hi) { const int mid = (lo + hi) >> 1; const uint2 v = *(const uint2*)&a[mid]; if (v.y < xh || (v.y == xh && v.x < xl)) lo = mid + 1; else hi = mid; }
+		const int i0 = lo;
+		auto first_in_reach = [&](int dist) {                 // first j <= i on the same strand | reference with x_i <= x_j + dist
+			int l2 = 0, h2 = i;
+			while (l2 < h2) {
+				const int mid = (l2 + h2) >> 1;
+				const uint2 v = *(const uint2*)&a[mid];
+				const bool in = v.y == xh && (unsigned long long)xl <= (unsigned long long)v.x + (unsigned)dist;
+				if (in) h2 = mid; else l2 = mid + 1;
+			}
+			return l2;
+		};
+		const int by_cap = i0 > cap ? i0 - cap : 0;
+		const int st = min(i, max(first_in_reach(max_dist), by_cap));
+		const int st_in = max_inner > 0 ? min(i, max(first_in_reach(max_inner), by_cap)) : i;
+		b.win[g] = make_int4(st, st_in, i0, 0);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_rmq_tree_init(RmqBatch b)
+{
+	const uint4 none = tnode_none();
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < 2 * b.n; g += (int64_t)gridDim.x * blockDim.x) b.tree[g] = none;
+}
+
+__global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqParams P)
+{
+	const int l = lane();
+	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
+	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;   // lchain.c:265
+	const double half_gap = 0.5 * (double)P.pen_gap;
+	for (;;) {
+		int r = 0;
+		if (l == 0) r = atomicAdd(b.cursor, 1);
+		r = uni(r);
+		if (r >= b.n_reads) break;
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const uint4 *a = b.raw + off;
+		const int4 *meta = b.meta + off, *win = b.win + off;
+		const int32_t *ord_idx = b.ord_idx + off;
+		int32_t *f = b.f + off, *p = b.p + off;
+		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
+		int ev = 0, ins = 0, tied = 0;                       // the tree holds the anchors of index [ev, ins)
+		long long d_tiles = 0, d_upd = 0, d_levels = 0, d_qloads = 0, d_bcast = 0;   // MM2GB_DEBUG_PHASES
+		for (int tb = 0; tb < n; tb += W) {
+			const int n_here = min(W, n - tb), i = tb + l;
+			const bool live = l < n_here;
+			const uint4 A = live ? a[i] : make_uint4(0, 0, 0, 0);
+			const int4 M = live ? meta[i] : make_int4(0, 1, 0, 0);             // rank, first and last rank of the query (dead lanes: empty)
+			const int4 Wn = live ? win[i] : make_int4(INT_MAX, INT_MAX, 0, 0);   // st, st_inner, i0 (dead lanes: nothing is in reach, nothing came before)
+			const unsigned xi = A.x;
+			const int yi = (int)A.z, q_i = (int)(A.w & 0xffu);
+			const int st_first = __builtin_amdgcn_readlane(Wn.x, 0), st_last = __builtin_amdgcn_readlane(Wn.x, n_here - 1);
+			const int stin_first = __builtin_amdgcn_readlane(Wn.y, 0);
+			const int hi = __builtin_amdgcn_readlane(Wn.z, 0);                   // every anchor before the first lane's run of equal x has entered for all lanes
+			const int lo = min(st_last, hi);                                       // ... and none from here on has left for any
+			++d_tiles;
+			// ---- the tree: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) ----
+			{
+				int e0 = ev, n0 = max(ins, lo);
+				const int e1 = min(lo, ins), n1 = hi;
+				while (e0 < e1 || n0 < n1) {
+					const int je = e0 + l, ji = n0 + l;
+					int pe = 0, pi = 0;
+					if (je < e1) { pe = n + meta[je].x; tree[pe] = tnode_none(); }
+					if (ji < n1) {
+						const uint4 e = a[ji];
+						const int rk = meta[ji].x;
+						const long long kk = key_order((double)f[ji] + half_gap * (double)((int)e.x + (int)e.z));
+						pi = n + rk;
+						tree[pi] = make_uint4((unsigned)kk, (unsigned)((unsigned long long)kk >> 32), (unsigned)rk, 0u);
+					}
+					d_upd += __popcll(__ballot(pe > 0)) + __popcll(__ballot(pi > 0));
+					wave_sync();
+					while (__ballot(pe > 1 || pi > 1) != 0) {
+						uint4 c0 = tnode_none(), c1 = c0, c2 = c0, c3 = c0;
+						if (pe > 1) { pe >>= 1; c0 = tree[2 * pe]; c1 = tree[2 * pe + 1]; } else pe = 0;
+						if (pi > 1) { pi >>= 1; c2 = tree[2 * pi]; c3 = tree[2 * pi + 1]; } else pi = 0;
+						if (pe > 0) tree[pe] = tnode_comb(c0, c1);
+						if (pi > 0 && pi != pe) tree[pi] = tnode_comb(c2, c3);
+						++d_levels;
+						wave_sync();
+					}
+					e0 += W; n0 += W;
+				}
+				ev = lo; ins = hi;
+			}
+			// ---- (1) every lane's query of the tree: the nodes that tile its rank interval, bottom up; the loads do not depend on each other ----
+			TileCand c;
+			c.key = RMQ_NONE; c.rank = -1; c.tie = 0; c.j = -1; c.x = 0; c.y = 0; c.span = 0; c.f = 0;
+			{
+				uint4 best = tnode_none();
+				int ql = n + M.y, qr = n + M.z + 1;                                // [ql, qr) over the leaves
+				bool go = live && M.y <= M.z && lo < hi;
+				while (__ballot(go && ql < qr) != 0) {
+					uint4 vl = tnode_none(), vr = vl;
+					if (go && ql < qr) {
+						if (ql & 1) vl = tree[ql++];
+						if (qr & 1) vr = tree[--qr];
+						ql >>= 1; qr >>= 1;
+					}
+					best = tnode_comb(best, tnode_comb(vl, vr));
+					++d_qloads;
+				}
+				if (tnode_key(best) != RMQ_NONE) {
+					const int rk = (int)(best.z & 0x7fffffffu);
+					const int j = ord_idx[rk];
+					const uint4 e = a[j];
+					c.key = tnode_key(best); c.rank = rk; c.tie = (int)(best.z >> 31); c.j = j; c.x = e.x; c.y = (int)e.z; c.span = (int)(e.w & 0xffu); c.f = f[j];
+				}
+			}
+			// ---- (2) anchors before the tile that are not in the tree for every lane, and the inner window: broadcast one by one ----
+			TileInner in;
+			in.s = 0; in.y = 0; in.j = -1;
+			const int y_top = yi - 1, y_bot = yi - max_inner;
+			auto sweep_range = [&](int from, int to, bool outer_all) {
+				// outer_all: every anchor of the range is outside the tree (it left the window for some lanes); else only those from hi on are
+				for (int base = from; base < to; base += W) {
+					const int j_l = base + l;
+					const bool have = j_l < to;
+					const uint4 e_l = have ? a[j_l] : make_uint4(0, 0, 0, 0);
+					const int f_l = have ? f[j_l] : 0, rk_l = have ? meta[j_l].x : 0;
+					const long long k_l = key_order((double)f_l + half_gap * (double)((int)e_l.x + (int)e_l.z));
+					const int cnt = min(W, to - base);
+					for (int k = 0; k < cnt; ++k) {
+						const int j = base + k;
+						const unsigned xj = (unsigned)__builtin_amdgcn_readlane((int)e_l.x, k);
+						const int yj = __builtin_amdgcn_readlane((int)e_l.z, k), sj = __builtin_amdgcn_readlane((int)e_l.w, k) & 0xff;
+						const int fj = __builtin_amdgcn_readlane(f_l, k), rkj = __builtin_amdgcn_readlane(rk_l, k);
+						const long long kj = (long long)readlane64((unsigned long long)k_l, k);
+						const bool before = j < Wn.z;                                    // strictly smaller x (lchain.c:279-292)
+						const bool out_ok = before && j >= Wn.x && (outer_all || j >= hi) && rkj >= M.y && rkj <= M.z;
+						tile_offer(c, out_ok, kj, rkj, 0, j, xj, yj, sj, fj);
+						if (max_inner > 0) {
+							const bool in_ok = before && j >= Wn.y && yj <= y_top && yj >= y_bot;
+							if (__ballot(in_ok) != 0) {
+								bool ex2; int w2;
+								const int s2 = fj + rmq_pair_score(xi, yi, xj, yj, sj, P, ex2, w2);
+								tile_offer_inner(in, in_ok && w2 <= P.bw, s2, yj, j);
+							}
+						}
+						++d_bcast;
+					}
+				}
+			};
+			sweep_range(st_first, lo, true);
+			sweep_range(max_inner > 0 ? max(min(stin_first, tb), lo) : max(hi, lo), tb, false);
+			// ---- (3) the tile's own anchors, one after the other ----
+			int f_l = q_i, p_l = 0;
+			long long k_l = 0;
+			for (int t = 0; t < n_here; ++t) {
+				// what lane t gets from its candidates as they stand (every lane computes; lane t's is final)
+				bool exact = false; int width = 0;
+				const bool has = c.key != RMQ_NONE;
+				const int sc = c.f + rmq_pair_score(xi, yi, c.x, c.y, c.span, P, exact, width);
+				int max_f = q_i, max_j = -1;
+				if (has && width <= P.bw && sc > max_f) { max_f = sc; max_j = c.j; }
+				if (has && !exact && max_inner > 0 && Wn.y < Wn.z && yi > 0 && in.j >= 0 && in.s > max_f) { max_f = in.s; max_j = in.j; }
+				if (l == t) {
+					f_l = max_f; p_l = max_j < 0 ? 0 : i - max_j;
+					k_l = key_order((double)max_f + half_gap * (double)((int)xi + yi));
+					tied += has && c.tie;
+				}
+				// lane t's anchor to the lanes above it
+				const int j = tb + t;
+				const unsigned xj = (unsigned)__builtin_amdgcn_readlane((int)A.x, t);
+				const int yj = __builtin_amdgcn_readlane((int)A.z, t), sj = __builtin_amdgcn_readlane((int)A.w, t) & 0xff;
+				const int fj = __builtin_amdgcn_readlane(f_l, t), rkj = __builtin_amdgcn_readlane(M.x, t);
+				const long long kj = (long long)readlane64((unsigned long long)k_l, t);
+				const bool before = j < Wn.z;
+				tile_offer(c, before && j >= Wn.x && rkj >= M.y && rkj <= M.z, kj, rkj, 0, j, xj, yj, sj, fj);
+				if (max_inner > 0) {
+					const bool in_ok = before && j >= Wn.y && yj <= y_top && yj >= y_bot;
+					if (__ballot(in_ok) != 0) {
+						bool ex2; int w2;
+						const int s2 = fj + rmq_pair_score(xi, yi, xj, yj, sj, P, ex2, w2);
+						tile_offer_inner(in, in_ok && w2 <= P.bw, s2, yj, j);
+					}
+				}
+			}
+			if (live) { f[i] = f_l; p[i] = p_l; }
+			wave_sync();
+		}
+		tied = (int)wave_sum_i32(tied);
+		if (l == 0) b.n_tied[r] = tied;
+		if (b.dbg && l == 0) {
+			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast, 0, 0 };
+			for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
+		}
+		wave_sync();
+	}
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // Either side of the path (N4).  k_sort_x: the seed sort of collect_seed_hits (map.c:329), one wave per read, the same exact
 // device form of radix_sort_128x that orders the chains.  k_gen_regs: mm_gen_regs (hit.c:52-88): chains ordered by
 // (score, hash of the first anchor) with the same sort, best first, then coordinates and fuzzy lengths (hit.c:8-38), one lane
@@ -1577,10 +1838,17 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 	sb.a = b.by_y; sb.offsets = b.offsets; sb.n_reads = b.n_reads; sb.cursor = nullptr; sb.grid_waves = b.grid_waves;
 	launch_sort_x(sb, s);
 	hipLaunchKernelGGL(k_rmq_prep_ranks, dim3(wide), dim3(256), 0, s, b);
-	hipLaunchKernelGGL(k_rmq_prep_ranges, dim3(wide), dim3(256), 0, s, b, P.max_dist < P.bw ? P.bw : P.max_dist);
+	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;
+	hipLaunchKernelGGL(k_rmq_prep_ranges, dim3(wide), dim3(256), 0, s, b, max_dist);
 	const int per = POST_THREADS / W;
 	const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + per - 1) / per, (int64_t)b.grid_waves / per));
-	hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
+	if (b.tree && b.win) {
+		// tile form: 64 anchors per step of a wave, a tournament tree over the ranks for what is settled for a whole tile
+		const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;
+		hipLaunchKernelGGL(k_rmq_prep_windows, dim3(wide), dim3(256), 0, s, b, max_dist, max_inner, P.cap_rmq_size);
+		hipLaunchKernelGGL(k_rmq_tree_init, dim3(wide), dim3(256), 0, s, b);
+		hipLaunchKernelGGL(k_rmq_fill_tiles, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
+	} else hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);   // one anchor per step (MM2GB_RMQ_KERNEL=steps)
 }
 
 } // namespace mm2gb

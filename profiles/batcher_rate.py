@@ -30,7 +30,7 @@ for post_threads, label in ((max(1, threads - 4), "host post-pass"), (0, "device
     for n_eng in args.engines:
         for prod in args.producers:
             with mm.Batcher(devices=[0] * n_eng, config=cfg, post_threads=post_threads, keep_results=False) as b:
-                for rep in range(2):                              # the first round grows the page-locked batch buffers
+                for rep in range(4):                              # the first rounds grow the page-locked batch buffers (every batch object once)
                     t0 = time.perf_counter()
                     b.feed(0, a, off, producers=prod)             # native producer threads (a Python loop would measure the interpreter)
                     t_fed = time.perf_counter() - t0
@@ -38,6 +38,6 @@ for post_threads, label in ((max(1, threads - 4), "host post-pass"), (0, "device
                     dt = time.perf_counter() - t0
                 st = b.stats()
             rows.append({"post": label, "post_threads": post_threads, "engines_on_gpu0": n_eng, "producers": prod, "reads": args.reads, "anchors": n,
-                         "seconds": round(dt, 4), "seconds_until_all_reads_were_added": round(t_fed, 4), "anchors_per_s": n / dt, "batches": st["batches"][0] // 2})
+                         "seconds": round(dt, 4), "seconds_until_all_reads_were_added": round(t_fed, 4), "anchors_per_s": n / dt, "batches_per_round": st["batches"][0] // 4})
             print(json.dumps(rows[-1]), flush=True)
 json.dump({"max_total_n": args.max_total_n, "usable_cpus": threads, "rows": rows}, open(args.out, "w"), indent=1)

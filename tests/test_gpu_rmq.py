@@ -44,9 +44,13 @@ def test_reference_vectors(engine, path):
         assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
 
 
-def test_batch_against_the_oracle(engine):
+@pytest.mark.parametrize("kernel", ["tiles", "steps"])
+def test_batch_against_the_oracle(engine, monkeypatch, kernel):
     """A batch of reads re-chained in one call: tie counts equal the oracle's, chains equal the oracle's (which uses the same
-    stated tie rule, so tied reads agree with IT too)."""
+    stated tie rule, so tied reads agree with IT too).  Both device forms: the tile kernel (64 anchors per step of a wave, a tournament
+    tree over the ranks; the default) and the one-anchor-per-step kernel (MM2GB_RMQ_KERNEL=steps)."""
+    if kernel == "steps":
+        monkeypatch.setenv("MM2GB_RMQ_KERNEL", "steps")
     a, off = mm.synth_reads(41, 0, 40, 10_000, 120_000)
     reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(40)]
     reads.insert(7, np.zeros((0, 2), np.uint64))
@@ -121,3 +125,31 @@ def test_batch_call_that_is_exact_for_every_read(engine, monkeypatch, deal):
             assert d["n_host_cost"] == 0 and d["n_host_tie"] >= 1          # the clouds tie: found on the device, redone on the host
         if deal == "host":
             assert d["n_device"] == 0 and (where == 1).all()
+
+
+def test_tile_kernel_on_odd_shapes(engine):
+    """The tile form's edges against the oracle: reads shorter than a tile, exactly one and two tiles, runs of equal x longer than a tile
+    (nobody in the run may chain to another), several references and strands in one read (window starts jump), a size cap that evicts
+    (cap_rmq_size below the window), gaps wider than max_dist (everything leaves at once), a dense cloud (ties, full inner windows)."""
+    rng = np.random.default_rng(11)
+    def cloud(n, xw, yw, rid=1, strand=0, x0=1000, y0=100):
+        return sc.pack(np.full(n, rid), np.full(n, strand, np.int64), x0 + rng.integers(0, xw, n), y0 + rng.integers(0, yw, n))
+    reads = []
+    for n in (1, 2, 63, 64, 65, 128, 129):
+        reads.append(orc.radix_sort_x(sc.sort_by_x(cloud(n, 40 * n + 10, 40 * n + 10))))
+    reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(300, 1), np.zeros(300, np.int64), np.repeat(5000 + np.arange(3) * 7, 100), 100 + rng.integers(0, 4000, 300)))))   # three runs of 100 equal x
+    reads.append(orc.radix_sort_x(sc.sort_by_x(np.concatenate([cloud(500, 3000, 3000, rid=r, strand=s) for r in (1, 2) for s in (0, 1)]))))
+    reads.append(orc.radix_sort_x(sc.sort_by_x(np.concatenate([cloud(400, 2000, 2000, x0=1000 + 50_000 * k, y0=100 + 900 * k) for k in range(4)]))))   # gaps of 50 kb
+    reads.append(orc.radix_sort_x(sc.sort_by_x(cloud(3000, 600, 600))))
+    a40, off40 = mm.synth_reads(47, 0, 6, 20_000, 90_000)
+    reads += [first_pass(a40[off40[r]:off40[r + 1]]) for r in range(6)]
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    for kw in (dict(), dict(cap_rmq_size=50), dict(cap_rmq_size=0), dict(max_dist_inner=0), dict(bw=100, max_dist=400, max_dist_inner=90), dict(max_dist=70_000, bw=70_000, max_dist_inner=3000)):
+        prm = orc.default_rmq_param(**kw)
+        res, tied, _ = engine.rmq_chain(allr, o2, to_lib(prm))
+        for r, x in enumerate(reads):
+            o = orc.lchain_rmq(x, prm)
+            assert int(tied[r]) == o["n_tied"], (kw, r, len(x))
+            assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r, len(x))
