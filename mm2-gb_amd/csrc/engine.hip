@@ -572,7 +572,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (rmq && debug_phases && n > 0) {
 		long long t[8] = { 0 };
 		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
-			fprintf(stderr, rmq_tree.ptr && !(getenv("MM2GB_RMQ_KERNEL") && !strcmp(getenv("MM2GB_RMQ_KERNEL"), "steps")) ? "[mm2gb rmq fill, tiles] %lld anchors: tiles %lld, tree leaves changed %lld, levels walked %lld, query rounds %lld, anchors broadcast %lld (%lld %lld)\n" :
+			fprintf(stderr, rmq_tree.ptr && !(getenv("MM2GB_RMQ_KERNEL") && !strcmp(getenv("MM2GB_RMQ_KERNEL"), "steps")) ? "[mm2gb rmq fill, tiles] %lld anchors, %lld tiles; wave time in 10 ns ticks, summed over reads: tree update %lld, queries %lld, broadcasts %lld (%lld anchors broadcast, %lld inner blocks passed over), in-tile steps %lld\n" :
 			        "[mm2gb rmq fill] %lld steps: late entries %lld, summaries rebuilt %lld, ties looked at %lld, summary loads %lld, inner blocks read %lld, winners read from memory %lld, eviction tests %lld\n",
 			        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
 	}

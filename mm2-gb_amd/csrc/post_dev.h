@@ -52,7 +52,7 @@ struct RmqBatch {
 	int32_t *bound;            // scratch, n / 64 + n_reads + 1: per 64 anchors (by index) the largest f + span
 	int4    *win;              // tile form, scratch, n: per anchor its window start, inner window start, start of its run of equal x (null: the one-anchor-per-step kernel)
 	uint4   *tree;             // tile form, scratch, 2 n: per read a binary tournament tree over its ranks (key low, key high, rank | several << 31, -)
-	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed over reads [0] steps [1] late entries [2] summaries rebuilt [3] ties looked at [4] summary loads [5] inner blocks read [6] winners read from memory [7] eviction tests (tile form: [0] anchors [1] tiles [2] leaves changed [3] tree levels walked [4] query rounds [5] anchors broadcast)
+	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed over reads [0] steps [1] late entries [2] summaries rebuilt [3] ties looked at [4] summary loads [5] inner blocks read [6] winners read from memory [7] eviction tests (tile form: [0] anchors [1] tiles [2] ticks of tree updates [3] of queries [4] of broadcasts [5] anchors broadcast [6] inner blocks passed over [7] ticks of in-tile steps)
 	int32_t *n_tied;           // out, per read: anchors whose range-minimum was shared by several elements (see post_kernels.hip)
 	int32_t *cursor;
 	int      grid_waves;

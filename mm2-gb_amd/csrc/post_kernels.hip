@@ -1334,23 +1334,37 @@ __device__ __forceinline__ uint4 tnode_comb(const uint4 &a, const uint4 &b)
 	return make_uint4(a.x, a.y, (ra > rb ? ra : rb) | 0x80000000u, 0u);   // equal keys: the larger (y, index) rank, and "several share it"
 }
 
-// the best candidate of the outer query a lane has seen so far, with what scoring it needs (lchain.c:316-318)
-struct TileCand { long long key; int rank, tie, j; unsigned x; int y, span, f; };
-__device__ __forceinline__ void tile_offer(TileCand &c, bool in, long long key, int rank, int tie, int j, unsigned x, int y, int span, int f)
+// the best candidate of the outer query a lane has seen so far (lchain.c:311-318): its key, its place in the tie rule, and what the lane
+// gets from it -- the pair's score, whether it is an exact diagonal extension, the diagonal distance -- computed when it is adopted
+struct TileCand { long long key; int rank, tie, j, sc, exact, width; };
+// (selects only, no branches: a lone wave on its SIMD pays every taken branch and every change of the execution mask in full)
+__device__ __forceinline__ void tile_offer(TileCand &c, bool in, long long key, int rank, int tie, int j, int sc, int exact, int width)
 {
-	if (!in) return;
-	if (key > c.key) { c.key = key; c.rank = rank; c.tie = tie; c.j = j; c.x = x; c.y = y; c.span = span; c.f = f; }
-	else if (key == c.key) {
-		c.tie = 1;
-		if (rank > c.rank) { c.rank = rank; c.j = j; c.x = x; c.y = y; c.span = span; c.f = f; }
-	}
+	const bool better = in & (key > c.key), same = in & (key == c.key);
+	const bool take = better | (same & (rank > c.rank));
+	c.tie = better ? tie : same ? 1 : c.tie;
+	c.key = take ? key : c.key;
+	c.rank = take ? rank : c.rank; c.j = take ? j : c.j; c.sc = take ? sc : c.sc; c.exact = take ? exact : c.exact; c.width = take ? width : c.width;
 }
 // the best of the inner window (lchain.c:328-341 with max_chn_skip = infinity): largest score, then largest (y, index)
 struct TileInner { int s, y, j; };
 __device__ __forceinline__ void tile_offer_inner(TileInner &c, bool in, int s2, int yj, int j)
 {
-	if (!in) return;
-	if (c.j < 0 || s2 > c.s || (s2 == c.s && (yj > c.y || (yj == c.y && j > c.j)))) { c.s = s2; c.y = yj; c.j = j; }
+	const bool take = in & ((c.j < 0) | (s2 > c.s) | ((s2 == c.s) & ((yj > c.y) | ((yj == c.y) & (j > c.j)))));
+	c.s = take ? s2 : c.s; c.y = take ? yj : c.y; c.j = take ? j : c.j;
+}
+// comput_sc_simple (lchain.c:232-248) without a branch: same arithmetic as rmq_pair_score, the penalty selected rather than skipped
+__device__ __forceinline__ int tile_pair_score(unsigned xi, int yi, unsigned xj, int yj, int q_span_j, const RmqParams &P, int &exact, int &width)
+{
+	const int dq = yi - yj, dr = (int)(xi - xj);
+	const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+	const int sc = q_span_j < dg ? q_span_j : dg;
+	width = dd;
+	exact = (dd == 0) & (dg <= q_span_j);
+	const float lin = P.pen_gap * (float)dd + P.pen_skip * (float)dg;
+	const float lg = dd >= 1 ? rmq_log2((float)(dd + 1)) : 0.0f;
+	const int pen = (int)(lin + .5f * lg);
+	return sc - (((dd != 0) | (dq > q_span_j)) ? pen : 0);
 }
 
 } // namespace
@@ -1410,8 +1424,9 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 		const int32_t *ord_idx = b.ord_idx + off;
 		int32_t *f = b.f + off, *p = b.p + off;
 		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
+		int32_t *bound = b.bound + (off >> 6) + r;           // per block of 64 anchors (by index) the largest f + span, once its tile is done
 		int ev = 0, ins = 0, tied = 0;                       // the tree holds the anchors of index [ev, ins)
-		long long d_tiles = 0, d_upd = 0, d_levels = 0, d_qloads = 0, d_bcast = 0;   // MM2GB_DEBUG_PHASES
+		long long d_tiles = 0, d_upd = 0, d_levels = 0, d_qloads = 0, d_bcast = 0, d_skip = 0, d_t3 = 0;   // MM2GB_DEBUG_PHASES: 100 MHz ticks of the tree update, the queries, the broadcasts, the in-tile steps
 		for (int tb = 0; tb < n; tb += W) {
 			const int n_here = min(W, n - tb), i = tb + l;
 			const bool live = l < n_here;
@@ -1425,6 +1440,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 			const int hi = __builtin_amdgcn_readlane(Wn.z, 0);                   // every anchor before the first lane's run of equal x has entered for all lanes
 			const int lo = min(st_last, hi);                                       // ... and none from here on has left for any
 			++d_tiles;
+			const long long ts0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			// ---- the tree: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) ----
 			{
 				int e0 = ev, n0 = max(ins, lo);
@@ -1440,7 +1456,6 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 						pi = n + rk;
 						tree[pi] = make_uint4((unsigned)kk, (unsigned)((unsigned long long)kk >> 32), (unsigned)rk, 0u);
 					}
-					d_upd += __popcll(__ballot(pe > 0)) + __popcll(__ballot(pi > 0));
 					wave_sync();
 					while (__ballot(pe > 1 || pi > 1) != 0) {
 						uint4 c0 = tnode_none(), c1 = c0, c2 = c0, c3 = c0;
@@ -1448,16 +1463,16 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 						if (pi > 1) { pi >>= 1; c2 = tree[2 * pi]; c3 = tree[2 * pi + 1]; } else pi = 0;
 						if (pe > 0) tree[pe] = tnode_comb(c0, c1);
 						if (pi > 0 && pi != pe) tree[pi] = tnode_comb(c2, c3);
-						++d_levels;
 						wave_sync();
 					}
 					e0 += W; n0 += W;
 				}
 				ev = lo; ins = hi;
 			}
+			const long long ts1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			// ---- (1) every lane's query of the tree: the nodes that tile its rank interval, bottom up; the loads do not depend on each other ----
 			TileCand c;
-			c.key = RMQ_NONE; c.rank = -1; c.tie = 0; c.j = -1; c.x = 0; c.y = 0; c.span = 0; c.f = 0;
+			c.key = RMQ_NONE; c.rank = -1; c.tie = 0; c.j = -1; c.sc = 0; c.exact = 0; c.width = 0;
 			{
 				uint4 best = tnode_none();
 				int ql = n + M.y, qr = n + M.z + 1;                                // [ql, qr) over the leaves
@@ -1470,15 +1485,17 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 						ql >>= 1; qr >>= 1;
 					}
 					best = tnode_comb(best, tnode_comb(vl, vr));
-					++d_qloads;
 				}
 				if (tnode_key(best) != RMQ_NONE) {
 					const int rk = (int)(best.z & 0x7fffffffu);
 					const int j = ord_idx[rk];
 					const uint4 e = a[j];
-					c.key = tnode_key(best); c.rank = rk; c.tie = (int)(best.z >> 31); c.j = j; c.x = e.x; c.y = (int)e.z; c.span = (int)(e.w & 0xffu); c.f = f[j];
+					int ex, wd;
+					const int sc = f[j] + tile_pair_score(xi, yi, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex, wd);
+					c.key = tnode_key(best); c.rank = rk; c.tie = (int)(best.z >> 31); c.j = j; c.sc = sc; c.exact = ex; c.width = wd;
 				}
 			}
+			const long long ts2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			// ---- (2) anchors before the tile that are not in the tree for every lane, and the inner window: broadcast one by one ----
 			TileInner in;
 			in.s = 0; in.y = 0; in.j = -1;
@@ -1492,40 +1509,67 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 					const int f_l = have ? f[j_l] : 0, rk_l = have ? meta[j_l].x : 0;
 					const long long k_l = key_order((double)f_l + half_gap * (double)((int)e_l.x + (int)e_l.z));
 					const int cnt = min(W, to - base);
-					for (int k = 0; k < cnt; ++k) {
-						const int j = base + k;
-						const unsigned xj = (unsigned)__builtin_amdgcn_readlane((int)e_l.x, k);
-						const int yj = __builtin_amdgcn_readlane((int)e_l.z, k), sj = __builtin_amdgcn_readlane((int)e_l.w, k) & 0xff;
-						const int fj = __builtin_amdgcn_readlane(f_l, k), rkj = __builtin_amdgcn_readlane(rk_l, k);
-						const long long kj = (long long)readlane64((unsigned long long)k_l, k);
-						const bool before = j < Wn.z;                                    // strictly smaller x (lchain.c:279-292)
-						const bool out_ok = before && j >= Wn.x && (outer_all || j >= hi) && rkj >= M.y && rkj <= M.z;
-						tile_offer(c, out_ok, kj, rkj, 0, j, xj, yj, sj, fj);
-						if (max_inner > 0) {
-							const bool in_ok = before && j >= Wn.y && yj <= y_top && yj >= y_bot;
-							if (__ballot(in_ok) != 0) {
-								bool ex2; int w2;
-								const int s2 = fj + rmq_pair_score(xi, yi, xj, yj, sj, P, ex2, w2);
-								tile_offer_inner(in, in_ok && w2 <= P.bw, s2, yj, j);
-							}
+					for (int k = 0; k < cnt; k += 2) {
+						// two anchors per round, straight-line: their arithmetic interleaves (the wave is alone on its SIMD: nothing else hides latency)
+						const int ja = base + k, jb2 = ja + 1;
+						const bool two = k + 1 < cnt;
+						const int kb = two ? k + 1 : k;
+						const bool outer_a = outer_all || ja >= hi, outer_b = two && (outer_all || jb2 >= hi);     // wave-uniform: in the tree otherwise
+						const bool inner_a = max_inner > 0 && ja >= stin_first, inner_b = two && max_inner > 0 && jb2 >= stin_first;   // wave-uniform
+						d_bcast += two ? 2 : 1;
+						if (!(outer_a || outer_b || inner_a || inner_b)) continue;
+						const int ya = __builtin_amdgcn_readlane((int)e_l.z, k), yb = __builtin_amdgcn_readlane((int)e_l.z, kb);
+						const int rka = __builtin_amdgcn_readlane(rk_l, k), rkb = __builtin_amdgcn_readlane(rk_l, kb);
+						const bool out_a = outer_a & (ja < Wn.z) & (ja >= Wn.x) & (rka >= M.y) & (rka <= M.z);
+						const bool out_b = outer_b & (jb2 < Wn.z) & (jb2 >= Wn.x) & (rkb >= M.y) & (rkb <= M.z);
+						const bool in_a = inner_a & (ja < Wn.z) & (ja >= Wn.y) & (ya <= y_top) & (ya >= y_bot);
+						const bool in_b = inner_b & (jb2 < Wn.z) & (jb2 >= Wn.y) & (yb <= y_top) & (yb >= y_bot);
+						const unsigned long long any_out = __ballot(out_a | out_b);
+						if ((any_out | __ballot(in_a | in_b)) == 0) continue;
+						const unsigned xa = (unsigned)__builtin_amdgcn_readlane((int)e_l.x, k), xb = (unsigned)__builtin_amdgcn_readlane((int)e_l.x, kb);
+						const int sa = __builtin_amdgcn_readlane((int)e_l.w, k) & 0xff, sb = __builtin_amdgcn_readlane((int)e_l.w, kb) & 0xff;
+						const int fa = __builtin_amdgcn_readlane(f_l, k), fb = __builtin_amdgcn_readlane(f_l, kb);
+						int exa, wa, exb, wb;
+						const int s2a = fa + tile_pair_score(xi, yi, xa, ya, sa, P, exa, wa);     // the same pair score serves the outer query and the inner scan
+						const int s2b = fb + tile_pair_score(xi, yi, xb, yb, sb, P, exb, wb);
+						if (any_out != 0) {
+							tile_offer(c, out_a, (long long)readlane64((unsigned long long)k_l, k), rka, 0, ja, s2a, exa, wa);
+							tile_offer(c, out_b, (long long)readlane64((unsigned long long)k_l, kb), rkb, 0, jb2, s2b, exb, wb);
 						}
-						++d_bcast;
+						tile_offer_inner(in, in_a & (wa <= P.bw), s2a, ya, ja);
+						tile_offer_inner(in, in_b & (wb <= P.bw), s2b, yb, jb2);
 					}
 				}
 			};
 			sweep_range(st_first, lo, true);
-			sweep_range(max_inner > 0 ? max(min(stin_first, tb), lo) : max(hi, lo), tb, false);
+			{
+				// From the newest block of 64 down: the nearest anchors carry the highest scores, so the lanes' inner bests rise at once, and a
+				// block whose largest f + span (`bound`, written when its tile was finished) cannot beat ANY lane's is passed over --
+				// comput_sc_simple never returns more than the span, the inner scan only ever replaces a result it BEATS (lchain.c:331), and an
+				// equal score wins only by a larger (y, index).  Without this every anchor of a dense window was scored against every lane:
+				// 5 266 broadcasts per tile on the mapper's reads (profiles/r03h_*), twenty times the work of the kernel above.
+				const int from = max_inner > 0 ? max(min(stin_first, tb), lo) : max(hi, lo);
+				for (int bb = (tb >> 6) - 1; bb >= 0 && ((bb + 1) << 6) > from; --bb) {
+					const int b_lo = max(bb << 6, from), b_hi = (bb + 1) << 6;
+					if (b_lo >= hi || max_inner <= 0) { sweep_range(b_lo, b_hi, false); continue; }     // holds anchors the outer query needs (not in the tree): no skipping
+					if (b_hi > hi) { sweep_range(b_lo, b_hi, false); continue; }
+					const int bnd = uni(bound[bb]);
+					const bool idle = !live || bnd <= q_i || (in.j >= 0 && bnd < in.s) || b_hi <= Wn.y || b_lo >= Wn.z;
+					if (__ballot(!idle) == 0) { ++d_skip; continue; }
+					sweep_range(b_lo, b_hi, false);
+				}
+			}
+			const long long ts3 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			// ---- (3) the tile's own anchors, one after the other ----
 			int f_l = q_i, p_l = 0;
 			long long k_l = 0;
 			for (int t = 0; t < n_here; ++t) {
-				// what lane t gets from its candidates as they stand (every lane computes; lane t's is final)
-				bool exact = false; int width = 0;
+				// what lane t gets from its candidates as they stand (every lane computes -- a handful of selects; lane t's is final)
 				const bool has = c.key != RMQ_NONE;
-				const int sc = c.f + rmq_pair_score(xi, yi, c.x, c.y, c.span, P, exact, width);
 				int max_f = q_i, max_j = -1;
-				if (has && width <= P.bw && sc > max_f) { max_f = sc; max_j = c.j; }
-				if (has && !exact && max_inner > 0 && Wn.y < Wn.z && yi > 0 && in.j >= 0 && in.s > max_f) { max_f = in.s; max_j = in.j; }
+				{ const bool use_out = has & (c.width <= P.bw) & (c.sc > max_f); max_f = use_out ? c.sc : max_f; max_j = use_out ? c.j : max_j; }
+				const bool use_in = has & !c.exact & (max_inner > 0) & (Wn.y < Wn.z) & (yi > 0) & (in.j >= 0) & (in.s > max_f);
+				max_f = use_in ? in.s : max_f; max_j = use_in ? in.j : max_j;
 				if (l == t) {
 					f_l = max_f; p_l = max_j < 0 ? 0 : i - max_j;
 					k_l = key_order((double)max_f + half_gap * (double)((int)xi + yi));
@@ -1533,28 +1577,30 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 				}
 				// lane t's anchor to the lanes above it
 				const int j = tb + t;
-				const unsigned xj = (unsigned)__builtin_amdgcn_readlane((int)A.x, t);
-				const int yj = __builtin_amdgcn_readlane((int)A.z, t), sj = __builtin_amdgcn_readlane((int)A.w, t) & 0xff;
-				const int fj = __builtin_amdgcn_readlane(f_l, t), rkj = __builtin_amdgcn_readlane(M.x, t);
-				const long long kj = (long long)readlane64((unsigned long long)k_l, t);
+				const int yj = __builtin_amdgcn_readlane((int)A.z, t), rkj = __builtin_amdgcn_readlane(M.x, t);
 				const bool before = j < Wn.z;
-				tile_offer(c, before && j >= Wn.x && rkj >= M.y && rkj <= M.z, kj, rkj, 0, j, xj, yj, sj, fj);
-				if (max_inner > 0) {
-					const bool in_ok = before && j >= Wn.y && yj <= y_top && yj >= y_bot;
-					if (__ballot(in_ok) != 0) {
-						bool ex2; int w2;
-						const int s2 = fj + rmq_pair_score(xi, yi, xj, yj, sj, P, ex2, w2);
-						tile_offer_inner(in, in_ok && w2 <= P.bw, s2, yj, j);
-					}
-				}
+				const bool out_ok = before & (j >= Wn.x) & (rkj >= M.y) & (rkj <= M.z);
+				const bool in_ok = (max_inner > 0) & before & (j >= Wn.y) & (yj <= y_top) & (yj >= y_bot);
+				if (__ballot(out_ok | in_ok) == 0) continue;
+				const unsigned xj = (unsigned)__builtin_amdgcn_readlane((int)A.x, t);
+				const int sj = __builtin_amdgcn_readlane((int)A.w, t) & 0xff, fj = __builtin_amdgcn_readlane(f_l, t);
+				int ex2, w2;
+				const int s2 = fj + tile_pair_score(xi, yi, xj, yj, sj, P, ex2, w2);
+				tile_offer(c, out_ok, (long long)readlane64((unsigned long long)k_l, t), rkj, 0, j, s2, ex2, w2);
+				tile_offer_inner(in, in_ok & (w2 <= P.bw), s2, yj, j);
 			}
 			if (live) { f[i] = f_l; p[i] = p_l; }
+			if (b.dbg) { const long long ts4 = (long long)__builtin_amdgcn_s_memrealtime(); d_upd += ts1 - ts0; d_levels += ts2 - ts1; d_qloads += ts3 - ts2; d_t3 += ts4 - ts3; }
+			{
+				const int top = wave_max_i32(live ? f_l + q_i : INT_MIN);
+				if (l == 0) bound[tb >> 6] = top;
+			}
 			wave_sync();
 		}
 		tied = (int)wave_sum_i32(tied);
 		if (l == 0) b.n_tied[r] = tied;
 		if (b.dbg && l == 0) {
-			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast, 0, 0 };
+			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast, d_skip, d_t3 };
 			for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
 		}
 		wave_sync();

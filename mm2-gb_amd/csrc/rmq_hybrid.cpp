@@ -48,11 +48,16 @@ ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n
 		s_out += (double)((w_out + 4095) / 4096) * STRIDE;
 	}
 	ReadCost c;
-	// measured (profiles/r03c_*): the kernel's estimate summed to 20.3 s where the call took 30.4 s, and 0.136 s for 0.246 s on reads
-	// with narrow windows: the rates below are the first guesses times 1.6.  The host form took 0.40 us per anchor of reads with
-	// narrow windows, 0.59 us on the mapper's reads, 0.9 us on a read inside a tandem array (its inner scan visits the candidates
-	// of one y-range, not the window: a few hundred at worst).
-	c.dev = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);
+	// The device form (k_rmq_fill_tiles, profiles/r03l_*): per tile of 64 anchors ~13 us of tree update, ~5 us of queries, ~30 us of in-tile
+	// steps, and 0.31 us per anchor it broadcasts -- the inner window of the tile plus ~128 around the edges, i.e. about s_in + 2 n over
+	// the read.  (The one-anchor-per-step kernel: 4.0 us per anchor + 0.42 us per block / summary round.)
+	// The host form took 0.40 us per anchor of reads with narrow windows, 0.59 us on the mapper's reads, 0.9 us on a read inside a tandem
+	// array (its inner scan visits the candidates of one y-range, not the window: a few hundred at worst).
+	{
+		const char *v = getenv("MM2GB_RMQ_KERNEL");
+		if (v && !strcmp(v, "steps")) c.dev = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);
+		else c.dev = 1.37e-6 * (double)n + 0.31e-6 * s_in;
+	}
 	c.host = (double)n * (0.40e-6 + 0.5e-6 * std::min(1.0, s_in / ((double)std::max<int64_t>(n, 1) * 100.0)));
 	return c;
 }
