@@ -106,6 +106,8 @@ struct Engine {
 	int64_t team4_min_n = 0;        // micro-batches from this many anchors on send wide-window heavy chunks to 4-wave teams (launch.team4_share_pct)
 	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)
 	int64_t last_split_chunks = 0, last_helped_items = 0;   // of the last call: chunks scored strip by strip, items other workgroups took
+	bool rmq_tiles_last = false;    // which form the last RMQ call ran (for the debug print)
+	int  rmq_kernel = 0;            // device form of the RMQ fill: 0 tiles (k_rmq_fill_tiles), 1 one anchor per step (k_rmq_fill); MM2GB_RMQ_KERNEL=steps|tiles overrides
 	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)
 	int64_t dual_stream_max_n = 16 * 1000 * 1000;   // micro-batches up to this many anchors alternate between the two compute streams
 

@@ -553,7 +553,9 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		{
 			// tile form (k_rmq_fill_tiles) unless MM2GB_RMQ_KERNEL=steps asks for the one-anchor-per-step kernel (A/B runs, tests)
 			const char *v = getenv("MM2GB_RMQ_KERNEL");
-			if (!(v && !strcmp(v, "steps"))) {
+			const bool steps = v ? !strcmp(v, "steps") : rmq_kernel == 1;
+			rmq_tiles_last = !steps;
+			if (!steps) {
 				if (rmq_win.ensure(nn * 16) || rmq_tree.ensure(nn * 32)) return -1;
 				rb.win = (int4*)rmq_win.ptr; rb.tree = (uint4*)rmq_tree.ptr;
 			}
@@ -571,10 +573,14 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (sync()) return -1;
 	if (rmq && debug_phases && n > 0) {
 		long long t[8] = { 0 };
-		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
-			fprintf(stderr, rmq_tree.ptr && !(getenv("MM2GB_RMQ_KERNEL") && !strcmp(getenv("MM2GB_RMQ_KERNEL"), "steps")) ? "[mm2gb rmq fill, tiles] %lld anchors, %lld tiles; wave time in 10 ns ticks, summed over reads: tree update %lld, queries %lld, broadcasts %lld (%lld anchors broadcast, %lld inner blocks passed over), in-tile steps %lld\n" :
-			        "[mm2gb rmq fill] %lld steps: late entries %lld, summaries rebuilt %lld, ties looked at %lld, summary loads %lld, inner blocks read %lld, winners read from memory %lld, eviction tests %lld\n",
-			        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+			if (rmq_tiles_last)
+				fprintf(stderr, "[mm2gb rmq fill, tiles] %lld anchors, %lld tiles; wave time in 10 ns ticks, summed over reads: tree update %lld, queries %lld, broadcasts %lld (%lld anchors broadcast, %lld blocks scanned for one lane, "
+				                "%lld inner blocks passed over, %lld lanes scanned their inner window again), in-tile steps %lld\n", t[0], t[1], t[2], t[3], t[4], t[5] & 0xfffffffffLL, t[5] >> 36, t[6] & 0xffffffffLL, t[6] >> 32, t[7]);
+			else
+				fprintf(stderr, "[mm2gb rmq fill] %lld steps: late entries %lld, summaries rebuilt %lld, ties looked at %lld, summary loads %lld, inner blocks read %lld, winners read from memory %lld, eviction tests %lld\n",
+				        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+		}
 	}
 	const int64_t n_u = n_reads > 0 ? h_post_totals[0] : 0, n_a = n_reads > 0 ? h_post_totals[1] : 0;
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
@@ -898,6 +904,7 @@ void mm2gb_engine_destroy(mm2gb_engine_t *eng)
 
 int mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc) { return eng ? eng->e.set_misc(misc) : fail("mm2gb: null engine"); }
 int mm2gb_engine_device(const mm2gb_engine_t *eng) { return eng ? eng->e.device : -1; }
+int mm2gb_engine_set_rmq_kernel(mm2gb_engine_t *eng, int kind) { if (!eng || kind < 0 || kind > 1) return fail("mm2gb_engine_set_rmq_kernel: bad argument"); eng->e.rmq_kernel = kind; return 0; }
 int mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads) { return eng ? eng->e.reserve(n_anchors, n_reads) : fail("mm2gb: null engine"); }
 void *mm2gb_engine_stream(mm2gb_engine_t *eng) { return eng ? (void*)eng->e.stream : nullptr; }
 float mm2gb_engine_last_kernel_ms(mm2gb_engine_t *eng) { return eng ? eng->e.last.ms_prep + eng->e.last.ms_score : 0.f; }

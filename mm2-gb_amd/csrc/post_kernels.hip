@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
 		int32_t *bound = b.bound + (off >> 6) + r;           // per block of 64 anchors (by index) the largest f + span, once its tile is done
 		int ev = 0, ins = 0, tied = 0;                       // the tree holds the anchors of index [ev, ins)
-		long long d_tiles = 0, d_upd = 0, d_levels = 0, d_qloads = 0, d_bcast = 0, d_skip = 0, d_t3 = 0;   // MM2GB_DEBUG_PHASES: 100 MHz ticks of the tree update, the queries, the broadcasts, the in-tile steps
+		long long d_tiles = 0, d_upd = 0, d_levels = 0, d_qloads = 0, d_bcast = 0, d_skip = 0, d_t3 = 0, d_redo = 0, d_single = 0;   // MM2GB_DEBUG_PHASES: 100 MHz ticks of the tree update, the queries, the broadcasts, the in-tile steps
 		for (int tb = 0; tb < n; tb += W) {
 			const int n_here = min(W, n - tb), i = tb + l;
 			const bool live = l < n_here;
@@ -1499,6 +1499,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 			// ---- (2) anchors before the tile that are not in the tree for every lane, and the inner window: broadcast one by one ----
 			TileInner in;
 			in.s = 0; in.y = 0; in.j = -1;
+			int relied = INT_MIN;                                 // the largest bound of a block this lane passed over on the strength of its outer candidate's score alone
 			const int y_top = yi - 1, y_bot = yi - max_inner;
 			auto sweep_range = [&](int from, int to, bool outer_all) {
 				// outer_all: every anchor of the range is outside the tree (it left the window for some lanes); else only those from hi on are
@@ -1554,9 +1555,40 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 					if (b_lo >= hi || max_inner <= 0) { sweep_range(b_lo, b_hi, false); continue; }     // holds anchors the outer query needs (not in the tree): no skipping
 					if (b_hi > hi) { sweep_range(b_lo, b_hi, false); continue; }
 					const int bnd = uni(bound[bb]);
-					const bool idle = !live || bnd <= q_i || (in.j >= 0 && bnd < in.s) || b_hi <= Wn.y || b_lo >= Wn.z;
-					if (__ballot(!idle) == 0) { ++d_skip; continue; }
-					sweep_range(b_lo, b_hi, false);
+					// what holds whatever happens: the block lies outside the lane's inner window, or cannot beat the span every anchor starts from, or the
+					// best the lane's inner scan has found.  And what holds as things stand: it cannot beat what the lane's outer candidate scores --
+					// the inner scan only replaces a result it beats (lchain.c:331), and that candidate is nearly always final or replaced by a
+					// better-scoring one (the previous anchor of the chain).  A lane that passes a block over on that ground alone remembers the
+					// largest such bound; if its outer result ends up below it, its inner window is scanned again, in full, when its turn comes.
+					const bool sure = !live || bnd <= q_i || (in.j >= 0 && bnd < in.s) || b_hi <= Wn.y || b_lo >= Wn.z;
+					const int spec = (c.key != RMQ_NONE && c.width <= P.bw) ? c.sc : INT_MIN;
+					const bool idle = sure || bnd <= spec;
+					const unsigned long long need = __ballot(!idle);
+					if (need == 0) { ++d_skip; relied = (!sure && bnd > relied) ? bnd : relied; continue; }
+					if (__popcll(need) >= 24) { sweep_range(b_lo, b_hi, false); continue; }
+					// Few lanes need this block (a read's chains interleave along x: a block bounded by the best chain's scores is of no use to
+					// the anchors of that chain, which sit far above it, but cannot be ruled out for the anchors of a weak one): those lanes
+					// take it one at a time, the block's 64 anchors side by side -- ~100 instructions per lane instead of ~2 600 for a broadcast
+					relied = (idle && !sure && bnd > relied) ? bnd : relied;
+					const int j_c = (bb << 6) + l;
+					const bool have = j_c >= b_lo && j_c < b_hi;
+					const uint4 e_c = have ? a[j_c] : make_uint4(0, 0, 0, 0);
+					const int f_c = have ? f[j_c] : 0;
+					for (unsigned long long m = need; m != 0; m &= m - 1) {
+						const int u = first_set(m);
+						const unsigned xu = (unsigned)__builtin_amdgcn_readlane((int)xi, u);
+						const int yu = __builtin_amdgcn_readlane(yi, u), from_u = __builtin_amdgcn_readlane(Wn.y, u), to_u = __builtin_amdgcn_readlane(Wn.z, u);
+						int ex2, w2;
+						const int s2 = f_c + tile_pair_score(xu, yu, e_c.x, (int)e_c.z, (int)(e_c.w & 0xffu), P, ex2, w2);
+						const bool ok = have & (j_c >= from_u) & (j_c < to_u) & ((int)e_c.z <= yu - 1) & ((int)e_c.z >= yu - max_inner) & (w2 <= P.bw);
+						const unsigned long long oks = __ballot(ok);
+						++d_single;
+						if (oks == 0) continue;
+						const int bs = wave_max_i32(ok ? s2 : INT_MIN);
+						const int by = wave_max_i32((ok & (s2 == bs)) ? (int)e_c.z : INT_MIN);
+						const int bj = wave_max_i32((ok & (s2 == bs) & ((int)e_c.z == by)) ? j_c : -1);
+						if (l == u) tile_offer_inner(in, true, bs, by, bj);
+					}
 				}
 			}
 			const long long ts3 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -1568,7 +1600,27 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 				const bool has = c.key != RMQ_NONE;
 				int max_f = q_i, max_j = -1;
 				{ const bool use_out = has & (c.width <= P.bw) & (c.sc > max_f); max_f = use_out ? c.sc : max_f; max_j = use_out ? c.j : max_j; }
-				const bool use_in = has & !c.exact & (max_inner > 0) & (Wn.y < Wn.z) & (yi > 0) & (in.j >= 0) & (in.s > max_f);
+				const bool inner_on = has & !c.exact & (max_inner > 0) & (Wn.y < Wn.z) & (yi > 0);
+				if (__builtin_amdgcn_readlane((int)(inner_on & (relied > max_f)), t) != 0) {
+					// lane t passed blocks over that its final outer result does not rule out: its whole inner window before the tile again, 64
+					// candidates at a time (the tile's own anchors have all been offered to it already)
+					++d_redo;
+					const unsigned xt = (unsigned)__builtin_amdgcn_readlane((int)xi, t);
+					const int yt = __builtin_amdgcn_readlane(yi, t), from_t = __builtin_amdgcn_readlane(Wn.y, t), to_t = min(__builtin_amdgcn_readlane(Wn.z, t), tb);
+					TileInner best; best.s = 0; best.y = 0; best.j = -1;
+					for (int base = from_t; base < to_t; base += W) {
+						const int j = base + l;
+						if (j < to_t) {
+							const uint4 e = a[j];
+							int ex2, w2;
+							const int s2 = f[j] + tile_pair_score(xt, yt, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex2, w2);
+							tile_offer_inner(best, ((int)e.z <= yt - 1) & ((int)e.z >= yt - max_inner) & (w2 <= P.bw), s2, (int)e.z, j);
+						}
+					}
+					for (int o = W / 2; o > 0; o >>= 1) tile_offer_inner(best, __shfl_xor(best.j, o) >= 0, __shfl_xor(best.s, o), __shfl_xor(best.y, o), __shfl_xor(best.j, o));
+					if (l == t) tile_offer_inner(in, best.j >= 0, best.s, best.y, best.j);
+				}
+				const bool use_in = inner_on & (in.j >= 0) & (in.s > max_f);
 				max_f = use_in ? in.s : max_f; max_j = use_in ? in.j : max_j;
 				if (l == t) {
 					f_l = max_f; p_l = max_j < 0 ? 0 : i - max_j;
@@ -1600,7 +1652,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 		tied = (int)wave_sum_i32(tied);
 		if (l == 0) b.n_tied[r] = tied;
 		if (b.dbg && l == 0) {
-			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast, d_skip, d_t3 };
+			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast + (d_single << 36), d_skip + (d_redo << 32), d_t3 };
 			for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
 		}
 		wave_sync();

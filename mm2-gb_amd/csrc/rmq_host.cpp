@@ -432,6 +432,10 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 							}
 						}
 						const int s2 = c.f + sc;
+						if (exhaustive) {                          // no skip limit: the marks of lchain.c:333-338 decide nothing -- no look at p[] and seen[] per candidate
+							if (s2 > max_f) { max_f = s2; max_j = c.j; }
+							continue;
+						}
 						if (s2 > max_f) { max_f = s2; max_j = c.j; if (n_skip > 0) --n_skip; }
 						else if (ws.seen[(size_t)c.j] == i) { if (++n_skip > P.max_chn_skip) { stop = true; break; } }
 						if (p_rel[c.j]) ws.seen[(size_t)(c.j - p_rel[c.j])] = i;

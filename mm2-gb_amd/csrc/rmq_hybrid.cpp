@@ -27,7 +27,7 @@ namespace {
 //   s_out  sum over anchors of ceil(anchors within max_dist before it / 4096): iterations over block summaries of the kernel's query
 // The constants are measured rates (profiles/r03_rmq_rate.json: counters of k_rmq_fill under MM2GB_DEBUG_PHASES against its time on
 // the read that ends a batch; rmq_host.cpp's thread-seconds per anchor); they only steer the deal, never a result.
-struct ReadCost { double dev, host; };
+struct ReadCost { double dev, dev_steps, host, s_in; };
 
 ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n)
 {
@@ -53,11 +53,9 @@ ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n
 	// the read.  (The one-anchor-per-step kernel: 4.0 us per anchor + 0.42 us per block / summary round.)
 	// The host form took 0.40 us per anchor of reads with narrow windows, 0.59 us on the mapper's reads, 0.9 us on a read inside a tandem
 	// array (its inner scan visits the candidates of one y-range, not the window: a few hundred at worst).
-	{
-		const char *v = getenv("MM2GB_RMQ_KERNEL");
-		if (v && !strcmp(v, "steps")) c.dev = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);
-		else c.dev = 1.37e-6 * (double)n + 0.31e-6 * s_in;
-	}
+	c.dev = 1.37e-6 * (double)n + 0.31e-6 * s_in;                         // tile kernel
+	c.dev_steps = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);          // one anchor per step
+	c.s_in = s_in;
 	c.host = (double)n * (0.40e-6 + 0.5e-6 * std::min(1.0, s_in / ((double)std::max<int64_t>(n, 1) * 100.0)));
 	return c;
 }
@@ -97,6 +95,19 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		work();
 		for (auto &th : pool) th.join();
 	}
+	// Which device form: the tile kernel broadcasts every anchor of a tile's inner windows to all 64 lanes, the step kernel passes blocks over
+	// per anchor -- with windows of many hundreds of anchors (the mapper's reads: every chain of a read interleaved along x) the latter does
+	// less work per anchor; measured, the tile kernel wins up to a few hundred (profiles/r03o_*).  MM2GB_RMQ_KERNEL overrides.
+	{
+		double sum_in = 0, sum_n = 0;
+		for (size_t r = 0; r < R; ++r) { sum_in += cost[r].s_in; sum_n += (double)(offsets[r + 1] - offsets[r]); }
+		const bool steps = sum_n > 0 && sum_in / sum_n * 64.0 > 400.0;      // mean inner window in anchors
+		const char *v = getenv("MM2GB_RMQ_KERNEL");
+		const bool use_steps = v ? !strcmp(v, "steps") : steps;
+		if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
+		if (!v) (void)mm2gb_engine_set_rmq_kernel(eng, use_steps ? 1 : 0);
+		if (deal) deal->device_kernel = use_steps ? 1 : 0;
+	}
 	std::vector<int64_t> by_dev(R);
 	for (size_t r = 0; r < R; ++r) by_dev[r] = (int64_t)r;
 	std::sort(by_dev.begin(), by_dev.end(), [&](int64_t u, int64_t v) { return cost[(size_t)u].dev != cost[(size_t)v].dev ? cost[(size_t)u].dev > cost[(size_t)v].dev : u < v; });
@@ -117,7 +128,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 			host_sum += c.host; host_max = std::max(host_max, c.host); dev_sum -= c.dev;
 			++n_host;
 		}
-	if (deal) { memset(deal, 0, sizeof(*deal)); deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
+	if (deal) { const int dk = deal->device_kernel; memset(deal, 0, sizeof(*deal)); deal->device_kernel = dk; deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
 
 	// ---- both sides at once ----
 	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, std::vector<mm2gb_anchor_t> &buf) {

@@ -49,8 +49,7 @@ def test_batch_against_the_oracle(engine, monkeypatch, kernel):
     """A batch of reads re-chained in one call: tie counts equal the oracle's, chains equal the oracle's (which uses the same
     stated tie rule, so tied reads agree with IT too).  Both device forms: the tile kernel (64 anchors per step of a wave, a tournament
     tree over the ranks; the default) and the one-anchor-per-step kernel (MM2GB_RMQ_KERNEL=steps)."""
-    if kernel == "steps":
-        monkeypatch.setenv("MM2GB_RMQ_KERNEL", "steps")
+    monkeypatch.setenv("MM2GB_RMQ_KERNEL", kernel)        # (without it the engine keeps the form mm2gb_rmq_chain last picked)
     a, off = mm.synth_reads(41, 0, 40, 10_000, 120_000)
     reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(40)]
     reads.insert(7, np.zeros((0, 2), np.uint64))
@@ -127,10 +126,11 @@ def test_batch_call_that_is_exact_for_every_read(engine, monkeypatch, deal):
             assert d["n_device"] == 0 and (where == 1).all()
 
 
-def test_tile_kernel_on_odd_shapes(engine):
+def test_tile_kernel_on_odd_shapes(engine, monkeypatch):
     """The tile form's edges against the oracle: reads shorter than a tile, exactly one and two tiles, runs of equal x longer than a tile
     (nobody in the run may chain to another), several references and strands in one read (window starts jump), a size cap that evicts
     (cap_rmq_size below the window), gaps wider than max_dist (everything leaves at once), a dense cloud (ties, full inner windows)."""
+    monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles")
     rng = np.random.default_rng(11)
     def cloud(n, xw, yw, rid=1, strand=0, x0=1000, y0=100):
         return sc.pack(np.full(n, rid), np.full(n, strand, np.int64), x0 + rng.integers(0, xw, n), y0 + rng.integers(0, yw, n))
