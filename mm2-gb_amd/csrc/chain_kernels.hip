@@ -945,6 +945,22 @@ __device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, in
 	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bestv) : "v"(bestv), "v"(v), "s"(take));
 }
 
+// the in-tile steps of the sources in `need` (bit t: source t), the next step's coordinate work issued ahead of the current step's chain
+__device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv)
+{
+	if (!need) return;
+	int t = __builtin_ctzll(need);
+	StepPre cur = tile_pre(tl, t);
+	for (;;) {
+		need &= need - 1;
+		const int tn = need ? __builtin_ctzll(need) : t;
+		const StepPre nxt = tile_pre(tl, tn);
+		tile_fin(cur, t, bcast(bestv, t), bestv);
+		if (!need) break;
+		cur = nxt; t = tn;
+	}
+}
+
 // lchain.c:113-138 for one pair with every input wave-uniform (single segment, no cDNA, chn_pen_skip == 0: the MODE_LUT
 // conditions).  The penalty is computed (same function that filled the table) rather than read: an LDS read would put a
 // memory round trip into the serial chain of the tile.
@@ -981,19 +997,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
-		unsigned long long need = __ballot(T.live && T.st < i) >> 1;
-		if (need) {
-			int t = __builtin_ctzll(need);
-			StepPre cur = tile_pre(tl, t);
-			for (;;) {
-				need &= need - 1;
-				const int tn = need ? __builtin_ctzll(need) : t;
-				const StepPre nxt = tile_pre(tl, tn);
-				tile_fin(cur, t, bcast(bestv, t), bestv);
-				if (!need) break;
-				cur = nxt; t = tn;
-			}
-		}
+		plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
 	} else {
 		// the state machine of lchain.c:189-205 runs on the scalar side.  Anchor t's fields come by v_readlane: scalar loads
 		// would share the wave's lgkm counter with the LDS reads of every step and expose their latency
@@ -1023,10 +1027,12 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			extra_v = (sc + keep.f) << 7;
 		}
 		StepPre cur = tile_pre(tl, 0);
-		for (int t = 0; t < n_here; ++t) {
+		int t = 0;
+		for (; t < n_here; ++t) {
+			if (mode == IN_TILE) break;                                              // the rest of the tile: plain steps, below
 			const int j = i0 + t;
 			const StepPre nxt = tile_pre(tl, t + 1 < n_here ? t + 1 : t);
-			if (mode == IN_TILE || (mode == ENTRY && !(slow >> t & 1))) {
+			if (mode == ENTRY && !(slow >> t & 1)) {
 				// lchain.c:196-201 with the precomputed candidate; strict: (V | 127) < 128*cand  <=>  V >> 7 < cand
 				if (mode == ENTRY && (extra >> t & 1)) {
 					const bool take = (lane == t) & ((bestv | 127) < extra_v);
@@ -1082,6 +1088,22 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			if (keep.idx < 0 || keep.f < ft) { keep.idx = j; keep.x = xt; keep.hi = ht; keep.y = yt; keep.tag = tgt; keep.f = ft; }
 			tile_fin(cur, t, s_bv, bestv);
 			cur = nxt;
+		}
+		if (mode == IN_TILE && t < n_here) {
+			// Once an anchor of this tile is the remembered one, nothing the state machine tests can happen before the tile ends: the
+			// remembered anchor lies inside every later window of the tile (no extra candidate, lchain.c:196), it is in reach, and it only
+			// changes to a later anchor of the tile with a higher score (lchain.c:204-205) -- which nobody looks at before the tile ends.
+			// So the remaining sources take the plain steps (those no later anchor reaches are skipped, as in the plain build), and the
+			// remembered anchor is brought up to date afterwards: the first anchor that holds the largest final score from here on, if that
+			// beats the one remembered now -- what updating at every step with a strict '<' leaves.  (Three quarters of the rescue
+			// build's in-tile steps are of this kind on the bench's reads: profiles/r03_block_kinds.json.)
+			const int t_from = t;
+			plain_steps(tl, (__ballot(T.live && T.st < i) >> 1) & (t_from < WAVE ? ~0ull << t_from : 0ull), bestv);
+			const int f_l = (lane >= t_from && lane < n_here) ? bestv >> 7 : INT_MIN;
+			int top = f_l;
+			for (int off = WAVE / 2; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));
+			top = first_lane(top);
+			if (top > keep.f) { keep.idx = i0 + __builtin_ctzll(__ballot(f_l == top)); keep.f = top; }
 		}
 		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile
 			const int k = keep.idx - i0;
@@ -1416,10 +1438,13 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 	// global memory, where every final score goes as well -- written by waves of this workgroup before they published the tile, read
 	// behind the acquire of that publication, one block ahead of its use.
 	int cur = 0;                                                 // the tile whose in-tile phase is running (for f_old)
+	// (the ring through an LDS pointer, not a generic one: a choice between a generic LDS address and a global one becomes a flat load of a
+	// selected address, whose cast the compiler gets wrong -- "Illegal instruction detected: Operand has incorrect register class", ROCm 7.2)
+	const lds_i32_ptr ring_l = (lds_i32_ptr)(uintptr_t)(unsigned)(uintptr_t)ring;
 	auto f_old = [&](int jj) {
 		const unsigned d = (unsigned)(jj - cs);
 		const int k = (int)(d / WAVE);
-		return k >= cur - n_slots ? ring[(unsigned)k % (unsigned)n_slots * WAVE + d % WAVE] : b.f[jj];
+		return k >= cur - n_slots ? ring_l[(unsigned)k % (unsigned)n_slots * WAVE + d % WAVE] : b.f[jj];
 	};
 	for (int pr = wave; 2 * pr < n_tiles; pr += n_waves) {
 		const int ta = 2 * pr, i0 = cs + ta * WAVE;              // tile A = tile ta of the chunk, tile B = ta + 1

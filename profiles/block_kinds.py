@@ -11,7 +11,7 @@ import mm2gb_amd as mm
 out = {}
 for name, lo, hi, n_reads in (("100-300kb", 100_000, 300_000, 1800), ("10-100kb", 10_000, 100_000, 6000)):
     a, off = mm.synth_reads(2024, 0, n_reads, lo, hi, threads=16)
-    cnt = (C.c_ulonglong * 8)()
+    cnt = (C.c_ulonglong * 16)()
     with mm.Engine() as e:
         e.set_misc(mm.default_misc())
         mm.lib().mm2gb_debug_block_counts(cnt, 1)
@@ -27,5 +27,7 @@ for name, lo, hi, n_reads in (("100-300kb", 100_000, 300_000, 1800), ("10-100kb"
     out[name] = {"anchors": int(len(a)), "pairs": int(st["n_pairs"]), "tile_blocks": dict(zip(names, c[:8])), "share": {k: round(v / tot, 4) for k, v in zip(names, c[:8])},
                  "valu_instructions_per_64_pairs_by_kind": {k: round(v * q / tot, 3) for k, v, q in zip(names, c[:8], per_step)},
                  "valu_instructions_per_64_pairs_from_shares": round(budget, 2),
+                 "rescue_build_in_tile": {"tiles": c[11], "steps_entry_mode": c[8], "steps_after_an_update_inside_the_tile": c[9], "steps_full_state_machine": c[10],
+                                          "share_of_all_in_tile_phases": round(c[11] / max(1, c[7]), 3)},
                  "note": "measured overall: roofline.valu_insts_per_64_pairs on the bench line (counters of the shipped build); the difference is block staging, loop control in vector registers and lanes of partly filled tiles"}
 print(json.dumps(out))

@@ -17,20 +17,24 @@ def put(after, text, count=1):
 put("constexpr int SCORE_THREADS = 1024;\n",
     "// counters of tile-blocks by sweep build: 0 two tiles FAR, 1 two tiles unchecked (not FAR), 2 two tiles with range test, 3 one tile FAR, 4 one tile unchecked,\n"
     "// 5 one tile with range test only, 6 one tile with window / equal-position tests, 7 in-tile phases\n"
-    "__device__ unsigned long long g_block_counts[8];\n"
+    "__device__ unsigned long long g_block_counts[16];\n"
     "__device__ __forceinline__ void count_block(int kind, int n) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_block_counts[kind], (unsigned long long)n); }\n")
 put("\tconst int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);\n\tint bestv = best << 7;\n",
     "\tcount_block(far_block ? 3 : free_block ? 4 : no_check ? 5 : 6, 1);\n")
 put("\tint bva = best_a << 7, bvb = best_b << 7;\n", "\tcount_block(far_block ? 0 : free_block ? 1 : 2, 2);\n")
 put("\tconst int lane = lane_id(), i = i0 + lane;\n\t// The in-tile phase is a chain of dependent instructions", "")
 src = src.replace("\t__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);\n\tstage[lane] = make_int4(0, (T.q - 1) * 4,", "\tcount_block(7, 1);\n\t__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);\n\tstage[lane] = make_int4(0, (T.q - 1) * 4,", 1)
-assert src.count("count_block(") == 4
+# steps of the rescue build's in-tile phase by mode: 8 entry, 9 after an update inside the tile, 10 the full state machine; 11 tiles of that build
+put("\t\t\tif (mode == IN_TILE || (mode == ENTRY && !(slow >> t & 1))) {\n", "\t\t\t\tcount_block(mode == IN_TILE ? 9 : 8, 1);\n")
+put("\t\t\tmode = FULL;                                                         // (only ever from ENTRY: IN_TILE stays in the branch above)\n", "\t\t\tcount_block(10, 1);\n")
+put("\t\tenum { ENTRY = 0, IN_TILE = 1, FULL = 2 };\n", "\t\tcount_block(11, 1);\n")
+assert src.count("count_block(") == 7
 src += '''
 extern "C" void mm2gb_debug_block_counts(unsigned long long *out, int reset)
 {
 	(void)hipDeviceSynchronize();
-	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_block_counts), 64);
-	if (reset) { unsigned long long z[8] = {0,0,0,0,0,0,0,0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm2gb::g_block_counts), z, 64); }
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_block_counts), 128);
+	if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm2gb::g_block_counts), z, 128); }
 }
 '''
 out_dir = os.path.join(PKG, "ab")
