@@ -11,6 +11,9 @@
 // (ShapeTree below) -- the chains are then the reference's for every read, ties included; nothing is left to report.
 #include <algorithm>
 #include <atomic>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -312,9 +315,15 @@ struct RankTree {
 };
 
 struct InnerCand { int32_t y, j, x, f; int32_t span; };
+// a bucket's anchors in (y, index) order, one array per field: the scan below reads eight candidates per instruction where AVX2 is there
+struct InnerBucket {
+	std::vector<int32_t> y, j, x, f, span;
+	size_t size() const { return y.size(); }
+	void clear() { y.clear(); j.clear(); x.clear(); f.clear(); span.clear(); }
+};
 struct InnerWindow {
 	static constexpr int SHIFT = 6;
-	std::vector<std::vector<InnerCand>> bucket;
+	std::vector<InnerBucket> bucket;
 	std::vector<int32_t> top;      // per bucket: the largest f + span in it: no pair with one of its anchors can score more (lchain.c:237: sc <= q_span)
 	int y0 = 0;
 	size_t count = 0;
@@ -325,31 +334,78 @@ struct InnerWindow {
 		if (bucket.size() < nb) { bucket.resize(nb); top.resize(nb); }
 		for (size_t b = 0; b < nb; ++b) { bucket[b].clear(); top[b] = INT32_MIN; }
 	}
-	static bool before(const InnerCand &u, int y, int j) { return u.y != y ? u.y < y : u.j < j; }
 	void insert(const InnerCand &c)
 	{
 		const size_t b = (size_t)((c.y - y0) >> SHIFT);
-		auto &v = bucket[b];
+		InnerBucket &v = bucket[b];
 		size_t at = v.size();
-		while (at > 0 && !before(v[at - 1], c.y, c.j)) --at;       // arrivals come in order of x; within a bucket that is mostly near the end
-		v.insert(v.begin() + (ptrdiff_t)at, c);
+		while (at > 0 && !(v.y[at - 1] != c.y ? v.y[at - 1] < c.y : v.j[at - 1] < c.j)) --at;       // arrivals come in order of x; within a bucket that is mostly near the end
+		v.y.insert(v.y.begin() + (ptrdiff_t)at, c.y); v.j.insert(v.j.begin() + (ptrdiff_t)at, c.j); v.x.insert(v.x.begin() + (ptrdiff_t)at, c.x);
+		v.f.insert(v.f.begin() + (ptrdiff_t)at, c.f); v.span.insert(v.span.begin() + (ptrdiff_t)at, c.span);
 		top[b] = std::max(top[b], c.f + c.span);
 		++count;
 	}
 	void erase(int y, int j)
 	{
 		const size_t b = (size_t)((y - y0) >> SHIFT);
-		auto &v = bucket[b];
+		InnerBucket &v = bucket[b];
 		for (size_t at = 0; at < v.size(); ++at)
-			if (v[at].j == j) {
-				v.erase(v.begin() + (ptrdiff_t)at); --count;
+			if (v.j[at] == j) {
+				v.y.erase(v.y.begin() + (ptrdiff_t)at); v.j.erase(v.j.begin() + (ptrdiff_t)at); v.x.erase(v.x.begin() + (ptrdiff_t)at);
+				v.f.erase(v.f.begin() + (ptrdiff_t)at); v.span.erase(v.span.begin() + (ptrdiff_t)at);
+				--count;
 				int32_t t = INT32_MIN;
-				for (const InnerCand &c : v) t = std::max(t, c.f + c.span);
+				for (size_t k = 0; k < v.size(); ++k) t = std::max(t, v.f[k] + v.span[k]);
 				top[b] = t;
 				return;
 			}
 	}
 };
+
+// The exhaustive inner scan of one bucket (lchain.c:328-341 with no skip limit and the penalty a function of the diagonal distance alone):
+// its candidates from the largest (y, index) down, eight at a time; a strictly better score replaces the best, so among equal scores the
+// first met -- the largest (y, index) -- stays.  AVX2; same integer arithmetic as the scalar loop (the penalty comes from the table).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void scan_bucket_avx2(const InnerBucket &v, int xi, int yi, int y_top, int y_bot, int bw, const int32_t *pen, int &max_f, int &max_j)
+{
+	const __m256i vxi = _mm256_set1_epi32(xi), vyi = _mm256_set1_epi32(yi), vtop = _mm256_set1_epi32(y_top), vbot = _mm256_set1_epi32(y_bot), vbw = _mm256_set1_epi32(bw);
+	const __m256i zero = _mm256_setzero_si256(), lowest = _mm256_set1_epi32(INT32_MIN);
+	size_t hi = v.size();
+	while (hi > 0) {
+		const size_t lo = hi >= 8 ? hi - 8 : 0, cnt = hi - lo;
+		// lanes 0 .. cnt-1 hold candidates lo .. hi-1 in ascending (y, index) order: the first met going down is the HIGHEST lane
+		const __m256i lane = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+		const __m256i have = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)cnt), lane);
+		const __m256i cy = _mm256_maskload_epi32(v.y.data() + lo, have), cx = _mm256_maskload_epi32(v.x.data() + lo, have);
+		const __m256i cf = _mm256_maskload_epi32(v.f.data() + lo, have), cs = _mm256_maskload_epi32(v.span.data() + lo, have);
+		const __m256i dq = _mm256_sub_epi32(vyi, cy), dr = _mm256_sub_epi32(vxi, cx);
+		const __m256i dd = _mm256_abs_epi32(_mm256_sub_epi32(dr, dq)), dg = _mm256_min_epi32(dr, dq);
+		// in range: y_bot <= y <= y_top, dd <= bw
+		__m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi32(cy, vtop), have);
+		ok = _mm256_andnot_si256(_mm256_cmpgt_epi32(vbot, cy), ok);
+		ok = _mm256_andnot_si256(_mm256_cmpgt_epi32(dd, vbw), ok);
+		if (_mm256_testz_si256(ok, ok)) { if (_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_and_si256(have, _mm256_cmpgt_epi32(vbot, cy)))) == (int)((1u << cnt) - 1)) return; hi = lo; continue; }
+		const __m256i p = _mm256_mask_i32gather_epi32(zero, pen, dd, ok, 4);
+		// sc = min(span, dg) - (dd != 0 || dq > span ? pen[dd] : 0)
+		const __m256i charged = _mm256_or_si256(_mm256_xor_si256(_mm256_cmpeq_epi32(dd, zero), _mm256_set1_epi32(-1)), _mm256_cmpgt_epi32(dq, cs));
+		const __m256i sc = _mm256_sub_epi32(_mm256_min_epi32(cs, dg), _mm256_and_si256(p, charged));
+		const __m256i s2 = _mm256_blendv_epi8(lowest, _mm256_add_epi32(cf, sc), ok);
+		// the largest score of the eight, and the highest lane that holds it
+		__m256i m = _mm256_max_epi32(s2, _mm256_permute2x128_si256(s2, s2, 1));
+		m = _mm256_max_epi32(m, _mm256_shuffle_epi32(m, 0x4e));
+		m = _mm256_max_epi32(m, _mm256_shuffle_epi32(m, 0xb1));
+		const int best = _mm256_cvtsi256_si32(m);
+		if (best > max_f) {
+			const unsigned who = (unsigned)_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_and_si256(_mm256_cmpeq_epi32(s2, m), ok)));
+			max_f = best; max_j = v.j[lo + (31 - (size_t)__builtin_clz(who))];
+		}
+		// every candidate below these is below the range too once the lowest of them is (a bucket is sorted by y)
+		if (v.y[lo] < y_bot) return;
+		hi = lo;
+	}
+}
+#endif
+
 struct FillScratch { ShapeTree tree; RankTree flat; InnerWindow inner; std::vector<int32_t> seen; };   // seen: the reference's t[] (lchain.c:333-338)
 
 // f[n], p_rel[n] (i - predecessor, 0 = none) of one read
@@ -362,6 +418,9 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                                   // lchain.c:264
 	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;         // lchain.c:265
 	const double half_gap = 0.5 * (double)P.chn_pen_gap;
+#if defined(__x86_64__)
+	const bool use_avx2 = __builtin_cpu_supports("avx2") && !getenv("MM2GB_RMQ_NO_SIMD");   // (MM2GB_RMQ_NO_SIMD: the scalar scan, for A/B runs and tests; read once per read)
+#endif
 	auto &tree = [&]() -> auto& { if constexpr (EXACT_SHAPE) return ws.tree; else return ws.flat; }();
 	if constexpr (EXACT_SHAPE) tree.reset(a, n); else tree.reset(a, n, max_dist);
 	ws.seen.assign((size_t)n, 0);
@@ -411,19 +470,23 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 				const int b_bot = (std::max(y_bot, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT;
 				bool stop = y_top < ws.inner.y0;
 				for (int b = b_top; b >= b_bot && !stop; --b) {
-					const auto &v = ws.inner.bucket[(size_t)b];
+					const InnerBucket &v = ws.inner.bucket[(size_t)b];
 					// without a skip limit a candidate matters only if it beats the best so far, and none of this bucket can
 					if (exhaustive && ws.inner.top[(size_t)b] <= max_f) continue;
+#if defined(__x86_64__)
+					if (exhaustive && pen && use_avx2) { scan_bucket_avx2(v, xi, yi, y_top, y_bot, P.bw, pen, max_f, max_j); continue; }
+#endif
 					for (size_t at = v.size(); at-- > 0;) {
-						const InnerCand &c = v[at];
-						if (c.y > y_top) continue;
-						if (c.y < y_bot) break;
+						const int cy = v.y[at];
+						if (cy > y_top) continue;
+						if (cy < y_bot) break;
 						// comput_sc_simple (lchain.c:232-248) on the copies
-						const int dq = yi - c.y, dr = xi - c.x, dd = dr > dq ? dr - dq : dq - dr;
+						const int cj = v.j[at], cspan = v.span[at];
+						const int dq = yi - cy, dr = xi - v.x[at], dd = dr > dq ? dr - dq : dq - dr;
 						if (dd > P.bw) continue;
 						const int dg = dr < dq ? dr : dq;
-						int sc = c.span < dg ? c.span : dg;
-						if (dd || dq > c.span) {
+						int sc = cspan < dg ? cspan : dg;
+						if (dd || dq > cspan) {
 							if (pen) sc -= pen[dd];
 							else {
 								const float lin = P.chn_pen_gap * (float)dd + P.chn_pen_skip * (float)dg;
@@ -431,14 +494,14 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 								sc -= (int)(lin + .5f * lg);
 							}
 						}
-						const int s2 = c.f + sc;
+						const int s2 = v.f[at] + sc;
 						if (exhaustive) {                          // no skip limit: the marks of lchain.c:333-338 decide nothing -- no look at p[] and seen[] per candidate
-							if (s2 > max_f) { max_f = s2; max_j = c.j; }
+							if (s2 > max_f) { max_f = s2; max_j = cj; }
 							continue;
 						}
-						if (s2 > max_f) { max_f = s2; max_j = c.j; if (n_skip > 0) --n_skip; }
-						else if (ws.seen[(size_t)c.j] == i) { if (++n_skip > P.max_chn_skip) { stop = true; break; } }
-						if (p_rel[c.j]) ws.seen[(size_t)(c.j - p_rel[c.j])] = i;
+						if (s2 > max_f) { max_f = s2; max_j = cj; if (n_skip > 0) --n_skip; }
+						else if (ws.seen[(size_t)cj] == i) { if (++n_skip > P.max_chn_skip) { stop = true; break; } }
+						if (p_rel[cj]) ws.seen[(size_t)(cj - p_rel[cj])] = i;
 					}
 				}
 			}

@@ -82,3 +82,24 @@ def test_ties_are_broken_like_the_reference():
             n_tied_reads += orc.lchain_rmq(x, prm)["n_tied"] > 0
             assert np.array_equal(res[r][0], ref["u"]) and np.array_equal(res[r][1], ref["a_out"]), (kw, r)
     assert n_tied_reads >= 8
+
+
+def test_vector_and_scalar_inner_scans_agree(monkeypatch):
+    """The exhaustive inner scan reads eight candidates per instruction where AVX2 is there (scan_bucket_avx2); MM2GB_RMQ_NO_SIMD=1 keeps the
+    scalar loop.  Same chains from both, on reads with full inner windows (dense clouds, many interleaved chains) under the parameter sets
+    that take the vector path (no skip limit, chn_pen_skip == 0)."""
+    rng = np.random.default_rng(17)
+    reads = batch_of_reads()
+    for n, w in ((5000, 900), (12000, 2500)):
+        reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(n, 1), np.zeros(n, np.int64), 1000 + rng.integers(0, w, n), 100 + rng.integers(0, w, n)))))
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    for kw in (dict(), dict(bw=20000, max_dist=5000, max_dist_inner=1000), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(bw=7, max_dist=900, max_dist_inner=300)):
+        prm = to_lib(orc.default_rmq_param(**kw))
+        monkeypatch.delenv("MM2GB_RMQ_NO_SIMD", raising=False)
+        fast, _ = mm.rmq_chain_host(allr, o2, prm, threads=4)
+        monkeypatch.setenv("MM2GB_RMQ_NO_SIMD", "1")
+        slow, _ = mm.rmq_chain_host(allr, o2, prm, threads=4)
+        for r in range(len(reads)):
+            assert np.array_equal(fast[r][0], slow[r][0]) and np.array_equal(fast[r][1], slow[r][1]), (kw, r)
