@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Instrumented build of the score kernel: where the serial chain through the tiles of a team's chunk spends its time.  A COPY of
+csrc/chain_kernels.hip with 100 MHz time stamps around the waits, the in-tile phases and the rescue rescans of the team code,
+compiled into mm2-gb_amd/ab/libchain.so (git-ignored, travels to the GPU box).   python profiles/experiments/make_chain_timing_build.py"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.join(ROOT, "mm2-gb_amd")
+src = open(os.path.join(PKG, "csrc", "chain_kernels.hip")).read()
+
+
+def sub(old, new, count=1):
+    global src
+    assert src.count(old) >= 1, old
+    src = src.replace(old, new, count)
+
+
+sub("constexpr int SCORE_THREADS = 1024;\n",
+    "constexpr int SCORE_THREADS = 1024;\n"
+    "// 0 ticks waiting for the earlier tiles before an in-tile phase, 1 ticks in in-tile phases, 2 in-tile phases, 3 rescans, 4 ticks in rescans, 5 full-state-machine steps,\n"
+    "// 6 entry-mode steps, 7 ticks from 'earlier tiles final' to 'this tile published' (the chain), 8 tiles of rescue chunks in team code, 9 blocks read by rescans\n"
+    "__device__ unsigned long long g_chain[16];\n"
+    "__device__ __forceinline__ long long tick() { return (long long)__builtin_amdgcn_s_memrealtime(); }\n"
+    "__device__ __forceinline__ void chain_add(int k, long long v) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_chain[k], (unsigned long long)v); }\n")
+# whole-workgroup / big-team path with one tile per wave (coop_chunk)
+sub("		const int my_slot = (int)((unsigned)t % (unsigned)n_slots);\n		wait_done(t);                                                    // every earlier tile is final\n",
+    "		const int my_slot = (int)((unsigned)t % (unsigned)n_slots);\n		const long long tk0 = tick();\n		wait_done(t);                                                    // every earlier tile is final\n		const long long tk1 = tick();\n")
+sub("		if (lane == 0) __hip_atomic_store(&sh->done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);\n	}\n}",
+    "		if (lane == 0) __hip_atomic_store(&sh->done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);\n		if (TRACK) { chain_add(0, tk1 - tk0); chain_add(7, tick() - tk1); chain_add(8, 1); }\n	}\n}")
+# the rescue rescan of the table build (first occurrence = in_tile_lut)
+sub("				int bf = INT_MIN, bi = -1;\n				for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)\n",
+    "				const long long rk0 = tick();\n				chain_add(3, 1); chain_add(9, (i0 - stt + 63) / 64);\n				int bf = INT_MIN, bi = -1;\n				for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)\n")
+sub("				keep.idx = first_lane(bi);\n				if (keep.idx >= 0) {\n					keep.f = first_lane(bf);\n					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;\n				}\n",
+    "				keep.idx = first_lane(bi);\n				if (keep.idx >= 0) {\n					keep.f = first_lane(bf);\n					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;\n				}\n				chain_add(4, tick() - rk0);\n")
+sub("			mode = FULL;                                                         // (only ever from ENTRY: IN_TILE stays in the branch above)\n",
+    "			mode = FULL;                                                         // (only ever from ENTRY: IN_TILE stays in the branch above)\n			chain_add(5, 1);\n")
+sub("			if (mode == ENTRY && !(slow >> t & 1)) {\n", "			if (mode == ENTRY && !(slow >> t & 1)) {\n				chain_add(6, 1);\n")
+# in-tile phases of the rescue build: ticks
+sub("		enum { ENTRY = 0, IN_TILE = 1, FULL = 2 };\n", "		enum { ENTRY = 0, IN_TILE = 1, FULL = 2 };\n		const long long ik0 = tick();\n		chain_add(2, 1);\n")
+sub("		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile\n",
+    "		chain_add(1, tick() - ik0);\n		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile\n")
+# split of the rescue build's in-tile phase: 10 ticks before the step loop (set-up, entry precomputation), 11 ticks in the step loop (entry / full steps), 12 ticks in the plain steps + keep update
+sub("		StepPre cur = tile_pre(tl, 0);\n		int t = 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;",
+    "		const long long ik1 = tick();\n		chain_add(10, ik1 - ik0);\n		StepPre cur = tile_pre(tl, 0);\n		int t = 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;")
+sub("		if (mode == IN_TILE && t < n_here) {\n", "		const long long ik2 = tick();\n		chain_add(11, ik2 - ik1);\n		if (mode == IN_TILE && t < n_here) {\n")
+sub("		chain_add(1, tick() - ik0);\n", "		chain_add(1, tick() - ik0); chain_add(12, tick() - ik2);\n")
+src += '''
+extern "C" void mm2gb_debug_chain_ticks(unsigned long long *out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_chain), 128);
+	if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm2gb::g_chain), z, 128); }
+}
+'''
+out_dir = os.path.join(PKG, "ab")
+os.makedirs(out_dir, exist_ok=True)
+tmp = os.path.join(PKG, "csrc", "chain_kernels_timing_tmp.hip")
+open(tmp, "w").write(src)
+try:
+    subprocess.check_call(["make", "-s", "-C", PKG])
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include")]
+    obj = os.path.join(out_dir, "chain_kernels_timing.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", tmp, "-o", obj])
+    others = [os.path.join(PKG, "build", f) for f in os.listdir(os.path.join(PKG, "build")) if f.endswith(".o") and f != "chain_kernels.o"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj] + others + ["-o", os.path.join(out_dir, "libchain.so"), "-lpthread"])
+finally:
+    os.remove(tmp)
+print(os.path.join(out_dir, "libchain.so"))
