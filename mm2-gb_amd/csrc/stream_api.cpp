@@ -460,12 +460,16 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	if (g_streams.ready) free_stream_gpu((int)g_streams.slots.size());
 	if (mm2gb_config_load(gpu_config_file, &g_streams.cfg)) die(mm2gb_last_error());
 	mm2gb_config_t &cfg = g_streams.cfg;
-	// Every stream id is an engine with three HIP streams (H2D, kernels, D2H).  The HIP runtime multiplexes streams onto 4
-	// hardware queues unless told otherwise, and streams that share a queue run one after the other: four host threads then
-	// gain 1.3x over one, with enough queues 3.5x (profiles/stream_api_rate.py).  Only effective before the runtime starts,
-	// i.e. when this is the first HIP call of the process, as it is in the minimap2 host.
-	if (cfg.num_streams > 1 && !getenv("GPU_MAX_HW_QUEUES"))
-		setenv("GPU_MAX_HW_QUEUES", std::to_string(std::min(3 * cfg.num_streams + 1, 32)).c_str(), 0);
+	// Every stream id is an engine with four HIP streams (copy in, two compute, copy out).  The HIP runtime multiplexes streams onto 4
+	// hardware queues unless told otherwise, and streams that share a queue run one after the other: four host threads driving 64-read
+	// batches reach 0.28-0.49 G anchors/s with 8 queues, 0.80 with 16 or more (one thread: 0.26; profiles/r03_small_batches.txt).
+	// Only effective before the runtime starts, i.e. when this is the first HIP call of the process, as it is in the minimap2 host;
+	// a value that is already set is the host's to choose, but one that is too small is worth a line.
+	const int want_queues = std::min(4 * cfg.num_streams + 2, 64);
+	if (const char *q = getenv("GPU_MAX_HW_QUEUES")) {
+		if (cfg.num_streams > 1 && atoi(q) < 4 * cfg.num_streams)
+			fprintf(stderr, "[mm2gb] GPU_MAX_HW_QUEUES=%s with num_streams=%d: streams will share hardware queues and serialise (four per stream id: %d)\n", q, cfg.num_streams, want_queues);
+	} else if (cfg.num_streams > 1) setenv("GPU_MAX_HW_QUEUES", std::to_string(want_queues).c_str(), 0);
 	if (!(cfg.has_max_total_n && cfg.has_max_read)) {
 		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's footprint per anchor:
 		// 16 B of work arrays + two staging sets of 24 B (raw in, f and p out)

@@ -12,7 +12,10 @@ from test_gpu_stream_api import ChainRead, libc
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stream_api_rate.json"))
 ap.add_argument("--threads", type=int, default=0, help="also drive this many streams at once (host threads, one stream id each; needs num_streams >= threads in the config)")
+ap.add_argument("--leave-queues-to-the-library", action="store_true", help="do not export GPU_MAX_HW_QUEUES here: init_stream_gpu sets it (if the HIP runtime has not started)")
 args = ap.parse_args()
+if args.threads > 1 and not args.leave_queues_to_the_library:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.threads + 2))      # four HIP streams per stream id; before the runtime starts
 L = mm.lib()
 L.init_stream_gpu.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, mm.Misc]
 L.chain_stream_gpu.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
