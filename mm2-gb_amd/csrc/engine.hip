@@ -446,6 +446,12 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)post_bins.ptr;
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
 	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream));
+	b.dbg_reads = nullptr;
+	if (debug_phases && !rmq) {
+		if (post_dbg_reads.ensure((size_t)std::max<int64_t>(n_reads, 1) * 32)) return -1;
+		MM2GB_HIP(hipMemsetAsync(post_dbg_reads.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * 32, stream));
+		b.dbg_reads = (long long*)post_dbg_reads.ptr;
+	}
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
 	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
 	if (rmq) { b.min_cnt = rmq->min_cnt; b.min_sc = rmq->min_sc; b.max_drop = rmq->bw; }   // lchain.c:253,355
@@ -978,6 +984,33 @@ int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_off
 		if (t[6])
 			fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
 			        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);
+		// the schedule: when the reads that finish last were started, and how long their parts took
+		if (n_reads > 0 && e.post_dbg_reads.ptr) {
+			std::vector<long long> tr((size_t)n_reads * 4);
+			std::vector<int64_t> off((size_t)n_reads + 1);
+			if (hipMemcpy(tr.data(), e.post_dbg_reads.ptr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+			    hipMemcpy(off.data(), d_offsets, off.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+				long long t_first = LLONG_MAX, t_last = 0;
+				for (int64_t r = 0; r < n_reads; ++r) if (tr[4 * r]) { t_first = std::min(t_first, tr[4 * r]); t_last = std::max(t_last, tr[4 * r + 3]); }
+				std::vector<int64_t> idx;
+				for (int64_t r = 0; r < n_reads; ++r) if (tr[4 * r]) idx.push_back(r);
+				std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b2) { return tr[4 * a + 3] > tr[4 * b2 + 3]; });
+				fprintf(stderr, "[mm2gb post-pass] k_post_chains: first read starts at 0, last ends at %.2f ms; the reads that end last (anchors | start | collect | sort | walks | end, ms):\n", (t_last - t_first) / 1e5);
+				for (size_t k = 0; k < std::min<size_t>(idx.size(), 12); ++k) {
+					const int64_t r = idx[k];
+					fprintf(stderr, "    read %6lld  %7lld | %6.2f | %5.2f | %6.2f | %6.2f | %6.2f\n", (long long)r, (long long)(off[r + 1] - off[r]), (tr[4 * r] - t_first) / 1e5,
+					        (tr[4 * r + 1] - tr[4 * r]) / 1e5, (tr[4 * r + 2] - tr[4 * r + 1]) / 1e5, (tr[4 * r + 3] - tr[4 * r + 2]) / 1e5, (tr[4 * r + 3] - t_first) / 1e5);
+				}
+				// reads in flight over time (how many wave slots still work at t)
+				const int n_bins = 14;
+				std::vector<int> busy(n_bins, 0);
+				const double span = std::max(1.0, (double)(t_last - t_first));
+				for (int64_t r : idx) for (int k = 0; k < n_bins; ++k) { const double at = t_first + span * (k + 0.5) / n_bins; if (tr[4 * r] <= at && at < tr[4 * r + 3]) ++busy[k]; }
+				fprintf(stderr, "    reads in flight at %d points of the kernel's time:", n_bins);
+				for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
+				fprintf(stderr, "\n");
+			}
+		}
 	}
 	float t = 0;
 	if (ms && hipEventElapsedTime(&t, e.post0, e.post1) == hipSuccess) *ms = t;

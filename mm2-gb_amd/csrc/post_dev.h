@@ -34,6 +34,7 @@ struct PostBatch {
 	int       grid_waves;      // waves to launch (one read per wave at a time)
 	int       team_reads;      // the largest reads of the batch that a whole workgroup starts on together (k_post_chains)
 	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed 100 MHz ticks of [0] candidate collection [1] sort [2] chain walks [3] emit
+	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES): per read 4 ticks: start, end of collection, end of sort, end of walks (k_post_chains)
 };
 void launch_post(const PostBatch &b, hipStream_t s);
 

@@ -54,6 +54,13 @@ __device__ __forceinline__ void wave_sync()
 #define MM2GB_POST_LINE_BYTES 6144
 #endif
 constexpr int LINE_STORE_BYTES = MM2GB_POST_LINE_BYTES;
+static_assert(LINE_STORE_BYTES % 1024 == 0 && LINE_STORE_BYTES / 8 >= 2 * 256 + 64, "line slots come in whole rounds of 64 for both element kinds (8 and 16 bytes), and every bucket owns at least two (8-byte elements): fewer and the lines cannot be laid out");
+// k_post_chains: registers are budgeted for this many waves per SIMD (= workgroups per CU; its LDS allows 3 at 6 KB of lines).  The kernel is a
+// sum of latencies: 168 registers and three waves per SIMD (6 spilled) against 184 and two: 58.5 -> 55.7 ms per 500 M anchors
+#ifndef MM2GB_POST_WAVES_PER_SIMD
+#define MM2GB_POST_WAVES_PER_SIMD 3
+#endif
+constexpr int POST_WAVES_PER_SIMD = MM2GB_POST_WAVES_PER_SIMD;
 struct alignas(16) PassLds {
 	int where[256];              // histogram first; then line start | line length << 16
 	int head[256], tail[256], anchor[256];
@@ -637,7 +644,7 @@ __device__ __forceinline__ int post_collect(const PostBatch &b, const int32_t *f
 // through 256 bucket heads, inherently serial (ksort.h:116-146) -- is wave 0's, and its buckets, which the host sorts independently of each
 // other (rs_sort's recursion, ksort.h:140-145), are dealt to the four waves, largest first.  The chain walks are wave 0's again (they
 // depend on each other through the marks); the other three waves go on to reads of their own.
-__global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b, int team_reads)
+__global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chains(PostBatch b, int team_reads)
 {
 	__shared__ PassLds lds[POST_THREADS / W];
 	__shared__ int s_team[8];                                // [0] the team's read (position in the order), [1..4] candidates per wave, [5] next task
@@ -754,6 +761,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_chains(PostBatch b, int t
 			b.n_kept[r] = n_v;
 			if (b.dbg) {
 				const long long t3 = (long long)__builtin_amdgcn_s_memrealtime();
+				if (b.dbg_reads) { b.dbg_reads[4 * r] = t0; b.dbg_reads[4 * r + 1] = t1; b.dbg_reads[4 * r + 2] = t2; b.dbg_reads[4 * r + 3] = t3; }
 				atomicAdd((unsigned long long*)&b.dbg[0], (unsigned long long)(t1 - t0));
 				atomicAdd((unsigned long long*)&b.dbg[1], (unsigned long long)(t2 - t1));
 				atomicAdd((unsigned long long*)&b.dbg[2], (unsigned long long)(t3 - t2));
