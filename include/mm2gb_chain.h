@@ -146,10 +146,13 @@ typedef struct {
 } mm2gb_rmq_param_t;
 int  mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                          mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats);
-typedef struct { int64_t n_device, n_host_cost, n_host_tie; double est_device_s, est_host_s, device_s, host_s, tie_s, total_s; int32_t device_kernel /* 0 tiles, 1 steps */, pad_; } mm2gb_rmq_deal_t;
+typedef struct { int64_t n_device, n_host_cost, n_host_tie; double est_device_s, est_host_s, device_s, host_s, tie_s, total_s; int32_t device_kernel /* 0 tiles, 1 steps */, n_team /* device reads a whole workgroup filled */; } mm2gb_rmq_deal_t;
 /* device form of the fill for this engine's later calls: 0 the tile kernel (64 anchors per step of a wave; best where inner windows hold up to a few hundred
  * anchors), 1 one anchor per step (best where they hold many: its inner scan passes blocks over per anchor).  mm2gb_rmq_chain picks per call. */
 int  mm2gb_engine_set_rmq_kernel(mm2gb_engine_t *eng, int kind);
+/* tile kernel, this engine's NEXT mm2gb_rmq_chain_gpu call only: its first n reads are filled by a whole workgroup each (the sweeps over a tile's inner
+ * window shared by its waves) instead of one wave -- for the few reads of a batch that would otherwise set its pace.  mm2gb_rmq_chain sets it. */
+int  mm2gb_engine_set_rmq_team_reads(mm2gb_engine_t *eng, int n);
 int  mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                      int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal);
 /* The same on host threads, O(log n) per anchor, the reference's answer for EVERY read at any max_chn_skip (csrc/rmq_host.cpp): a read

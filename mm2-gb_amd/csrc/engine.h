@@ -79,7 +79,7 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_dbg_reads, post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
+	DevBuf post_dbg_reads, rmq_dbg_reads, post_z, post_mark, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
 	DevBuf sd_seeds, sd_seed_off, sd_hit_off, sd_hits, sd_qlen, sd_q_rank, sd_ref_len, sd_ref_rank, sd_seed_read, sd_tmp, sd_n_kept, sd_a_off, sd_out;   // mm2gb_collect_seeds_gpu
 	// what the post-pass leaves for the host, two sets: the boundary keeps two batches in flight (the results of batch k are
 	// fetched after batch k+1 has been launched)
@@ -107,6 +107,7 @@ struct Engine {
 	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)
 	int64_t last_split_chunks = 0, last_helped_items = 0;   // of the last call: chunks scored strip by strip, items other workgroups took
 	bool rmq_tiles_last = false;    // which form the last RMQ call ran (for the debug print)
+	int  rmq_team_reads = 0;        // tile form, the NEXT device call only: its first reads that get a whole workgroup each (mm2gb_rmq_chain puts the costliest first); MM2GB_RMQ_TEAM_READS overrides
 	int  rmq_kernel = 0;            // device form of the RMQ fill: 0 tiles (k_rmq_fill_tiles), 1 one anchor per step (k_rmq_fill); MM2GB_RMQ_KERNEL=steps|tiles overrides
 	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)
 	int64_t dual_stream_max_n = 16 * 1000 * 1000;   // micro-batches up to this many anchors alternate between the two compute streams

@@ -277,7 +277,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -567,8 +567,17 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			}
 		}
 		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;
+		rb.n_team = rmq_team_reads;
+		rmq_team_reads = 0;
+		if (const char *v = getenv("MM2GB_RMQ_TEAM_READS")) rb.n_team = std::max(0, atoi(v));
 		rb.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1536) : nullptr;
 		if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1536, 0, 64, stream));
+		rb.dbg_reads = nullptr;
+		if (debug_phases) {
+			if (rmq_dbg_reads.ensure((size_t)std::max<int64_t>(n_reads, 1) * 64)) return -1;
+			MM2GB_HIP(hipMemsetAsync(rmq_dbg_reads.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * 64, stream));
+			rb.dbg_reads = (long long*)rmq_dbg_reads.ptr;
+		}
 		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
 		launch_rmq_fill(rb, rp, stream);
 		MM2GB_HIP(hipGetLastError());
@@ -580,6 +589,19 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (rmq && debug_phases && n > 0) {
 		long long t[8] = { 0 };
 		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+			if (rmq_tiles_last && rmq_dbg_reads.ptr && n_reads > 0) {
+				std::vector<long long> tr((size_t)n_reads * 8);
+				if (hipMemcpy(tr.data(), rmq_dbg_reads.ptr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+					std::vector<int64_t> idx((size_t)n_reads);
+					for (int64_t r = 0; r < n_reads; ++r) idx[(size_t)r] = r;
+					std::sort(idx.begin(), idx.end(), [&](int64_t u, int64_t v) { return tr[8 * u + 2] > tr[8 * v + 2]; });
+					fprintf(stderr, "[mm2gb rmq fill, tiles] the slowest reads (position in the call | anchors | waves | ms whole | tree update | queries | broadcasts (incl. waiting for the team) | in-tile steps | anchors broadcast by wave 0):\n");
+					for (size_t k = 0; k < std::min<size_t>(idx.size(), 8); ++k) {
+						const long long *o = tr.data() + 8 * idx[k];
+						fprintf(stderr, "    %6lld | %8lld | %2lld | %8.2f | %8.2f | %8.2f | %8.2f | %8.2f | %lld\n", (long long)idx[k], o[0], o[1], o[2] / 1e5, o[3] / 1e5, o[4] / 1e5, o[5] / 1e5, o[6] / 1e5, o[7] & 0xfffffffffLL);
+					}
+				}
+			}
 			if (rmq_tiles_last)
 				fprintf(stderr, "[mm2gb rmq fill, tiles] %lld anchors, %lld tiles; wave time in 10 ns ticks, summed over reads: tree update %lld, queries %lld, broadcasts %lld (%lld anchors broadcast, %lld blocks scanned for one lane, "
 				                "%lld inner blocks passed over, %lld lanes scanned their inner window again), in-tile steps %lld\n", t[0], t[1], t[2], t[3], t[4], t[5] & 0xfffffffffLL, t[5] >> 36, t[6] & 0xffffffffLL, t[6] >> 32, t[7]);
@@ -910,6 +932,7 @@ void mm2gb_engine_destroy(mm2gb_engine_t *eng)
 
 int mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc) { return eng ? eng->e.set_misc(misc) : fail("mm2gb: null engine"); }
 int mm2gb_engine_device(const mm2gb_engine_t *eng) { return eng ? eng->e.device : -1; }
+int mm2gb_engine_set_rmq_team_reads(mm2gb_engine_t *eng, int n) { if (!eng || n < 0) return fail("mm2gb_engine_set_rmq_team_reads: bad argument"); eng->e.rmq_team_reads = n; return 0; }
 int mm2gb_engine_set_rmq_kernel(mm2gb_engine_t *eng, int kind) { if (!eng || kind < 0 || kind > 1) return fail("mm2gb_engine_set_rmq_kernel: bad argument"); eng->e.rmq_kernel = kind; return 0; }
 int mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads) { return eng ? eng->e.reserve(n_anchors, n_reads) : fail("mm2gb: null engine"); }
 void *mm2gb_engine_stream(mm2gb_engine_t *eng) { return eng ? (void*)eng->e.stream : nullptr; }

@@ -392,8 +392,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			mm2gb_rmq_deal_t deal;
 			if (mm2gb_rmq_chain(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, where.data(), &deal)) { free_matches(); return -1; }
 			for (size_t q = 0; q < redo.size(); ++q) tied[q] = where[q] == 2;
-			if (verbose) fprintf(stderr, "[mm2gb] re-chaining deal: %lld reads on the device (%.3f s, estimated %.3f), %lld on host threads by cost (%.3f s, estimated %.3f), %lld redone after a tie (%.3f s)\n",
-			                     (long long)deal.n_device, deal.device_s, deal.est_device_s, (long long)deal.n_host_cost, deal.host_s, deal.est_host_s, (long long)deal.n_host_tie, deal.tie_s);
+			if (verbose) fprintf(stderr, "[mm2gb] re-chaining deal: %lld reads on the device, %d of them a whole workgroup's (%.3f s, estimated %.3f), %lld on host threads by cost (%.3f s, estimated %.3f), %lld redone after a tie (%.3f s)\n",
+			                     (long long)deal.n_device, (int)deal.n_team, deal.device_s, deal.est_device_s, (long long)deal.n_host_cost, deal.host_s, deal.est_host_s, (long long)deal.n_host_tie, deal.tie_s);
 		} else if (opt.rechain_on_device > 0) {
 			if (mm2gb_rmq_chain_gpu(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), &rc, tied.data(), nullptr)) { free_matches(); return -1; }
 			std::vector<int64_t> to(1, 0);

@@ -55,8 +55,10 @@ struct RmqBatch {
 	uint4   *tree;             // tile form, scratch, 2 n: per read a binary tournament tree over its ranks (key low, key high, rank | several << 31, -)
 	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed over reads [0] steps [1] late entries [2] summaries rebuilt [3] ties looked at [4] summary loads [5] inner blocks read [6] winners read from memory [7] eviction tests (tile form: [0] anchors [1] tiles [2] ticks of tree updates [3] of queries [4] of broadcasts [5] anchors broadcast [6] inner blocks passed over [7] ticks of in-tile steps)
 	int32_t *n_tied;           // out, per read: anchors whose range-minimum was shared by several elements (see post_kernels.hip)
-	int32_t *cursor;
+	int32_t *cursor;           // two work cursors: reads taken by single waves, reads taken by teams
 	int      grid_waves;
+	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES), tile form: per read 8 values: anchors, waves, ticks whole / tree update / queries / broadcasts / in-tile steps, anchors broadcast (wave 0 of a team)
+	int      n_team;           // tile form: the first n_team reads of the batch are filled by a whole workgroup each (k_rmq_fill_tiles)
 };
 void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);
 

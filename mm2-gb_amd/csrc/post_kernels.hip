@@ -1414,17 +1414,22 @@ __global__ __launch_bounds__(256) void k_rmq_tree_init(RmqBatch b)
 	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < 2 * b.n; g += (int64_t)gridDim.x * blockDim.x) b.tree[g] = none;
 }
 
-__global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqParams P)
+// One read, by NW waves (1: the wave alone; RMQ_TEAM: a whole workgroup, wave w of it).  In a team wave 0 does what is serial -- the tree, the
+// queries, the 64 steps of the tile's own anchors -- and all NW share the broadcast sweeps, block by block in turn (a tile's sweeps are most
+// of its time on reads with hundreds of anchors in the inner window); their results per lane -- the best outer candidate, the best of the
+// inner window, the largest bound a lane relied on -- meet in LDS (`s_m`) and are combined by the rules of tile_offer / tile_offer_inner,
+// which do not depend on the order of the offers.  Two workgroup barriers per tile: before the combination, and after the tile's scores are out.
+constexpr int RMQ_THREADS = 1024;              // k_rmq_fill_tiles: 16 waves -- one read each, or all 16 on one read
+constexpr int RMQ_TEAM = RMQ_THREADS / W;
+constexpr int RMQ_MERGE_WORDS = 12;
+template <int NW>
+__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W])
 {
 	const int l = lane();
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
 	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;   // lchain.c:265
 	const double half_gap = 0.5 * (double)P.pen_gap;
-	for (;;) {
-		int r = 0;
-		if (l == 0) r = atomicAdd(b.cursor, 1);
-		r = uni(r);
-		if (r >= b.n_reads) break;
+	{
 		const int64_t off = b.offsets[r];
 		const int n = (int)(b.offsets[r + 1] - off);
 		const uint4 *a = b.raw + off;
@@ -1434,6 +1439,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
 		int32_t *bound = b.bound + (off >> 6) + r;           // per block of 64 anchors (by index) the largest f + span, once its tile is done
 		int ev = 0, ins = 0, tied = 0;                       // the tree holds the anchors of index [ev, ins)
+		const long long t_read0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		long long d_tiles = 0, d_upd = 0, d_levels = 0, d_qloads = 0, d_bcast = 0, d_skip = 0, d_t3 = 0, d_redo = 0, d_single = 0;   // MM2GB_DEBUG_PHASES: 100 MHz ticks of the tree update, the queries, the broadcasts, the in-tile steps
 		for (int tb = 0; tb < n; tb += W) {
 			const int n_here = min(W, n - tb), i = tb + l;
@@ -1450,7 +1456,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 			++d_tiles;
 			const long long ts0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			// ---- the tree: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) ----
-			{
+			if (NW == 1 || w == 0) {
 				int e0 = ev, n0 = max(ins, lo);
 				const int e1 = min(lo, ins), n1 = hi;
 				while (e0 < e1 || n0 < n1) {
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 			{
 				uint4 best = tnode_none();
 				int ql = n + M.y, qr = n + M.z + 1;                                // [ql, qr) over the leaves
-				bool go = live && M.y <= M.z && lo < hi;
+				bool go = (NW == 1 || w == 0) && live && M.y <= M.z && lo < hi;
 				while (__ballot(go && ql < qr) != 0) {
 					uint4 vl = tnode_none(), vr = vl;
 					if (go && ql < qr) {
@@ -1509,9 +1515,10 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 			in.s = 0; in.y = 0; in.j = -1;
 			int relied = INT_MIN;                                 // the largest bound of a block this lane passed over on the strength of its outer candidate's score alone
 			const int y_top = yi - 1, y_bot = yi - max_inner;
-			auto sweep_range = [&](int from, int to, bool outer_all) {
+			auto sweep_range = [&](int from, int to, bool outer_all, bool in_turn = false) {
 				// outer_all: every anchor of the range is outside the tree (it left the window for some lanes); else only those from hi on are
 				for (int base = from; base < to; base += W) {
+					if (NW > 1 && in_turn && (((base - from) >> 6) % NW) != w) continue;       // a team's waves take the blocks of the range in turn
 					const int j_l = base + l;
 					const bool have = j_l < to;
 					const uint4 e_l = have ? a[j_l] : make_uint4(0, 0, 0, 0);
@@ -1550,7 +1557,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 					}
 				}
 			};
-			sweep_range(st_first, lo, true);
+			sweep_range(st_first, lo, true, true);
 			{
 				// From the newest block of 64 down: the nearest anchors carry the highest scores, so the lanes' inner bests rise at once, and a
 				// block whose largest f + span (`bound`, written when its tile was finished) cannot beat ANY lane's is passed over --
@@ -1559,6 +1566,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 				// 5 266 broadcasts per tile on the mapper's reads (profiles/r03h_*), twenty times the work of the kernel above.
 				const int from = max_inner > 0 ? max(min(stin_first, tb), lo) : max(hi, lo);
 				for (int bb = (tb >> 6) - 1; bb >= 0 && ((bb + 1) << 6) > from; --bb) {
+					if (NW > 1 && (bb % NW) != w) continue;
 					const int b_lo = max(bb << 6, from), b_hi = (bb + 1) << 6;
 					if (b_lo >= hi || max_inner <= 0) { sweep_range(b_lo, b_hi, false); continue; }     // holds anchors the outer query needs (not in the tree): no skipping
 					if (b_hi > hi) { sweep_range(b_lo, b_hi, false); continue; }
@@ -1599,8 +1607,27 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 					}
 				}
 			}
+			if (NW > 1) {
+				// the team's results of this tile, per lane, to wave 0
+				if (w > 0) {
+					int (*m)[W] = s_m[w - 1];
+					m[0][l] = (int)(unsigned)(unsigned long long)c.key; m[1][l] = (int)(unsigned)((unsigned long long)c.key >> 32); m[2][l] = c.rank; m[3][l] = c.tie; m[4][l] = c.j; m[5][l] = c.sc;
+					m[6][l] = c.exact; m[7][l] = c.width; m[8][l] = in.s; m[9][l] = in.y; m[10][l] = in.j; m[11][l] = relied;
+				}
+				__syncthreads();
+				if (w == 0) {
+					for (int k = 0; k < NW - 1; ++k) {
+						int (*m)[W] = s_m[k];
+						const long long key = (long long)((unsigned long long)(unsigned)m[1][l] << 32 | (unsigned)m[0][l]);
+						tile_offer(c, key != RMQ_NONE, key, m[2][l], m[3][l], m[4][l], m[5][l], m[6][l], m[7][l]);
+						tile_offer_inner(in, m[10][l] >= 0, m[8][l], m[9][l], m[10][l]);
+						relied = max(relied, m[11][l]);
+					}
+				}
+			}
 			const long long ts3 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-			// ---- (3) the tile's own anchors, one after the other ----
+			// ---- (3) the tile's own anchors, one after the other (a team: wave 0) ----
+			if (NW == 1 || w == 0) {
 			int f_l = q_i, p_l = 0;
 			long long k_l = 0;
 			for (int t = 0; t < n_here; ++t) {
@@ -1655,15 +1682,46 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill_tiles(RmqBatch b, Rmq
 				const int top = wave_max_i32(live ? f_l + q_i : INT_MIN);
 				if (l == 0) bound[tb >> 6] = top;
 			}
+			}
 			wave_sync();
+			if (NW > 1) { __threadfence_block(); __syncthreads(); }      // the tile's scores and its bound are out: the next tile's sweeps read them
 		}
 		tied = (int)wave_sum_i32(tied);
-		if (l == 0) b.n_tied[r] = tied;
-		if (b.dbg && l == 0) {
+		if (l == 0 && (NW == 1 || w == 0)) b.n_tied[r] = tied;
+		if (b.dbg && l == 0 && (NW == 1 || w == 0)) {
 			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast + (d_single << 36), d_skip + (d_redo << 32), d_t3 };
 			for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
+			if (b.dbg_reads) {
+				long long *o = b.dbg_reads + 8 * (int64_t)r;
+				o[0] = n; o[1] = NW; o[2] = (long long)__builtin_amdgcn_s_memrealtime() - t_read0; o[3] = d_upd; o[4] = d_levels; o[5] = d_qloads; o[6] = d_t3; o[7] = d_bcast;
+			}
 		}
 		wave_sync();
+	}
+}
+
+// The first b.n_team reads of the batch (the caller puts the most expensive first) are a whole workgroup's each, the rest one wave's.
+__global__ __launch_bounds__(RMQ_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqParams P)
+{
+	__shared__ int s_m[RMQ_TEAM - 1][RMQ_MERGE_WORDS][W];
+	__shared__ int s_read;
+	const int l = lane(), w = uni(threadIdx.x / W);
+	const int n_team = (int)min((int64_t)b.n_team, b.n_reads);
+	for (;;) {
+		if (n_team <= 0) break;
+		if (threadIdx.x == 0) s_read = atomicAdd(b.cursor + 1, 1);
+		__syncthreads();
+		const int r = uni(s_read);
+		__syncthreads();
+		if (r >= n_team) break;
+		rmq_fill_read_tiles<RMQ_TEAM>(b, P, r, w, s_m);
+	}
+	for (;;) {
+		int r = 0;
+		if (l == 0) r = atomicAdd(b.cursor, 1);
+		r = uni(r) + n_team;
+		if (r >= b.n_reads) break;
+		rmq_fill_read_tiles<1>(b, P, r, 0, nullptr);
 	}
 }
 
@@ -1937,7 +1995,7 @@ void launch_post(const PostBatch &b, hipStream_t s)
 void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 {
 	if (b.n_reads <= 0 || b.n <= 0) { if (b.n_reads > 0) (void)hipMemsetAsync(b.n_tied, 0, (size_t)b.n_reads * sizeof(int32_t), s); return; }
-	(void)hipMemsetAsync(b.cursor, 0, sizeof(int32_t), s);
+	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
 	const unsigned wide = (unsigned)std::min<int64_t>((b.n + 255) / 256, (int64_t)b.grid_waves * 4);
 	hipLaunchKernelGGL(k_rmq_prep_keys, dim3(wide), dim3(256), 0, s, b);
 	SortBatch sb;
@@ -1953,7 +2011,10 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 		const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;
 		hipLaunchKernelGGL(k_rmq_prep_windows, dim3(wide), dim3(256), 0, s, b, max_dist, max_inner, P.cap_rmq_size);
 		hipLaunchKernelGGL(k_rmq_tree_init, dim3(wide), dim3(256), 0, s, b);
-		hipLaunchKernelGGL(k_rmq_fill_tiles, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
+		const int per_t = RMQ_THREADS / W;
+		const int64_t singles = std::max<int64_t>(0, b.n_reads - b.n_team);
+		const unsigned grid_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>((singles + per_t - 1) / per_t, b.n_team), (int64_t)b.grid_waves / per_t));   // a workgroup per team read
+		hipLaunchKernelGGL(k_rmq_fill_tiles, dim3(grid_t), dim3(RMQ_THREADS), 0, s, b, P);
 	} else hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);   // one anchor per step (MM2GB_RMQ_KERNEL=steps)
 }
 

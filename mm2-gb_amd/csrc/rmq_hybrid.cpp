@@ -27,7 +27,7 @@ namespace {
 //   s_out  sum over anchors of ceil(anchors within max_dist before it / 4096): iterations over block summaries of the kernel's query
 // The constants are measured rates (profiles/r03_rmq_rate.json: counters of k_rmq_fill under MM2GB_DEBUG_PHASES against its time on
 // the read that ends a batch; rmq_host.cpp's thread-seconds per anchor); they only steer the deal, never a result.
-struct ReadCost { double dev, dev_steps, host, s_in; };
+struct ReadCost { double dev, dev_steps, dev_team, host, s_in; bool team; };
 
 ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n)
 {
@@ -55,9 +55,24 @@ ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n
 	// array (its inner scan visits the candidates of one y-range, not the window: a few hundred at worst).
 	c.dev = 1.37e-6 * (double)n + 0.31e-6 * s_in;                         // tile kernel
 	c.dev_steps = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);          // one anchor per step
+	// a whole workgroup on the read (tile kernel): the serial part of a tile (tree, queries, its own 64 steps: ~48 us) stays, the broadcasts are shared by its 16 waves
+	c.dev_team = 0.85e-6 * (double)n + 0.03e-6 * s_in;
+	c.team = false;
 	c.s_in = s_in;
 	c.host = (double)n * (0.40e-6 + 0.5e-6 * std::min(1.0, s_in / ((double)std::max<int64_t>(n, 1) * 100.0)));
 	return c;
+}
+
+// copies of read-sized pieces, dealt to threads (a batch's anchors are a gigabyte: one thread copies at ~5 GB/s)
+template <class F>
+void parallel_reads(size_t n, int nt, F &&fn)
+{
+	std::atomic<size_t> next(0);
+	auto work = [&]() { for (;;) { const size_t lo = next.fetch_add(64); if (lo >= n) break; for (size_t k = lo; k < std::min(n, lo + 64); ++k) fn(k); } };
+	std::vector<std::thread> pool;
+	for (int t = 1; t < std::max(1, std::min<int>(nt, (int)((n + 63) / 64))); ++t) pool.emplace_back(work);
+	work();
+	for (auto &th : pool) th.join();
 }
 
 void append(mm2gb_chains_t &dst, size_t r, const mm2gb_chains_t &src, size_t q)
@@ -95,25 +110,34 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		work();
 		for (auto &th : pool) th.join();
 	}
-	// Which device form: the tile kernel broadcasts every anchor of a tile's inner windows to all 64 lanes, the step kernel passes blocks over
-	// per anchor -- with windows of many hundreds of anchors (the mapper's reads: every chain of a read interleaved along x) the latter does
-	// less work per anchor; measured, the tile kernel wins up to a few hundred (profiles/r03o_*).  MM2GB_RMQ_KERNEL overrides.
+	// Which device form: the tile kernel (64 anchors per step of a wave, a whole workgroup on the reads whose inner windows hold thousands of
+	// anchors) unless MM2GB_RMQ_KERNEL=steps asks for the one-anchor-per-step kernel.  (Round 3, before the workgroup reads: the step kernel won
+	// on the mapper's batches -- windows of many hundreds of anchors, every chain of a read interleaved along x -- 2.25 s against 2.5 s for the
+	// device's share; with them the tile kernel takes 1.8 s and more of the reads, profiles/r03_rmq_teams.txt.)
 	{
 		double sum_in = 0, sum_n = 0;
 		for (size_t r = 0; r < R; ++r) { sum_in += cost[r].s_in; sum_n += (double)(offsets[r + 1] - offsets[r]); }
-		const bool steps = sum_n > 0 && sum_in / sum_n * 64.0 > 400.0;      // mean inner window in anchors
+		const bool steps = false;
+		(void)sum_in; (void)sum_n;
 		const char *v = getenv("MM2GB_RMQ_KERNEL");
 		const bool use_steps = v ? !strcmp(v, "steps") : steps;
 		if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
-		if (!v) (void)mm2gb_engine_set_rmq_kernel(eng, use_steps ? 1 : 0);
-		if (deal) deal->device_kernel = use_steps ? 1 : 0;
+		// tile kernel: the reads that would set the device's pace get a whole workgroup each (there are far fewer reads than the chip holds waves)
+		// -- those whose time is the broadcasts (a team's 15 helpers idle through the serial part of every tile: a read that is mostly
+		// serial would hold 16 wave slots for the work of one).  Measured on the mapper's reads: the slowest single-wave reads spend 1.5-1.9 s
+		// of 1.6-1.9 s in broadcasts (2-4 M anchors each, profiles/r03_rmq_teams.txt)
+		else if (!getenv("MM2GB_RMQ_NO_TEAMS"))
+			for (size_t r = 0; r < R; ++r) {
+				const double n = (double)(offsets[r + 1] - offsets[r]);
+				if (cost[r].dev > 5e-3 && 0.31e-6 * cost[r].s_in >= 2.0 * 1.37e-6 * n && cost[r].dev_team < cost[r].dev) { cost[r].dev = cost[r].dev_team; cost[r].team = true; }
+			}
 	}
 	std::vector<int64_t> by_dev(R);
 	for (size_t r = 0; r < R; ++r) by_dev[r] = (int64_t)r;
 	std::sort(by_dev.begin(), by_dev.end(), [&](int64_t u, int64_t v) { return cost[(size_t)u].dev != cost[(size_t)v].dev ? cost[(size_t)u].dev > cost[(size_t)v].dev : u < v; });
 	const double slots = std::max(64.0, (double)eng->e.n_cu * 12.0);     // waves k_rmq_fill keeps resident (LDS-bound)
 	double dev_sum = 0, host_sum = 0, host_max = 0;
-	for (size_t r = 0; r < R; ++r) dev_sum += cost[r].dev;
+	for (size_t r = 0; r < R; ++r) dev_sum += cost[r].dev * (cost[r].team ? 16.0 : 1.0);      // in wave slots
 	size_t n_host = 0;                                                   // the first n_host reads of by_dev go to the host threads
 	int policy = 0;                                                      // MM2GB_RMQ_DEAL=device / host: everything one side (A/B runs, tests)
 	if (const char *v = getenv("MM2GB_RMQ_DEAL")) policy = !strcmp(v, "device") ? 1 : !strcmp(v, "host") ? 2 : 0;
@@ -125,22 +149,21 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 			const double dev_now = launch_s + std::max(c.dev, dev_sum / slots);                       // with this read still on the device
 			const double host_then = std::max(std::max(host_max, c.host), (host_sum + c.host) / nt);  // with it on the host threads
 			if (host_then >= dev_now) break;
-			host_sum += c.host; host_max = std::max(host_max, c.host); dev_sum -= c.dev;
+			host_sum += c.host; host_max = std::max(host_max, c.host); dev_sum -= c.dev * (c.team ? 16.0 : 1.0);
 			++n_host;
 		}
 	if (deal) { const int dk = deal->device_kernel; memset(deal, 0, sizeof(*deal)); deal->device_kernel = dk; deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
 
 	// ---- both sides at once ----
+	int gather_threads = nt;                                             // (the device side's gather runs beside the host side: a few threads)
 	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, std::vector<mm2gb_anchor_t> &buf) {
-		off.assign(1, 0);
-		int64_t total = 0;
-		for (size_t q = from; q < to; ++q) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
-		buf.resize((size_t)std::max<int64_t>(total, 1));
-		for (size_t q = from; q < to; ++q) {
-			const int64_t r = by_dev[q], n = offsets[r + 1] - offsets[r];
-			if (n) memcpy(buf.data() + off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
-			off.push_back(off.back() + n);
-		}
+		off.assign(to - from + 1, 0);
+		for (size_t q = from; q < to; ++q) off[q - from + 1] = off[q - from] + (offsets[by_dev[q] + 1] - offsets[by_dev[q]]);
+		buf.resize((size_t)std::max<int64_t>(off.back(), 1));
+		parallel_reads(to - from, gather_threads, [&](size_t k) {
+			const int64_t r = by_dev[from + k], n = offsets[r + 1] - offsets[r];
+			if (n) memcpy(buf.data() + off[k], anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
+		});
 	};
 	std::vector<int64_t> h_off, d_off, t_off;
 	std::vector<mm2gb_anchor_t> h_a, d_a, t_a;
@@ -152,6 +175,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	std::thread host_side;
 	if (n_host > 0) {
 		gather(0, n_host, h_off, h_a);
+		gather_threads = std::max(1, nt / 4);
 		// the host side leaves one thread to the device call's own host work when it shares the machine with it
 		const int h_threads = n_host < R ? std::max(1, nt - 1) : nt;
 		host_side = std::thread([&, h_threads]() {
@@ -165,6 +189,12 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	int d_rc = 0;
 	double d_seconds = 0;
 	if (n_host < R) {
+		// the reads of whole workgroups first (the kernel takes its first n_team reads that way), each part most expensive first
+		std::stable_partition(by_dev.begin() + (std::ptrdiff_t)n_host, by_dev.end(), [&](int64_t r) { return cost[(size_t)r].team; });
+		int64_t n_team = 0;
+		for (size_t q = n_host; q < R; ++q) n_team += cost[(size_t)by_dev[q]].team;
+		if (deal) deal->n_team = (int32_t)n_team;
+		(void)mm2gb_engine_set_rmq_team_reads(eng, (int)n_team);
 		gather(n_host, R, d_off, d_a);                                   // most expensive first: a wave takes reads in this order
 		const auto td = std::chrono::steady_clock::now();
 		d_rc = mm2gb_rmq_chain_gpu(eng, prm, (int64_t)(R - n_host), d_off.data(), d_a.data(), &d_out, tied.data(), nullptr);
@@ -218,13 +248,13 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	out->u = (uint64_t*)malloc(((size_t)out->u_off[R] + 1) * 8);
 	out->a = (mm2gb_anchor_t*)malloc(((size_t)out->a_off[R] + 1) * 16);
 	if (!out->u || !out->a) { mm2gb_chains_free(out); return give_up("mm2gb_rmq_chain: out of memory"); }
-	for (size_t r = 0; r < R; ++r) {
+	parallel_reads(R, nt, [&](size_t r) {
 		const mm2gb_chains_t &c = *src[r].c;
 		const size_t q = src[r].q;
 		const int64_t nu = c.u_off[q + 1] - c.u_off[q], na = c.a_off[q + 1] - c.a_off[q];
 		if (nu) memcpy(out->u + out->u_off[r], c.u + c.u_off[q], (size_t)nu * 8);
 		if (na) memcpy(out->a + out->a_off[r], c.a + c.a_off[q], (size_t)na * 16);
-	}
+	});
 	mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out);
 	if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
 	return 0;

@@ -44,12 +44,15 @@ def test_reference_vectors(engine, path):
         assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
 
 
-@pytest.mark.parametrize("kernel", ["tiles", "steps"])
+@pytest.mark.parametrize("kernel", ["tiles", "steps", "tiles, whole workgroups on the first 5 reads", "tiles, whole workgroups on every read"])
 def test_batch_against_the_oracle(engine, monkeypatch, kernel):
     """A batch of reads re-chained in one call: tie counts equal the oracle's, chains equal the oracle's (which uses the same
     stated tie rule, so tied reads agree with IT too).  Both device forms: the tile kernel (64 anchors per step of a wave, a tournament
     tree over the ranks; the default) and the one-anchor-per-step kernel (MM2GB_RMQ_KERNEL=steps)."""
-    monkeypatch.setenv("MM2GB_RMQ_KERNEL", kernel)        # (without it the engine keeps the form mm2gb_rmq_chain last picked)
+    monkeypatch.setenv("MM2GB_RMQ_KERNEL", kernel.split(",")[0])        # (without it the engine keeps the form mm2gb_rmq_chain last picked)
+    if "," in kernel:
+        # a read that a whole workgroup fills (k_rmq_fill_tiles: the sweeps of a tile shared by four waves, their results combined in LDS)
+        monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", "5" if "first 5" in kernel else "1000000")
     a, off = mm.synth_reads(41, 0, 40, 10_000, 120_000)
     reads = [first_pass(a[off[r]:off[r + 1]]) for r in range(40)]
     reads.insert(7, np.zeros((0, 2), np.uint64))
@@ -126,11 +129,13 @@ def test_batch_call_that_is_exact_for_every_read(engine, monkeypatch, deal):
             assert d["n_device"] == 0 and (where == 1).all()
 
 
-def test_tile_kernel_on_odd_shapes(engine, monkeypatch):
+@pytest.mark.parametrize("team_reads", ["0", "1000000"])
+def test_tile_kernel_on_odd_shapes(engine, monkeypatch, team_reads):
     """The tile form's edges against the oracle: reads shorter than a tile, exactly one and two tiles, runs of equal x longer than a tile
     (nobody in the run may chain to another), several references and strands in one read (window starts jump), a size cap that evicts
     (cap_rmq_size below the window), gaps wider than max_dist (everything leaves at once), a dense cloud (ties, full inner windows)."""
     monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles")
+    monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", team_reads)       # one wave per read / a whole workgroup per read
     rng = np.random.default_rng(11)
     def cloud(n, xw, yw, rid=1, strand=0, x0=1000, y0=100):
         return sc.pack(np.full(n, rid), np.full(n, strand, np.int64), x0 + rng.integers(0, xw, n), y0 + rng.integers(0, yw, n))
