@@ -277,7 +277,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -564,6 +564,21 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			if (!steps) {
 				if (rmq_win.ensure(nn * 16) || rmq_tree.ensure(nn * 32)) return -1;
 				rb.win = (int4*)rmq_win.ptr; rb.tree = (uint4*)rmq_tree.ptr;
+			}
+		}
+		rb.skey_in = rb.skey = nullptr; rb.sa = nullptr; rb.srange = nullptr; rb.sort_tmp = nullptr; rb.sort_tmp_bytes = 0;
+		const RmqParams rp0 = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
+		rb.strip_shift = rmq_strip_shift(rp0);
+		{
+			// scratch of the batch's key sorts (ranks by y; the strip order), and -- tile kernel, MM2GB_RMQ_STRIPS=0 turns it off for A/B runs and
+			// tests -- the inner window by strips of y (k_rmq_strip_ranges)
+			const size_t tmp = rmq_strip_sort_temp_bytes(n, n_reads);
+			if (rmq_skey_in.ensure(nn * 8) || rmq_skey.ensure(nn * 8) || rmq_sort_tmp.ensure(tmp)) return -1;
+			rb.skey_in = (unsigned long long*)rmq_skey_in.ptr; rb.skey = (unsigned long long*)rmq_skey.ptr; rb.sort_tmp = rmq_sort_tmp.ptr; rb.sort_tmp_bytes = tmp;
+			const char *v = getenv("MM2GB_RMQ_STRIPS");
+			if (rb.tree && rb.strip_shift > 0 && !(v && atoi(v) == 0)) {
+				if (rmq_sa.ensure(nn * 16) || rmq_srange.ensure(nn * 16)) return -1;
+				rb.sa = (uint4*)rmq_sa.ptr; rb.srange = (int4*)rmq_srange.ptr;
 			}
 		}
 		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;

@@ -57,10 +57,20 @@ struct RmqBatch {
 	int32_t *n_tied;           // out, per read: anchors whose range-minimum was shared by several elements (see post_kernels.hip)
 	int32_t *cursor;           // two work cursors: reads taken by single waves, reads taken by teams
 	int      grid_waves;
+	// tile form, the inner window by strips of y (null: the inner window is swept block by block): every read's anchors sorted by (y >> strip_shift, index) --
+	// a lane's inner candidates, y within max_dist_inner below its own, lie in at most two strips, and inside a strip its index window is one range
+	unsigned long long *skey_in, *skey;   // scratch, n each: (strip << 32 | index), unsorted / sorted within each read
+	uint4   *sa;               // scratch, n: the anchors in that order (x, y, index, q_span)
+	int4    *srange;           // scratch, n: per anchor [begin, end) in the lower strip and [begin, end) in the upper one (positions in its read's order)
+	void    *sort_tmp;         // scratch of the segmented sort
+	size_t   sort_tmp_bytes;
+	int      strip_shift;
 	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES), tile form: per read 8 values: anchors, waves, ticks whole / tree update / queries / broadcasts / in-tile steps, anchors broadcast (wave 0 of a team)
 	int      n_team;           // tile form: the first n_team reads of the batch are filled by a whole workgroup each (k_rmq_fill_tiles)
 };
 void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);
+size_t rmq_strip_sort_temp_bytes(int64_t n, int64_t n_reads);   // what RmqBatch::sort_tmp must hold
+int    rmq_strip_shift(const RmqParams &P);                      // 2^shift >= max_dist_inner (0: no inner window)
 
 // Formats either side of the path: the seed sort upstream (radix_sort_128x of the collected anchors, map.c:329) and the
 // conversion of chains into hit records downstream (mm_gen_regs, hit.c:52-88).

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <limits.h>
 #include <algorithm>
+#include <rocprim/device/device_segmented_radix_sort.hpp>   // the (strip, index) order of the RMQ fill's inner windows: a plain segmented key sort
 #include "chain_dev.h"
 #include "post_dev.h"
 
@@ -989,12 +990,17 @@ __global__ __launch_bounds__(256) void k_rmq_prep_keys(RmqBatch b)
 {
 	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
 		const int64_t r = rmq_read_of(b.offsets, b.n_reads, g);
-		b.by_y[g] = make_ulonglong2((unsigned long long)b.raw[g].z << 32 | (unsigned long long)(g - b.offsets[r]), 0ULL);
+		const unsigned long long k = (unsigned long long)b.raw[g].z << 32 | (unsigned long long)(g - b.offsets[r]);
+		if (b.skey_in) b.skey_in[g] = k; else b.by_y[g] = make_ulonglong2(k, 0ULL);
 		((long long*)b.key)[g] = RMQ_NONE;
 	}
 	const int64_t nb = (b.n >> 6) + b.n_reads + 1;
 	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nb; g += (int64_t)gridDim.x * blockDim.x)
 		b.l1[g] = make_uint4(0u, 0x80000000u, 0x7fffffffu, 0u);   // RMQ_NONE, nobody
+}
+__global__ __launch_bounds__(256) void k_rmq_keys_to_by_y(RmqBatch b)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) b.by_y[g] = make_ulonglong2(b.skey[g], 0ULL);
 }
 __global__ __launch_bounds__(256) void k_rmq_prep_ranks(RmqBatch b)
 {
@@ -1414,6 +1420,55 @@ __global__ __launch_bounds__(256) void k_rmq_tree_init(RmqBatch b)
 	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < 2 * b.n; g += (int64_t)gridDim.x * blockDim.x) b.tree[g] = none;
 }
 
+// ---- the inner window by strips of y ---------------------------------------------------------------------------------------
+// The inner scan of lchain.c:323-341 takes, for anchor i, the anchors still in the inner tree -- indices [st_inner, i0) -- whose y lies in
+// [y_i - max_dist_inner, y_i - 1].  Where a read crosses a tandem array thousands of anchors share that index window and a few hundred
+// that y range: sweeping the window (every anchor against all 64 lanes of a tile) was 96 % of the slowest reads' time.  So every read's
+// anchors are also kept sorted by (y >> shift, index) with 2^shift >= max_dist_inner: a lane's candidates then lie in at most two strips, and
+// within a strip its index window is ONE range of that order -- found here, for every anchor, by bisection.  The fill kernel walks the two
+// ranges lane by lane: what it scores is what the reference's tree iteration visits, times at most two.
+__global__ __launch_bounds__(256) void k_rmq_strip_keys(RmqBatch b)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t off = b.offsets[rmq_read_of(b.offsets, b.n_reads, g)];
+		b.skey_in[g] = (unsigned long long)(b.raw[g].z >> b.strip_shift) << 32 | (unsigned)(g - off);
+	}
+}
+__global__ __launch_bounds__(256) void k_rmq_strip_fill(RmqBatch b)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t off = b.offsets[rmq_read_of(b.offsets, b.n_reads, g)];
+		const unsigned j = (unsigned)b.skey[g];
+		const uint4 e = b.raw[off + j];
+		b.sa[g] = make_uint4(e.x, e.z, j, e.w & 0xffu);
+	}
+}
+__global__ __launch_bounds__(256) void k_rmq_strip_ranges(RmqBatch b, int max_inner)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r = rmq_read_of(b.offsets, b.n_reads, g);
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const unsigned long long *k = b.skey + off;
+		const int4 wn = b.win[g];                                 // st, st_inner, i0
+		const int yi = (int)b.raw[g].z;
+		int4 out = make_int4(0, 0, 0, 0);
+		if (max_inner > 0 && yi > 0 && wn.y < wn.z) {
+			auto first_not_below = [&](unsigned long long key) {
+				int lo = 0, hi = n;
+				while (lo < hi) { const int mid = (lo + hi) >> 1; if (k[mid] < key) lo = mid + 1; else hi = mid; }
+				return lo;
+			};
+			const unsigned long long s_hi = (unsigned long long)((unsigned)(yi - 1) >> b.strip_shift);
+			const int y_bot = yi - max_inner;
+			const unsigned long long s_lo = y_bot > 0 ? (unsigned long long)((unsigned)y_bot >> b.strip_shift) : 0ull;
+			out.z = first_not_below(s_hi << 32 | (unsigned)wn.y); out.w = first_not_below(s_hi << 32 | (unsigned)wn.z);
+			if (s_lo < s_hi) { out.x = first_not_below(s_lo << 32 | (unsigned)wn.y); out.y = first_not_below(s_lo << 32 | (unsigned)wn.z); }
+		}
+		b.srange[g] = out;
+	}
+}
+
 // One read, by NW waves (1: the wave alone; RMQ_TEAM: a whole workgroup, wave w of it).  In a team wave 0 does what is serial -- the tree, the
 // queries, the 64 steps of the tile's own anchors -- and all NW share the broadcast sweeps, block by block in turn (a tile's sweeps are most
 // of its time on reads with hundreds of anchors in the inner window); their results per lane -- the best outer candidate, the best of the
@@ -1434,6 +1489,9 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 		const int n = (int)(b.offsets[r + 1] - off);
 		const uint4 *a = b.raw + off;
 		const int4 *meta = b.meta + off, *win = b.win + off;
+		const bool strips = b.sa != nullptr && max_inner > 0;     // the inner window by strips of y (k_rmq_strip_ranges) instead of block sweeps
+		const uint4 *sa = b.sa + off;
+		const int4 *srange = b.srange + off;
 		const int32_t *ord_idx = b.ord_idx + off;
 		int32_t *f = b.f + off, *p = b.p + off;
 		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
@@ -1531,7 +1589,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 						const bool two = k + 1 < cnt;
 						const int kb = two ? k + 1 : k;
 						const bool outer_a = outer_all || ja >= hi, outer_b = two && (outer_all || jb2 >= hi);     // wave-uniform: in the tree otherwise
-						const bool inner_a = max_inner > 0 && ja >= stin_first, inner_b = two && max_inner > 0 && jb2 >= stin_first;   // wave-uniform
+						const bool inner_a = !strips && max_inner > 0 && ja >= stin_first, inner_b = !strips && two && max_inner > 0 && jb2 >= stin_first;   // wave-uniform
 						d_bcast += two ? 2 : 1;
 						if (!(outer_a || outer_b || inner_a || inner_b)) continue;
 						const int ya = __builtin_amdgcn_readlane((int)e_l.z, k), yb = __builtin_amdgcn_readlane((int)e_l.z, kb);
@@ -1564,7 +1622,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				// comput_sc_simple never returns more than the span, the inner scan only ever replaces a result it BEATS (lchain.c:331), and an
 				// equal score wins only by a larger (y, index).  Without this every anchor of a dense window was scored against every lane:
 				// 5 266 broadcasts per tile on the mapper's reads (profiles/r03h_*), twenty times the work of the kernel above.
-				const int from = max_inner > 0 ? max(min(stin_first, tb), lo) : max(hi, lo);
+				const int from = (max_inner > 0 && !strips) ? max(min(stin_first, tb), lo) : max(hi, lo);
 				for (int bb = (tb >> 6) - 1; bb >= 0 && ((bb + 1) << 6) > from; --bb) {
 					if (NW > 1 && (bb % NW) != w) continue;
 					const int b_lo = max(bb << 6, from), b_hi = (bb + 1) << 6;
@@ -1604,6 +1662,36 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 						const int by = wave_max_i32((ok & (s2 == bs)) ? (int)e_c.z : INT_MIN);
 						const int bj = wave_max_i32((ok & (s2 == bs) & ((int)e_c.z == by)) ? j_c : -1);
 						if (l == u) tile_offer_inner(in, true, bs, by, bj);
+					}
+				}
+			}
+			if (strips) {
+				// the inner window, lane by lane: the lane's two ranges of its read's (strip, index) order, up to the anchors of this tile (theirs come
+				// with the in-tile steps); four candidates per round, their loads side by side.  A team's waves take a part of every range each.
+				const int4 R4 = live ? srange[i] : make_int4(0, 0, 0, 0);
+				for (int pass = 0; pass < 2; ++pass) {
+					const int r_lo = pass ? R4.z : R4.x, r_hi = pass ? R4.w : R4.y;
+					const int part = NW > 1 ? (r_hi - r_lo + NW - 1) / NW : r_hi - r_lo;
+					int pp = r_lo + (NW > 1 ? w * part : 0);
+					const int pe = NW > 1 ? min(r_hi, pp + part) : r_hi;
+					while (__ballot(pp < pe) != 0) {
+						if (pp < pe) {
+							uint4 cq[4];
+							int fq[4];
+							bool okq[4];
+#pragma unroll
+							for (int q = 0; q < 4; ++q) cq[q] = sa[min(pp + q, pe - 1)];
+#pragma unroll
+							for (int q = 0; q < 4; ++q) { okq[q] = (pp + q < pe) & ((int)cq[q].z < tb); fq[q] = okq[q] ? f[(int)cq[q].z] : 0; }
+#pragma unroll
+							for (int q = 0; q < 4; ++q) {
+								int ex, wd;
+								const int s2 = fq[q] + tile_pair_score(xi, yi, cq[q].x, (int)cq[q].y, (int)cq[q].w, P, ex, wd);
+								tile_offer_inner(in, okq[q] & ((int)cq[q].y <= y_top) & ((int)cq[q].y >= y_bot) & (wd <= P.bw), s2, (int)cq[q].y, (int)cq[q].z);
+							}
+							++d_single;
+							pp = (okq[0] & okq[1] & okq[2] & okq[3]) ? pp + 4 : pe;   // indices rise along a range: from the first anchor of this tile on, nothing is final
+						}
 					}
 				}
 			}
@@ -1992,15 +2080,41 @@ void launch_post(const PostBatch &b, hipStream_t s)
 	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);
 }
 
+size_t rmq_strip_sort_temp_bytes(int64_t n, int64_t n_reads)
+{
+	size_t bytes = 0;
+	const int64_t *no_offsets = nullptr;
+	(void)rocprim::segmented_radix_sort_keys(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned)std::max<int64_t>(n, 1), (unsigned)std::max<int64_t>(n_reads, 1),
+	                                         no_offsets, no_offsets, 0, 64, (hipStream_t)0);
+	return bytes + 256;
+}
+int rmq_strip_shift(const RmqParams &P)
+{
+	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;
+	const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;
+	if (max_inner <= 0) return 0;
+	int sh = 0;
+	while ((1 << sh) < max_inner && sh < 30) ++sh;
+	return sh;
+}
+
 void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 {
 	if (b.n_reads <= 0 || b.n <= 0) { if (b.n_reads > 0) (void)hipMemsetAsync(b.n_tied, 0, (size_t)b.n_reads * sizeof(int32_t), s); return; }
 	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
 	const unsigned wide = (unsigned)std::min<int64_t>((b.n + 255) / 256, (int64_t)b.grid_waves * 4);
 	hipLaunchKernelGGL(k_rmq_prep_keys, dim3(wide), dim3(256), 0, s, b);
-	SortBatch sb;
-	sb.a = b.by_y; sb.offsets = b.offsets; sb.n_reads = b.n_reads; sb.cursor = nullptr; sb.grid_waves = b.grid_waves;
-	launch_sort_x(sb, s);
+	if (b.skey_in && b.skey && b.sort_tmp) {
+		// every read's anchors by (y, index): the keys are all different, any sort will do -- a segmented radix sort of the whole batch (the order
+		// of chains and seeds, where equal keys must fall as the host's unstable sort leaves them, is what k_sort_x is for: one wave per read)
+		size_t tmp = b.sort_tmp_bytes;
+		(void)rocprim::segmented_radix_sort_keys(b.sort_tmp, tmp, b.skey_in, b.skey, (unsigned)b.n, (unsigned)b.n_reads, b.offsets, b.offsets + 1, 0, 64, s);
+		hipLaunchKernelGGL(k_rmq_keys_to_by_y, dim3(wide), dim3(256), 0, s, b);
+	} else {
+		SortBatch sb;
+		sb.a = b.by_y; sb.offsets = b.offsets; sb.n_reads = b.n_reads; sb.cursor = nullptr; sb.grid_waves = b.grid_waves;
+		launch_sort_x(sb, s);
+	}
 	hipLaunchKernelGGL(k_rmq_prep_ranks, dim3(wide), dim3(256), 0, s, b);
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;
 	hipLaunchKernelGGL(k_rmq_prep_ranges, dim3(wide), dim3(256), 0, s, b, max_dist);
@@ -2011,6 +2125,13 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 		const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;
 		hipLaunchKernelGGL(k_rmq_prep_windows, dim3(wide), dim3(256), 0, s, b, max_dist, max_inner, P.cap_rmq_size);
 		hipLaunchKernelGGL(k_rmq_tree_init, dim3(wide), dim3(256), 0, s, b);
+		if (b.sa && max_inner > 0) {
+			hipLaunchKernelGGL(k_rmq_strip_keys, dim3(wide), dim3(256), 0, s, b);
+			size_t tmp = b.sort_tmp_bytes;
+			(void)rocprim::segmented_radix_sort_keys(b.sort_tmp, tmp, b.skey_in, b.skey, (unsigned)b.n, (unsigned)b.n_reads, b.offsets, b.offsets + 1, 0, 64, s);
+			hipLaunchKernelGGL(k_rmq_strip_fill, dim3(wide), dim3(256), 0, s, b);
+			hipLaunchKernelGGL(k_rmq_strip_ranges, dim3(wide), dim3(256), 0, s, b, max_inner);
+		}
 		const int per_t = RMQ_THREADS / W;
 		const int64_t singles = std::max<int64_t>(0, b.n_reads - b.n_team);
 		const unsigned grid_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>((singles + per_t - 1) / per_t, b.n_team), (int64_t)b.grid_waves / per_t));   // a workgroup per team read

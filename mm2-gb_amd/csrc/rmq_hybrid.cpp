@@ -53,10 +53,12 @@ ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n
 	// the read.  (The one-anchor-per-step kernel: 4.0 us per anchor + 0.42 us per block / summary round.)
 	// The host form took 0.40 us per anchor of reads with narrow windows, 0.59 us on the mapper's reads, 0.9 us on a read inside a tandem
 	// array (its inner scan visits the candidates of one y-range, not the window: a few hundred at worst).
-	c.dev = 1.37e-6 * (double)n + 0.31e-6 * s_in;                         // tile kernel
+	// (round 3, inner windows by strips of y: what a window costs is the candidates of its y range, a fraction of the window that s_in counts --
+	// 0.07 us per anchor of window on the mapper's densest reads, profiles/r03_rmq_teams.txt)
+	c.dev = 1.37e-6 * (double)n + 0.07e-6 * s_in;                         // tile kernel
 	c.dev_steps = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);          // one anchor per step
 	// a whole workgroup on the read (tile kernel): the serial part of a tile (tree, queries, its own 64 steps: ~48 us) stays, the broadcasts are shared by its 16 waves
-	c.dev_team = 0.85e-6 * (double)n + 0.03e-6 * s_in;
+	c.dev_team = 0.95e-6 * (double)n + 0.0045e-6 * s_in;
 	c.team = false;
 	c.s_in = s_in;
 	c.host = (double)n * (0.40e-6 + 0.5e-6 * std::min(1.0, s_in / ((double)std::max<int64_t>(n, 1) * 100.0)));
@@ -129,7 +131,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		else if (!getenv("MM2GB_RMQ_NO_TEAMS"))
 			for (size_t r = 0; r < R; ++r) {
 				const double n = (double)(offsets[r + 1] - offsets[r]);
-				if (cost[r].dev > 5e-3 && 0.31e-6 * cost[r].s_in >= 2.0 * 1.37e-6 * n && cost[r].dev_team < cost[r].dev) { cost[r].dev = cost[r].dev_team; cost[r].team = true; }
+				if (cost[r].dev > 5e-3 && 0.07e-6 * cost[r].s_in >= 0.5 * 1.37e-6 * n && cost[r].dev_team < cost[r].dev) { cost[r].dev = cost[r].dev_team; cost[r].team = true; }
 			}
 	}
 	std::vector<int64_t> by_dev(R);

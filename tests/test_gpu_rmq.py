@@ -129,13 +129,14 @@ def test_batch_call_that_is_exact_for_every_read(engine, monkeypatch, deal):
             assert d["n_device"] == 0 and (where == 1).all()
 
 
-@pytest.mark.parametrize("team_reads", ["0", "1000000"])
-def test_tile_kernel_on_odd_shapes(engine, monkeypatch, team_reads):
+@pytest.mark.parametrize("team_reads,strips", [("0", "1"), ("1000000", "1"), ("0", "0"), ("1000000", "0")])
+def test_tile_kernel_on_odd_shapes(engine, monkeypatch, team_reads, strips):
     """The tile form's edges against the oracle: reads shorter than a tile, exactly one and two tiles, runs of equal x longer than a tile
     (nobody in the run may chain to another), several references and strands in one read (window starts jump), a size cap that evicts
     (cap_rmq_size below the window), gaps wider than max_dist (everything leaves at once), a dense cloud (ties, full inner windows)."""
     monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles")
     monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", team_reads)       # one wave per read / a whole workgroup per read
+    monkeypatch.setenv("MM2GB_RMQ_STRIPS", strips)               # the inner window lane by lane over the (y strip, index) order / swept block by block
     rng = np.random.default_rng(11)
     def cloud(n, xw, yw, rid=1, strand=0, x0=1000, y0=100):
         return sc.pack(np.full(n, rid), np.full(n, strand, np.int64), x0 + rng.integers(0, xw, n), y0 + rng.integers(0, yw, n))
