@@ -420,14 +420,28 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		}
 		std::vector<uint64_t> nu((size_t)nu_off[R]);
 		std::vector<mm2gb_anchor_t> nc((size_t)nc_off[R]);
-		for (size_t r = 0; r < R; ++r) {
-			const int q = which[r];
-			const mm2gb_chains_t &from = q >= 0 && tie_slot[(size_t)q] >= 0 ? rc_tie : rc;
-			const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
-			const uint64_t *su = q < 0 ? u.data() + u_off[r] : from.u + from.u_off[qq];
-			const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : from.a + from.a_off[qq];
-			if (nu_off[r + 1] > nu_off[r]) memcpy(nu.data() + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);
-			if (nc_off[r + 1] > nc_off[r]) memcpy(nc.data() + nc_off[r], sa, (size_t)(nc_off[r + 1] - nc_off[r]) * sizeof(mm2gb_anchor_t));
+		{
+			// (a batch's kept anchors are a gigabyte: the copies go to all host threads)
+			std::atomic<size_t> next(0);
+			auto work = [&]() {
+				for (;;) {
+					const size_t lo = next.fetch_add(32);
+					if (lo >= R) break;
+					for (size_t r = lo; r < std::min(R, lo + 32); ++r) {
+						const int q = which[r];
+						const mm2gb_chains_t &from = q >= 0 && tie_slot[(size_t)q] >= 0 ? rc_tie : rc;
+						const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
+						const uint64_t *su = q < 0 ? u.data() + u_off[r] : from.u + from.u_off[qq];
+						const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : from.a + from.a_off[qq];
+						if (nu_off[r + 1] > nu_off[r]) memcpy(nu.data() + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);
+						if (nc_off[r + 1] > nc_off[r]) memcpy(nc.data() + nc_off[r], sa, (size_t)(nc_off[r + 1] - nc_off[r]) * sizeof(mm2gb_anchor_t));
+					}
+				}
+			};
+			std::vector<std::thread> pool;
+			for (int t = 1; t < std::max(1, opt.host_threads); ++t) pool.emplace_back(work);
+			work();
+			for (auto &th : pool) th.join();
 		}
 		mm2gb_chains_free(&rc); mm2gb_chains_free(&rc_tie);
 		u.swap(nu); ca.swap(nc); u_off.swap(nu_off); c_off.swap(nc_off);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -156,6 +157,8 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		}
 	if (deal) { const int dk = deal->device_kernel; memset(deal, 0, sizeof(*deal)); deal->device_kernel = dk; deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
 
+	const double s_estimate = seconds_since(t0);
+	double s_gather = 0, s_merge = 0;
 	// ---- both sides at once ----
 	int gather_threads = nt;                                             // (the device side's gather runs beside the host side: a few threads)
 	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, std::vector<mm2gb_anchor_t> &buf) {
@@ -176,7 +179,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	double h_seconds = 0;
 	std::thread host_side;
 	if (n_host > 0) {
-		gather(0, n_host, h_off, h_a);
+		{ const auto tg = std::chrono::steady_clock::now(); gather(0, n_host, h_off, h_a); s_gather += seconds_since(tg); }
 		gather_threads = std::max(1, nt / 4);
 		// the host side leaves one thread to the device call's own host work when it shares the machine with it
 		const int h_threads = n_host < R ? std::max(1, nt - 1) : nt;
@@ -197,7 +200,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		for (size_t q = n_host; q < R; ++q) n_team += cost[(size_t)by_dev[q]].team;
 		if (deal) deal->n_team = (int32_t)n_team;
 		(void)mm2gb_engine_set_rmq_team_reads(eng, (int)n_team);
-		gather(n_host, R, d_off, d_a);                                   // most expensive first: a wave takes reads in this order
+		{ const auto tg = std::chrono::steady_clock::now(); gather(n_host, R, d_off, d_a); s_gather += seconds_since(tg); }   // most expensive first: a wave takes reads in this order
 		const auto td = std::chrono::steady_clock::now();
 		d_rc = mm2gb_rmq_chain_gpu(eng, prm, (int64_t)(R - n_host), d_off.data(), d_a.data(), &d_out, tied.data(), nullptr);
 		d_seconds = seconds_since(td);
@@ -232,6 +235,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	}
 
 	// ---- one result, in the caller's read order ----
+	const auto tm = std::chrono::steady_clock::now();
 	out->u_off = (int64_t*)malloc((R + 1) * 8);
 	out->a_off = (int64_t*)malloc((R + 1) * 8);
 	if (!out->u_off || !out->a_off) { mm2gb_chains_free(out); return give_up("mm2gb_rmq_chain: out of memory"); }
@@ -258,6 +262,9 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		if (na) memcpy(out->a + out->a_off[r], c.a + c.a_off[q], (size_t)na * 16);
 	});
 	mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out);
+	s_merge = seconds_since(tm);
+	if (getenv("MM2GB_DEBUG_PHASES"))
+		fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, merge %.3f s, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, s_merge, seconds_since(t0));
 	if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
 	return 0;
 }
