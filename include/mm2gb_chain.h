@@ -163,6 +163,8 @@ int  mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t 
  * done again, else 0: information only, the chains are exact either way. */
 int  mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
                           mm2gb_chains_t *out, int32_t *n_tied);
+/* the same for reads that are known to meet a tie (a device call counted it): the reference's tree for every read at once */
+int  mm2gb_rmq_chain_host_tied(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads, mm2gb_chains_t *out);
 mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
                                  float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km);
 void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls);   /* single-read calls so far, and how many of them met a tie */

@@ -463,7 +463,9 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	// the kernel's LDS).  There a batch ends with its largest read and the helpers have nothing else to do.  In a batch that fills the
 	// chip the helpers' wait for the serial top pass costs as many wave slots as the sharing saves: measured at 500 M anchors / 9 016
 	// reads, k_post_chains + lift + emit 58.9 ms with no teams, 59.3 / 62.6 / 65.3 ms with 64 / 256 / 640 (profiles/r03_post_teams.txt).
-	b.team_reads = n_reads <= (int64_t)n_cu * 3 ? (int)n_reads : 0;
+	// (a batch of a few thousand reads -- the re-chained reads of a mapper's chunk -- still ends with its largest: its 64 largest get a workgroup,
+	// which costs nothing measurable there: +0.4 ms at 9 016 reads)
+	b.team_reads = n_reads <= (int64_t)n_cu * 3 ? (int)n_reads : n_reads <= (int64_t)n_cu * 16 ? 64 : 0;
 	if (const char *v = getenv("MM2GB_POST_TEAM_READS")) b.team_reads = std::max(0, atoi(v));
 	MM2GB_HIP(hipEventRecord(post0, stream));
 	launch_post(b, stream);

@@ -517,10 +517,8 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 
 using namespace mm2gb;
 
-extern "C" {
-
-int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
-                         mm2gb_chains_t *out, int32_t *n_tied)
+static int rmq_chain_host_impl(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
+                               mm2gb_chains_t *out, int32_t *n_tied, bool reference_tree_only)
 {
 	if (!prm || !out || n_reads < 0 || !offsets || offsets[0] != 0) return fail("mm2gb_rmq_chain_host: offsets[0] must be 0");
 	memset(out, 0, sizeof(*out));
@@ -554,7 +552,7 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 	HostAlloc libc_mem;
 	if (n_tied) for (int64_t r = 0; r < n_reads; ++r) n_tied[r] = 0;   // becomes 1 for a read that met a tie and was done with the reference's tree
 	const char *force = getenv("MM2GB_RMQ_TREE");
-	const bool exact_only = force && !strcmp(force, "avl");              // MM2GB_RMQ_TREE=avl: the reference's tree for every read
+	const bool exact_only = reference_tree_only || (force && !strcmp(force, "avl"));   // MM2GB_RMQ_TREE=avl: the reference's tree for every read
 	auto work = [&]() {
 		FillScratch ws;
 		BacktrackScratch bs;
@@ -591,6 +589,20 @@ int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const in
 		free(u_of[r]); free(a_of[r]);
 	}
 	return 0;
+}
+
+extern "C" {
+
+int mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,
+                         mm2gb_chains_t *out, int32_t *n_tied)
+{
+	return rmq_chain_host_impl(prm, n_reads, offsets, anchors, n_threads, out, n_tied, false);
+}
+
+// Reads that are KNOWN to meet a tie (the device form counted it): the reference's tree at once, without the attempt that would stop at the tie
+int mm2gb_rmq_chain_host_tied(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads, mm2gb_chains_t *out)
+{
+	return rmq_chain_host_impl(prm, n_reads, offsets, anchors, n_threads, out, nullptr, true);
 }
 
 } // extern "C"

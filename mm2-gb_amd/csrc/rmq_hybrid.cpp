@@ -228,7 +228,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 				t_off.push_back(t_off.back() + n);
 			}
 			const auto tt = std::chrono::steady_clock::now();
-			if (mm2gb_rmq_chain_host(prm, (int64_t)redo.size(), t_off.data(), t_a.data(), nt, &t_out, nullptr)) return give_up(mm2gb_last_error());
+			if (mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_a.data(), nt, &t_out)) return give_up(mm2gb_last_error());
 			t_seconds = seconds_since(tt);
 		}
 		if (deal) deal->n_host_tie = (int64_t)redo.size();

@@ -159,3 +159,52 @@ def test_tile_kernel_on_odd_shapes(engine, monkeypatch, team_reads, strips):
             o = orc.lchain_rmq(x, prm)
             assert int(tied[r]) == o["n_tied"], (kw, r, len(x))
             assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r, len(x))
+
+
+def test_fuzz_random_reads_and_parameters(engine, monkeypatch):
+    """Random reads (clouds of every density, several references and strands, runs of equal x, first-pass chains of simulated reads) under random
+    parameters -- window, band, inner distance, size cap, penalties -- and a random device form for every batch (one wave or a whole workgroup
+    per read, inner windows by strips of y or swept block by block), against the oracle: tie counts and chains, read by read.  The seed moves
+    with the sources (tests/test_gpu_parity.py::fuzz_seed) and is printed."""
+    from test_gpu_parity import fuzz_seed
+    seed = fuzz_seed()
+    print("rmq fuzz seed", seed)
+    rng = np.random.default_rng(seed)
+
+    def cloud(n, xw, yw, rid, strand, x0, y0):
+        return sc.pack(np.full(n, rid), np.full(n, strand, np.int64), x0 + rng.integers(0, max(1, xw), n), y0 + rng.integers(0, max(1, yw), n))
+
+    for it in range(40):
+        reads = []
+        for _ in range(int(rng.integers(3, 9))):
+            kind = int(rng.integers(0, 5))
+            if kind == 0:      # a dense cloud: full inner windows, ties
+                n = int(rng.integers(1, 2500)); w = int(rng.integers(30, 3000))
+                reads.append(orc.radix_sort_x(sc.sort_by_x(cloud(n, w, w, 1, 0, 1000, 100))))
+            elif kind == 1:    # several references / strands, windows that jump
+                parts = [cloud(int(rng.integers(1, 600)), 4000, 4000, r, s, 1000, 100) for r in (1, 2, 3) for s in (0, 1) if rng.random() < 0.7]
+                reads.append(orc.radix_sort_x(sc.sort_by_x(np.concatenate(parts))) if parts else np.zeros((0, 2), np.uint64))
+            elif kind == 2:    # runs of equal x
+                k = int(rng.integers(1, 6)); m = int(rng.integers(1, 150))
+                reads.append(orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(k * m, 1), np.zeros(k * m, np.int64), np.repeat(5000 + np.arange(k) * int(rng.integers(1, 50)), m), 100 + rng.integers(0, 5000, k * m)))))
+            elif kind == 3:    # islands further apart than max_dist
+                reads.append(orc.radix_sort_x(sc.sort_by_x(np.concatenate([cloud(int(rng.integers(1, 500)), 2500, 2500, 1, 0, 1000 + 60_000 * k, 100 + 800 * k) for k in range(int(rng.integers(1, 5)))]))))
+            else:              # what the first chaining keeps of a simulated read
+                a1, o1 = mm.synth_reads(int(rng.integers(1, 1 << 20)), 0, 1, 5_000, 60_000)
+                reads.append(first_pass(a1[o1[0]:o1[1]]))
+        o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+        o2[1:] = np.cumsum([len(x) for x in reads])
+        allr = np.concatenate(reads) if o2[-1] else np.zeros((0, 2), np.uint64)
+        max_dist = int(rng.choice([300, 1500, 5000, 20000, 70000]))
+        bw = int(rng.choice([100, 500, 2000, 20000]))
+        kw = dict(max_dist=max_dist, bw=bw, max_dist_inner=int(rng.choice([0, 90, 200, 1000, 3000])), cap_rmq_size=int(rng.choice([0, 50, 100000])),
+                  pen_gap=np.float32(rng.choice([0.12, 0.3, 0.8])), pen_skip=np.float32(rng.choice([0.0, 0.05])))
+        prm = orc.default_rmq_param(**kw)
+        monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles" if rng.random() < 0.8 else "steps")
+        monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", str(int(rng.choice([0, 2, 1000000]))))
+        monkeypatch.setenv("MM2GB_RMQ_STRIPS", str(int(rng.random() < 0.7)))
+        res, tied, _ = engine.rmq_chain(allr, o2, to_lib(prm))
+        for r, x in enumerate(reads):
+            o = orc.lchain_rmq(x, prm)
+            assert int(tied[r]) == o["n_tied"], (seed, it, kw, r, len(x))
+            assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (seed, it, kw, r, len(x))
