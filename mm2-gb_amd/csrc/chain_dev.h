@@ -54,18 +54,15 @@ static_assert(sizeof(SplitSlot) == 128, "one slot per 128-byte line");
 constexpr int SPLIT_MAX_ITEMS = 128;                   // per strip: 8 tile pairs x at most 16 items
 constexpr int SPLIT_STRIP_TILES = 16;                  // = waves of a score workgroup
 
-// Everything one micro-batch needs in HBM.  SoA: one array per field, anchors of all reads concatenated.
+// Everything one micro-batch needs in HBM: the caller's anchors (16 B each, all reads concatenated) and one array per derived field.
 struct DevBatch {
 	// inputs
 	const uint4   *raw;        // mm128_t as 4 dwords: x.lo x.hi y.lo y.hi          16 B/anchor
 	const int64_t *offsets;    // n_reads + 1
 	int64_t        n;          // anchors
 	int64_t        n_reads;
-	// SoA (written by k_window)
-	int32_t  *x;               // ref_pos  = (int32)a.x                                4 B
-	int32_t  *y;               // qry_pos  = (int32)a.y                                4 B
-	int32_t  *tag;             // seg_id<<8 | q_span (a dword so the scalar path can fetch it) 4 B
-	// range selection
+	// (reference position, query position, span and segment id are read straight from `raw`: x.lo, y.lo, y.hi -- chain_kernels.hip, a_x / a_y / a_tag)
+	// range selection (written by k_window)
 	int32_t  *st;              // first predecessor index of each anchor (lchain.c:172-173)   4 B
 	// outputs
 	int32_t  *f;               // score                                                4 B

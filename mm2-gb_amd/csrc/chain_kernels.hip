@@ -26,6 +26,15 @@ namespace mm2gb {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// An anchor's fields straight from the caller's array (mm128_t as four dwords: x.lo x.hi y.lo y.hi): reference position = x.lo, query position
+// = y.lo, q_span = y.hi & 0xff (lchain.c:125), segment id = y.hi >> 16 & 0xff (lchain.c:116).  Until round 3 k_window copied them into
+// arrays of their own (12 B written and read again per anchor: a third of that kernel's traffic) -- the score kernel reads a source block once
+// per 128 targets, where the stride of 16 bytes costs nothing that shows.
+__device__ __forceinline__ int a_x(const DevBatch &b, int i) { return ((const int*)b.raw)[(size_t)i * 4]; }
+__device__ __forceinline__ int a_y(const DevBatch &b, int i) { return ((const int*)b.raw)[(size_t)i * 4 + 2]; }
+__device__ __forceinline__ int a_span(const DevBatch &b, int i) { return (int)(((const unsigned*)b.raw)[(size_t)i * 4 + 3] & 0xffu); }
+__device__ __forceinline__ int tag_of(unsigned y_hi) { return (int)(((y_hi >> 8) & 0xff00u) | (y_hi & 0xffu)); }      // seg_id << 8 | q_span
+__device__ __forceinline__ int a_tag(const DevBatch &b, int i) { return tag_of(((const unsigned*)b.raw)[(size_t)i * 4 + 3]); }
 
 
 // --------------------------------------------------------------------------------------------------------------
@@ -91,7 +100,6 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 			v = b.raw[g];
 			const unsigned span = v.w & 0xffu;            // y>>32 & 0xff      (lchain.c:125)
 			const unsigned seg = (v.w >> 16) & 0xffu;     // (y & MM_SEED_SEG_MASK) >> 48 (lchain.c:116)
-			b.x[g] = (int32_t)v.x; b.y[g] = (int32_t)v.z; b.tag[g] = (int32_t)(seg << 8 | span);
 			any_seg |= seg != 0;
 			big_y |= v.z >= (1u << 22) || span == 0;
 		}
@@ -576,10 +584,10 @@ __device__ __forceinline__ scalar_i32_ptr as_scalar(const void *p) { return (sca
 struct SrcGroup { int x[4], y[4], t[4]; };
 __device__ __forceinline__ SrcGroup load_group(const DevBatch &b, int j0)
 {
-	const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y), st = as_scalar(b.tag);
+	const scalar_i32_ptr sr = as_scalar(b.raw);
 	SrcGroup g;
 #pragma unroll
-	for (int u = 0; u < 4; ++u) { g.x[u] = sx[j0 + u]; g.y[u] = sy[j0 + u]; g.t[u] = st[j0 + u]; }
+	for (int u = 0; u < 4; ++u) { const size_t at = (size_t)(j0 + u) * 4; g.x[u] = sr[at]; g.y[u] = sr[at + 2]; g.t[u] = tag_of((unsigned)sr[at + 3]); }
 	return g;
 }
 // MODE_LUT sweep.  A block's 64 sources are first written to this wave's LDS scratch; each step then takes ONE LDS
@@ -685,7 +693,7 @@ __device__ __forceinline__ void stage_block_lut(int xs, int ys, int sf, int sq, 
 __device__ __forceinline__ void stage_block_lut(const DevBatch &b, int jb, int sf, int sq, int4 *stage)
 {
 	const int js = jb + lane_id();
-	stage_block_lut(b.x[js], b.y[js], sf, sq, stage);
+	stage_block_lut(a_x(b, js), a_y(b, js), sf, sq, stage);
 }
 // ... and are swept against one tile ...
 struct TileXY { int x, y, st; };          // what a sweep needs of a tile: position, query position, window start (INT_MAX: dead lane)
@@ -861,7 +869,7 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
                                           int4 *stage, const DevParams &P, const int *lut, int &best, int &arg)
 {
 	if (MODE == MODE_LUT) {
-		const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
+		const int xs = a_x(b, jb + lane_id()), ys = a_y(b, jb + lane_id());
 		const TileXY xy = { T.x, T.y, T.st };
 		// (dead lanes of a tile repeat its last live anchor; sweep_block_lut2_free for the conditions)
 		const bool free_block = no_check && P.free_sweep && (unsigned)(bcast(T.x, WAVE - 1) - first_lane(xs)) <= (unsigned)(P.dq_lim - P.bw);
@@ -881,10 +889,10 @@ __device__ __forceinline__ void sweep_any(const DevBatch &b, const Target &T, in
 // First anchor of the run of equal reference positions that ends at anchor i0 (scalar walk, bounded).
 __device__ __forceinline__ int equal_x_run_start(const DevBatch &b, int cs, int i0, int x0)
 {
-	const scalar_i32_ptr sx = as_scalar(b.x);
+	const scalar_i32_ptr sr = as_scalar(b.raw);
 	int e = i0;
-	for (int n = 0; n < 64 && e > cs && sx[e - 1] == x0; ++n) --e;
-	if (e > cs && sx[e - 1] == x0) e = cs;                  // longer than the bound: check everything
+	for (int n = 0; n < 64 && e > cs && sr[(size_t)(e - 1) * 4] == x0; ++n) --e;
+	if (e > cs && sr[(size_t)(e - 1) * 4] == x0) e = cs;                  // longer than the bound: check everything
 	return e;
 }
 
@@ -894,7 +902,7 @@ __device__ __forceinline__ Target load_target(const DevBatch &b, int i0, int ce,
 	const int i = i0 + lane_id();
 	T.live = i < ce;
 	const int il = T.live ? i : ce - 1;
-	T.x = b.x[il]; T.y = b.y[il]; T.tag = b.tag[il];
+	T.x = a_x(b, il); T.y = a_y(b, il); T.tag = a_tag(b, il);
 	T.hi = want_hi ? (int)((const uint2*)&b.raw[il])->y : 0;   // strand | rid, only the rescue state machine looks at it
 	T.st = T.live ? b.st[il] : INT_MAX;          // dead lanes never activate
 	T.q = T.tag & 0xff; T.seg = T.tag >> 8;
@@ -1001,7 +1009,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	} else {
 		// the state machine of lchain.c:189-205 runs on the scalar side.  Anchor t's fields come by v_readlane: scalar loads
 		// would share the wave's lgkm counter with the LDS reads of every step and expose their latency
-		const scalar_i32_ptr sx = as_scalar(b.x), sy = as_scalar(b.y), stg = as_scalar(b.tag);
+		const scalar_i32_ptr sr = as_scalar(b.raw);
 		// In a tile whose windows all start before the tile (the usual case where windows are cut by max_iter) only the anchor
 		// remembered at the tile's START can ever be out of reach or an extra candidate: one remembered later is an anchor of
 		// this tile, hence inside every later window.  What the state machine needs about the entry anchor is computed for all
@@ -1069,7 +1077,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 				keep.idx = first_lane(bi);
 				if (keep.idx >= 0) {
 					keep.f = first_lane(bf);
-					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;
+					{ const size_t at = (size_t)keep.idx * 4; keep.x = sr[at]; keep.y = sr[at + 2]; keep.tag = tag_of((unsigned)sr[at + 3]); keep.hi = ht; }
 				}
 			}
 			// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf)
@@ -1169,7 +1177,7 @@ __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int 
 			keep.idx = first_lane(bi);
 			if (keep.idx >= 0) {
 				keep.f = first_lane(bf);
-				keep.x = b.x[keep.idx]; keep.y = b.y[keep.idx]; keep.tag = b.tag[keep.idx]; keep.hi = ht;
+				keep.x = a_x(b, keep.idx); keep.y = a_y(b, keep.idx); keep.tag = a_tag(b, keep.idx); keep.hi = ht;
 			}
 		}
 		// lchain.c:196-201: one more candidate if the scan stopped before reaching it (end_j = st-1 at max_skip=inf)
@@ -1206,11 +1214,11 @@ __device__ __forceinline__ void run_chunk(const DevBatch &b, const DevParams &P,
 		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));
 		if (jb < i0) {
 			const int eq_lo = MODE == MODE_LUT ? equal_x_run_start(b, cs, i0, first_lane(T.x)) : i0;
-			int sf = b.f[jb + lane], sq = MODE == MODE_LUT ? b.tag[jb + lane] & 0xff : 0;
+			int sf = b.f[jb + lane], sq = MODE == MODE_LUT ? a_span(b, jb + lane) : 0;
 			for (; jb < i0; jb += WAVE) {
 				// next block's scores are requested before this block is consumed
 				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
-				const int nf = b.f[jn], nq = MODE == MODE_LUT ? b.tag[jn] & 0xff : 0;
+				const int nf = b.f[jn], nq = MODE == MODE_LUT ? a_span(b, jn) : 0;
 				const int k_from = tile_lo > jb ? tile_lo - jb : 0;
 				sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);
 				sf = nf; sq = nq;
@@ -1245,9 +1253,9 @@ __device__ __forceinline__ TileXY load_xy(const DevBatch &b, int i0, int ce, int
 	const bool live = i < ce;
 	const int il = live ? i : ce - 1;
 	TileXY t;
-	t.x = b.x[il]; t.y = b.y[il];
+	t.x = a_x(b, il); t.y = a_y(b, il);
 	t.st = live ? b.st[il] : INT_MAX;
-	best = (b.tag[il] & 0xff) + 1;                  // threshold form: nothing beats q_span without exceeding it
+	best = a_span(b, il) + 1;                  // threshold form: nothing beats q_span without exceeding it
 	return t;
 }
 
@@ -1272,7 +1280,7 @@ __device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t,
 	const bool nc_a = jb >= t.hi_a && jb + WAVE <= eq_lo;
 	const bool use_b = t.n_b > 0 && jb + WAVE > t.lo_b;                      // the block reaches into B's windows
 	const bool nc_b = use_b && jb >= t.hi_b && jb + WAVE <= eq_lo;           // (sources left of A are left of B, or share A's first x)
-	const int xs = b.x[jb + lane_id()], ys = b.y[jb + lane_id()];
+	const int xs = a_x(b, jb + lane_id()), ys = a_y(b, jb + lane_id());
 	// every pair of this block has dr + bw <= dq_lim (sources are sorted by position: the block's first source and the pair's last
 	// anchor give the largest dr): the gather rejects by itself (sweep_block_lut2_free)
 	// A chunk may hold several runs of anchors (reads, strands): positions are only comparable between a block and the tiles whose
@@ -1315,11 +1323,11 @@ __device__ __forceinline__ void run_chunk_pairs(const DevBatch &b, const DevPara
 		int jb = cs + ((t.lo_a - cs) & ~(WAVE - 1));
 		if (jb < i0) {
 			const int eq_lo = equal_x_run_start(b, cs, i0, first_lane(t.A.x));
-			int sf = b.f[jb + lane], sq = b.tag[jb + lane] & 0xff;
+			int sf = b.f[jb + lane], sq = a_span(b, jb + lane);
 			for (; jb < i0; jb += WAVE) {
 				// next block's scores are requested before this block is consumed
 				const int jn = jb + WAVE < i0 ? jb + WAVE + lane : jb + lane;
-				const int nf = b.f[jn], nq = b.tag[jn] & 0xff;
+				const int nf = b.f[jn], nq = a_span(b, jn);
 				sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
 				sf = nf; sq = nq;
 			}
@@ -1395,7 +1403,7 @@ __device__ __forceinline__ void coop_chunk(const DevBatch &b, const DevParams &P
 		// this chunk's widest window plus the tile being written)
 		int slot = (int)((unsigned)((jb - cs) / WAVE) % (unsigned)n_slots);
 		for (; jb < i0; jb += WAVE) {
-			const int sq = MODE == MODE_LUT ? b.tag[jb + lane] & 0xff : 0;
+			const int sq = MODE == MODE_LUT ? a_span(b, jb + lane) : 0;
 			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring
 			const int sf = ring[slot * WAVE + lane];
 			slot = slot + 1 == n_slots ? 0 : slot + 1;
@@ -1456,7 +1464,7 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 		int nf = 0;
 		if (jb < i0 && (jb - cs) / WAVE < first_in_ring) { wait_done((jb - cs) / WAVE + 1); nf = b.f[jb + lane]; }
 		for (; jb < i0; jb += WAVE) {
-			const int sq = b.tag[jb + lane] & 0xff;
+			const int sq = a_span(b, jb + lane);
 			const int k = (jb - cs) / WAVE;
 			wait_done(k + 1);                                          // that tile's scores are final (and in the ring, if recent)
 			int sf;
@@ -1550,7 +1558,7 @@ __device__ __forceinline__ void split_do_item(const DevBatch &b, const DevParams
 	TilePair t = load_pair(b, i0, ce);
 	const int eq_lo = equal_x_run_start(b, cs, i0, first_lane(t.A.x));
 	for (int jb = jb0; jb < jb1; jb += WAVE) {
-		const int sf = b.f[jb + lane_id()], sq = b.tag[jb + lane_id()] & 0xff;
+		const int sf = b.f[jb + lane_id()], sq = a_span(b, jb + lane_id());
 		sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
 	}
 	unsigned long long *part = b.split_part + ((size_t)wg * SPLIT_MAX_ITEMS + it) * 2 * WAVE;
@@ -1703,7 +1711,7 @@ __device__ __forceinline__ void split_chunk(const DevBatch &b, const DevParams &
 			const int eq_lo = jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(T.x)) : i0;
 			for (; jb < i0; jb += WAVE) {
 				const int src = (jb - i_s) / WAVE;                  // tile of this strip, one of the waves before this one
-				const int sq = b.tag[jb + lane] & 0xff;
+				const int sq = a_span(b, jb + lane);
 				wait_done(src + 1);
 				const int sf = ring[src * WAVE + lane];
 				const int k_from = tile_lo > jb ? tile_lo - jb : 0;

@@ -66,13 +66,13 @@ struct Engine {
 	struct WorkSet {
 		hipStream_t stream = nullptr;
 		int64_t cap_n = 0, cap_reads = 0, cap_blocks = 0;
-		DevBuf x, y, tag, st;
+		DevBuf st;
 		DevBuf blk_firstcut, blk_pairs, blk_clamped, blk_wmax, blk_read;
 		DevBuf chunk_start, chunk_end, chunk_cost, chunk_track, order, long_list, mid_list;
 		DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
 		DevBuf counters, totals, flags;
 		DevBuf split_slots, split_part;       // one chunk on several workgroups (k_score's SPLIT build): allocated when first used
-		std::vector<DevBuf*> all() { return { &x, &y, &tag, &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_wmax, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
+		std::vector<DevBuf*> all() { return { &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_wmax, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
 		                                      &chunk_track, &order, &long_list, &mid_list, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins, &counters, &totals, &flags, &split_slots, &split_part }; }
 	};
 	WorkSet work[2];

@@ -309,7 +309,7 @@ int Engine::reserve(int64_t n, int64_t n_reads, int set)
 		// on a short (or null) buffer.
 		const int64_t had_reads = w.cap_reads;
 		w.cap_n = w.cap_blocks = w.cap_reads = 0;
-		if (w.x.ensure(nn * 4) || w.y.ensure(nn * 4) || w.tag.ensure(nn * 4) || w.st.ensure(nn * 4)) return -1;
+		if (w.st.ensure(nn * 4)) return -1;
 		if (w.blk_firstcut.ensure(nb * 4) || w.blk_pairs.ensure(nb * 8) || w.blk_clamped.ensure(nb * 4) || w.blk_wmax.ensure(nb * 8) || w.blk_read.ensure(nb * 4)) return -1;
 		if (w.chunk_start.ensure(nb * 4) || w.chunk_end.ensure(nb * 4) || w.chunk_cost.ensure(nb * 8) || w.chunk_track.ensure(nb) ||
 		    w.order.ensure(nb * 4) || w.long_list.ensure(nb * 4) || w.mid_list.ensure(nb * 4) || w.chunk_pp.ensure(nb * 8) || w.chunk_kk.ensure(nb * 4) || w.chunk_blk.ensure(nb * 4) ||
@@ -335,7 +335,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	if (reserve(n, n_reads, set)) return -1;
 	WorkSet &w = work[set];
 	hipStream_t stream = w.stream;                                    // (shadows the member: everything below belongs to this set)
-	DevBuf &x = w.x, &y = w.y, &tag = w.tag, &st = w.st, &blk_firstcut = w.blk_firstcut, &blk_pairs = w.blk_pairs, &blk_clamped = w.blk_clamped, &blk_wmax = w.blk_wmax,
+	DevBuf &st = w.st, &blk_firstcut = w.blk_firstcut, &blk_pairs = w.blk_pairs, &blk_clamped = w.blk_clamped, &blk_wmax = w.blk_wmax,
 	       &blk_read = w.blk_read, &chunk_start = w.chunk_start, &chunk_end = w.chunk_end, &chunk_cost = w.chunk_cost, &chunk_track = w.chunk_track, &order = w.order,
 	       &long_list = w.long_list, &mid_list = w.mid_list, &chunk_pp = w.chunk_pp, &chunk_kk = w.chunk_kk, &chunk_blk = w.chunk_blk, &tile_sums = w.tile_sums,
 	       &tile_base = w.tile_base, &bins = w.bins, &counters = w.counters, &totals = w.totals, &flags = w.flags;
@@ -344,7 +344,7 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 	if (want_stats) for (hipEvent_t *e : { &bs.prep0, &bs.prep1, &bs.score1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
 	DevBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads;
-	b.x = (int32_t*)x.ptr; b.y = (int32_t*)y.ptr; b.tag = (int32_t*)tag.ptr; b.st = (int32_t*)st.ptr;
+	b.st = (int32_t*)st.ptr;
 	b.f = d_f; b.p = d_p;
 	b.blk_firstcut = (int32_t*)blk_firstcut.ptr; b.blk_pairs = (int64_t*)blk_pairs.ptr; b.blk_clamped = (int32_t*)blk_clamped.ptr; b.blk_wmax = (int32_t*)blk_wmax.ptr; b.blk_read = (int32_t*)blk_read.ptr;
 	b.n_blocks = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
