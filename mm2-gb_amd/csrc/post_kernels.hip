@@ -52,7 +52,7 @@ __device__ __forceinline__ void wave_sync()
 // round trip, and when a head runs off its line all lines are fetched again together: one round trip for the lot, every few
 // hundred steps whatever the distribution of the keys.
 #ifndef MM2GB_POST_LINE_BYTES
-#define MM2GB_POST_LINE_BYTES 6144
+#define MM2GB_POST_LINE_BYTES 7168
 #endif
 constexpr int LINE_STORE_BYTES = MM2GB_POST_LINE_BYTES;
 static_assert(LINE_STORE_BYTES % 1024 == 0 && LINE_STORE_BYTES / 8 >= 2 * 256 + 64, "line slots come in whole rounds of 64 for both element kinds (8 and 16 bytes), and every bucket owns at least two (8-byte elements): fewer and the lines cannot be laid out");
