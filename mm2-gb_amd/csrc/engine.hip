@@ -861,7 +861,11 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 	if (const char *v = getenv("MM2GB_SLICE_ANCHORS")) slice = std::max<int64_t>(1, atoll(v));
 	std::vector<int64_t> first(1, 0);
 	if (n > slice + slice / 2) {
-		const int64_t tail = slice / 4;                    // anchors kept for the last slice
+		int64_t tail = slice / 4;                          // anchors kept for the last slice
+		if (const char *v = getenv("MM2GB_SLICE_TAIL_ANCHORS")) tail = std::max<int64_t>(1, atoll(v));
+		// nothing runs before the first slice has arrived: a smaller one starts the kernels earlier
+		int64_t first_slice = slice;
+		if (const char *v = getenv("MM2GB_SLICE_FIRST_ANCHORS")) first_slice = std::max<int64_t>(1, atoll(v));
 		int64_t acc = 0;
 		bool tail_cut = false;
 		for (int64_t r = 0; r < n_reads; ++r) {
@@ -869,7 +873,7 @@ int Engine::score_host(int64_t n_reads, const int64_t *offsets, const mm2gb_anch
 			const int64_t left = offsets[n_reads] - offsets[r + 1];
 			if (r + 1 >= n_reads || tail_cut) continue;
 			if (left <= tail && acc > tail) { first.push_back(r + 1); acc = 0; tail_cut = true; }             // ... [rest of a slice][tail]
-			else if (acc >= slice && left > tail + slice / 4) { first.push_back(r + 1); acc = 0; }            // a full slice, enough left for more
+			else if (acc >= (first.size() == 1 ? first_slice : slice) && left > tail + slice / 4) { first.push_back(r + 1); acc = 0; }   // a full slice, enough left for more
 		}
 	}
 	first.push_back(n_reads);
