@@ -459,13 +459,12 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.grid_waves = n_cu * 32;
 	if (const char *v = getenv("MM2GB_POST_WAVES")) b.grid_waves = std::max(4, atoi(v));
 	// Whole workgroups start on the largest reads together (k_post_chains: collection and the buckets of the sort's top pass shared by the
-	// four waves) only in batches that leave the chip idle anyway -- at most one read per workgroup the chip holds at a time (3 per CU by
-	// the kernel's LDS).  There a batch ends with its largest read and the helpers have nothing else to do.  In a batch that fills the
-	// chip the helpers' wait for the serial top pass costs as many wave slots as the sharing saves: measured at 500 M anchors / 9 016
-	// reads, k_post_chains + lift + emit 58.9 ms with no teams, 59.3 / 62.6 / 65.3 ms with 64 / 256 / 640 (profiles/r03_post_teams.txt).
-	// (a batch of a few thousand reads -- the re-chained reads of a mapper's chunk -- still ends with its largest: its 64 largest get a workgroup,
-	// which costs nothing measurable there: +0.4 ms at 9 016 reads)
-	b.team_reads = n_reads <= (int64_t)n_cu * 3 ? (int)n_reads : n_reads <= (int64_t)n_cu * 16 ? 64 : 0;
+	// four waves): every read of a batch that leaves the chip idle anyway (at most one read per workgroup the chip holds at a time, 3 per CU by
+	// the kernel's LDS), the 64 largest of any other.  The kernel ends with its largest reads (sort + walks of the largest: 49 ms on one wave, 45
+	// with a workgroup's start), and since it runs three waves per SIMD the helpers' wait for the serial top pass no longer costs what it saves:
+	// k_post_chains + lift + emit at 500 M anchors / 9 016 reads 54.1-54.3 ms with no teams, 51.5-52.4 with 16 ... 128, 52.9 with 256, 55.1-55.7
+	// with 640 or 1 500 (profiles/r03_post_teams.txt; at two waves per SIMD every setting lost).
+	b.team_reads = n_reads <= (int64_t)n_cu * 3 ? (int)n_reads : 64;
 	if (const char *v = getenv("MM2GB_POST_TEAM_READS")) b.team_reads = std::max(0, atoi(v));
 	MM2GB_HIP(hipEventRecord(post0, stream));
 	launch_post(b, stream);
