@@ -595,7 +595,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			rb.dbg_reads = (long long*)rmq_dbg_reads.ptr;
 		}
 		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
-		launch_rmq_fill(rb, rp, stream);
+		if (launch_rmq_fill(rb, rp, stream)) { (void)hipStreamSynchronize(stream); return fail("mm2gb_rmq_chain_gpu: the segmented sort of the batch's keys failed"); }
 		MM2GB_HIP(hipGetLastError());
 		last.n_anchors += n; last.n_reads += n_reads;
 	}

@@ -68,7 +68,7 @@ struct RmqBatch {
 	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES), tile form: per read 8 values: anchors, waves, ticks whole / tree update / queries / broadcasts / in-tile steps, anchors broadcast (wave 0 of a team)
 	int      n_team;           // tile form: the first n_team reads of the batch are filled by a whole workgroup each (k_rmq_fill_tiles)
 };
-void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);
+int  launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);   // -1: a library sort refused (nothing usable was launched after it)
 size_t rmq_strip_sort_temp_bytes(int64_t n, int64_t n_reads);   // what RmqBatch::sort_tmp must hold
 int    rmq_strip_shift(const RmqParams &P);                      // 2^shift >= max_dist_inner (0: no inner window)
 

@@ -2098,9 +2098,9 @@ int rmq_strip_shift(const RmqParams &P)
 	return sh;
 }
 
-void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
+int launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 {
-	if (b.n_reads <= 0 || b.n <= 0) { if (b.n_reads > 0) (void)hipMemsetAsync(b.n_tied, 0, (size_t)b.n_reads * sizeof(int32_t), s); return; }
+	if (b.n_reads <= 0 || b.n <= 0) { if (b.n_reads > 0) (void)hipMemsetAsync(b.n_tied, 0, (size_t)b.n_reads * sizeof(int32_t), s); return 0; }
 	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
 	const unsigned wide = (unsigned)std::min<int64_t>((b.n + 255) / 256, (int64_t)b.grid_waves * 4);
 	hipLaunchKernelGGL(k_rmq_prep_keys, dim3(wide), dim3(256), 0, s, b);
@@ -2108,7 +2108,7 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 		// every read's anchors by (y, index): the keys are all different, any sort will do -- a segmented radix sort of the whole batch (the order
 		// of chains and seeds, where equal keys must fall as the host's unstable sort leaves them, is what k_sort_x is for: one wave per read)
 		size_t tmp = b.sort_tmp_bytes;
-		(void)rocprim::segmented_radix_sort_keys(b.sort_tmp, tmp, b.skey_in, b.skey, (unsigned)b.n, (unsigned)b.n_reads, b.offsets, b.offsets + 1, 0, 64, s);
+		if (rocprim::segmented_radix_sort_keys(b.sort_tmp, tmp, b.skey_in, b.skey, (unsigned)b.n, (unsigned)b.n_reads, b.offsets, b.offsets + 1, 0, 64, s) != hipSuccess) return -1;
 		hipLaunchKernelGGL(k_rmq_keys_to_by_y, dim3(wide), dim3(256), 0, s, b);
 	} else {
 		SortBatch sb;
@@ -2128,7 +2128,7 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 		if (b.sa && max_inner > 0) {
 			hipLaunchKernelGGL(k_rmq_strip_keys, dim3(wide), dim3(256), 0, s, b);
 			size_t tmp = b.sort_tmp_bytes;
-			(void)rocprim::segmented_radix_sort_keys(b.sort_tmp, tmp, b.skey_in, b.skey, (unsigned)b.n, (unsigned)b.n_reads, b.offsets, b.offsets + 1, 0, 64, s);
+			if (rocprim::segmented_radix_sort_keys(b.sort_tmp, tmp, b.skey_in, b.skey, (unsigned)b.n, (unsigned)b.n_reads, b.offsets, b.offsets + 1, 0, 64, s) != hipSuccess) return -1;
 			hipLaunchKernelGGL(k_rmq_strip_fill, dim3(wide), dim3(256), 0, s, b);
 			hipLaunchKernelGGL(k_rmq_strip_ranges, dim3(wide), dim3(256), 0, s, b, max_inner);
 		}
@@ -2137,6 +2137,7 @@ void launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 		const unsigned grid_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>((singles + per_t - 1) / per_t, b.n_team), (int64_t)b.grid_waves / per_t));   // a workgroup per team read
 		hipLaunchKernelGGL(k_rmq_fill_tiles, dim3(grid_t), dim3(RMQ_THREADS), 0, s, b, P);
 	} else hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);   // one anchor per step (MM2GB_RMQ_KERNEL=steps)
+	return 0;
 }
 
 } // namespace mm2gb
