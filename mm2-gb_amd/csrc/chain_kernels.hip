@@ -1034,8 +1034,40 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			extra = __ballot((unsigned)(dq - 1) < (unsigned)P.dq_lim && dr != 0 && keep0 < T.st - 1);
 			extra_v = (sc + keep.f) << 7;
 		}
+		// The whole tile in entry mode, at the cost of the plain build (round 3: entry steps were a third of this build's steps and cost 2.6 times a plain
+		// one).  Where the state machine has nothing to rescan (`slow` empty), all it does until an anchor of the tile becomes the remembered
+		// one -- step t_s, the first with a final score above the entry anchor's -- is to offer the entry anchor to lane t when lane t's turn comes,
+		// strictly ('>' of lchain.c:199).  A maximum does not care in which order its candidates arrive, and the packed score keeps the tie rule
+		// (an anchor of the window beats the extra candidate at equal score: its low bits are not zero), so the offer is made to every lane that
+		// has it BEFORE the steps, the plain steps run, and t_s is read off the final scores (lanes up to t_s have had nothing they should not).
+		// A lane beyond t_s has no extra candidate in the reference (the remembered anchor is inside its window by then): if one of them ENDS with
+		// it, the tile is done again the long way -- a remembered anchor far behind the window that still beats everything inside it, after a
+		// better anchor has turned up in the tile: rare.  The remembered anchor afterwards: the first anchor holding the tile's largest score, if
+		// that beats the entry anchor's (what the running '<' of lchain.c:204-205 leaves).
+		bool done_fast = false;
+		const unsigned long long live_m = n_here >= WAVE ? ~0ull : ((1ull << n_here) - 1ull);
+		if (mode == ENTRY && (slow & live_m) == 0ull) {
+			const int bestv0 = bestv, arg0 = arg;
+			const bool took = ((extra >> lane) & 1ull) != 0ull && ((bestv | 127) < extra_v);
+			bestv = took ? extra_v : bestv;
+			arg = took ? keep0 : arg;
+			plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
+			const int f_l = lane < n_here ? bestv >> 7 : INT_MIN;
+			const unsigned long long above = __ballot(f_l > keep.f);
+			const int t_s = above ? (int)__builtin_ctzll(above) : WAVE;
+			if (__ballot(took && lane > t_s && lane < n_here && bestv == extra_v) == 0ull) {
+				if (above) {
+					int top = f_l;
+					for (int off = WAVE / 2; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));
+					top = first_lane(top);
+					keep.idx = i0 + (int)__builtin_ctzll(__ballot(f_l == top)); keep.f = top;
+					mode = IN_TILE;                                   // (its other fields below)
+				}
+				done_fast = true;
+			} else { bestv = bestv0; arg = arg0; }
+		}
 		StepPre cur = tile_pre(tl, 0);
-		int t = 0;
+		int t = done_fast ? n_here : 0;
 		for (; t < n_here; ++t) {
 			if (mode == IN_TILE) break;                                              // the rest of the tile: plain steps, below
 			const int j = i0 + t;
