@@ -18,7 +18,7 @@ L = mm.lib()
 buf = (C.c_ulonglong * 16)()
 names = ["ticks waiting before in-tile", "ticks in in-tile phases (rescue build)", "in-tile phases (rescue build)", "rescans", "ticks in rescans", "full-state-machine steps",
          "entry-mode steps", "ticks earlier-tiles-final -> published (one tile per wave)", "tiles (one tile per wave, rescue)", "blocks read by rescans",
-         "ticks in-tile before the step loop", "ticks in the entry / full step loop", "ticks in plain steps + keep update"]
+         "ticks in-tile before the step loop (incl. a whole tile in entry mode on the plain steps)", "ticks in the entry / full step loop", "ticks in plain steps + keep update"]
 for name, env in (("whole workgroup", {}), ("8-wave teams", {"MM2GB_WHOLE_WG_PCT": "0"})):
     os.environ.update(env)
     with mm.Engine() as e:

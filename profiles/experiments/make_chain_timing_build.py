@@ -29,8 +29,8 @@ sub("		if (lane == 0) __hip_atomic_store(&sh->done, t + 1, __ATOMIC_RELEASE, __H
 # the rescue rescan of the table build (first occurrence = in_tile_lut)
 sub("				int bf = INT_MIN, bi = -1;\n				for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)\n",
     "				const long long rk0 = tick();\n				chain_add(3, 1); chain_add(9, (i0 - stt + 63) / 64);\n				int bf = INT_MIN, bi = -1;\n				for (int jj = stt + lane; jj < i0; jj += WAVE) {              // earlier tiles (ascending per lane)\n")
-sub("				keep.idx = first_lane(bi);\n				if (keep.idx >= 0) {\n					keep.f = first_lane(bf);\n					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;\n				}\n",
-    "				keep.idx = first_lane(bi);\n				if (keep.idx >= 0) {\n					keep.f = first_lane(bf);\n					keep.x = sx[keep.idx]; keep.y = sy[keep.idx]; keep.tag = stg[keep.idx]; keep.hi = ht;\n				}\n				chain_add(4, tick() - rk0);\n")
+sub("					{ const size_t at = (size_t)keep.idx * 4; keep.x = sr[at]; keep.y = sr[at + 2]; keep.tag = tag_of((unsigned)sr[at + 3]); keep.hi = ht; }\n				}\n",
+    "					{ const size_t at = (size_t)keep.idx * 4; keep.x = sr[at]; keep.y = sr[at + 2]; keep.tag = tag_of((unsigned)sr[at + 3]); keep.hi = ht; }\n				}\n				chain_add(4, tick() - rk0);\n")
 sub("			mode = FULL;                                                         // (only ever from ENTRY: IN_TILE stays in the branch above)\n",
     "			mode = FULL;                                                         // (only ever from ENTRY: IN_TILE stays in the branch above)\n			chain_add(5, 1);\n")
 sub("			if (mode == ENTRY && !(slow >> t & 1)) {\n", "			if (mode == ENTRY && !(slow >> t & 1)) {\n				chain_add(6, 1);\n")
@@ -39,8 +39,8 @@ sub("		enum { ENTRY = 0, IN_TILE = 1, FULL = 2 };\n", "		enum { ENTRY = 0, IN_TI
 sub("		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile\n",
     "		chain_add(1, tick() - ik0);\n		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile\n")
 # split of the rescue build's in-tile phase: 10 ticks before the step loop (set-up, entry precomputation), 11 ticks in the step loop (entry / full steps), 12 ticks in the plain steps + keep update
-sub("		StepPre cur = tile_pre(tl, 0);\n		int t = 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;",
-    "		const long long ik1 = tick();\n		chain_add(10, ik1 - ik0);\n		StepPre cur = tile_pre(tl, 0);\n		int t = 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;")
+sub("		StepPre cur = tile_pre(tl, 0);\n		int t = done_fast ? n_here : 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;",
+    "		const long long ik1 = tick();\n		chain_add(10, ik1 - ik0);\n		StepPre cur = tile_pre(tl, 0);\n		int t = done_fast ? n_here : 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;")
 sub("		if (mode == IN_TILE && t < n_here) {\n", "		const long long ik2 = tick();\n		chain_add(11, ik2 - ik1);\n		if (mode == IN_TILE && t < n_here) {\n")
 sub("		chain_add(1, tick() - ik0);\n", "		chain_add(1, tick() - ik0); chain_add(12, tick() - ik2);\n")
 src += '''
