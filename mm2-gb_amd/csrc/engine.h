@@ -107,6 +107,8 @@ struct Engine {
 	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)
 	int64_t last_split_chunks = 0, last_helped_items = 0;   // of the last call: chunks scored strip by strip, items other workgroups took
 	bool rmq_tiles_last = false;    // which form the last RMQ call ran (for the debug print)
+	std::function<void(const int32_t*)> rmq_tied_ready;   // the NEXT device re-chaining call only: called on the calling thread as soon as the fill's tie counts are on the host, while the call's post-pass and copies still run
+	hipEvent_t rmq_fill_done = nullptr;
 	int  rmq_team_reads = 0;        // tile form, the NEXT device call only: its first reads that get a whole workgroup each (mm2gb_rmq_chain puts the costliest first); MM2GB_RMQ_TEAM_READS overrides
 	int  rmq_kernel = 0;            // device form of the RMQ fill: 0 tiles (k_rmq_fill_tiles), 1 one anchor per step (k_rmq_fill); MM2GB_RMQ_KERNEL=steps|tiles overrides
 	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)

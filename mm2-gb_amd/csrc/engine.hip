@@ -286,7 +286,7 @@ void Engine::shutdown()
 		if (po.h_totals) { (void)hipHostFree(po.h_totals); po.h_totals = nullptr; }
 		if (po.done) { (void)hipEventDestroy(po.done); po.done = nullptr; }
 	}
-	for (hipEvent_t *e : { &post0, &post1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+	for (hipEvent_t *e : { &post0, &post1, &rmq_fill_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	if (h_counters) (void)hipHostFree(h_counters);
 	if (h_totals) (void)hipHostFree(h_totals);
 	for (hipStream_t *s : { &s_in, &work[0].stream, &work[1].stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
@@ -598,8 +598,23 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		if (launch_rmq_fill(rb, rp, stream)) { (void)hipStreamSynchronize(stream); return fail("mm2gb_rmq_chain_gpu: the segmented sort of the batch's keys failed"); }
 		MM2GB_HIP(hipGetLastError());
 		last.n_anchors += n; last.n_reads += n_reads;
+		if (rmq_tied_ready && n_tied && n_reads > 0) {
+			if (!rmq_fill_done) MM2GB_HIP(hipEventCreateWithFlags(&rmq_fill_done, hipEventDisableTiming));
+			MM2GB_HIP(hipEventRecord(rmq_fill_done, stream));
+		}
 	}
 	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, rmq)) return -1;
+	if (rmq && rmq_tied_ready) {
+		// the tie counts are known when the fill is done: hand them over while the post-pass runs (the copy goes by the D2H stream, past the kernels)
+		std::function<void(const int32_t*)> cb;
+		cb.swap(rmq_tied_ready);
+		if (n_tied && n_reads > 0) {
+			MM2GB_HIP(hipStreamWaitEvent(s_out, rmq_fill_done, 0));
+			MM2GB_HIP(hipMemcpyAsync(n_tied, rmq_tied.ptr, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s_out));
+			MM2GB_HIP(hipStreamSynchronize(s_out));
+			cb(n_tied);
+		}
+	}
 	s.used = false;                                     // nothing of this set is in flight once the call returns
 	if (sync()) return -1;
 	if (rmq && debug_phases && n > 0) {

@@ -191,6 +191,12 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		});
 	}
 	std::vector<int32_t> tied(R - n_host + 1, 0);
+	std::vector<int64_t> tie_slot(R, -1);
+	std::vector<size_t> redo;
+	std::thread tie_side;
+	int t_rc = 0;
+	std::string t_err;
+	double t_seconds = 0;
 	int d_rc = 0;
 	double d_seconds = 0;
 	if (n_host < R) {
@@ -202,22 +208,11 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		(void)mm2gb_engine_set_rmq_team_reads(eng, (int)n_team);
 		{ const auto tg = std::chrono::steady_clock::now(); gather(n_host, R, d_off, d_a); s_gather += seconds_since(tg); }   // most expensive first: a wave takes reads in this order
 		const auto td = std::chrono::steady_clock::now();
-		d_rc = mm2gb_rmq_chain_gpu(eng, prm, (int64_t)(R - n_host), d_off.data(), d_a.data(), &d_out, tied.data(), nullptr);
-		d_seconds = seconds_since(td);
-	}
-	const std::string d_err = d_rc ? mm2gb_last_error() : "";
-	if (host_side.joinable()) host_side.join();
-	auto give_up = [&](const std::string &why) { mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out); return fail(why); };
-	if (d_rc) return give_up(d_err);
-	if (h_rc) return give_up(h_err);
-
-	// ---- reads that met a tie on the device: the host form, which keeps the reference's tree ----
-	std::vector<int64_t> tie_slot(R, -1);
-	double t_seconds = 0;
-	{
-		std::vector<size_t> redo;
-		for (size_t q = n_host; q < R; ++q) if (tied[q - n_host]) { tie_slot[q] = (int64_t)redo.size(); redo.push_back(q); }
-		if (!redo.empty()) {
+		// the reads that met a tie are known when the device's fill is done: they are redone on host threads while its post-pass and its copies
+		// still run (and beside what is left of the host side's own share)
+		eng->e.rmq_tied_ready = [&](const int32_t *tc) {
+			for (size_t q = n_host; q < R; ++q) if (tc[q - n_host]) { tie_slot[q] = (int64_t)redo.size(); redo.push_back(q); }
+			if (redo.empty()) return;
 			t_off.assign(1, 0);
 			int64_t total = 0;
 			for (size_t q : redo) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
@@ -227,12 +222,27 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 				memcpy(t_a.data() + t_off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
 				t_off.push_back(t_off.back() + n);
 			}
-			const auto tt = std::chrono::steady_clock::now();
-			if (mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_a.data(), nt, &t_out)) return give_up(mm2gb_last_error());
-			t_seconds = seconds_since(tt);
-		}
-		if (deal) deal->n_host_tie = (int64_t)redo.size();
+			tie_side = std::thread([&]() {
+				const auto tt = std::chrono::steady_clock::now();
+				t_rc = mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_a.data(), nt, &t_out);
+				if (t_rc) t_err = mm2gb_last_error();
+				t_seconds = seconds_since(tt);
+			});
+		};
+		d_rc = mm2gb_rmq_chain_gpu(eng, prm, (int64_t)(R - n_host), d_off.data(), d_a.data(), &d_out, tied.data(), nullptr);
+		eng->e.rmq_tied_ready = nullptr;
+		d_seconds = seconds_since(td);
 	}
+	const std::string d_err = d_rc ? mm2gb_last_error() : "";
+	if (host_side.joinable()) host_side.join();
+	if (tie_side.joinable()) tie_side.join();
+	auto give_up = [&](const std::string &why) { mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out); return fail(why); };
+	if (d_rc) return give_up(d_err);
+	if (h_rc) return give_up(h_err);
+
+	// ---- reads that met a tie on the device: the host form, which keeps the reference's tree (started from inside the device call) ----
+	if (t_rc) return give_up(t_err);
+	if (deal) deal->n_host_tie = (int64_t)redo.size();
 
 	// ---- one result, in the caller's read order ----
 	const auto tm = std::chrono::steady_clock::now();
