@@ -160,7 +160,7 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	const double s_estimate = seconds_since(t0);
 	double s_gather = 0, s_merge = 0;
 	// ---- both sides at once ----
-	int gather_threads = nt;                                             // (the device side's gather runs beside the host side: a few threads)
+	const int gather_threads = nt;
 	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, std::vector<mm2gb_anchor_t> &buf) {
 		off.assign(to - from + 1, 0);
 		for (size_t q = from; q < to; ++q) off[q - from + 1] = off[q - from] + (offsets[by_dev[q] + 1] - offsets[by_dev[q]]);
@@ -178,9 +178,16 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	std::string h_err;
 	double h_seconds = 0;
 	std::thread host_side;
+	if (n_host < R) {
+		// the device's share first, on every thread: its side is the longer one and cannot start before its anchors are in one piece
+		// (the reads of whole workgroups first -- the kernel takes its first n_team reads that way --, each part most expensive first)
+		std::stable_partition(by_dev.begin() + (std::ptrdiff_t)n_host, by_dev.end(), [&](int64_t r) { return cost[(size_t)r].team; });
+		const auto tg = std::chrono::steady_clock::now();
+		gather(n_host, R, d_off, d_a);
+		s_gather += seconds_since(tg);
+	}
 	if (n_host > 0) {
 		{ const auto tg = std::chrono::steady_clock::now(); gather(0, n_host, h_off, h_a); s_gather += seconds_since(tg); }
-		gather_threads = std::max(1, nt / 4);
 		// the host side leaves one thread to the device call's own host work when it shares the machine with it
 		const int h_threads = n_host < R ? std::max(1, nt - 1) : nt;
 		host_side = std::thread([&, h_threads]() {
@@ -200,13 +207,10 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	int d_rc = 0;
 	double d_seconds = 0;
 	if (n_host < R) {
-		// the reads of whole workgroups first (the kernel takes its first n_team reads that way), each part most expensive first
-		std::stable_partition(by_dev.begin() + (std::ptrdiff_t)n_host, by_dev.end(), [&](int64_t r) { return cost[(size_t)r].team; });
 		int64_t n_team = 0;
 		for (size_t q = n_host; q < R; ++q) n_team += cost[(size_t)by_dev[q]].team;
 		if (deal) deal->n_team = (int32_t)n_team;
 		(void)mm2gb_engine_set_rmq_team_reads(eng, (int)n_team);
-		{ const auto tg = std::chrono::steady_clock::now(); gather(n_host, R, d_off, d_a); s_gather += seconds_since(tg); }   // most expensive first: a wave takes reads in this order
 		const auto td = std::chrono::steady_clock::now();
 		// the reads that met a tie are known when the device's fill is done: they are redone on host threads while its post-pass and its copies
 		// still run (and beside what is left of the host side's own share)
