@@ -351,7 +351,10 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	if (!redo.empty()) {
 		std::vector<int64_t> ro(redo.size() + 1, 0);
 		for (size_t q = 0; q < redo.size(); ++q) ro[q + 1] = ro[q] + (c_off[(size_t)redo[q] + 1] - c_off[(size_t)redo[q]]);
-		std::vector<mm2gb_anchor_t> ra((size_t)ro.back());
+		// (kept between the calls of a thread, like the gathers of mm2gb_rmq_chain: fresh pages cost more to touch than to fill)
+		static thread_local std::vector<mm2gb_anchor_t> ra;
+		ra.resize((size_t)ro.back());
+		mm2gb_anchor_t *const ra_ptr = ra.data();               // (for the threads below: `ra` names each thread's own)
 		{
 			std::atomic<int64_t> next(0);
 			auto work = [&]() {
@@ -359,8 +362,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 					const int64_t q = next.fetch_add(1);
 					if (q >= (int64_t)redo.size()) break;
 					const size_t r = (size_t)redo[(size_t)q];
-					memcpy(ra.data() + ro[(size_t)q], ca.data() + c_off[r], (size_t)(ro[(size_t)q + 1] - ro[(size_t)q]) * sizeof(mm2gb_anchor_t));
-					sort_by_x_like_host(ra.data() + ro[(size_t)q], ra.data() + ro[(size_t)q + 1]);
+					memcpy(ra_ptr + ro[(size_t)q], ca.data() + c_off[r], (size_t)(ro[(size_t)q + 1] - ro[(size_t)q]) * sizeof(mm2gb_anchor_t));
+					sort_by_x_like_host(ra_ptr + ro[(size_t)q], ra_ptr + ro[(size_t)q + 1]);
 				}
 			};
 			const int nt = std::max(1, std::min<int>(opt.host_threads, (int)redo.size()));
@@ -418,8 +421,12 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			nu_off[r + 1] = nu_off[r] + (q < 0 ? u_off[r + 1] - u_off[r] : from.u_off[qq + 1] - from.u_off[qq]);
 			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : from.a_off[qq + 1] - from.a_off[qq]);
 		}
-		std::vector<uint64_t> nu((size_t)nu_off[R]);
-		std::vector<mm2gb_anchor_t> nc((size_t)nc_off[R]);
+		// (this thread's from call to call: they are swapped with `u` / `ca` below, so what they hold next time is this call's old arrays -- touched pages)
+		static thread_local std::vector<uint64_t> nu;
+		static thread_local std::vector<mm2gb_anchor_t> nc;
+		nu.resize((size_t)nu_off[R]); nc.resize((size_t)nc_off[R]);
+		uint64_t *const nu_ptr = nu.data();
+		mm2gb_anchor_t *const nc_ptr = nc.data();
 		{
 			// (a batch's kept anchors are a gigabyte: the copies go to all host threads)
 			std::atomic<size_t> next(0);
@@ -433,8 +440,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 						const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
 						const uint64_t *su = q < 0 ? u.data() + u_off[r] : from.u + from.u_off[qq];
 						const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : from.a + from.a_off[qq];
-						if (nu_off[r + 1] > nu_off[r]) memcpy(nu.data() + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);
-						if (nc_off[r + 1] > nc_off[r]) memcpy(nc.data() + nc_off[r], sa, (size_t)(nc_off[r + 1] - nc_off[r]) * sizeof(mm2gb_anchor_t));
+						if (nu_off[r + 1] > nu_off[r]) memcpy(nu_ptr + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);
+						if (nc_off[r + 1] > nc_off[r]) memcpy(nc_ptr + nc_off[r], sa, (size_t)(nc_off[r + 1] - nc_off[r]) * sizeof(mm2gb_anchor_t));
 					}
 				}
 			};

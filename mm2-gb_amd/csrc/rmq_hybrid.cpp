@@ -171,7 +171,8 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		});
 	};
 	std::vector<int64_t> h_off, d_off, t_off;
-	std::vector<mm2gb_anchor_t> h_a, d_a, t_a;
+	// (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
+	static thread_local std::vector<mm2gb_anchor_t> h_a, d_a, t_a;
 	mm2gb_chains_t h_out, d_out, t_out;
 	memset(&h_out, 0, sizeof h_out); memset(&d_out, 0, sizeof d_out); memset(&t_out, 0, sizeof t_out);
 	int h_rc = 0;
@@ -190,9 +191,10 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		{ const auto tg = std::chrono::steady_clock::now(); gather(0, n_host, h_off, h_a); s_gather += seconds_since(tg); }
 		// the host side leaves one thread to the device call's own host work when it shares the machine with it
 		const int h_threads = n_host < R ? std::max(1, nt - 1) : nt;
-		host_side = std::thread([&, h_threads]() {
+		const mm2gb_anchor_t *h_ptr = h_a.data();          // (h_a is this thread's: the new thread must not name it)
+		host_side = std::thread([&, h_threads, h_ptr]() {
 			const auto th = std::chrono::steady_clock::now();
-			h_rc = mm2gb_rmq_chain_host(prm, (int64_t)n_host, h_off.data(), h_a.data(), h_threads, &h_out, nullptr);
+			h_rc = mm2gb_rmq_chain_host(prm, (int64_t)n_host, h_off.data(), h_ptr, h_threads, &h_out, nullptr);
 			if (h_rc) h_err = mm2gb_last_error();
 			h_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - th).count();
 		});
@@ -226,9 +228,10 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 				memcpy(t_a.data() + t_off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
 				t_off.push_back(t_off.back() + n);
 			}
-			tie_side = std::thread([&]() {
+			const mm2gb_anchor_t *t_ptr = t_a.data();
+			tie_side = std::thread([&, t_ptr]() {
 				const auto tt = std::chrono::steady_clock::now();
-				t_rc = mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_a.data(), nt, &t_out);
+				t_rc = mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_ptr, nt, &t_out);
 				if (t_rc) t_err = mm2gb_last_error();
 				t_seconds = seconds_since(tt);
 			});
