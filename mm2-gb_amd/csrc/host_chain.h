@@ -2,6 +2,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 #include <vector>
 #include "../../include/mm2gb_chain.h"
 
@@ -47,5 +48,20 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 
 // CPUs this process may use at once: affinity mask and cgroup quota, whichever is smaller (stream_api.cpp)
 int usable_cpus();
+
+// mm2gb_rmq_chain (rmq_hybrid.cpp) without its last step: the results stay where the three sides left them -- host threads, device, reads
+// redone after a tie -- and read r's chains are chains[which[r]] at position slot[r].  For a caller that copies them on anyway (the mapper
+// splices them into its own arrays: one copy of a gigabyte instead of two).
+struct RmqParts {
+	mm2gb_chains_t chains[3];
+	std::vector<unsigned char> which;
+	std::vector<int64_t> slot;
+	RmqParts() { memset(chains, 0, sizeof chains); }
+	~RmqParts() { for (mm2gb_chains_t &c : chains) mm2gb_chains_free(&c); }
+	RmqParts(const RmqParts&) = delete;
+	RmqParts &operator=(const RmqParts&) = delete;
+};
+int rmq_chain_parts(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                    int n_threads, RmqParts &parts, int32_t *where, mm2gb_rmq_deal_t *deal);
 
 } // namespace mm2gb

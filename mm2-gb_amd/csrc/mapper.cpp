@@ -386,6 +386,9 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		mm2gb_chains_t rc_tie; memset(&rc_tie, 0, sizeof rc_tie);
 		std::vector<int32_t> tied(redo.size(), 0);
 		std::vector<int> tie_slot(redo.size(), -1);          // reads the device reported a tie for: their place in the host call that follows
+		RmqParts parts;                                      // the default path: the results of the call's three sides, spliced from where they are
+		std::vector<unsigned char> q_side(redo.size(), 0);   // per re-chained read: which result holds it (0: rc, 1: rc_tie, 2 + k: parts.chains[k]) ...
+		std::vector<int64_t> q_slot(redo.size(), 0);         // ... and where
 		// mg_lchain_rmq's fill.  Default: mm2gb_rmq_chain (csrc/rmq_hybrid.cpp) -- the kernel form takes the bulk of the reads, the host
 		// threads, at the same time, the few whose windows are so dense that one wave would still be on them long after the rest of the
 		// batch is done, and afterwards the reads the kernel reported a tie for (where the reference's answer follows from the shape of
@@ -393,8 +396,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		if (opt.rechain_on_device == 0) {
 			std::vector<int32_t> where(redo.size(), 0);
 			mm2gb_rmq_deal_t deal;
-			if (mm2gb_rmq_chain(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, where.data(), &deal)) { free_matches(); return -1; }
-			for (size_t q = 0; q < redo.size(); ++q) tied[q] = where[q] == 2;
+			if (rmq_chain_parts(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), parts, where.data(), &deal)) { free_matches(); return -1; }
+			for (size_t q = 0; q < redo.size(); ++q) { tied[q] = where[q] == 2; q_side[q] = (unsigned char)(2 + parts.which[q]); q_slot[q] = parts.slot[q]; }
 			if (verbose) fprintf(stderr, "[mm2gb] re-chaining deal: %lld reads on the device, %d of them a whole workgroup's (%.3f s, estimated %.3f), %lld on host threads by cost (%.3f s, estimated %.3f), %lld redone after a tie (%.3f s)\n",
 			                     (long long)deal.n_device, (int)deal.n_team, deal.device_s, deal.est_device_s, (long long)deal.n_host_cost, deal.host_s, deal.est_host_s, (long long)deal.n_host_tie, deal.tie_s);
 		} else if (opt.rechain_on_device > 0) {
@@ -409,6 +412,9 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 				}
 			if (to.size() > 1 && mm2gb_rmq_chain_host(&rp, (int64_t)to.size() - 1, to.data(), ta.data(), std::max(1, opt.host_threads), &rc_tie, nullptr)) { mm2gb_chains_free(&rc); free_matches(); return -1; }
 		} else if (mm2gb_rmq_chain_host(&rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), &rc, tied.data())) { free_matches(); return -1; }
+		if (opt.rechain_on_device != 0)
+			for (size_t q = 0; q < redo.size(); ++q) { q_side[q] = tie_slot[q] >= 0 ? 1 : 0; q_slot[q] = tie_slot[q] >= 0 ? tie_slot[q] : (int64_t)q; }
+		const mm2gb_chains_t *const side[5] = { &rc, &rc_tie, &parts.chains[0], &parts.chains[1], &parts.chains[2] };
 		const auto t_filled = std::chrono::steady_clock::now();
 		// splice the re-chained reads back in
 		std::vector<int64_t> nu_off(R + 1, 0), nc_off(R + 1, 0);
@@ -416,8 +422,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		for (size_t q = 0; q < redo.size(); ++q) { which[(size_t)redo[q]] = (int)q; if (tied[q]) ++st_local.n_rmq_tied; }
 		for (size_t r = 0; r < R; ++r) {
 			const int q = which[r];
-			const mm2gb_chains_t &from = q >= 0 && tie_slot[(size_t)q] >= 0 ? rc_tie : rc;
-			const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
+			const mm2gb_chains_t &from = *side[q >= 0 ? q_side[(size_t)q] : 0];
+			const int64_t qq = q >= 0 ? q_slot[(size_t)q] : 0;
 			nu_off[r + 1] = nu_off[r] + (q < 0 ? u_off[r + 1] - u_off[r] : from.u_off[qq + 1] - from.u_off[qq]);
 			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : from.a_off[qq + 1] - from.a_off[qq]);
 		}
@@ -436,8 +442,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 					if (lo >= R) break;
 					for (size_t r = lo; r < std::min(R, lo + 32); ++r) {
 						const int q = which[r];
-						const mm2gb_chains_t &from = q >= 0 && tie_slot[(size_t)q] >= 0 ? rc_tie : rc;
-						const int qq = q >= 0 && tie_slot[(size_t)q] >= 0 ? tie_slot[(size_t)q] : q;
+						const mm2gb_chains_t &from = *side[q >= 0 ? q_side[(size_t)q] : 0];
+						const int64_t qq = q >= 0 ? q_slot[(size_t)q] : 0;
 						const uint64_t *su = q < 0 ? u.data() + u_off[r] : from.u + from.u_off[qq];
 						const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : from.a + from.a_off[qq];
 						if (nu_off[r + 1] > nu_off[r]) memcpy(nu_ptr + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);

@@ -89,13 +89,13 @@ void append(mm2gb_chains_t &dst, size_t r, const mm2gb_chains_t &src, size_t q)
 
 using namespace mm2gb;
 
-extern "C" {
-
-int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
-                    int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal)
+namespace {
+// `out`: one result in the caller's read order; or `parts`: the three sides' results as they are (host_chain.h, RmqParts)
+int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                   int n_threads, mm2gb_chains_t *out, mm2gb::RmqParts *parts, int32_t *where, mm2gb_rmq_deal_t *deal)
 {
-	if (!eng || !prm || !out || n_reads < 0 || !offsets || offsets[0] != 0) return fail("mm2gb_rmq_chain: null argument, or offsets[0] is not 0");
-	memset(out, 0, sizeof(*out));
+	if (!eng || !prm || (!out && !parts) || n_reads < 0 || !offsets || offsets[0] != 0) return fail("mm2gb_rmq_chain: null argument, or offsets[0] is not 0");
+	if (out) memset(out, 0, sizeof(*out));
 	for (int64_t r = 0; r < n_reads; ++r) if (offsets[r + 1] < offsets[r]) return fail("mm2gb_rmq_chain: offsets must be non-decreasing");
 	if (offsets[n_reads] > 0 && !anchors) return fail("mm2gb_rmq_chain: null buffer");
 	const size_t R = (size_t)n_reads;
@@ -251,6 +251,22 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 	if (t_rc) return give_up(t_err);
 	if (deal) deal->n_host_tie = (int64_t)redo.size();
 
+	if (parts) {
+		// ---- the caller takes the three results as they are ----
+		parts->which.assign(R, 0); parts->slot.assign(R, 0);
+		for (size_t q = 0; q < R; ++q) {
+			const size_t r = (size_t)by_dev[q];
+			if (q < n_host) { parts->which[r] = 0; parts->slot[r] = (int64_t)q; }
+			else if (tie_slot[q] >= 0) { parts->which[r] = 2; parts->slot[r] = tie_slot[q]; }
+			else { parts->which[r] = 1; parts->slot[r] = (int64_t)(q - n_host); }
+			if (where) where[r] = q < n_host ? 1 : tie_slot[q] >= 0 ? 2 : 0;
+		}
+		parts->chains[0] = h_out; parts->chains[1] = d_out; parts->chains[2] = t_out;      // (theirs to free now)
+		if (getenv("MM2GB_DEBUG_PHASES"))
+			fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, results left in place, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, seconds_since(t0));
+		if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
+		return 0;
+	}
 	// ---- one result, in the caller's read order ----
 	const auto tm = std::chrono::steady_clock::now();
 	out->u_off = (int64_t*)malloc((R + 1) * 8);
@@ -284,6 +300,24 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
 		fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, merge %.3f s, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, s_merge, seconds_since(t0));
 	if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
 	return 0;
+}
+} // namespace
+
+namespace mm2gb {
+int rmq_chain_parts(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                    int n_threads, RmqParts &parts, int32_t *where, mm2gb_rmq_deal_t *deal)
+{
+	return rmq_chain_impl(eng, prm, n_reads, offsets, anchors, n_threads, nullptr, &parts, where, deal);
+}
+} // namespace mm2gb
+
+extern "C" {
+
+int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
+                    int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal)
+{
+	if (!out) return fail("mm2gb_rmq_chain: null argument");
+	return rmq_chain_impl(eng, prm, n_reads, offsets, anchors, n_threads, out, nullptr, where, deal);
 }
 
 } // extern "C"
