@@ -132,6 +132,7 @@ struct Engine {
 	// h_post_totals once the stream has been synchronised.
 	int  reserve_post(int64_t n_anchors, int64_t n_reads);                 // work arrays of the post kernels (shared by both result sets)
 	int  reserve_post_out(int set, int64_t n_anchors, int64_t n_reads);    // result buffers of one set; never touches the other
+	void print_post_debug(int64_t n_reads, const int64_t *d_offsets);   // MM2GB_DEBUG_PHASES: the last post-pass kernel's records, to stderr
 	int  enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n, const int32_t *d_f, const int32_t *d_p,
 	                  const mm2gb_rmq_param_t *rmq = nullptr, int out_set = 0);   // rmq given: thresholds of the re-chaining call (lchain.c:355) instead of misc's
 	// the boundary's device post-pass: host anchors in (page-locked), H2D + score kernels + post kernels enqueued, nothing waited

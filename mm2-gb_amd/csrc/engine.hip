@@ -12,6 +12,7 @@
 #include <vector>
 #include <string>
 #include "engine.h"
+#include "host_chain.h"
 
 namespace mm2gb {
 
@@ -447,7 +448,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
 	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream));
 	b.dbg_reads = nullptr;
-	if (debug_phases && !rmq) {
+	if (debug_phases) {
 		if (post_dbg_reads.ensure((size_t)std::max<int64_t>(n_reads, 1) * 32)) return -1;
 		MM2GB_HIP(hipMemsetAsync(post_dbg_reads.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * 32, stream));
 		b.dbg_reads = (long long*)post_dbg_reads.ptr;
@@ -511,7 +512,7 @@ int Engine::fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out)
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->u = (uint64_t*)malloc((size_t)(n_u + 1) * 8);
-	out->a = (mm2gb_anchor_t*)malloc((size_t)(n_a + 1) * 16);
+	out->a = (mm2gb_anchor_t*)result_alloc((size_t)(n_a + 1) * 16);
 	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb: out of host memory"); }
 	out->u_off[0] = out->a_off[0] = 0;
 	if (n_reads > 0) {
@@ -616,7 +617,9 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		}
 	}
 	s.used = false;                                     // nothing of this set is in flight once the call returns
+	const double s_enqueued = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	if (sync()) return -1;
+	const double s_synced = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	if (rmq && debug_phases && n > 0) {
 		long long t[8] = { 0 };
 		if (hipMemcpy(t, (char*)post_misc.ptr + 1536, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -645,7 +648,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->u = (uint64_t*)malloc((size_t)(n_u + 1) * 8);
-	out->a = (mm2gb_anchor_t*)malloc((size_t)(n_a + 1) * 16);
+	out->a = (mm2gb_anchor_t*)result_alloc((size_t)(n_a + 1) * 16);
 	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb_chain_gpu: out of host memory"); }
 	out->u_off[0] = out->a_off[0] = 0;
 	if (n_reads > 0) {
@@ -658,6 +661,10 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	float ms = 0;
 	if (n_reads > 0 && hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
 	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	if (debug_phases && n > 0 && rmq) print_post_debug(n_reads, (const int64_t*)s.offsets.ptr);
+	if (debug_phases && n > 0)
+		fprintf(stderr, "[mm2gb chain_gpu%s] %lld anchors in, %lld kept: enqueued at %.1f ms, device done at %.1f ms (post-pass %.1f ms), results copied at %.1f ms\n", rmq ? ", rmq" : "",
+		        (long long)n, (long long)n_a, s_enqueued * 1e3, s_synced * 1e3, ms, last.ms_total);
 	return 0;
 }
 
@@ -993,6 +1000,48 @@ int mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets
 	return 0;
 }
 
+// MM2GB_DEBUG_PHASES: what the last post-pass kernel recorded (to stderr)
+void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
+{
+	long long t[48] = { 0 };
+	if (hipMemcpy(t, (char*)post_misc.ptr + 1024, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
+		for (int lv = 0; lv < 3; ++lv)
+			fprintf(stderr, "[mm2gb post-pass] sort level %d: %.1f ms; %lld radix passes over %lld elements: %lld cycles, %lld steps, refills of one line %lld, of all lines %lld\n",
+			        lv, t[13 + lv] / 1e5, t[24 + 6 * lv + 5], t[24 + 6 * lv + 4], t[24 + 6 * lv + 3], t[24 + 6 * lv], t[24 + 6 * lv + 1], t[24 + 6 * lv + 2]);
+	if (t[6])
+		fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld, candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[12]);
+	if (t[6])
+		fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
+		        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);
+	// the schedule: when the reads that finish last were started, and how long their parts took
+	if (n_reads > 0 && post_dbg_reads.ptr) {
+		std::vector<long long> tr((size_t)n_reads * 4);
+		std::vector<int64_t> off((size_t)n_reads + 1);
+		if (hipMemcpy(tr.data(), post_dbg_reads.ptr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+		    hipMemcpy(off.data(), d_offsets, off.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			long long t_first = LLONG_MAX, t_last = 0;
+			for (int64_t r = 0; r < n_reads; ++r) if (tr[4 * r]) { t_first = std::min(t_first, tr[4 * r]); t_last = std::max(t_last, tr[4 * r + 3]); }
+			std::vector<int64_t> idx;
+			for (int64_t r = 0; r < n_reads; ++r) if (tr[4 * r]) idx.push_back(r);
+			std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b2) { return tr[4 * a + 3] > tr[4 * b2 + 3]; });
+			fprintf(stderr, "[mm2gb post-pass] k_post_chains: first read starts at 0, last ends at %.2f ms; the reads that end last (anchors | start | collect | sort | walks | end, ms):\n", (t_last - t_first) / 1e5);
+			for (size_t k = 0; k < std::min<size_t>(idx.size(), 12); ++k) {
+				const int64_t r = idx[k];
+				fprintf(stderr, "    read %6lld  %7lld | %6.2f | %5.2f | %6.2f | %6.2f | %6.2f\n", (long long)r, (long long)(off[r + 1] - off[r]), (tr[4 * r] - t_first) / 1e5,
+				        (tr[4 * r + 1] - tr[4 * r]) / 1e5, (tr[4 * r + 2] - tr[4 * r + 1]) / 1e5, (tr[4 * r + 3] - tr[4 * r + 2]) / 1e5, (tr[4 * r + 3] - t_first) / 1e5);
+			}
+			// reads in flight over time (how many wave slots still work at t)
+			const int n_bins = 14;
+			std::vector<int> busy(n_bins, 0);
+			const double span = std::max(1.0, (double)(t_last - t_first));
+			for (int64_t r : idx) for (int k = 0; k < n_bins; ++k) { const double at = t_first + span * (k + 0.5) / n_bins; if (tr[4 * r] <= at && at < tr[4 * r + 3]) ++busy[k]; }
+			fprintf(stderr, "    reads in flight at %d points of the kernel's time:", n_bins);
+			for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
+			fprintf(stderr, "\n");
+		}
+	}
+}
+
 int mm2gb_rmq_chain_gpu(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                         mm2gb_chains_t *out, int32_t *n_tied, mm2gb_stats_t *stats)
 {
@@ -1031,45 +1080,7 @@ int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_off
 	MM2GB_HIP(hipStreamSynchronize(e.stream));
 	if (n_chains) *n_chains = e.h_post_totals[0];
 	if (n_kept) *n_kept = e.h_post_totals[1];
-	if (e.debug_phases) {
-		long long t[48] = { 0 };
-		if (hipMemcpy(t, (char*)e.post_misc.ptr + 1024, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
-			for (int lv = 0; lv < 3; ++lv)
-				fprintf(stderr, "[mm2gb post-pass] sort level %d: %.1f ms; %lld radix passes over %lld elements: %lld cycles, %lld steps, refills of one line %lld, of all lines %lld\n",
-				        lv, t[13 + lv] / 1e5, t[24 + 6 * lv + 5], t[24 + 6 * lv + 4], t[24 + 6 * lv + 3], t[24 + 6 * lv], t[24 + 6 * lv + 1], t[24 + 6 * lv + 2]);
-		if (t[6])
-			fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld, candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[12]);
-		if (t[6])
-			fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
-			        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);
-		// the schedule: when the reads that finish last were started, and how long their parts took
-		if (n_reads > 0 && e.post_dbg_reads.ptr) {
-			std::vector<long long> tr((size_t)n_reads * 4);
-			std::vector<int64_t> off((size_t)n_reads + 1);
-			if (hipMemcpy(tr.data(), e.post_dbg_reads.ptr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-			    hipMemcpy(off.data(), d_offsets, off.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-				long long t_first = LLONG_MAX, t_last = 0;
-				for (int64_t r = 0; r < n_reads; ++r) if (tr[4 * r]) { t_first = std::min(t_first, tr[4 * r]); t_last = std::max(t_last, tr[4 * r + 3]); }
-				std::vector<int64_t> idx;
-				for (int64_t r = 0; r < n_reads; ++r) if (tr[4 * r]) idx.push_back(r);
-				std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b2) { return tr[4 * a + 3] > tr[4 * b2 + 3]; });
-				fprintf(stderr, "[mm2gb post-pass] k_post_chains: first read starts at 0, last ends at %.2f ms; the reads that end last (anchors | start | collect | sort | walks | end, ms):\n", (t_last - t_first) / 1e5);
-				for (size_t k = 0; k < std::min<size_t>(idx.size(), 12); ++k) {
-					const int64_t r = idx[k];
-					fprintf(stderr, "    read %6lld  %7lld | %6.2f | %5.2f | %6.2f | %6.2f | %6.2f\n", (long long)r, (long long)(off[r + 1] - off[r]), (tr[4 * r] - t_first) / 1e5,
-					        (tr[4 * r + 1] - tr[4 * r]) / 1e5, (tr[4 * r + 2] - tr[4 * r + 1]) / 1e5, (tr[4 * r + 3] - tr[4 * r + 2]) / 1e5, (tr[4 * r + 3] - t_first) / 1e5);
-				}
-				// reads in flight over time (how many wave slots still work at t)
-				const int n_bins = 14;
-				std::vector<int> busy(n_bins, 0);
-				const double span = std::max(1.0, (double)(t_last - t_first));
-				for (int64_t r : idx) for (int k = 0; k < n_bins; ++k) { const double at = t_first + span * (k + 0.5) / n_bins; if (tr[4 * r] <= at && at < tr[4 * r + 3]) ++busy[k]; }
-				fprintf(stderr, "    reads in flight at %d points of the kernel's time:", n_bins);
-				for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
-				fprintf(stderr, "\n");
-			}
-		}
-	}
+	if (e.debug_phases) e.print_post_debug(n_reads, d_offsets);
 	float t = 0;
 	if (ms && hipEventElapsedTime(&t, e.post0, e.post1) == hipSuccess) *ms = t;
 	return 0;

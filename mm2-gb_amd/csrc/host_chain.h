@@ -3,6 +3,9 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <new>
 #include <vector>
 #include "../../include/mm2gb_chain.h"
 
@@ -48,6 +51,30 @@ int backtrack_compact(const mm2gb_misc_t &misc, int64_t n, const mm2gb_anchor_t 
 
 // CPUs this process may use at once: affinity mask and cgroup quota, whichever is smaller (stream_api.cpp)
 int usable_cpus();
+
+// A large result array (kept anchors: a gigabyte per batch): huge pages where the system offers them on request -- first touch is most of what
+// filling it costs, and giving it back is cheaper too; free() applies as to any malloc'd block.
+inline void *result_alloc(size_t bytes)
+{
+	void *mem = nullptr;
+	if (bytes >= ((size_t)64 << 20) && posix_memalign(&mem, (size_t)2 << 20, bytes) == 0) { (void)madvise(mem, bytes, MADV_HUGEPAGE); return mem; }
+	return malloc(bytes ? bytes : 1);
+}
+
+// A host thread's large scratch array, kept from call to call (static thread_local at its users): grows, never shrinks, nothing initialised.
+template <class T> struct BigBuf {
+	T *p = nullptr;
+	size_t n = 0, cap = 0;
+	BigBuf() {}
+	BigBuf(const BigBuf&) = delete;
+	BigBuf &operator=(const BigBuf&) = delete;
+	~BigBuf() { free(p); }
+	void resize(size_t want) { if (want > cap) { free(p); cap = want + want / 8; p = (T*)result_alloc(cap * sizeof(T)); if (!p) { cap = n = 0; throw std::bad_alloc(); } } n = want; }
+	T *data() { return p; }
+	const T *data() const { return p; }
+	T *begin() { return p; }
+	size_t size() const { return n; }
+};
 
 // mm2gb_rmq_chain (rmq_hybrid.cpp) without its last step: the results stay where the three sides left them -- host threads, device, reads
 // redone after a tie -- and read r's chains are chains[which[r]] at position slot[r].  For a caller that copies them on anyway (the mapper

@@ -299,11 +299,29 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		for (int s = 0; s < mt[r].n_seeds; ++s) { hit_off[(size_t)(seed_off[r] + s) + 1] = hit_off[(size_t)(seed_off[r] + s)] + mt[r].seeds[s].n; }
 		n_hits += mt[r].n_hits;
 	}
-	std::vector<uint64_t> hits((size_t)n_hits);
-	{ int64_t at = 0; for (size_t r = 0; r < R; ++r) { if (mt[r].n_hits) memcpy(hits.data() + at, mt[r].hits, (size_t)mt[r].n_hits * 8); at += mt[r].n_hits; } }
+	// (the batch's two largest arrays are this thread's from call to call: a gigabyte of fresh pages costs more to touch than to fill)
+	static thread_local BigBuf<uint64_t> hits;
+	static thread_local BigBuf<mm2gb_anchor_t> anchors;
+	hits.resize((size_t)n_hits);
+	{
+		uint64_t *const hits_ptr = hits.data();
+		std::atomic<size_t> next(0);
+		auto work = [&]() {
+			for (;;) {
+				const size_t lo = next.fetch_add(16);
+				if (lo >= R) break;
+				for (size_t r = lo; r < std::min(R, lo + 16); ++r)
+					if (mt[r].n_hits) memcpy(hits_ptr + hit_off[(size_t)seed_off[r]], mt[r].hits, (size_t)mt[r].n_hits * 8);
+			}
+		};
+		std::vector<std::thread> pool;
+		for (int t = 1; t < std::max(1, opt.host_threads); ++t) pool.emplace_back(work);
+		work();
+		for (auto &th : pool) th.join();
+	}
 	std::vector<int32_t> qlen(lens, lens + n_reads);
 	std::vector<int64_t> a_off(R + 1, 0);
-	std::vector<mm2gb_anchor_t> anchors((size_t)std::max<int64_t>(n_hits, 1));
+	anchors.resize((size_t)std::max<int64_t>(n_hits, 1));
 	// on the device for large batches (mm2gb_collect_seeds_gpu: matches up, anchors down, one wave sorts a read); below that the host
 	// threads are quicker: the largest read's sort alone is hundreds of milliseconds for one wave, milliseconds for a core
 	const bool seeds_on_device = opt.seeds_on_device > 0 || (opt.seeds_on_device == 0 && n_hits >= 400000000);
@@ -321,7 +339,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	misc.max_skip = INT32_MAX; misc.bw = opt.bw; misc.min_cnt = opt.min_cnt; misc.min_score = opt.min_chain_score; misc.is_cdna = 0; misc.n_seg = 1;
 	misc.chn_pen_gap = (float)(opt.chain_gap_scale * 0.01 * k); misc.chn_pen_skip = (float)(opt.chain_skip_scale * 0.01 * k);
 	if (mm2gb_engine_set_misc(eng, &misc)) { free_matches(); return -1; }
-	mm2gb_chains_t ch; memset(&ch, 0, sizeof ch);
+	struct Chains { mm2gb_chains_t c; Chains() { memset(&c, 0, sizeof c); } ~Chains() { mm2gb_chains_free(&c); } } ch_own;   // (freed on every way out)
+	mm2gb_chains_t &ch = ch_own.c;
 	// backtrack + compaction as kernels for large batches; below that on host threads, overlapped with the device: a single huge read (a
 	// tandem array) keeps one wave busy for hundreds of milliseconds where a core needs tens
 	if (a_off[R] >= 200000000 ? mm2gb_chain_gpu(eng, n_reads, a_off.data(), anchors.data(), &ch, nullptr)
@@ -330,9 +349,9 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	// 4. re-chaining of long reads whose best chain leaves much of the read uncovered (map.c:697-708): the chained anchors, sorted
 	//    again, through mg_lchain_rmq's fill
 	std::vector<int64_t> u_off(ch.u_off, ch.u_off + R + 1), c_off(ch.a_off, ch.a_off + R + 1);
-	std::vector<uint64_t> u(ch.u, ch.u + u_off[R]);
-	std::vector<mm2gb_anchor_t> ca(ch.a, ch.a + c_off[R]);
-	mm2gb_chains_free(&ch);
+	// (the chains are read where the chaining call left them -- a gigabyte of kept anchors per batch is not copied again)
+	const uint64_t *u = ch.u;
+	const mm2gb_anchor_t *ca = ch.a;
 	lap(st_local.s_chain);
 	tr.reset(); tr.reset(new TraceRange("mm2gb:map_rechain"));
 	std::vector<int32_t> redo;
@@ -340,7 +359,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	if (opt.bw_long > opt.bw) {
 		for (size_t r = 0; r < R; ++r) {
 			if (u_off[r + 1] - u_off[r] <= 1) continue;
-			const mm2gb_anchor_t *a = ca.data() + c_off[r];
+			const mm2gb_anchor_t *a = ca + c_off[r];
 			const int st = (int32_t)a[0].y, en = (int32_t)a[(int32_t)u[(size_t)u_off[r]] - 1].y;
 			if (lens[r] - (en - st) > opt.rmq_rescue_size || en - st > lens[r] * opt.rmq_rescue_ratio) redo.push_back((int32_t)r);
 		}
@@ -352,7 +371,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		std::vector<int64_t> ro(redo.size() + 1, 0);
 		for (size_t q = 0; q < redo.size(); ++q) ro[q + 1] = ro[q] + (c_off[(size_t)redo[q] + 1] - c_off[(size_t)redo[q]]);
 		// (kept between the calls of a thread, like the gathers of mm2gb_rmq_chain: fresh pages cost more to touch than to fill)
-		static thread_local std::vector<mm2gb_anchor_t> ra;
+		static thread_local BigBuf<mm2gb_anchor_t> ra;
 		ra.resize((size_t)ro.back());
 		mm2gb_anchor_t *const ra_ptr = ra.data();               // (for the threads below: `ra` names each thread's own)
 		{
@@ -362,7 +381,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 					const int64_t q = next.fetch_add(1);
 					if (q >= (int64_t)redo.size()) break;
 					const size_t r = (size_t)redo[(size_t)q];
-					memcpy(ra_ptr + ro[(size_t)q], ca.data() + c_off[r], (size_t)(ro[(size_t)q + 1] - ro[(size_t)q]) * sizeof(mm2gb_anchor_t));
+					memcpy(ra_ptr + ro[(size_t)q], ca + c_off[r], (size_t)(ro[(size_t)q + 1] - ro[(size_t)q]) * sizeof(mm2gb_anchor_t));
 					sort_by_x_like_host(ra_ptr + ro[(size_t)q], ra_ptr + ro[(size_t)q + 1]);
 				}
 			};
@@ -427,9 +446,9 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			nu_off[r + 1] = nu_off[r] + (q < 0 ? u_off[r + 1] - u_off[r] : from.u_off[qq + 1] - from.u_off[qq]);
 			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : from.a_off[qq + 1] - from.a_off[qq]);
 		}
-		// (this thread's from call to call: they are swapped with `u` / `ca` below, so what they hold next time is this call's old arrays -- touched pages)
-		static thread_local std::vector<uint64_t> nu;
-		static thread_local std::vector<mm2gb_anchor_t> nc;
+		// (this thread's from call to call: touched pages)
+		static thread_local BigBuf<uint64_t> nu;
+		static thread_local BigBuf<mm2gb_anchor_t> nc;
 		nu.resize((size_t)nu_off[R]); nc.resize((size_t)nc_off[R]);
 		uint64_t *const nu_ptr = nu.data();
 		mm2gb_anchor_t *const nc_ptr = nc.data();
@@ -444,8 +463,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 						const int q = which[r];
 						const mm2gb_chains_t &from = *side[q >= 0 ? q_side[(size_t)q] : 0];
 						const int64_t qq = q >= 0 ? q_slot[(size_t)q] : 0;
-						const uint64_t *su = q < 0 ? u.data() + u_off[r] : from.u + from.u_off[qq];
-						const mm2gb_anchor_t *sa = q < 0 ? ca.data() + c_off[r] : from.a + from.a_off[qq];
+						const uint64_t *su = q < 0 ? u + u_off[r] : from.u + from.u_off[qq];
+						const mm2gb_anchor_t *sa = q < 0 ? ca + c_off[r] : from.a + from.a_off[qq];
 						if (nu_off[r + 1] > nu_off[r]) memcpy(nu_ptr + nu_off[r], su, (size_t)(nu_off[r + 1] - nu_off[r]) * 8);
 						if (nc_off[r + 1] > nc_off[r]) memcpy(nc_ptr + nc_off[r], sa, (size_t)(nc_off[r + 1] - nc_off[r]) * sizeof(mm2gb_anchor_t));
 					}
@@ -457,7 +476,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			for (auto &th : pool) th.join();
 		}
 		mm2gb_chains_free(&rc); mm2gb_chains_free(&rc_tie);
-		u.swap(nu); ca.swap(nc); u_off.swap(nu_off); c_off.swap(nc_off);
+		u = nu_ptr; ca = nc_ptr; u_off.swap(nu_off); c_off.swap(nc_off);
+		mm2gb_chains_free(&ch);
 		if (verbose) fprintf(stderr, "[mm2gb] re-chaining %zu reads (%lld redone on the host after a tie), %lld anchors: sort %.3f s, fill %.3f s, splice %.3f s\n", redo.size(), (long long)st_local.n_rmq_tied, (long long)ro.back(), std::chrono::duration<double>(t_sorted - t_rechain).count(),
 		                     std::chrono::duration<double>(t_filled - t_sorted).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_filled).count());
 	}
@@ -474,7 +494,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	}
 	std::vector<mm2gb_reg_t> regs((size_t)std::max<int64_t>(u_off[R], 1));
 	{
-		mm2gb_chains_t view; view.u_off = u_off.data(); view.u = u.data(); view.a_off = c_off.data(); view.a = ca.data();
+		mm2gb_chains_t view; view.u_off = u_off.data(); view.u = const_cast<uint64_t*>(u); view.a_off = c_off.data(); view.a = const_cast<mm2gb_anchor_t*>(ca);
 		if (mm2gb_gen_regs_gpu(eng, n_reads, &view, qlen.data(), hash.data(), 0, regs.data())) { free_matches(); return -1; }
 	}
 
@@ -502,7 +522,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 				if (hs.empty()) continue;
 				set_parent(opt.mask_level, opt.mask_len, hs, false);                                     // map.c:336
 				select_sub(opt.pri_ratio, k * 2, opt.best_n, true, (int)(opt.max_gap * 0.8), hs);          // map.c:337
-				estimate_divergence(lens[r], ref_len_v, hs, ca.data() + c_off[r], mt[r].n_mini_pos, mt[r].mini_pos);   // map.c:751
+				estimate_divergence(lens[r], ref_len_v, hs, ca + c_off[r], mt[r].n_mini_pos, mt[r].mini_pos);   // map.c:751
 				filter_strand_retained(hs);                                                              // map.c:752
 				set_mapq(hs, opt.min_chain_score, mt[r].rep_len);                                        // map.c:758
 				for (const Hit &h : hs) write_paf(lines[r], names[r] ? names[r] : "*", lens[r], h, ref_names[h.rid], ref_lens[h.rid], mt[r].rep_len);

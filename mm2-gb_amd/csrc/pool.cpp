@@ -205,13 +205,7 @@ int chain_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_read
 		out->a_off[r + 1] = out->a_off[r] + of[(size_t)r].n_kept;
 	}
 	out->u = (uint64_t*)malloc((size_t)(out->u_off[n_reads] + 1) * 8);
-	{   // large result: ask for huge pages where the system offers them (first touch is most of the copy's cost); free() still applies
-		const size_t bytes = (size_t)(out->a_off[n_reads] + 1) * 16;
-		void *mem = nullptr;
-		if (bytes >= ((size_t)64 << 20) && posix_memalign(&mem, (size_t)2 << 20, bytes) == 0) (void)madvise(mem, bytes, MADV_HUGEPAGE);
-		else mem = malloc(bytes);
-		out->a = (mm2gb_anchor_t*)mem;
-	}
+	out->a = (mm2gb_anchor_t*)result_alloc((size_t)(out->a_off[n_reads] + 1) * 16);   // (huge pages if it is large)
 	std::atomic<int64_t> next(0);
 	on_threads(n_reads < 128 ? 1 : n_threads, [&](int) {
 		for (;;) {

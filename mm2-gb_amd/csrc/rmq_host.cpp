@@ -582,7 +582,7 @@ static int rmq_chain_host_impl(const mm2gb_rmq_param_t *prm, int64_t n_reads, co
 	out->u_off[0] = out->a_off[0] = 0;
 	for (size_t r = 0; r < R; ++r) { out->u_off[r + 1] = out->u_off[r] + nu_of[r]; out->a_off[r + 1] = out->a_off[r] + na_of[r]; }
 	out->u = (uint64_t*)malloc(((size_t)out->u_off[R] + 1) * 8);
-	out->a = (mm2gb_anchor_t*)malloc(((size_t)out->a_off[R] + 1) * 16);
+	out->a = (mm2gb_anchor_t*)mm2gb::result_alloc(((size_t)out->a_off[R] + 1) * 16);
 	if (!out->u || !out->a) { mm2gb_chains_free(out); return fail("mm2gb_rmq_chain_host: out of memory"); }
 	for (size_t r = 0; r < R; ++r) {
 		if (nu_of[r] > 0) { memcpy(out->u + out->u_off[r], u_of[r], (size_t)nu_of[r] * 8); memcpy(out->a + out->a_off[r], a_of[r], (size_t)na_of[r] * 16); }

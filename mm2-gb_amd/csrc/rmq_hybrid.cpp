@@ -161,7 +161,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	double s_gather = 0, s_merge = 0;
 	// ---- both sides at once ----
 	const int gather_threads = nt;
-	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, std::vector<mm2gb_anchor_t> &buf) {
+	auto gather = [&](size_t from, size_t to, std::vector<int64_t> &off, BigBuf<mm2gb_anchor_t> &buf) {
 		off.assign(to - from + 1, 0);
 		for (size_t q = from; q < to; ++q) off[q - from + 1] = off[q - from] + (offsets[by_dev[q] + 1] - offsets[by_dev[q]]);
 		buf.resize((size_t)std::max<int64_t>(off.back(), 1));
@@ -172,7 +172,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	};
 	std::vector<int64_t> h_off, d_off, t_off;
 	// (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
-	static thread_local std::vector<mm2gb_anchor_t> h_a, d_a, t_a;
+	static thread_local BigBuf<mm2gb_anchor_t> h_a, d_a, t_a;
 	mm2gb_chains_t h_out, d_out, t_out;
 	memset(&h_out, 0, sizeof h_out); memset(&d_out, 0, sizeof d_out); memset(&t_out, 0, sizeof t_out);
 	int h_rc = 0;
@@ -285,7 +285,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	for (size_t r = 0; r < R; ++r) append(*out, r, *src[r].c, src[r].q);
 	for (size_t r = 0; r < R; ++r) { out->u_off[r + 1] += out->u_off[r]; out->a_off[r + 1] += out->a_off[r]; }
 	out->u = (uint64_t*)malloc(((size_t)out->u_off[R] + 1) * 8);
-	out->a = (mm2gb_anchor_t*)malloc(((size_t)out->a_off[R] + 1) * 16);
+	out->a = (mm2gb_anchor_t*)result_alloc(((size_t)out->a_off[R] + 1) * 16);
 	if (!out->u || !out->a) { mm2gb_chains_free(out); return give_up("mm2gb_rmq_chain: out of memory"); }
 	parallel_reads(R, nt, [&](size_t r) {
 		const mm2gb_chains_t &c = *src[r].c;
