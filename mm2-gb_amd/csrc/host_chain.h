@@ -69,12 +69,16 @@ template <class T> struct BigBuf {
 	BigBuf(const BigBuf&) = delete;
 	BigBuf &operator=(const BigBuf&) = delete;
 	~BigBuf() { free(p); }
+	void release() { free(p); p = nullptr; n = cap = 0; }
 	void resize(size_t want) { if (want > cap) { free(p); cap = want + want / 8; p = (T*)result_alloc(cap * sizeof(T)); if (!p) { cap = n = 0; throw std::bad_alloc(); } } n = want; }
 	T *data() { return p; }
 	const T *data() const { return p; }
 	T *begin() { return p; }
 	size_t size() const { return n; }
 };
+
+// gives back what the calling thread's re-chaining calls keep between calls (rmq_hybrid.cpp; part of mm2gb_host_scratch_release, mapper.cpp)
+void release_rmq_scratch();
 
 // mm2gb_rmq_chain (rmq_hybrid.cpp) without its last step: the results stay where the three sides left them -- host threads, device, reads
 // redone after a tie -- and read r's chains are chains[which[r]] at position slot[r].  For a caller that copies them on anyway (the mapper

@@ -225,6 +225,12 @@ void write_paf(std::string &out, const char *qname, int qlen, const Hit &h, cons
 
 using namespace mm2gb;
 
+namespace {
+// a mapping thread's largest arrays, kept from batch to batch (mm2gb_host_scratch_release gives them back)
+struct MapScratch { BigBuf<uint64_t> hits, nu; BigBuf<mm2gb_anchor_t> anchors, ra, nc; };
+thread_local MapScratch tl_scratch;
+}
+
 extern "C" {
 
 void mm2gb_map_opt_init(mm2gb_map_opt_t *o)       // mm_mapopt_init (options.c:15-75), the fields this path looks at
@@ -236,6 +242,12 @@ void mm2gb_map_opt_init(mm2gb_map_opt_t *o)       // mm_mapopt_init (options.c:1
 	o->chain_gap_scale = 0.8f; o->chain_skip_scale = 0.0f; o->max_max_occ = 4095; o->occ_dist = 500;
 	o->mask_level = 0.5f; o->mask_len = INT32_MAX; o->pri_ratio = 0.8f; o->best_n = 5;
 	o->host_threads = 0;           // 0: as many as the process may use, at most 32
+}
+
+void mm2gb_host_scratch_release(void)
+{
+	tl_scratch.hits.release(); tl_scratch.nu.release(); tl_scratch.anchors.release(); tl_scratch.ra.release(); tl_scratch.nc.release();
+	release_rmq_scratch();
 }
 
 int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
@@ -300,8 +312,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		n_hits += mt[r].n_hits;
 	}
 	// (the batch's two largest arrays are this thread's from call to call: a gigabyte of fresh pages costs more to touch than to fill)
-	static thread_local BigBuf<uint64_t> hits;
-	static thread_local BigBuf<mm2gb_anchor_t> anchors;
+	BigBuf<uint64_t> &hits = tl_scratch.hits;
+	BigBuf<mm2gb_anchor_t> &anchors = tl_scratch.anchors;
 	hits.resize((size_t)n_hits);
 	{
 		uint64_t *const hits_ptr = hits.data();
@@ -371,7 +383,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		std::vector<int64_t> ro(redo.size() + 1, 0);
 		for (size_t q = 0; q < redo.size(); ++q) ro[q + 1] = ro[q] + (c_off[(size_t)redo[q] + 1] - c_off[(size_t)redo[q]]);
 		// (kept between the calls of a thread, like the gathers of mm2gb_rmq_chain: fresh pages cost more to touch than to fill)
-		static thread_local BigBuf<mm2gb_anchor_t> ra;
+		BigBuf<mm2gb_anchor_t> &ra = tl_scratch.ra;
 		ra.resize((size_t)ro.back());
 		mm2gb_anchor_t *const ra_ptr = ra.data();               // (for the threads below: `ra` names each thread's own)
 		{
@@ -447,8 +459,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : from.a_off[qq + 1] - from.a_off[qq]);
 		}
 		// (this thread's from call to call: touched pages)
-		static thread_local BigBuf<uint64_t> nu;
-		static thread_local BigBuf<mm2gb_anchor_t> nc;
+		BigBuf<uint64_t> &nu = tl_scratch.nu;
+		BigBuf<mm2gb_anchor_t> &nc = tl_scratch.nc;
 		nu.resize((size_t)nu_off[R]); nc.resize((size_t)nc_off[R]);
 		uint64_t *const nu_ptr = nu.data();
 		mm2gb_anchor_t *const nc_ptr = nc.data();

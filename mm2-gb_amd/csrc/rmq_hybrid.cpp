@@ -90,6 +90,9 @@ void append(mm2gb_chains_t &dst, size_t r, const mm2gb_chains_t &src, size_t q)
 using namespace mm2gb;
 
 namespace {
+// the gathers of a call: host share, device share, tie redo (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy)
+thread_local BigBuf<mm2gb_anchor_t> tl_gather[3];
+
 // `out`: one result in the caller's read order; or `parts`: the three sides' results as they are (host_chain.h, RmqParts)
 int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                    int n_threads, mm2gb_chains_t *out, mm2gb::RmqParts *parts, int32_t *where, mm2gb_rmq_deal_t *deal)
@@ -172,7 +175,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	};
 	std::vector<int64_t> h_off, d_off, t_off;
 	// (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
-	static thread_local BigBuf<mm2gb_anchor_t> h_a, d_a, t_a;
+	BigBuf<mm2gb_anchor_t> &h_a = tl_gather[0], &d_a = tl_gather[1], &t_a = tl_gather[2];
 	mm2gb_chains_t h_out, d_out, t_out;
 	memset(&h_out, 0, sizeof h_out); memset(&d_out, 0, sizeof d_out); memset(&t_out, 0, sizeof t_out);
 	int h_rc = 0;
@@ -304,6 +307,8 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 } // namespace
 
 namespace mm2gb {
+void release_rmq_scratch() { for (auto &b : tl_gather) b.release(); }
+
 int rmq_chain_parts(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                     int n_threads, RmqParts &parts, int32_t *where, mm2gb_rmq_deal_t *deal)
 {

@@ -85,6 +85,25 @@ def test_reads_that_map_nowhere_and_odd_input(engine):
     assert by["upper"] == open(os.path.join(GOLD, "real_mt_inf.paf")).read().strip().replace("MT_orang", "upper", 1)
 
 
+def test_batches_of_different_sizes_on_one_thread_and_scratch_release(engine, tmp_path):
+    """A thread keeps its largest host arrays from call to call (matches, anchors, the re-chaining gathers, the spliced chains) without clearing
+    them: a large batch, a small one, the large one again, and once more after mm2gb_host_scratch_release -- the same PAF every time."""
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    refs, rd = read_fasta(ref), read_fasta(reads)
+    want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
+    names = [n for n, _ in refs]
+    with mm.SeedIndex([s for _, s in refs]) as ix:
+        assert mm.map_reads(engine, ix, names, rd)[0] == want
+        few = mm.map_reads(engine, ix, names, rd[5:9])[0]
+        assert few == "".join(ln + "\n" for ln in want.splitlines() if ln.split("\t")[0] in {n.decode() if isinstance(n, bytes) else n for n, _ in rd[5:9]})
+        assert mm.map_reads(engine, ix, names, rd)[0] == want
+        mm.host_scratch_release()
+        assert mm.map_reads(engine, ix, names, rd[5:9])[0] == few
+        assert mm.map_reads(engine, ix, names, rd)[0] == want
+
+
 def test_reads_sharded_over_several_engines(engine, tmp_path):
     """mm2gb_map_reads_multi with three engines on the one GPU (the multi-GPU path without a multi-GPU box, as tests/test_gpu_pool.py does for
     the chaining calls): same PAF as one engine, in read order."""
