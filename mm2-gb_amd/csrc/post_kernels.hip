@@ -1477,8 +1477,15 @@ __global__ __launch_bounds__(256) void k_rmq_strip_ranges(RmqBatch b, int max_in
 constexpr int RMQ_THREADS = 1024;              // k_rmq_fill_tiles: 16 waves -- one read each, or all 16 on one read
 constexpr int RMQ_TEAM = RMQ_THREADS / W;
 constexpr int RMQ_MERGE_WORDS = 12;
+// A team's read keeps the top of its tournament tree -- nodes 1 .. RMQ_TOP_NODES - 1, eleven levels -- in LDS (`s_top`; only wave 0 touches the
+// tree): a tile's update climbs every level behind a store and a load of the level below, ~1.6 us per level in global memory, 31 us per tile
+// of a 450 k-anchor read (19 levels), a third of such a read's time (profiles/r03_rmq_teams.txt).
+#ifndef MM2GB_RMQ_TOP_NODES
+#define MM2GB_RMQ_TOP_NODES 2048
+#endif
+constexpr int RMQ_TOP_NODES = MM2GB_RMQ_TOP_NODES;
 template <int NW>
-__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W])
+__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W], uint4 *s_top)
 {
 	const int l = lane();
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
@@ -1495,6 +1502,10 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 		const int32_t *ord_idx = b.ord_idx + off;
 		int32_t *f = b.f + off, *p = b.p + off;
 		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
+		const int top_nodes = NW > 1 && RMQ_TOP_NODES > 1 ? RMQ_TOP_NODES : 0;   // nodes below this index live in s_top for the read's time
+		auto tld = [&](int q) -> uint4 { if (NW > 1 && q < top_nodes) return s_top[q]; return tree[q]; };
+		auto tst = [&](int q, const uint4 &v) { if (NW > 1 && q < top_nodes) s_top[q] = v; else tree[q] = v; };
+		if (NW > 1 && w == 0) { for (int q = l; q < top_nodes; q += W) s_top[q] = tnode_none(); wave_sync(); }
 		int32_t *bound = b.bound + (off >> 6) + r;           // per block of 64 anchors (by index) the largest f + span, once its tile is done
 		int ev = 0, ins = 0, tied = 0;                       // the tree holds the anchors of index [ev, ins)
 		const long long t_read0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -1520,21 +1531,21 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				while (e0 < e1 || n0 < n1) {
 					const int je = e0 + l, ji = n0 + l;
 					int pe = 0, pi = 0;
-					if (je < e1) { pe = n + meta[je].x; tree[pe] = tnode_none(); }
+					if (je < e1) { pe = n + meta[je].x; tst(pe, tnode_none()); }
 					if (ji < n1) {
 						const uint4 e = a[ji];
 						const int rk = meta[ji].x;
 						const long long kk = key_order((double)f[ji] + half_gap * (double)((int)e.x + (int)e.z));
 						pi = n + rk;
-						tree[pi] = make_uint4((unsigned)kk, (unsigned)((unsigned long long)kk >> 32), (unsigned)rk, 0u);
+						tst(pi, make_uint4((unsigned)kk, (unsigned)((unsigned long long)kk >> 32), (unsigned)rk, 0u));
 					}
 					wave_sync();
 					while (__ballot(pe > 1 || pi > 1) != 0) {
 						uint4 c0 = tnode_none(), c1 = c0, c2 = c0, c3 = c0;
-						if (pe > 1) { pe >>= 1; c0 = tree[2 * pe]; c1 = tree[2 * pe + 1]; } else pe = 0;
-						if (pi > 1) { pi >>= 1; c2 = tree[2 * pi]; c3 = tree[2 * pi + 1]; } else pi = 0;
-						if (pe > 0) tree[pe] = tnode_comb(c0, c1);
-						if (pi > 0 && pi != pe) tree[pi] = tnode_comb(c2, c3);
+						if (pe > 1) { pe >>= 1; c0 = tld(2 * pe); c1 = tld(2 * pe + 1); } else pe = 0;
+						if (pi > 1) { pi >>= 1; c2 = tld(2 * pi); c3 = tld(2 * pi + 1); } else pi = 0;
+						if (pe > 0) tst(pe, tnode_comb(c0, c1));
+						if (pi > 0 && pi != pe) tst(pi, tnode_comb(c2, c3));
 						wave_sync();
 					}
 					e0 += W; n0 += W;
@@ -1552,8 +1563,8 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				while (__ballot(go && ql < qr) != 0) {
 					uint4 vl = tnode_none(), vr = vl;
 					if (go && ql < qr) {
-						if (ql & 1) vl = tree[ql++];
-						if (qr & 1) vr = tree[--qr];
+						if (ql & 1) vl = tld(ql++);
+						if (qr & 1) vr = tld(--qr);
 						ql >>= 1; qr >>= 1;
 					}
 					best = tnode_comb(best, tnode_comb(vl, vr));
@@ -1792,6 +1803,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 __global__ __launch_bounds__(RMQ_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqParams P)
 {
 	__shared__ int s_m[RMQ_TEAM - 1][RMQ_MERGE_WORDS][W];
+	__shared__ uint4 s_top[RMQ_TOP_NODES];
 	__shared__ int s_read;
 	const int l = lane(), w = uni(threadIdx.x / W);
 	const int n_team = (int)min((int64_t)b.n_team, b.n_reads);
@@ -1802,14 +1814,14 @@ __global__ __launch_bounds__(RMQ_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqP
 		const int r = uni(s_read);
 		__syncthreads();
 		if (r >= n_team) break;
-		rmq_fill_read_tiles<RMQ_TEAM>(b, P, r, w, s_m);
+		rmq_fill_read_tiles<RMQ_TEAM>(b, P, r, w, s_m, s_top);
 	}
 	for (;;) {
 		int r = 0;
 		if (l == 0) r = atomicAdd(b.cursor, 1);
 		r = uni(r) + n_team;
 		if (r >= b.n_reads) break;
-		rmq_fill_read_tiles<1>(b, P, r, 0, nullptr);
+		rmq_fill_read_tiles<1>(b, P, r, 0, nullptr, nullptr);
 	}
 }
 

@@ -21,19 +21,22 @@ with mm.Engine() as e:
     o2 = np.zeros(len(reads) + 1, np.int64); o2[1:] = np.cumsum([len(x) for x in reads])
     allr = np.concatenate(reads)
     prm = mm.default_rmq_param()
-    best = None
+    best = best_c = best_xc = None
     for _ in range(3):
         t0 = time.perf_counter(); res, tied, st = e.rmq_chain(allr, o2, prm); dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+        best_c = st["ms_total"] / 1e3 if best_c is None else min(best_c, st["ms_total"] / 1e3)      # the C call alone (its own clock): without the wrapper's per-read numpy copies
     # the call the product answers with: device and host threads at the same time, exact for every read (csrc/rmq_hybrid.cpp)
     best_x, deal = None, {}
     for _ in range(3):
         t0 = time.perf_counter(); _, where, deal = e.rmq_chain_exact(allr, o2, prm, threads=threads); dt = time.perf_counter() - t0
         best_x = dt if best_x is None else min(best_x, dt)
+        best_xc = deal["total_s"] if best_xc is None else min(best_xc, deal["total_s"])
     # and the host form alone on the same threads
     t0 = time.perf_counter(); mm.rmq_chain_host(allr, o2, prm, threads=threads); t_host_form = time.perf_counter() - t0
 doc = {"exact_call_s": round(best_x, 4), "exact_call_anchors_per_s": o2[-1] / best_x, "exact_call_deal": deal, "host_form_s": round(t_host_form, 4), "host_threads": threads,
        "reads": args.reads, "anchors_first_pass": int(off[-1]), "anchors_rechained": int(o2[-1]), "first_pass_chain_host_s": round(t_first, 3),
+       "gpu_rmq_call_s": round(best_c, 4), "exact_call_c_s": round(best_xc, 4),
        "gpu_rmq_chain_s": round(best, 4), "gpu_anchors_per_s": o2[-1] / best, "reads_with_a_tie": int((tied > 0).sum()), "ms_post": st["ms_post"]}
 ref_path = os.path.join(orc.REF_DIR, "libmm2ref.so")
 if os.path.exists(ref_path):
@@ -53,6 +56,8 @@ if os.path.exists(ref_path):
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex: list(ex.map(one, range(len(reads))))
     dt = time.perf_counter() - t0
-    doc.update({"reference_cpu_s": round(dt, 3), "reference_cpu_threads": threads, "reference_anchors_per_s": o2[-1] / dt, "gpu_over_reference": dt / best, "exact_call_over_reference": dt / best_x})
+    doc.update({"reference_cpu_s": round(dt, 3), "reference_cpu_threads": threads, "reference_anchors_per_s": o2[-1] / dt, "gpu_over_reference": dt / best, "exact_call_over_reference": dt / best_x,
+                "gpu_call_over_reference": dt / best_c, "exact_call_c_over_reference": dt / best_xc,
+                "note": "gpu_rmq_chain_s / exact_call_s are timed around the Python wrappers, which copy every read's result into numpy arrays; *_call_s / *_c_s are the C calls alone"})
 json.dump(doc, open(args.out, "w"), indent=1)
 print(json.dumps(doc))
