@@ -77,6 +77,9 @@ template <class T> struct BigBuf {
 	size_t size() const { return n; }
 };
 
+// mm2gb_collect_matches (seeding.cpp) without the copy of the occurrences: refs[s] points at kept seed s's occurrences in the index, out->hits stays null
+int collect_matches_refs(const mm2gb_index_t *ix, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out, std::vector<const uint64_t*> *refs);
+
 // gives back what the calling thread's re-chaining calls keep between calls (rmq_hybrid.cpp; part of mm2gb_host_scratch_release, mapper.cpp)
 void release_rmq_scratch();
 

@@ -273,6 +273,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	// 1. matches on host threads
 	std::unique_ptr<TraceRange> tr(new TraceRange("mm2gb:map_seed"));   // stage ranges for rocprofv3 --marker-trace / rocprof-sys
 	std::vector<mm2gb_matches_t> mt(R);
+	std::vector<std::vector<const uint64_t*>> occ(R);     // per read and kept seed: its occurrences, where the index holds them (copied once, into the batch's array)
 	for (auto &m : mt) memset(&m, 0, sizeof m);
 	const mm2gb_seed_opt_t so = { opt.mid_occ, opt.max_max_occ, opt.occ_dist, opt.q_occ_frac };
 	{
@@ -284,7 +285,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 			for (;;) {
 				const int32_t r = next.fetch_add(1);
 				if (r >= n_reads) break;
-				if (lens[r] > 0 && mm2gb_collect_matches(ix, seqs[r], lens[r], &so, &mt[(size_t)r])) {
+				if (lens[r] > 0 && collect_matches_refs(ix, seqs[r], lens[r], &so, &mt[(size_t)r], &occ[(size_t)r])) {
 					std::lock_guard<std::mutex> g(why_lock);
 					if (!bad.exchange(1)) why = mm2gb_last_error();
 				}
@@ -323,7 +324,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 				const size_t lo = next.fetch_add(16);
 				if (lo >= R) break;
 				for (size_t r = lo; r < std::min(R, lo + 16); ++r)
-					if (mt[r].n_hits) memcpy(hits_ptr + hit_off[(size_t)seed_off[r]], mt[r].hits, (size_t)mt[r].n_hits * 8);
+					for (int32_t q = 0; q < mt[r].n_seeds; ++q)
+						memcpy(hits_ptr + hit_off[(size_t)seed_off[r] + (size_t)q], occ[r][(size_t)q], (size_t)mt[r].seeds[q].n * 8);
 			}
 		};
 		std::vector<std::thread> pool;

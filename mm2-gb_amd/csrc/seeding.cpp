@@ -103,10 +103,31 @@ struct SeedIndex {
 	std::vector<uint64_t> keys;             // distinct minimizers (x >> 8), ascending
 	std::vector<int64_t> first;             // keys.size() + 1: where each one's occurrences begin
 	std::vector<uint64_t> where;            // occurrences, ascending within a minimizer
+	// keys by their top bits: bucket[b] = first key with (key >> bucket_shift) >= b.  The hash spreads minimizers evenly over their 2k bits,
+	// so a bucket holds a key or two and a look-up is one probe of this table and a search among those (a binary search over all keys:
+	// ~20 dependent probes of a table that does not fit the cache, ~200 ns per minimizer of a read, most of what seeding cost)
+	std::vector<uint32_t> bucket;
+	int bucket_shift = 0;
+	void build_buckets()
+	{
+		int bits = 1;
+		while (bits < 2 * k && ((size_t)1 << bits) < keys.size()) ++bits;   // about one key per bucket
+		bits = std::min(bits, 26);
+		bucket_shift = 2 * k - bits;
+		bucket.assign(((size_t)1 << bits) + 1, 0);
+		size_t at = 0;
+		for (size_t b = 0; b <= (size_t)1 << bits; ++b) {
+			while (at < keys.size() && (keys[at] >> bucket_shift) < b) ++at;
+			bucket[b] = (uint32_t)at;
+		}
+	}
 	const uint64_t *find(uint64_t minier, int *n) const
 	{
-		const auto it = std::lower_bound(keys.begin(), keys.end(), minier);
-		if (it == keys.end() || *it != minier) { *n = 0; return nullptr; }
+		const uint64_t b = minier >> bucket_shift;
+		if (b + 1 >= bucket.size()) { *n = 0; return nullptr; }
+		const auto lo = keys.begin() + bucket[(size_t)b], hi = keys.begin() + bucket[(size_t)b + 1];
+		const auto it = std::lower_bound(lo, hi, minier);
+		if (it == hi || *it != minier) { *n = 0; return nullptr; }
 		const size_t at = (size_t)(it - keys.begin());
 		*n = (int)(first[at + 1] - first[at]);
 		return where.data() + first[at];
@@ -204,6 +225,8 @@ mm2gb_index_t *mm2gb_index_build(int k, int w, int32_t n_seq, const char *const 
 		ix->where[i] = all[i].y;
 	}
 	ix->first.push_back((int64_t)all.size());
+	if (ix->keys.size() >= ((size_t)1 << 32)) { delete ix; fail("mm2gb_index_build: more than 2^32 distinct minimizers"); return nullptr; }
+	ix->build_buckets();
 	return reinterpret_cast<mm2gb_index_t*>(ix);
 }
 
@@ -236,7 +259,16 @@ int32_t mm2gb_index_mid_occ(const mm2gb_index_t *ix_, float frac, int32_t min_mi
 	return occ;
 }
 
-int mm2gb_collect_matches(const mm2gb_index_t *ix_, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out)
+int mm2gb_collect_matches(const mm2gb_index_t *ix, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out)
+{
+	return collect_matches_refs(ix, seq, len, opt, out, nullptr);
+}
+
+} // extern "C"
+
+// refs == nullptr: out->hits is a copy of every kept seed's occurrences; otherwise out->hits stays null and refs[s] points at seed s's
+// occurrences in the index (the mapper copies them straight into the batch's array: host_chain.h)
+int mm2gb::collect_matches_refs(const mm2gb_index_t *ix_, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out, std::vector<const uint64_t*> *refs)
 {
 	const SeedIndex *ix = reinterpret_cast<const SeedIndex*>(ix_);
 	if (!ix || !opt || !out || len < 0 || (len > 0 && !seq)) return fail("mm2gb_collect_matches: null argument");
@@ -245,19 +277,23 @@ int mm2gb_collect_matches(const mm2gb_index_t *ix_, const char *seq, int32_t len
 	if (len > 0) sketch(seq, len, ix->w, ix->k, 0, mv);                       // map.c:186-199, one segment
 	// seed.c:5-30: a minimizer that makes up more than q_occ_frac of the read's minimizers (and more than mid_occ of them) goes
 	if (opt->q_occ_frac > 0.0f && opt->mid_occ > 0 && (int64_t)mv.size() > opt->mid_occ) {
-		std::vector<std::pair<uint64_t, uint32_t>> byx(mv.size());
-		for (size_t i = 0; i < mv.size(); ++i) byx[i] = { mv[i].x, (uint32_t)i };
-		std::sort(byx.begin(), byx.end());
-		std::vector<char> drop(mv.size(), 0);
-		for (size_t st = 0, i = 1; i <= byx.size(); ++i) {
-			if (i < byx.size() && byx[i].first == byx[st].first) continue;
-			const int32_t cnt = (int32_t)(i - st);
-			if (cnt > opt->mid_occ && cnt > mv.size() * opt->q_occ_frac) for (size_t j = st; j < i; ++j) drop[byx[j].second] = 1;
-			st = i;
+		// occurrences of every minimizer value in the read, counted in an open-addressed table (the reference sorts a copy, seed.c:12-16; what
+		// is dropped depends on the counts only)
+		size_t cap = 64;
+		while (cap < 2 * mv.size()) cap <<= 1;
+		std::vector<uint64_t> key(cap, ~0ull);
+		std::vector<int32_t> cnt(cap, 0);
+		auto slot_of = [&](uint64_t x) { size_t h = (size_t)((x * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1); while (key[h] != ~0ull && key[h] != x) h = (h + 1) & (cap - 1); return h; };
+		bool any = false;
+		for (const Mini &q : mv) { const size_t h = slot_of(q.x); key[h] = q.x; any |= ++cnt[h] > opt->mid_occ; }
+		if (any) {
+			size_t kept = 0;
+			for (size_t i = 0; i < mv.size(); ++i) {
+				const int32_t c = cnt[slot_of(mv[i].x)];
+				if (!(c > opt->mid_occ && c > mv.size() * opt->q_occ_frac)) mv[kept++] = mv[i];
+			}
+			mv.resize(kept);
 		}
-		size_t kept = 0;
-		for (size_t i = 0; i < mv.size(); ++i) if (!drop[i]) mv[kept++] = mv[i];
-		mv.resize(kept);
 	}
 	// seed.c:32-54
 	std::vector<Match> m;
@@ -280,9 +316,10 @@ int mm2gb_collect_matches(const mm2gb_index_t *ix_, const char *seq, int32_t len
 	size_t n_keep = 0;
 	for (const Match &q : m) if (!q.flt) { n_hits += q.n; ++n_keep; }
 	out->seeds = (mm2gb_seed_t*)malloc((n_keep + 1) * sizeof(mm2gb_seed_t));
-	out->hits = (uint64_t*)malloc(((size_t)n_hits + 1) * 8);
+	out->hits = refs ? nullptr : (uint64_t*)malloc(((size_t)n_hits + 1) * 8);
 	out->mini_pos = (uint64_t*)malloc((n_keep + 1) * 8);
-	if (!out->seeds || !out->hits || !out->mini_pos) { mm2gb_matches_free(out); return fail("mm2gb_collect_matches: out of memory"); }
+	if (refs) { refs->clear(); refs->reserve(n_keep); }
+	if (!out->seeds || (!refs && !out->hits) || !out->mini_pos) { mm2gb_matches_free(out); return fail("mm2gb_collect_matches: out of memory"); }
 	int rep_st = 0, rep_en = 0, rep_len = 0;
 	int64_t at = 0;
 	for (const Match &q : m) {
@@ -293,7 +330,8 @@ int mm2gb_collect_matches(const mm2gb_index_t *ix_, const char *seq, int32_t len
 		} else {
 			mm2gb_seed_t &s = out->seeds[out->n_seeds];
 			s.n = q.n; s.q_pos = q.q_pos; s.span_flt = q.q_span; s.seg_tandem = q.seg_id | (q.tandem ? 1u << 31 : 0u);
-			memcpy(out->hits + at, q.cr, (size_t)q.n * 8);
+			if (refs) refs->push_back(q.cr);
+			else memcpy(out->hits + at, q.cr, (size_t)q.n * 8);
 			at += q.n;
 			out->mini_pos[out->n_seeds++] = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
 		}
@@ -303,6 +341,8 @@ int mm2gb_collect_matches(const mm2gb_index_t *ix_, const char *seq, int32_t len
 	out->n_mini_pos = out->n_seeds;
 	return 0;
 }
+
+extern "C" {
 
 // collect_seed_hits (map.c:295-331) with skip_seed (map.c:205-227) on host threads: the same function as mm2gb_collect_seeds_gpu, for
 // batches small enough that the trip over the link and one wave sorting the largest read cost more than they save
