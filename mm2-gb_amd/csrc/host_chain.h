@@ -83,6 +83,16 @@ int collect_matches_refs(const mm2gb_index_t *ix, const char *seq, int32_t len, 
 // gives back what the calling thread's re-chaining calls keep between calls (rmq_hybrid.cpp; part of mm2gb_host_scratch_release, mapper.cpp)
 void release_rmq_scratch();
 
+// a result set that is freed on every way out of its scope
+struct ChainsOwner {
+	mm2gb_chains_t c;
+	ChainsOwner() { memset(&c, 0, sizeof c); }
+	ChainsOwner(const ChainsOwner&) = delete;
+	ChainsOwner &operator=(const ChainsOwner&) = delete;
+	~ChainsOwner() { mm2gb_chains_free(&c); }
+	mm2gb_chains_t release() { const mm2gb_chains_t r = c; memset(&c, 0, sizeof c); return r; }
+};
+
 // mm2gb_rmq_chain (rmq_hybrid.cpp) without its last step: the results stay where the three sides left them -- host threads, device, reads
 // redone after a tie -- and read r's chains are chains[which[r]] at position slot[r].  For a caller that copies them on anyway (the mapper
 // splices them into its own arrays: one copy of a gigabyte instead of two).

@@ -250,9 +250,22 @@ void mm2gb_host_scratch_release(void)
 	release_rmq_scratch();
 }
 
+static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
+                          const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
+                          char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats);
+
 int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
                     const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
                     char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats)
+{
+	// a batch's arrays are gigabytes: running out of host memory on this thread is an error of the call, not the end of the process
+	try { return map_reads_body(eng, ix, k, ref_names, ref_lens, n_ref, opt_in, n_reads, names, seqs, lens, paf_out, paf_len, stats); }
+	catch (const std::bad_alloc&) { return fail("mm2gb_map_reads: out of host memory"); }
+}
+
+static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
+                          const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
+                          char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats)
 {
 	if (!eng || !ix || !opt_in || !paf_out || !paf_len || n_reads < 0 || n_ref <= 0 || !ref_names || !ref_lens || (n_reads > 0 && (!names || !seqs || !lens)))
 		return fail("mm2gb_map_reads: null argument");
@@ -272,7 +285,9 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 
 	// 1. matches on host threads
 	std::unique_ptr<TraceRange> tr(new TraceRange("mm2gb:map_seed"));   // stage ranges for rocprofv3 --marker-trace / rocprof-sys
-	std::vector<mm2gb_matches_t> mt(R);
+	struct MatchSet { std::vector<mm2gb_matches_t> v; ~MatchSet() { for (auto &m : v) mm2gb_matches_free(&m); } } mt_own;   // (freed on every way out)
+	std::vector<mm2gb_matches_t> &mt = mt_own.v;
+	mt.resize(R);
 	std::vector<std::vector<const uint64_t*>> occ(R);     // per read and kept seed: its occurrences, where the index holds them (copied once, into the batch's array)
 	for (auto &m : mt) memset(&m, 0, sizeof m);
 	const mm2gb_seed_opt_t so = { opt.mid_occ, opt.max_max_occ, opt.occ_dist, opt.q_occ_frac };
@@ -353,7 +368,7 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 	misc.max_skip = INT32_MAX; misc.bw = opt.bw; misc.min_cnt = opt.min_cnt; misc.min_score = opt.min_chain_score; misc.is_cdna = 0; misc.n_seg = 1;
 	misc.chn_pen_gap = (float)(opt.chain_gap_scale * 0.01 * k); misc.chn_pen_skip = (float)(opt.chain_skip_scale * 0.01 * k);
 	if (mm2gb_engine_set_misc(eng, &misc)) { free_matches(); return -1; }
-	struct Chains { mm2gb_chains_t c; Chains() { memset(&c, 0, sizeof c); } ~Chains() { mm2gb_chains_free(&c); } } ch_own;   // (freed on every way out)
+	ChainsOwner ch_own;                                  // (freed on every way out)
 	mm2gb_chains_t &ch = ch_own.c;
 	// backtrack + compaction as kernels for large batches; below that on host threads, overlapped with the device: a single huge read (a
 	// tandem array) keeps one wave busy for hundreds of milliseconds where a core needs tens
@@ -415,8 +430,8 @@ int mm2gb_map_reads(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const c
 		}
 		const auto t_sorted = std::chrono::steady_clock::now();
 		const mm2gb_rmq_param_t rp = { opt.max_gap, opt.rmq_inner_dist, opt.bw_long, INT32_MAX, opt.rmq_size_cap, opt.min_cnt, opt.min_chain_score, misc.chn_pen_gap, misc.chn_pen_skip };
-		mm2gb_chains_t rc; memset(&rc, 0, sizeof rc);
-		mm2gb_chains_t rc_tie; memset(&rc_tie, 0, sizeof rc_tie);
+		ChainsOwner rc_own, rc_tie_own;
+		mm2gb_chains_t &rc = rc_own.c, &rc_tie = rc_tie_own.c;
 		std::vector<int32_t> tied(redo.size(), 0);
 		std::vector<int> tie_slot(redo.size(), -1);          // reads the device reported a tie for: their place in the host call that follows
 		RmqParts parts;                                      // the default path: the results of the call's three sides, spliced from where they are

@@ -176,12 +176,13 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	std::vector<int64_t> h_off, d_off, t_off;
 	// (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
 	BigBuf<mm2gb_anchor_t> &h_a = tl_gather[0], &d_a = tl_gather[1], &t_a = tl_gather[2];
-	mm2gb_chains_t h_out, d_out, t_out;
-	memset(&h_out, 0, sizeof h_out); memset(&d_out, 0, sizeof d_out); memset(&t_out, 0, sizeof t_out);
+	ChainsOwner h_own, d_own, t_own;
+	mm2gb_chains_t &h_out = h_own.c, &d_out = d_own.c, &t_out = t_own.c;
 	int h_rc = 0;
 	std::string h_err;
 	double h_seconds = 0;
-	std::thread host_side;
+	std::thread host_side, tie_side;
+	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_host{ host_side }, join_tie{ tie_side };   // (also when this thread runs out of memory)
 	if (n_host < R) {
 		// the device's share first, on every thread: its side is the longer one and cannot start before its anchors are in one piece
 		// (the reads of whole workgroups first -- the kernel takes its first n_team reads that way --, each part most expensive first)
@@ -205,7 +206,6 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	std::vector<int32_t> tied(R - n_host + 1, 0);
 	std::vector<int64_t> tie_slot(R, -1);
 	std::vector<size_t> redo;
-	std::thread tie_side;
 	int t_rc = 0;
 	std::string t_err;
 	double t_seconds = 0;
@@ -225,7 +225,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			t_off.assign(1, 0);
 			int64_t total = 0;
 			for (size_t q : redo) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
-			t_a.resize((size_t)total);
+			try { t_a.resize((size_t)total); } catch (const std::bad_alloc&) { t_rc = -1; t_err = "mm2gb_rmq_chain: out of host memory"; return; }   // (called from inside the engine: nothing may pass through it)
 			for (size_t q : redo) {
 				const int64_t r = by_dev[q], n = offsets[r + 1] - offsets[r];
 				memcpy(t_a.data() + t_off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
@@ -264,7 +264,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			else { parts->which[r] = 1; parts->slot[r] = (int64_t)(q - n_host); }
 			if (where) where[r] = q < n_host ? 1 : tie_slot[q] >= 0 ? 2 : 0;
 		}
-		parts->chains[0] = h_out; parts->chains[1] = d_out; parts->chains[2] = t_out;      // (theirs to free now)
+		parts->chains[0] = h_own.release(); parts->chains[1] = d_own.release(); parts->chains[2] = t_own.release();      // (theirs to free now)
 		if (getenv("MM2GB_DEBUG_PHASES"))
 			fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, results left in place, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, seconds_since(t0));
 		if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
@@ -312,7 +312,8 @@ void release_rmq_scratch() { for (auto &b : tl_gather) b.release(); }
 int rmq_chain_parts(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                     int n_threads, RmqParts &parts, int32_t *where, mm2gb_rmq_deal_t *deal)
 {
-	return rmq_chain_impl(eng, prm, n_reads, offsets, anchors, n_threads, nullptr, &parts, where, deal);
+	try { return rmq_chain_impl(eng, prm, n_reads, offsets, anchors, n_threads, nullptr, &parts, where, deal); }
+	catch (const std::bad_alloc&) { return fail("mm2gb_rmq_chain: out of host memory"); }
 }
 } // namespace mm2gb
 
@@ -322,7 +323,8 @@ int mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n
                     int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal)
 {
 	if (!out) return fail("mm2gb_rmq_chain: null argument");
-	return rmq_chain_impl(eng, prm, n_reads, offsets, anchors, n_threads, out, nullptr, where, deal);
+	try { return rmq_chain_impl(eng, prm, n_reads, offsets, anchors, n_threads, out, nullptr, where, deal); }
+	catch (const std::bad_alloc&) { mm2gb_chains_free(out); return fail("mm2gb_rmq_chain: out of host memory"); }
 }
 
 } // extern "C"
