@@ -78,6 +78,32 @@ def test_small_genome_against_itself():
         assert check_reads(ix, [(None, s) for s in seqs], "self_x") == 3
 
 
+@pytest.mark.parametrize("k,w", [(4, 3), (7, 5), (11, 10), (15, 10), (21, 11), (28, 19)])
+def test_index_lookup_against_a_dictionary_of_the_sketch(k, w):
+    """The index answers a look-up through a table of key prefixes (csrc/seeding.cpp, SeedIndex::bucket): for every k-mer size -- few bits per
+    key and many keys per prefix, or many bits and empty prefixes -- what a read's minimizers find is what a dictionary built from the
+    reference's own sketch holds, occurrence for occurrence and in the index's order (ascending by reference and position)."""
+    rng = np.random.default_rng(100 + k)
+    refs = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)) for n in (6000, 2500, 1)]
+    table = {}
+    for rid, s in enumerate(refs):
+        for x, y in mm.sketch(s, w, k, rid=rid):
+            table.setdefault(int(x) >> 8, []).append(int(y))
+    reads = [refs[0][1000:3000], refs[1][::-1], bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 1500)), refs[0][:k], b""]
+    with mm.SeedIndex(refs, k=k, w=w, threads=2) as ix:
+        assert ix.size()[0] == len(table) and ix.size()[1] == sum(len(v) for v in table.values())
+        for rd in reads:
+            m = ix.matches(rd, mid_occ=1 << 30, max_max_occ=1 << 30, occ_dist=0, q_occ_frac=0.0)
+            want_seeds, want_hits = [], []
+            for x, y in mm.sketch(rd, w, k):
+                occ = table.get(int(x) >> 8)
+                if occ:
+                    want_seeds.append((len(occ), int(y) & 0xffffffff))
+                    want_hits += sorted(occ)
+            assert [(int(a), int(b)) for a, b in m["seeds"][:, :2]] == want_seeds
+            assert m["hits"].tolist() == want_hits
+
+
 def test_sketch_edge_cases():
     assert mm.sketch(b"", 10, 15).shape == (0, 2)
     assert mm.sketch(b"ACGTACGTAC", 10, 15).shape == (0, 2)                      # shorter than k
