@@ -635,7 +635,7 @@ int mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const m
 // per device are the point: each has its own streams and arenas -- has a host thread that takes the next chunk and maps it from
 // seeding to PAF.  A chunk's stages alternate between host threads and the device, so with two or three engines on a GPU one chunk is
 // being seeded or post-processed while another one's kernels run; with engines on several GPUs the reads shard (no
-// exchange).  The host threads of opt are shared out with some over-subscription, because a chunk's threads idle while its kernels run.
+// exchange).  The host threads of opt are shared out with over-subscription (2.5 x), because a chunk's threads idle while its kernels run.
 // PAF in read order; stats: counts summed, s_* = seconds of each stage SUMMED over chunks (they overlap: not wall time).
 int mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens,
                            int32_t n_ref, const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
@@ -651,7 +651,11 @@ int mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const 
 	mm2gb_map_opt_t opt = *opt_in;
 	const int all_threads = opt_in->host_threads > 0 ? opt_in->host_threads : std::min(32, usable_cpus());
 	const int workers = (int)std::min<size_t>((size_t)n_engines, std::max<size_t>(1, n_chunks));
-	opt.host_threads = std::max(1, workers == 1 ? all_threads : (all_threads * 3 / 2 + workers - 1) / workers);
+	// host threads of all workers together, in % of opt's (MM2GB_STREAM_THREADS_PCT): a chunk's threads idle while its kernels run, and the reads its
+	// re-chaining gives to host threads want a core each when they come.  1.05 Gbp, four engines, 16 threads: 100 % 8.0 s, 150 % 6.8-7.1, 250 % 6.3-6.5, 400 % 6.6-6.9
+	int oversub_pct = 250;
+	if (const char *v = getenv("MM2GB_STREAM_THREADS_PCT")) oversub_pct = std::max(25, atoi(v));
+	opt.host_threads = std::max(1, workers == 1 ? all_threads : (all_threads * oversub_pct / 100 + workers - 1) / workers);
 	if (opt.mid_occ <= 0) opt.mid_occ = mm2gb_index_mid_occ(ix, opt.mid_occ_frac, opt.min_mid_occ, opt.max_mid_occ);     // once, not per chunk
 	std::vector<char*> part(n_chunks, nullptr);
 	std::vector<int64_t> part_len(n_chunks, 0);

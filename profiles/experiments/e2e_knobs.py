@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """mm2gb_map_reads_stream on ~0.26 Gbp of simulated reads (bench.py's e2e mix) per number of engines on the GPU and chunk size.
-usage: python profiles/experiments/e2e_knobs.py"""
+usage: python profiles/experiments/e2e_knobs.py [copies [ENGINESxCHUNK_MBP,...]]"""
 import os, sys, time, json, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "profiles"))
@@ -27,6 +27,8 @@ mm.map_reads_stream(engs, ix, names, reads[:48], opt=opt, chunk_bases=500_000)
 first = None
 grid = ((3, 48_000_000), (2, 48_000_000), (4, 48_000_000), (6, 48_000_000), (3, 24_000_000), (4, 24_000_000), (6, 16_000_000), (3, 96_000_000)) if copies == 1 else \
        ((3, 48_000_000), (4, 24_000_000), (4, 32_000_000), (5, 24_000_000), (3, 48_000_000), (4, 24_000_000))
+if len(sys.argv) > 2:                                        # e.g. "4x32,4x32": engines x chunk Mbp, in this order
+    grid = tuple((int(a), int(b) * 1_000_000) for a, b in (g.split("x") for g in sys.argv[2].split(",")))
 for n_eng, chunk in grid:
     t0 = time.perf_counter()
     paf, st = mm.map_reads_stream(engs[:n_eng], ix, names, reads, opt=opt, chunk_bases=chunk)
