@@ -261,10 +261,10 @@ int  mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const 
 int  mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens,
                             int32_t n_ref, const mm2gb_map_opt_t *opt, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
                             int64_t chunk_bases, char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats);
-/* A thread that maps (or re-chains: mm2gb_rmq_chain) keeps its largest host arrays -- matches, anchors, the re-chaining gathers and the
- * spliced chains, several gigabytes for a 100 M-anchor batch -- from call to call, because touching fresh pages costs more than filling
- * them; they go when the thread ends (mm2gb_map_reads_stream's workers: with the call).  This gives the calling thread's back at once. */
-void mm2gb_host_scratch_release(void);
+/* An engine that maps (or re-chains: mm2gb_rmq_chain) keeps the largest host arrays of those calls -- matches, anchors, the re-chaining
+ * gathers and the spliced chains, about 70 bytes per anchor of its largest batch so far, several gigabytes at 100 M anchors -- from call to
+ * call, because touching fresh pages costs more than filling them.  They go with the engine; this gives the memory back at once. */
+int  mm2gb_engine_release_host_scratch(mm2gb_engine_t *eng);
 
 /* ---- several devices in one process: reads are independent, so a batch is dealt to the devices as contiguous
  *      runs of reads with about the same number of anchors; each device has its own engine (arenas, three streams) and host

@@ -85,7 +85,7 @@ CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "m
                 "mm2gb_batcher_create", "mm2gb_batcher_add", "mm2gb_batcher_feed", "mm2gb_batcher_flush", "mm2gb_batcher_stats", "mm2gb_batcher_destroy",
                 "mm2gb_plan_batches", "mm2gb_rmq_chain_gpu", "mm2gb_lchain_rmq", "mm2gb_lchain_rmq_counts",
                 "mm2gb_sort_seeds_gpu", "mm2gb_gen_regs_gpu", "mm2gb_collect_seeds_gpu",
-                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_host_scratch_release", "mm2gb_rmq_chain_host", "mm2gb_rmq_chain_host_tied", "mm2gb_rmq_chain", "mm2gb_engine_set_rmq_kernel", "mm2gb_engine_set_rmq_team_reads", "mm2gb_has_split_build", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi", "mm2gb_map_reads_stream"]
+                "mm2gb_sketch", "mm2gb_index_build", "mm2gb_index_destroy", "mm2gb_index_size", "mm2gb_index_mid_occ", "mm2gb_collect_matches", "mm2gb_matches_free", "mm2gb_map_opt_init", "mm2gb_map_reads", "mm2gb_engine_release_host_scratch", "mm2gb_rmq_chain_host", "mm2gb_rmq_chain_host_tied", "mm2gb_rmq_chain", "mm2gb_engine_set_rmq_kernel", "mm2gb_engine_set_rmq_team_reads", "mm2gb_has_split_build", "mm2gb_collect_seeds_host", "mm2gb_map_reads_multi", "mm2gb_map_reads_stream"]
 BOUNDARY_SYMBOLS = ["init_stream_gpu", "chain_stream_gpu", "finish_stream_gpu", "free_stream_gpu"]
 
 
@@ -754,12 +754,14 @@ def map_reads_multi(engines, index, ref_names, reads, opt=None, k=15):
     return text, st.as_dict()
 
 
-def host_scratch_release():
-    """Give back the large host arrays the calling thread's mapping / re-chaining calls keep between calls (mm2gb_host_scratch_release)."""
+def _engine_release_host_scratch(self):
+    """Give back the large host arrays the engine's mapping / re-chaining calls keep between calls (mm2gb_engine_release_host_scratch)."""
     L = lib()
-    L.mm2gb_host_scratch_release.argtypes = []
-    L.mm2gb_host_scratch_release.restype = None
-    L.mm2gb_host_scratch_release()
+    L.mm2gb_engine_release_host_scratch.argtypes = [C.c_void_p]
+    _check(L.mm2gb_engine_release_host_scratch(self._h))
+
+
+Engine.release_host_scratch = _engine_release_host_scratch
 
 
 def map_reads_stream(engines, index, ref_names, reads, opt=None, k=15, chunk_bases=0):

@@ -155,7 +155,9 @@ struct Engine {
 
 } // namespace mm2gb
 
-struct mm2gb_engine { mm2gb::Engine e; };
+// host_scratch: what the engine's host-side callers keep from call to call (the mapper's and the re-chaining call's large arrays, host_chain.h
+// HostScratch): an engine serves one thread at a time, so its scratch needs no lock, and it outlives the threads that use it
+struct mm2gb_engine { mm2gb::Engine e; void *host_scratch = nullptr; void (*host_scratch_free)(void*) = nullptr; };
 
 namespace mm2gb {
 // pool.cpp: one engine, host buffers in, chains out, post-pass on n_threads host threads overlapped with the device

@@ -969,6 +969,7 @@ void mm2gb_engine_destroy(mm2gb_engine_t *eng)
 {
 	if (!eng) return;
 	eng->e.shutdown();
+	if (eng->host_scratch && eng->host_scratch_free) eng->host_scratch_free(eng->host_scratch);
 	delete eng;
 }
 

@@ -80,8 +80,17 @@ template <class T> struct BigBuf {
 // mm2gb_collect_matches (seeding.cpp) without the copy of the occurrences: refs[s] points at kept seed s's occurrences in the index, out->hits stays null
 int collect_matches_refs(const mm2gb_index_t *ix, const char *seq, int32_t len, const mm2gb_seed_opt_t *opt, mm2gb_matches_t *out, std::vector<const uint64_t*> *refs);
 
-// gives back what the calling thread's re-chaining calls keep between calls (rmq_hybrid.cpp; part of mm2gb_host_scratch_release, mapper.cpp)
-void release_rmq_scratch();
+// The large host arrays of an engine's mapping and re-chaining calls, kept from call to call (first touch of a gigabyte of fresh pages costs
+// more than filling it) and owned by the engine: matches, anchors, the re-chained reads' anchors, the spliced chains (mapper.cpp); the gathers of
+// the hybrid re-chaining call -- host share, device share, tie redo (rmq_hybrid.cpp).  host_scratch() makes it on first use (mapper.cpp);
+// mm2gb_engine_release_host_scratch gives the memory back, mm2gb_engine_destroy the object.
+struct HostScratch {
+	BigBuf<uint64_t> hits, nu;
+	BigBuf<mm2gb_anchor_t> anchors, ra, nc;
+	BigBuf<mm2gb_anchor_t> gather[3];
+	void release() { hits.release(); nu.release(); anchors.release(); ra.release(); nc.release(); for (auto &g : gather) g.release(); }
+};
+HostScratch &host_scratch(mm2gb_engine_t *eng);
 
 // a result set that is freed on every way out of its scope
 struct ChainsOwner {

@@ -225,10 +225,15 @@ void write_paf(std::string &out, const char *qname, int qlen, const Hit &h, cons
 
 using namespace mm2gb;
 
-namespace {
-// a mapping thread's largest arrays, kept from batch to batch (mm2gb_host_scratch_release gives them back)
-struct MapScratch { BigBuf<uint64_t> hits, nu; BigBuf<mm2gb_anchor_t> anchors, ra, nc; };
-thread_local MapScratch tl_scratch;
+namespace mm2gb {
+HostScratch &host_scratch(mm2gb_engine_t *eng)
+{
+	if (!eng->host_scratch) {
+		eng->host_scratch = new HostScratch;
+		eng->host_scratch_free = [](void *p) { delete static_cast<HostScratch*>(p); };
+	}
+	return *static_cast<HostScratch*>(eng->host_scratch);
+}
 }
 
 extern "C" {
@@ -244,10 +249,11 @@ void mm2gb_map_opt_init(mm2gb_map_opt_t *o)       // mm_mapopt_init (options.c:1
 	o->host_threads = 0;           // 0: as many as the process may use, at most 32
 }
 
-void mm2gb_host_scratch_release(void)
+int mm2gb_engine_release_host_scratch(mm2gb_engine_t *eng)
 {
-	tl_scratch.hits.release(); tl_scratch.nu.release(); tl_scratch.anchors.release(); tl_scratch.ra.release(); tl_scratch.nc.release();
-	release_rmq_scratch();
+	if (!eng) return fail("mm2gb: null engine");
+	if (eng->host_scratch) static_cast<HostScratch*>(eng->host_scratch)->release();
+	return 0;
 }
 
 static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens, int32_t n_ref,
@@ -327,9 +333,9 @@ static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, c
 		for (int s = 0; s < mt[r].n_seeds; ++s) { hit_off[(size_t)(seed_off[r] + s) + 1] = hit_off[(size_t)(seed_off[r] + s)] + mt[r].seeds[s].n; }
 		n_hits += mt[r].n_hits;
 	}
-	// (the batch's two largest arrays are this thread's from call to call: a gigabyte of fresh pages costs more to touch than to fill)
-	BigBuf<uint64_t> &hits = tl_scratch.hits;
-	BigBuf<mm2gb_anchor_t> &anchors = tl_scratch.anchors;
+	// (the batch's two largest arrays are the engine's from call to call: a gigabyte of fresh pages costs more to touch than to fill)
+	BigBuf<uint64_t> &hits = host_scratch(eng).hits;
+	BigBuf<mm2gb_anchor_t> &anchors = host_scratch(eng).anchors;
 	hits.resize((size_t)n_hits);
 	{
 		uint64_t *const hits_ptr = hits.data();
@@ -400,7 +406,7 @@ static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, c
 		std::vector<int64_t> ro(redo.size() + 1, 0);
 		for (size_t q = 0; q < redo.size(); ++q) ro[q + 1] = ro[q] + (c_off[(size_t)redo[q] + 1] - c_off[(size_t)redo[q]]);
 		// (kept between the calls of a thread, like the gathers of mm2gb_rmq_chain: fresh pages cost more to touch than to fill)
-		BigBuf<mm2gb_anchor_t> &ra = tl_scratch.ra;
+		BigBuf<mm2gb_anchor_t> &ra = host_scratch(eng).ra;
 		ra.resize((size_t)ro.back());
 		mm2gb_anchor_t *const ra_ptr = ra.data();               // (for the threads below: `ra` names each thread's own)
 		{
@@ -475,9 +481,9 @@ static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, c
 			nu_off[r + 1] = nu_off[r] + (q < 0 ? u_off[r + 1] - u_off[r] : from.u_off[qq + 1] - from.u_off[qq]);
 			nc_off[r + 1] = nc_off[r] + (q < 0 ? c_off[r + 1] - c_off[r] : from.a_off[qq + 1] - from.a_off[qq]);
 		}
-		// (this thread's from call to call: touched pages)
-		BigBuf<uint64_t> &nu = tl_scratch.nu;
-		BigBuf<mm2gb_anchor_t> &nc = tl_scratch.nc;
+		// (the engine's from call to call: touched pages)
+		BigBuf<uint64_t> &nu = host_scratch(eng).nu;
+		BigBuf<mm2gb_anchor_t> &nc = host_scratch(eng).nc;
 		nu.resize((size_t)nu_off[R]); nc.resize((size_t)nc_off[R]);
 		uint64_t *const nu_ptr = nu.data();
 		mm2gb_anchor_t *const nc_ptr = nc.data();

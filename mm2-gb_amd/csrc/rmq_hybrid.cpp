@@ -90,9 +90,6 @@ void append(mm2gb_chains_t &dst, size_t r, const mm2gb_chains_t &src, size_t q)
 using namespace mm2gb;
 
 namespace {
-// the gathers of a call: host share, device share, tie redo (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy)
-thread_local BigBuf<mm2gb_anchor_t> tl_gather[3];
-
 // `out`: one result in the caller's read order; or `parts`: the three sides' results as they are (host_chain.h, RmqParts)
 int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                    int n_threads, mm2gb_chains_t *out, mm2gb::RmqParts *parts, int32_t *where, mm2gb_rmq_deal_t *deal)
@@ -175,7 +172,8 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	};
 	std::vector<int64_t> h_off, d_off, t_off;
 	// (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
-	BigBuf<mm2gb_anchor_t> &h_a = tl_gather[0], &d_a = tl_gather[1], &t_a = tl_gather[2];
+	HostScratch &hs = host_scratch(eng);                 // (the engine's: kept between calls)
+	BigBuf<mm2gb_anchor_t> &h_a = hs.gather[0], &d_a = hs.gather[1], &t_a = hs.gather[2];
 	ChainsOwner h_own, d_own, t_own;
 	mm2gb_chains_t &h_out = h_own.c, &d_out = d_own.c, &t_out = t_own.c;
 	int h_rc = 0;
@@ -307,8 +305,6 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 } // namespace
 
 namespace mm2gb {
-void release_rmq_scratch() { for (auto &b : tl_gather) b.release(); }
-
 int rmq_chain_parts(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors,
                     int n_threads, RmqParts &parts, int32_t *where, mm2gb_rmq_deal_t *deal)
 {

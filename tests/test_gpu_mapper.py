@@ -85,9 +85,10 @@ def test_reads_that_map_nowhere_and_odd_input(engine):
     assert by["upper"] == open(os.path.join(GOLD, "real_mt_inf.paf")).read().strip().replace("MT_orang", "upper", 1)
 
 
-def test_batches_of_different_sizes_on_one_thread_and_scratch_release(engine, tmp_path):
-    """A thread keeps its largest host arrays from call to call (matches, anchors, the re-chaining gathers, the spliced chains) without clearing
-    them: a large batch, a small one, the large one again, and once more after mm2gb_host_scratch_release -- the same PAF every time."""
+def test_batches_of_different_sizes_on_one_engine_and_scratch_release(engine, tmp_path):
+    """An engine keeps the largest host arrays of its mapping calls from call to call (matches, anchors, the re-chaining gathers, the spliced
+    chains) without clearing them: a large batch, a small one, the large one again, and once more after mm2gb_engine_release_host_scratch -- the
+    same PAF every time."""
     meta = json.load(open(os.path.join(GOLD, "sim160.json")))
     ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
     sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
@@ -99,7 +100,7 @@ def test_batches_of_different_sizes_on_one_thread_and_scratch_release(engine, tm
         few = mm.map_reads(engine, ix, names, rd[5:9])[0]
         assert few == "".join(ln + "\n" for ln in want.splitlines() if ln.split("\t")[0] in {n.decode() if isinstance(n, bytes) else n for n, _ in rd[5:9]})
         assert mm.map_reads(engine, ix, names, rd)[0] == want
-        mm.host_scratch_release()
+        engine.release_host_scratch()
         assert mm.map_reads(engine, ix, names, rd[5:9])[0] == few
         assert mm.map_reads(engine, ix, names, rd)[0] == want
 
