@@ -405,7 +405,7 @@ static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, c
 	if (!redo.empty()) {
 		std::vector<int64_t> ro(redo.size() + 1, 0);
 		for (size_t q = 0; q < redo.size(); ++q) ro[q + 1] = ro[q] + (c_off[(size_t)redo[q] + 1] - c_off[(size_t)redo[q]]);
-		// (kept between the calls of a thread, like the gathers of mm2gb_rmq_chain: fresh pages cost more to touch than to fill)
+		// (the engine's, kept between calls like the gathers of mm2gb_rmq_chain: fresh pages cost more to touch than to fill)
 		BigBuf<mm2gb_anchor_t> &ra = host_scratch(eng).ra;
 		ra.resize((size_t)ro.back());
 		mm2gb_anchor_t *const ra_ptr = ra.data();               // (for the threads below: `ra` names each thread's own)

@@ -171,7 +171,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		});
 	};
 	std::vector<int64_t> h_off, d_off, t_off;
-	// (kept between the calls of a thread: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
+	// (the engine's, kept between calls: a gigabyte of fresh pages costs more to touch than to copy; a mapper's worker re-chains chunk after chunk)
 	HostScratch &hs = host_scratch(eng);                 // (the engine's: kept between calls)
 	BigBuf<mm2gb_anchor_t> &h_a = hs.gather[0], &d_a = hs.gather[1], &t_a = hs.gather[2];
 	ChainsOwner h_own, d_own, t_own;
@@ -193,7 +193,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		{ const auto tg = std::chrono::steady_clock::now(); gather(0, n_host, h_off, h_a); s_gather += seconds_since(tg); }
 		// the host side leaves one thread to the device call's own host work when it shares the machine with it
 		const int h_threads = n_host < R ? std::max(1, nt - 1) : nt;
-		const mm2gb_anchor_t *h_ptr = h_a.data();          // (h_a is this thread's: the new thread must not name it)
+		const mm2gb_anchor_t *h_ptr = h_a.data();          // (a plain pointer for the new thread)
 		host_side = std::thread([&, h_threads, h_ptr]() {
 			const auto th = std::chrono::steady_clock::now();
 			h_rc = mm2gb_rmq_chain_host(prm, (int64_t)n_host, h_off.data(), h_ptr, h_threads, &h_out, nullptr);
