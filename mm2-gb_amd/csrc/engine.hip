@@ -840,6 +840,11 @@ int Engine::collect_stats()
 			}
 			if (n) fprintf(stderr, "[mm2gb phases] workgroups %d | end of big-team phase: mean %.2f max %.2f ms | end of 4-wave phase: mean %.2f max %.2f ms | end: mean %.2f max %.2f ms\n",
 			               n, s1 / 1e5 / n, e1 / 1e5, s2 / 1e5 / n, e2 / 1e5, s3 / 1e5 / n, e3 / 1e5);
+			if (n && e3 > 0) {                                   // how many workgroups are still at work at eighths of the kernel's time
+				int busy[8] = { 0 };
+				for (int w = 0; w < launch.score_grid; ++w) if (h[4 * w]) for (int k = 0; k < 8; ++k) busy[k] += h[4 * w + 3] - t0 > e3 * k / 8;
+				fprintf(stderr, "[mm2gb phases] workgroups still at work after 0/8 ... 7/8 of the kernel's time: %d %d %d %d %d %d %d %d\n", busy[0], busy[1], busy[2], busy[3], busy[4], busy[5], busy[6], busy[7]);
+			}
 		}
 	}
 	for (int k = 0; k < n_slots; ++k) {
