@@ -920,6 +920,8 @@ struct TileLut {
 	unsigned lim4, base, last_at;   // table: address of entry 0, of the rejecting entry
 	const int4 *stage;
 	bool edges;              // some window starts inside the tile, or two of its anchors share a reference position
+	int kind;                // ROWS_*: what plain_steps has to test in this tile
+	int km1;                 // per lane t: the last lane that shares source t's position (t itself if none does)
 };
 
 // Source t against the lanes above it, in two parts.  tile_pre: everything that does not depend on scores -- LDS broadcast of
@@ -953,20 +955,124 @@ __device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, in
 	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bestv) : "v"(bestv), "v"(v), "s"(take));
 }
 
-// the in-tile steps of the sources in `need` (bit t: source t), the next step's coordinate work issued ahead of the current step's chain
+// The in-tile steps of the sources in `need` (bit t: source t).  Round 4.  A lone wave issues one instruction every ~5 cycles whatever its
+// kind, a dependent vector instruction after ~8, and a hop through the scalar unit (v_readlane -> s_or -> v_add) costs ~20 more
+// (profiles/ubench/lone_wave.hip) -- so what bounds a chunk's chain of in-tile phases is the NUMBER of instructions the one wave issues
+// per source, and the scalar hops of its chain.  Per source now:
+//   row (independent of every score, ROWS_AHEAD sources at a time, their two LDS trips overlapping the previous group's steps):
+//       M_t = 128 * min3' + (LUT_BIAS - 128 pen) + (128 - LUT_BIAS)    -- broadcast read, 2 sub, sad, gather, min3, shift-add, add
+//     FREE tiles (no window starts inside the tile, no two anchors share a position, the tile spans at most dq_lim - bw bases, unclamped
+//     table): no test at all -- dq <= 0 and dq > dq_lim reject through the saturating table address exactly as in sweep_block_lut2_free,
+//     dr >= 1 holds for every lane above the source; other tiles: the tests as ballots, one v_cndmask puts -2^30 where a pair is not allowed;
+//   step (the dependent chain, one asm statement per group):
+//       v_readlane lane t's packed value -> v_add M_t -> v_and_or (low 7 bits := t + 1) -> v_max, under exec = lanes above t
+//     (max instead of compare + select: two sources never tie, their codes differ; the code of lane t's own winner rides along in the
+//     sum and is overwritten by the v_and_or: no scalar instruction in the chain).
+// 10 vector instructions per source instead of 12 (13-15 in tiles with edges), 3 scalar instead of 8, and a chain of four dependent
+// vector instructions instead of readlane -> s_or -> s_add -> v_add -> v_cmp -> s_and -> v_cndmask.
+// A group without a needed source is skipped; the other rows of a group that holds one are computed with it (a source no later lane
+// reaches fails `lo <= t` in every lane).  Applying a row twice changes nothing (max), so a caller may ask again for rows that ran before.
+constexpr int ROWS_AHEAD = 2;
+enum { ROWS_FREE = 0, ROWS_CHECKED = 1, ROWS_CLAMPED = 2 };   // no test at all | dq range and window start | those and a clamped table index
+
+template <int KIND>
+__device__ __forceinline__ void tile_row(const TileLut &tl, const int4 s4, const int t, int &t1, unsigned &at, unsigned long long &ok)
+{
+	const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
+	at = lut_address(drm, dqm, tl.base);
+	if (KIND == ROWS_CLAMPED) at = at < tl.last_at ? at : tl.last_at;   // else: an address beyond the table reads 0 = reject
+	const int dg = drm < dqm ? drm : dqm;
+	t1 = ((s4.y < dg ? s4.y : dg) << 5) + s4.x;                  // s4.x = 128 - LUT_BIAS (in_tile_lut stages it)
+	// (dr == 0 is not tested here: the lanes that share the source's position are kept out of its step, tl.km1)
+	if (KIND != ROWS_FREE) ok = __ballot((unsigned)dqm < tl.lim4) & __ballot(tl.lo <= t);
+}
+
+// two steps (sources tp, tp + 1; their rows m0, m1), one statement: the execution mask is narrowed to the source's lanes and put back inside it.
+// Lanes that share the source's position (dr == 0, lchain.c:120) follow it directly (sorted by position): the step's lanes start behind the
+// last of them, km1 + 1 -- exec = -2 << km1 (km1 = t where no lane does; 63: nobody).  Wait states (gfx940 family): a scalar written by
+// v_readlane may be read by a vector instruction two instructions later, a lane written by v_max by v_readlane one instruction later.
+__device__ __forceinline__ void two_steps(int &bestv, const int tp, const int m0, const int m1, const int km1, const int keep_hi)
+{
+	unsigned long long saved;
+	int sc, sk, tn, tmp;
+	asm volatile("s_mov_b64 %[sv], exec\n\t"
+	             "v_readlane_b32 %[sk], %[km], %[tp]\n\t"
+	             "s_add_i32 %[tn], %[tp], 1\n\t"
+	             "v_readlane_b32 %[sc], %[b], %[tp]\n\t"
+	             "s_lshl_b64 exec, -2, %[sk]\n\t"
+	             "s_nop 0\n\t"
+	             "v_add_u32 %[tmp], %[sc], %[m0]\n\t"
+	             "v_and_or_b32 %[tmp], %[tmp], %[hi], %[tn]\n\t"
+	             "v_max_i32 %[b], %[tmp], %[b]\n\t"
+	             "v_readlane_b32 %[sk], %[km], %[tn]\n\t"
+	             "v_readlane_b32 %[sc], %[b], %[tn]\n\t"
+	             "s_add_i32 %[tn], %[tn], 1\n\t"
+	             "s_lshl_b64 exec, -2, %[sk]\n\t"
+	             "v_add_u32 %[tmp], %[sc], %[m1]\n\t"
+	             "v_and_or_b32 %[tmp], %[tmp], %[hi], %[tn]\n\t"
+	             "v_max_i32 %[b], %[tmp], %[b]\n\t"
+	             "s_mov_b64 exec, %[sv]"
+	             : [b] "+v"(bestv), [sv] "=&s"(saved), [sc] "=&s"(sc), [sk] "=&s"(sk), [tn] "=&s"(tn), [tmp] "=&v"(tmp)
+	             : [tp] "s"(tp), [m0] "v"(m0), [m1] "v"(m1), [hi] "v"(keep_hi), [km] "v"(km1) : "scc");
+}
+
+template <int KIND>
+__device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsigned long long need, int &bestv)
+{
+	constexpr int R = ROWS_AHEAD;
+	static_assert(R == 2 || R == 4, "groups of two or four rows");
+	int negv = INT_MIN / 2, keep_hi = ~127;
+	asm volatile("" : "+v"(negv), "+v"(keep_hi));                 // VGPRs (v_and_or may read one scalar only: the code)
+	// the groups that hold a needed source, in order (bit R g of gm: group g); a tile's needed sources come in runs, and half of a typical
+	// tile's sources are needed by nobody (profiles/experiments/intile_counts.py)
+	unsigned long long gm = need | need >> 1;
+	if (R == 4) gm |= gm >> 2;
+	gm &= R == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
+	int t0 = (int)__builtin_ctzll(gm), tp = -1;
+	gm &= gm - 1;
+	int4 s4[R];
+	int M[R];
+#pragma unroll
+	for (int u = 0; u < R; ++u) s4[u] = tl.stage[t0 + u];
+	for (;;) {
+		int t1[R], pen[R];
+		unsigned at[R];
+		unsigned long long ok[R];
+		int tnext = -1;
+		if (t0 >= 0) {
+#pragma unroll
+			for (int u = 0; u < R; ++u) tile_row<KIND>(tl, s4[u], t0 + u, t1[u], at[u], ok[u]);
+#pragma unroll
+			for (int u = 0; u < R; ++u) pen[u] = *(lds_i32_ptr)(uintptr_t)at[u];
+			// the next group's sources are on their way while the previous group's steps run
+			if (gm) {
+				tnext = (int)__builtin_ctzll(gm);
+				gm &= gm - 1;
+#pragma unroll
+				for (int u = 0; u < R; ++u) s4[u] = tl.stage[tnext + u];
+			}
+		}
+		if (tp >= 0) {
+			two_steps(bestv, tp, M[0], M[1], tl.km1, keep_hi);
+			if (R == 4) two_steps(bestv, tp + 2, M[2], M[3], tl.km1, keep_hi);
+		}
+		if (t0 < 0) break;
+#pragma unroll
+		for (int u = 0; u < R; ++u) {
+			const int sum = t1[u] + pen[u];
+			if (KIND == ROWS_FREE) M[u] = sum;
+			else asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(M[u]) : "v"(negv), "v"(sum), "s"(ok[u]));
+		}
+		tp = t0; t0 = tnext;
+	}
+}
+
 __device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv)
 {
 	if (!need) return;
-	int t = __builtin_ctzll(need);
-	StepPre cur = tile_pre(tl, t);
-	for (;;) {
-		need &= need - 1;
-		const int tn = need ? __builtin_ctzll(need) : t;
-		const StepPre nxt = tile_pre(tl, tn);
-		tile_fin(cur, t, bcast(bestv, t), bestv);
-		if (!need) break;
-		cur = nxt; t = tn;
-	}
+	if (tl.kind == ROWS_FREE) plain_steps_impl<ROWS_FREE>(tl, need, bestv);
+	else if (tl.kind == ROWS_CHECKED) plain_steps_impl<ROWS_CHECKED>(tl, need, bestv);
+	else plain_steps_impl<ROWS_CLAMPED>(tl, need, bestv);
 }
 
 // lchain.c:113-138 for one pair with every input wave-uniform (single segment, no cDNA, chn_pen_skip == 0: the MODE_LUT
@@ -990,7 +1096,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	// The in-tile phase is a chain of dependent instructions, and in a team every other wave's next tile waits for it: while it lasts
 	// this wave goes first among the 8 waves of its SIMD (the sweeping ones have independent work to fill the slots it leaves).
 	__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
-	stage[lane] = make_int4(0, (T.q - 1) * 4, (int)((unsigned)T.x << 2), (int)((unsigned)T.y << 2));
+	stage[lane] = make_int4(128 - LUT_BIAS, (T.q - 1) * 4, (int)((unsigned)T.x << 2), (int)((unsigned)T.y << 2));   // .x: plain_steps
 	__builtin_amdgcn_wave_barrier();
 	TileLut tl;
 	tl.tx4 = (int)(((unsigned)T.x - 1u) << 2); tl.ty4 = (int)(((unsigned)T.y - 1u) << 2);
@@ -1002,6 +1108,18 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	// neighbours are equal.  Lanes past the end of the chunk may then accept anything: they are never stored nor broadcast.
 	const int x_prev = __shfl_up(T.x, 1);
 	tl.edges = __ballot(T.live && (T.st > i0 || (lane > 0 && T.x == x_prev))) != 0;
+	// (dead lanes repeat the tile's last live anchor: what they accept is never stored nor broadcast)
+	// plain_steps: no test at all where no window starts inside the tile, the tile spans at most dq_lim - bw bases (dq > dq_lim is then
+	// beyond bw: the table rejects it) and the table is the unclamped one
+	tl.kind = P.lut_clamp ? ROWS_CLAMPED : (P.free_sweep && __ballot(T.live && T.st > i0) == 0 &&
+	          (unsigned)(bcast(T.x, WAVE - 1) - first_lane(T.x)) <= (unsigned)(P.dq_lim - P.bw)) ? ROWS_FREE : ROWS_CHECKED;
+	// (dead lanes repeat the tile's last live anchor: what they accept is never stored nor broadcast)
+	const unsigned long long newx = __ballot(lane == 0 || T.x != x_prev);            // lanes that start a new position
+	tl.km1 = lane;
+	if (newx != ~0ull) {
+		const unsigned long long rest = lane < WAVE - 1 ? newx >> (lane + 1) : 0ull;
+		tl.km1 = rest ? lane + (int)__builtin_ctzll(rest) : WAVE - 1;
+	}
 	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)

@@ -43,12 +43,33 @@ sub("		StepPre cur = tile_pre(tl, 0);\n		int t = done_fast ? n_here : 0;\n		for 
     "		const long long ik1 = tick();\n		chain_add(10, ik1 - ik0);\n		StepPre cur = tile_pre(tl, 0);\n		int t = done_fast ? n_here : 0;\n		for (; t < n_here; ++t) {\n			if (mode == IN_TILE) break;")
 sub("		if (mode == IN_TILE && t < n_here) {\n", "		const long long ik2 = tick();\n		chain_add(11, ik2 - ik1);\n		if (mode == IN_TILE && t < n_here) {\n")
 sub("		chain_add(1, tick() - ik0);\n", "		chain_add(1, tick() - ik0); chain_add(12, tick() - ik2);\n")
+
+# ---- round 4: a per-tile trace of the chain in the one-tile-per-wave team code (coop_chunk): s_memtime stamps per tile of the FIRST chunk a
+# launch scores that way: 0 before the wait for the last source block, 1 after it, 2 after that block's sweep, 3 after "every earlier tile is
+# final", 4 after the in-tile phase, 5 after the publication, 6 the wave's first look at this tile (tile loop top)
+sub("__device__ unsigned long long g_chain[16];\n",
+    "__device__ unsigned long long g_chain[16];\n__device__ long long g_trace[8192 * 8];\n"
+    "__device__ __forceinline__ long long ctick() { return (long long)__builtin_amdgcn_s_memtime(); }\n"
+    "__device__ __forceinline__ void trace(int t, int k, long long v) { if ((threadIdx.x & 63) == 0 && t < 8192) g_trace[t * 8 + k] = v; }\n")
+sub("		const Target T = load_target(b, i0, ce, TRACK);\n		const int n_here = min(WAVE, ce - i0);\n		int best = T.q + 1, arg = -1;\n		const int tile_lo = first_lane(T.st);\n		const int st_hi = bcast(T.st, n_here - 1);\n		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));\n		const int eq_lo = MODE == MODE_LUT && jb < i0",
+    "		trace(t, 6, ctick());\n		const Target T = load_target(b, i0, ce, TRACK);\n		const int n_here = min(WAVE, ce - i0);\n		int best = T.q + 1, arg = -1;\n		const int tile_lo = first_lane(T.st);\n		const int st_hi = bcast(T.st, n_here - 1);\n		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));\n		const int eq_lo = MODE == MODE_LUT && jb < i0")
+sub("			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring\n			const int sf = ring[slot * WAVE + lane];\n			slot = slot + 1 == n_slots ? 0 : slot + 1;\n			const int k_from = tile_lo > jb ? tile_lo - jb : 0;\n			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);\n",
+    "			const bool last_blk = jb + WAVE >= i0;\n			if (last_blk) trace(t, 0, ctick());\n			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring\n			if (last_blk) trace(t, 1, ctick());\n			const int sf = ring[slot * WAVE + lane];\n			slot = slot + 1 == n_slots ? 0 : slot + 1;\n			const int k_from = tile_lo > jb ? tile_lo - jb : 0;\n			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);\n			if (last_blk) trace(t, 2, ctick());\n")
+sub("		const long long tk1 = tick();\n", "		const long long tk1 = tick();\n		trace(t, 3, ctick());\n")
+sub("		const int i = i0 + lane;\n		const int fi = arg < 0 ? T.q : best;\n		if (T.live) {\n			ring[my_slot * WAVE + lane] = fi;",
+    "		trace(t, 4, ctick());\n		const int i = i0 + lane;\n		const int fi = arg < 0 ? T.q : best;\n		if (T.live) {\n			ring[my_slot * WAVE + lane] = fi;")
+sub("		if (TRACK) { chain_add(0, tk1 - tk0); chain_add(7, tick() - tk1); chain_add(8, 1); }\n", "		trace(t, 5, ctick());\n		if (TRACK) { chain_add(0, tk1 - tk0); chain_add(7, tick() - tk1); chain_add(8, 1); }\n")
 src += '''
 extern "C" void mm2gb_debug_chain_ticks(unsigned long long *out, int reset)
 {
 	(void)hipDeviceSynchronize();
 	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_chain), 128);
 	if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm2gb::g_chain), z, 128); }
+}
+extern "C" void mm2gb_debug_chain_trace(long long *out, int n_tiles)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_trace), (size_t)n_tiles * 8 * sizeof(long long));
 }
 '''
 out_dir = os.path.join(PKG, "ab")
