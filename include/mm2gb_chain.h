@@ -80,6 +80,13 @@ int  mm2gb_engine_device(const mm2gb_engine_t *eng);
  * up to MM2GB_SPLIT_MAX_ANCHORS anchors; 0 = never, the default: the build is exact but measured slower), and the items
  * of such chunks that workgroups other than the owner took */
 void mm2gb_engine_split_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64_t *helped_items);
+/* of the engine's last completed call: chunks that a GANG of workgroups scored -- a chunk whose share of the micro-batch's pairs is worth two
+ * workgroups or more is cut into strips that several workgroups take in turn (what plscore.cu's long-segment kernel does with one block per
+ * segment, plscore.cu:187-290, cannot: a segment there is one block's) -- and the workgroups that started in a gang.  MM2GB_GANG_MAX (default 8,
+ * 0 = off) bounds the workgroups per chunk; micro-batches of more than MM2GB_GANG_MAX_ANCHORS anchors (default 150 M) run the kernel without
+ * the gang phase: they fill the machine with whole chunks */
+void mm2gb_engine_gang_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64_t *workgroups);
+int  mm2gb_has_gang_build(void);    /* 1 (round 3: the gang phase was a build option) */
 int  mm2gb_has_split_build(void);   /* 1 if the library was built with `make SPLIT=1` (k_score's one-chunk-on-several-workgroups build; MM2GB_SPLIT_MAX_ANCHORS is ignored otherwise) */
 /* make sure arenas can take a micro-batch of this size (grows, never shrinks) */
 int  mm2gb_engine_reserve(mm2gb_engine_t *eng, int64_t n_anchors, int64_t n_reads);

@@ -76,7 +76,7 @@ _lib = None
 
 # every symbol include/mm2gb_chain.h and include/mm2gb_plutils.h declare
 CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "mm2gb_config_parse", "mm2gb_config_load",
-                "mm2gb_device_count", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device", "mm2gb_engine_split_counts",
+                "mm2gb_device_count", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device", "mm2gb_engine_split_counts", "mm2gb_engine_gang_counts", "mm2gb_has_gang_build",
                 "mm2gb_engine_reserve", "mm2gb_score_host", "mm2gb_score_device", "mm2gb_engine_sync", "mm2gb_engine_stats",
                 "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chain_gpu", "mm2gb_post_device", "mm2gb_chains_free", "mm2gb_backtrack_host",
                 "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
@@ -247,6 +247,14 @@ class Engine:
         lib().mm2gb_engine_split_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib().mm2gb_engine_split_counts.restype = None
         lib().mm2gb_engine_split_counts(self._h, C.byref(c), C.byref(h))
+        return c.value, h.value
+
+    def gang_counts(self):
+        """Of the last completed call: (chunks scored by a gang of workgroups, workgroups that started in a gang)."""
+        c, h = C.c_int64(), C.c_int64()
+        lib().mm2gb_engine_gang_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib().mm2gb_engine_gang_counts.restype = None
+        lib().mm2gb_engine_gang_counts(self._h, C.byref(c), C.byref(h))
         return c.value, h.value
 
     def score(self, anchors, offsets):

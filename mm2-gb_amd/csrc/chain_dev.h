@@ -54,6 +54,24 @@ static_assert(sizeof(SplitSlot) == 128, "one slot per 128-byte line");
 constexpr int SPLIT_MAX_ITEMS = 128;                   // per strip: 8 tile pairs x at most 16 items
 constexpr int SPLIT_STRIP_TILES = 16;                  // = waves of a score workgroup
 
+// A GANG: several workgroups on ONE chunk (k_score's first phase; chain_kernels.hip, gang_chunk_pairs).  A batch that cannot fill
+// the machine ends with its largest chunks, and a team is bounded by one CU.  The chunk is cut into strips of GANG_STRIP_PAIRS tile pairs
+// (one pair per wave of a workgroup); the workgroups the planner assigned to the chunk take strips from a counter and run the team
+// pipeline across workgroups: final scores travel through global memory (agent-scope stores / loads), "tiles done" is a counter in
+// the chunk's slot.  Nothing waits for a workgroup that may not be running: a strip is only ever waited for by workgroups that took a
+// LATER strip, and it was taken by a workgroup that is executing.
+struct GangSlot {
+	int next_strip;            // strips handed out so far
+	int done;                  // leading tiles of the chunk whose scores are final and visible
+	int keep[6];               // the remembered anchor (rescue state) behind tile `done`: keep[0] = index + 1 (0: none)
+	int chunk;                 // chunk id
+	int first_wg, n_wg;        // workgroups [first_wg, first_wg + n_wg) start on this chunk
+	int pad_[21];
+};
+static_assert(sizeof(GangSlot) == 128, "one slot per 128-byte line");
+constexpr int GANG_MAX_CHUNKS = 64;                    // chunks per batch that may get a gang
+constexpr int GANG_STRIP_PAIRS = 16;                   // tile pairs per strip = waves of a score workgroup
+
 // Everything one micro-batch needs in HBM: the caller's anchors (16 B each, all reads concatenated) and one array per derived field.
 struct DevBatch {
 	// inputs
@@ -95,13 +113,17 @@ struct DevBatch {
 	// for the partial results of one strip's items per workgroup; null when the build is not used
 	SplitSlot          *split_slots;
 	unsigned long long *split_part;
+	GangSlot           *gang_slots;   // GANG_MAX_CHUNKS of them, set up by plan_gangs; null: no gangs
 };
 enum { CNT_NCHUNK = 0, CNT_CURSOR = 1, CNT_NLONG = 2, CNT_LCURSOR = 3, CNT_NTRACK = 4, CNT_NCLAMP = 5, CNT_NMID = 6, CNT_MCURSOR = 7,
        CNT_SPLIT_OPEN = 8,      // score workgroups that have started and not yet left the whole-workgroup phase
        CNT_NSPLIT = 9,          // chunks scored strip by strip with other workgroups' help
        CNT_HELPED = 10,         // items of such chunks that a workgroup other than the chunk's owner took
        CNT_SPLIT_ANY = 11,      // strips that are open for items right now (what idle waves poll)
-       CNT_WORDS = 12 };
+       CNT_NGANG = 12,          // chunks scored by a gang of workgroups
+       CNT_GANG_STRIPS = 13,    // strips of such chunks
+       CNT_GANG_WGS = 14,       // workgroups that started in a gang
+       CNT_WORDS = 16 };
 
 struct LaunchCfg {
 	int score_grid;          // persistent 1024-thread workgroups of k_score
@@ -112,6 +134,8 @@ struct LaunchCfg {
 	int team4_all;           // 1: every heavy chunk of the table build goes to a 4-wave team, whatever its widest window (for A/B runs)
 	int team4_share_pct;     // a wide-window heavy chunk goes to a 4-wave team unless it costs more than this % of a 4-wave team's fair share
 	                         // of the batch's pairs (then: a big team); 0 = wide windows always go to big teams
+	int gang_max;            // most workgroups the planner gives one chunk (0: no gangs)
+	int gang_pct;            // a chunk gets gang_pct % of the workgroups its share of the batch's pairs would give it, if that is at least two
 	int split;               // 1: launch the SPLIT build (such chunks strip by strip, idle workgroups help); the host's choice by batch size
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode

@@ -442,6 +442,51 @@ __global__ __launch_bounds__(256) void plan_scatter(DevBatch b)
 	}
 }
 
+// Gangs (chain_dev.h, GangSlot): the chunks at the head of the big-team list whose share of the batch's pairs is worth two workgroups or
+// more.  A chunk that costs c of the batch's C gets c / C of the launch's workgroups (x gang_pct %), at most gang_max and never more
+// than it has strips; the workgroups [first_wg, first_wg + n_wg) start on it.  One workgroup; the list is ordered by cost bin, so the
+// candidates are among its first entries.
+__global__ __launch_bounds__(256) void plan_gangs(DevBatch b, LaunchCfg cfg)
+{
+	__shared__ int s_want[256], s_pos[256], s_first[256];
+	const int n_long = b.counters[CNT_NLONG];
+	const int t = threadIdx.x;
+	int want = 0, ci = -1;
+	if (t < n_long && cfg.gang_max >= 2 && !(b.flags[0] & (FLAG_ANY_SEGID | FLAG_NO_LUT))) {
+		ci = b.long_list[t];
+		const long long cost = b.chunk_cost[ci], total = b.totals[0] + (long long)b.n * COST_PER_ANCHOR;
+		const int n_tiles = (b.chunk_end[ci] - b.chunk_start[ci] + WAVE - 1) / WAVE;
+		const int n_strips = (n_tiles + 2 * GANG_STRIP_PAIRS - 1) / (2 * GANG_STRIP_PAIRS);
+		const long long share = cost * cfg.score_grid * cfg.gang_pct / (max(1ll, total) * 100);
+		want = (int)min((long long)min(cfg.gang_max, n_strips), share);
+		if (want < 2) want = 0;
+	}
+	s_want[t] = want;
+	__syncthreads();
+	if (t == 0) {
+		int n = 0, wg = 0;
+		for (int k = 0; k < 256; ++k) {
+			s_pos[k] = -1;
+			if (s_want[k] == 0 || n >= GANG_MAX_CHUNKS) continue;
+			const int w = min(s_want[k], cfg.score_grid - wg);
+			if (w < 2) continue;
+			s_pos[k] = n++; s_first[k] = wg; s_want[k] = w; wg += w;
+		}
+		b.counters[CNT_NGANG] = n;
+		b.counters[CNT_GANG_WGS] = wg;
+	}
+	__syncthreads();
+	if (s_pos[t] >= 0) {
+		GangSlot g;
+		g.next_strip = 0; g.done = 0;
+		for (int k = 0; k < 6; ++k) g.keep[k] = 0;
+		g.chunk = ci; g.first_wg = s_first[t]; g.n_wg = s_want[t];
+		for (int k = 0; k < 21; ++k) g.pad_[k] = 0;
+		b.gang_slots[s_pos[t]] = g;
+		b.chunk_track[ci] |= 8;                       // the team phases pass it over
+	}
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // Pair score, lchain.c:113-138 (+ mmpriv.h:118-126).  Three builds of the same arithmetic:
 //   MODE_LUT      single query segment, not cDNA, chn_pen_skip == 0 (what --gpu-chain runs with stock presets,
@@ -921,7 +966,6 @@ struct TileLut {
 	const int4 *stage;
 	bool edges;              // some window starts inside the tile, or two of its anchors share a reference position
 	int kind;                // ROWS_*: what plain_steps has to test in this tile
-	int km1;                 // per lane t: the last lane that shares source t's position (t itself if none does)
 };
 
 // Source t against the lanes above it, in two parts.  tile_pre: everything that does not depend on scores -- LDS broadcast of
@@ -958,113 +1002,79 @@ __device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, in
 // The in-tile steps of the sources in `need` (bit t: source t).  Round 4.  A lone wave issues one instruction every ~5 cycles whatever its
 // kind, a dependent vector instruction after ~8, and a hop through the scalar unit (v_readlane -> s_or -> v_add) costs ~20 more
 // (profiles/ubench/lone_wave.hip) -- so what bounds a chunk's chain of in-tile phases is the NUMBER of instructions the one wave issues
-// per source, and the scalar hops of its chain.  Per source now:
-//   row (independent of every score, ROWS_AHEAD sources at a time, their two LDS trips overlapping the previous group's steps):
-//       M_t = 128 * min3' + (LUT_BIAS - 128 pen) + (128 - LUT_BIAS)    -- broadcast read, 2 sub, sad, gather, min3, shift-add, add
-//     FREE tiles (no window starts inside the tile, no two anchors share a position, the tile spans at most dq_lim - bw bases, unclamped
-//     table): no test at all -- dq <= 0 and dq > dq_lim reject through the saturating table address exactly as in sweep_block_lut2_free,
-//     dr >= 1 holds for every lane above the source; other tiles: the tests as ballots, one v_cndmask puts -2^30 where a pair is not allowed;
-//   step (the dependent chain, one asm statement per group):
-//       v_readlane lane t's packed value -> v_add M_t -> v_and_or (low 7 bits := t + 1) -> v_max, under exec = lanes above t
-//     (max instead of compare + select: two sources never tie, their codes differ; the code of lane t's own winner rides along in the
-//     sum and is overwritten by the v_and_or: no scalar instruction in the chain).
-// 10 vector instructions per source instead of 12 (13-15 in tiles with edges), 3 scalar instead of 8, and a chain of four dependent
-// vector instructions instead of readlane -> s_or -> s_add -> v_add -> v_cmp -> s_and -> v_cndmask.
-// A group without a needed source is skipped; the other rows of a group that holds one are computed with it (a source no later lane
+// per source and the scalar hops of its chain, and both LDS trips of a source must be asked for long before they are needed.  Per source:
+//   row (independent of every score; two sources per group, a group's broadcast reads asked for two groups ahead, its gathers one):
+//       M_t = 128 * min3' + (LUT_BIAS - 128 pen) + (128 - LUT_BIAS)    -- 2 sub, and, sad, gather, min3, shift, add3
+//     The table address rejects by itself whatever a source may not reach: with the query distance's sign bit cleared, dq <= 0 or
+//     dr <= 0 -- a lane at or below the source, a lane that shares its position (lchain.c:120) -- puts |4(dr-1) - 4(dq-1)| near 2^31 or
+//     above, beyond the table and beyond LDS: the gather reads 0 and the pair ends ~2^30 below any score (lut_address, sweep_block_lut2_free).
+//     FREE tiles (no window starts inside the tile, it spans at most dq_lim - bw bases, unclamped table) need nothing else: dq > dq_lim
+//     is a distance beyond bw there.  Other tiles: dq range and window start as ballots, one v_cndmask puts -2^30 where they fail.
+//   step (the dependent chain): v_readlane lane t's packed value -> v_add M_t -> v_and_or (low 7 bits := t + 1) -> v_max
+//     (max, not compare + select: two sources never tie, their codes differ; the code of lane t's own winner rides along in the sum
+//     and is overwritten: no scalar instruction in the chain, no execution-mask change, nothing the compiler cannot interleave).
+// 11 vector instructions per source (13 in tiles with tests) and ~4 scalar, against 13-15 and ~14 of the step-by-step form (tile_pre /
+// tile_fin, which the rescue state machine still uses); the steps alone on a dense tile: profiles/experiments/steps_alone.py.
+// A group without a needed source is skipped; the other row of a group that holds one is computed with it (a source no later lane
 // reaches fails `lo <= t` in every lane).  Applying a row twice changes nothing (max), so a caller may ask again for rows that ran before.
-constexpr int ROWS_AHEAD = 2;
 enum { ROWS_FREE = 0, ROWS_CHECKED = 1, ROWS_CLAMPED = 2 };   // no test at all | dq range and window start | those and a clamped table index
-
-template <int KIND>
-__device__ __forceinline__ void tile_row(const TileLut &tl, const int4 s4, const int t, int &t1, unsigned &at, unsigned long long &ok)
-{
-	const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
-	at = lut_address(drm, dqm, tl.base);
-	if (KIND == ROWS_CLAMPED) at = at < tl.last_at ? at : tl.last_at;   // else: an address beyond the table reads 0 = reject
-	const int dg = drm < dqm ? drm : dqm;
-	t1 = ((s4.y < dg ? s4.y : dg) << 5) + s4.x;                  // s4.x = 128 - LUT_BIAS (in_tile_lut stages it)
-	// (dr == 0 is not tested here: the lanes that share the source's position are kept out of its step, tl.km1)
-	if (KIND != ROWS_FREE) ok = __ballot((unsigned)dqm < tl.lim4) & __ballot(tl.lo <= t);
-}
-
-// two steps (sources tp, tp + 1; their rows m0, m1), one statement: the execution mask is narrowed to the source's lanes and put back inside it.
-// Lanes that share the source's position (dr == 0, lchain.c:120) follow it directly (sorted by position): the step's lanes start behind the
-// last of them, km1 + 1 -- exec = -2 << km1 (km1 = t where no lane does; 63: nobody).  Wait states (gfx940 family): a scalar written by
-// v_readlane may be read by a vector instruction two instructions later, a lane written by v_max by v_readlane one instruction later.
-__device__ __forceinline__ void two_steps(int &bestv, const int tp, const int m0, const int m1, const int km1, const int keep_hi)
-{
-	unsigned long long saved;
-	int sc, sk, tn, tmp;
-	asm volatile("s_mov_b64 %[sv], exec\n\t"
-	             "v_readlane_b32 %[sk], %[km], %[tp]\n\t"
-	             "s_add_i32 %[tn], %[tp], 1\n\t"
-	             "v_readlane_b32 %[sc], %[b], %[tp]\n\t"
-	             "s_lshl_b64 exec, -2, %[sk]\n\t"
-	             "s_nop 0\n\t"
-	             "v_add_u32 %[tmp], %[sc], %[m0]\n\t"
-	             "v_and_or_b32 %[tmp], %[tmp], %[hi], %[tn]\n\t"
-	             "v_max_i32 %[b], %[tmp], %[b]\n\t"
-	             "v_readlane_b32 %[sk], %[km], %[tn]\n\t"
-	             "v_readlane_b32 %[sc], %[b], %[tn]\n\t"
-	             "s_add_i32 %[tn], %[tn], 1\n\t"
-	             "s_lshl_b64 exec, -2, %[sk]\n\t"
-	             "v_add_u32 %[tmp], %[sc], %[m1]\n\t"
-	             "v_and_or_b32 %[tmp], %[tmp], %[hi], %[tn]\n\t"
-	             "v_max_i32 %[b], %[tmp], %[b]\n\t"
-	             "s_mov_b64 exec, %[sv]"
-	             : [b] "+v"(bestv), [sv] "=&s"(saved), [sc] "=&s"(sc), [sk] "=&s"(sk), [tn] "=&s"(tn), [tmp] "=&v"(tmp)
-	             : [tp] "s"(tp), [m0] "v"(m0), [m1] "v"(m1), [hi] "v"(keep_hi), [km] "v"(km1) : "scc");
-}
 
 template <int KIND>
 __device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsigned long long need, int &bestv)
 {
-	constexpr int R = ROWS_AHEAD;
-	static_assert(R == 2 || R == 4, "groups of two or four rows");
-	int negv = INT_MIN / 2, keep_hi = ~127;
-	asm volatile("" : "+v"(negv), "+v"(keep_hi));                 // VGPRs (v_and_or may read one scalar only: the code)
-	// the groups that hold a needed source, in order (bit R g of gm: group g); a tile's needed sources come in runs, and half of a typical
-	// tile's sources are needed by nobody (profiles/experiments/intile_counts.py)
-	unsigned long long gm = need | need >> 1;
-	if (R == 4) gm |= gm >> 2;
-	gm &= R == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
-	int t0 = (int)__builtin_ctzll(gm), tp = -1;
-	gm &= gm - 1;
-	int4 s4[R];
-	int M[R];
-#pragma unroll
-	for (int u = 0; u < R; ++u) s4[u] = tl.stage[t0 + u];
-	for (;;) {
-		int t1[R], pen[R];
-		unsigned at[R];
-		unsigned long long ok[R];
-		int tnext = -1;
-		if (t0 >= 0) {
-#pragma unroll
-			for (int u = 0; u < R; ++u) tile_row<KIND>(tl, s4[u], t0 + u, t1[u], at[u], ok[u]);
-#pragma unroll
-			for (int u = 0; u < R; ++u) pen[u] = *(lds_i32_ptr)(uintptr_t)at[u];
-			// the next group's sources are on their way while the previous group's steps run
-			if (gm) {
-				tnext = (int)__builtin_ctzll(gm);
-				gm &= gm - 1;
-#pragma unroll
-				for (int u = 0; u < R; ++u) s4[u] = tl.stage[tnext + u];
-			}
-		}
-		if (tp >= 0) {
-			two_steps(bestv, tp, M[0], M[1], tl.km1, keep_hi);
-			if (R == 4) two_steps(bestv, tp + 2, M[2], M[3], tl.km1, keep_hi);
-		}
-		if (t0 < 0) break;
-#pragma unroll
-		for (int u = 0; u < R; ++u) {
-			const int sum = t1[u] + pen[u];
-			if (KIND == ROWS_FREE) M[u] = sum;
-			else asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(M[u]) : "v"(negv), "v"(sum), "s"(ok[u]));
-		}
-		tp = t0; t0 = tnext;
+	int negv = INT_MIN / 2, keep_hi = ~127, pos = 0x7fffffff;
+	asm volatile("" : "+v"(negv), "+v"(keep_hi), "+v"(pos));      // VGPRs, not literals per row
+	struct Row { int t1; unsigned at; unsigned long long ok; };
+	auto row = [&](const int4 s4, const int t) {
+		Row r;
+		const int dqm = tl.ty4 - s4.w, drm = tl.tx4 - s4.z;
+		r.at = lut_address(drm, dqm & pos, tl.base);
+		if (KIND == ROWS_CLAMPED) r.at = r.at < tl.last_at ? r.at : tl.last_at;   // else: an address beyond the table reads 0 = reject
+		const int dg = drm < dqm ? drm : dqm;
+		r.t1 = ((s4.y < dg ? s4.y : dg) << 5) + s4.x;             // s4.x = 128 - LUT_BIAS (in_tile_lut stages it)
+		// (a tile with a window start inside it may hold several reads: only there can a lane BELOW the source lie right of it, and needs the mask)
+		r.ok = KIND == ROWS_FREE ? 0ull : __ballot((unsigned)dqm < tl.lim4) & __ballot(tl.lo <= t) & (t < WAVE - 1 ? ~0ull << (t + 1) : 0ull);
+		return r;
+	};
+	auto finish = [&](const Row &r, const int pen) {
+		const int sum = r.t1 + pen;
+		if (KIND == ROWS_FREE) return sum;
+		int m;
+		asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(m) : "v"(negv), "v"(sum), "s"(r.ok));
+		return m;
+	};
+	auto step = [&](const int t, const int m) {
+		int v = bcast(bestv, t) + m;
+		asm("v_and_or_b32 %0, %0, %1, %2" : "+v"(v) : "v"(keep_hi), "s"(t + 1));     // (the compiler splits it into v_and + v_or3 when it likes the scalar side better)
+		bestv = v > bestv ? v : bestv;
+	};
+	// the groups (two sources each) that hold a needed source, in order: bit 2 g of gm.  A tile's needed sources come in runs, and half
+	// of a typical tile's sources are needed by nobody (profiles/experiments/intile_counts.py)
+	unsigned long long gm = (need | need >> 1) & 0x5555555555555555ull;
+	auto next_group = [&]() { const int t = gm ? (int)__builtin_ctzll(gm) : -1; gm &= gm - 1; return t; };
+	int tc = next_group();                                        // the group whose steps run in this turn of the loop
+	int tn = next_group();                                        // the one after it: its rows are computed meanwhile
+	int4 sa = tl.stage[tc], sb = tl.stage[tc + 1];
+	Row ra = row(sa, tc), rb = row(sb, tc + 1);
+	int pa = *(lds_i32_ptr)(uintptr_t)ra.at, pb = *(lds_i32_ptr)(uintptr_t)rb.at;
+	// (loads that nobody will use read the current group again: an unconditional load keeps the registers of sa / sb in place, a
+	// conditional one makes the compiler copy eight registers per turn.  A third group in flight -- the gathers a whole turn ahead too --
+	// was tried: the rotation costs copies that wait for the gathers, two turns per trip with swapped registers 45 spilled registers)
+	{ const int tl0 = tn >= 0 ? tn : tc; sa = tl.stage[tl0]; sb = tl.stage[tl0 + 1]; }
+	while (tn >= 0) {
+		const int m0 = finish(ra, pa), m1 = finish(rb, pb);
+		const int tnn = next_group();
+		step(tc, m0);                                               // (its chain has room for the rows' instructions)
+		ra = row(sa, tn); rb = row(sb, tn + 1);
+		pa = *(lds_i32_ptr)(uintptr_t)ra.at; pb = *(lds_i32_ptr)(uintptr_t)rb.at;
+		const int tl1 = tnn >= 0 ? tnn : tn;
+		sa = tl.stage[tl1]; sb = tl.stage[tl1 + 1];
+		__builtin_amdgcn_sched_barrier(0);                          // the reads stay HERE, a whole turn ahead of their use (the scheduler likes them next to it)
+		step(tc + 1, m1);
+		tc = tn; tn = tnn;
 	}
+	step(tc, finish(ra, pa));
+	step(tc + 1, finish(rb, pb));
 }
 
 __device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv)
@@ -1110,16 +1120,11 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	tl.edges = __ballot(T.live && (T.st > i0 || (lane > 0 && T.x == x_prev))) != 0;
 	// (dead lanes repeat the tile's last live anchor: what they accept is never stored nor broadcast)
 	// plain_steps: no test at all where no window starts inside the tile, the tile spans at most dq_lim - bw bases (dq > dq_lim is then
-	// beyond bw: the table rejects it) and the table is the unclamped one
+	// beyond bw: the table rejects it; and at most 2^22, whatever the user's distances: a lane BELOW a source has dr < 0, and the span term
+	// 128 * 4(dr - 1) of its rejected pair must not wrap around into the scores) and the table is the unclamped one
 	tl.kind = P.lut_clamp ? ROWS_CLAMPED : (P.free_sweep && __ballot(T.live && T.st > i0) == 0 &&
-	          (unsigned)(bcast(T.x, WAVE - 1) - first_lane(T.x)) <= (unsigned)(P.dq_lim - P.bw)) ? ROWS_FREE : ROWS_CHECKED;
+	          (unsigned)(bcast(T.x, WAVE - 1) - first_lane(T.x)) <= (unsigned)min(P.dq_lim - P.bw, 1 << 22)) ? ROWS_FREE : ROWS_CHECKED;
 	// (dead lanes repeat the tile's last live anchor: what they accept is never stored nor broadcast)
-	const unsigned long long newx = __ballot(lane == 0 || T.x != x_prev);            // lanes that start a new position
-	tl.km1 = lane;
-	if (newx != ~0ull) {
-		const unsigned long long rest = lane < WAVE - 1 ? newx >> (lane + 1) : 0ull;
-		tl.km1 = rest ? lane + (int)__builtin_ctzll(rest) : WAVE - 1;
-	}
 	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
@@ -1509,8 +1514,17 @@ __device__ __forceinline__ void run_chunk_pairs(const DevBatch &b, const DevPara
 // waves through an LDS ring indexed by anchor number (the sliding predecessor window, max_iter + slack entries);
 // "tiles done" is a release/acquire counter in LDS.  No block barrier inside a chunk.
 struct CoopShared { int done; int keep[6]; int chunk; int bar_count; int bar_gen; };   // one per team
+// Gangs (several workgroups on one chunk, gang_chunk_pairs) are an instantiation of their own, k_score<MODE_LUT, false, true>: the gang code
+// costs the plain kernel registers (250 -> 283 spilled scalars) and 1-3 % at 500 M anchors, where no chunk gets a gang anyway; the host
+// launches it for the micro-batches small enough to end with their largest chunks (Engine: gang_max_n).
+// what crosses workgroups (gangs, the SPLIT build): agent-scope accesses -- they go past the caches that are not coherent between CUs / XCDs
+#define MM2GB_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ int  gload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, MM2GB_AGENT); }
+__device__ __forceinline__ void gstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, MM2GB_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int SMALL_TEAM = 4, N_SMALL_TEAMS = SCORE_THREADS / WAVE / SMALL_TEAM;
 constexpr int N_TEAM_RECORDS = N_SMALL_TEAMS + 3;      // four small teams, two big ones, the whole workgroup
+constexpr int TAB_INTS = 36;                           // behind the team records: 24 ints of the SPLIT build's strip table, 9 of a gang's turns
 
 // Barrier among the waves of one small team (a workgroup barrier would stall the other teams): sense-reversing counter
 // in LDS, one lane per wave takes part.
@@ -1665,6 +1679,135 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 }
 
 
+// ---- a gang: the team pipeline of coop_chunk_pairs across workgroups (chain_dev.h, GangSlot) -----------------------------------
+// The chunk's tile pairs are dealt in strips of 16 (pair 16 s + w of strip s is wave w's); a workgroup's wave 0 takes the next strip from
+// the slot's counter for all 16 waves (`tab`: the strips of this workgroup's last 8 turns, tab[8] = turns announced so far; `seq` counts
+// the workgroup's turns over the whole launch).  Scores: a tile this workgroup wrote in one of its last three strips is read from its
+// LDS ring, every other one from global memory, where all scores are stored with agent scope.  "Tiles done": the slot's counter (global,
+// published in tile order: a wave makes sure its predecessor's publication is out before its own) and the team record's (LDS: what
+// this workgroup knows to be final -- its own tiles the moment they are, the others' when a wave has seen the global counter).
+// A wave remembers the largest count it has seen (`known`), so tiles that have long been final cost no look at either.
+// The rescue state travels like the scores: through LDS inside a strip, through the slot between strips.
+template <bool TRACK>
+__device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int n_slots, CoopShared *sh,
+                                 GangSlot *gs, int *tab, int &seq, const int cs, const int ce, const int wave)
+{
+	const int lane = lane_id();
+	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
+	constexpr int STRIP_TILES = 2 * GANG_STRIP_PAIRS;
+	int known = 0, known_global = 0;                               // leading tiles known final (from anywhere / from the global counter itself)
+	auto look_global = [&]() { known_global = max(known_global, first_lane(gload(&gs->done))); known = max(known, known_global); };
+	auto wait_done = [&](int need) {
+		if (known >= need) return;
+		for (;;) {
+			known = max(known, first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)));
+			if (known >= need) return;
+			look_global();
+			if (known >= need) { if (lane == 0) __hip_atomic_fetch_max(&sh->done, known, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+			__builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP);
+		}
+	};
+	auto wait_done_global = [&](int need) { while (known_global < need) { look_global(); if (known_global < need) __builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP); } };
+	int s0 = -1, s1 = -1, s2 = -1;                                  // this workgroup's strips, newest first
+	int cur = 0;
+	const lds_i32_ptr ring_l = (lds_i32_ptr)(uintptr_t)(unsigned)(uintptr_t)ring;
+	auto in_ring = [&](int k) { const int sk = k / STRIP_TILES; return (sk == s0 || sk == s1 || sk == s2) && k >= cur - n_slots; };
+	auto f_old = [&](int jj) {
+		const unsigned d = (unsigned)(jj - cs);
+		const int k = (int)(d / WAVE);
+		return in_ring(k) ? ring_l[(unsigned)k % (unsigned)n_slots * WAVE + d % WAVE] : gload(&b.f[jj]);
+	};
+	for (;; ++seq) {
+		int s = 0;
+		if (wave == 0) {
+			if (lane == 0) {
+				s = __hip_atomic_fetch_add(&gs->next_strip, 1, __ATOMIC_RELAXED, MM2GB_AGENT);
+				tab[seq & 7] = s;
+				__hip_atomic_store(&tab[8], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			s = first_lane(s);
+		} else {
+			while (first_lane(__hip_atomic_load(&tab[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= seq) __builtin_amdgcn_s_sleep(2);
+			s = first_lane(tab[seq & 7]);
+		}
+		if (s * STRIP_TILES >= n_tiles) { ++seq; break; }            // no strip left (every wave of the workgroup sees the same turn)
+		s2 = s1; s1 = s0; s0 = s;
+		const int pr = s * GANG_STRIP_PAIRS + wave;
+		if (2 * pr >= n_tiles) continue;                             // the chunk's last strip is a short one
+		const int ta = 2 * pr, i0 = cs + ta * WAVE;                  // tile A = tile ta of the chunk, tile B = ta + 1
+		cur = ta;
+		TilePair t = load_pair(b, i0, ce);
+		int jb = cs + ((t.lo_a - cs) & ~(WAVE - 1));
+		const int eq_lo = jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(t.A.x)) : i0;
+		bool have = false;
+		int nf = 0;
+		for (; jb < i0; jb += WAVE) {
+			const int sq = a_span(b, jb + lane);
+			const int k = (jb - cs) / WAVE;
+			wait_done(k + 1);                                          // that tile's scores are final
+			int sf;
+			if (in_ring(k)) sf = ring[(unsigned)k % (unsigned)n_slots * WAVE + lane];
+			else sf = have ? nf : gload(&b.f[jb + lane]);
+			// the next block's scores one block ahead, if they come from memory and are final already (no waiting ahead: the last
+			// blocks of a window are the chunk's newest tiles)
+			have = jb + WAVE < i0 && known >= k + 2 && !in_ring(k + 1);
+			if (have) nf = gload(&b.f[jb + WAVE + lane]);
+			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
+		}
+		const int slot_a = (int)((unsigned)ta % (unsigned)n_slots), slot_b = slot_a + 1 == n_slots ? 0 : slot_a + 1;
+		wait_done(ta);                                               // every earlier tile is final
+		Keep keep;
+		keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
+		if (TRACK && ta > 0) {
+			if (wave > 0 || s1 == s - 1) {                             // the pair before this one was this workgroup's: its state is in LDS
+				keep.idx = first_lane(sh->keep[0]); keep.x = first_lane(sh->keep[1]); keep.hi = first_lane(sh->keep[2]); keep.y = first_lane(sh->keep[3]); keep.tag = first_lane(sh->keep[4]); keep.f = first_lane(sh->keep[5]);
+			} else {
+				wait_done_global(ta);                                    // the slot's copy was stored before that count
+				keep.idx = first_lane(gload(&gs->keep[0])) - 1; keep.x = first_lane(gload(&gs->keep[1])); keep.hi = first_lane(gload(&gs->keep[2]));
+				keep.y = first_lane(gload(&gs->keep[3])); keep.tag = first_lane(gload(&gs->keep[4])); keep.f = first_lane(gload(&gs->keep[5]));
+			}
+		}
+		const Target TA = load_target(b, i0, ce, TRACK);
+		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);
+		__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
+		const int f_a = t.arg_a < 0 ? TA.q : t.best_a;
+		if (TA.live) {
+			const int i = i0 + lane;
+			ring[slot_a * WAVE + lane] = f_a;
+			gstore(&b.f[i], f_a);
+			b.p[i] = t.arg_a < 0 ? 0 : i - t.arg_a;
+		}
+		if (t.n_b > 0) {
+			if (lane == 0) __hip_atomic_fetch_max(&sh->done, ta + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);
+			const Target TB = load_target(b, i0 + WAVE, ce, TRACK);
+			cur = ta + 1;
+			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);
+			__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
+			if (TB.live) {
+				const int i = i0 + WAVE + lane;
+				const int f_b = t.arg_b < 0 ? TB.q : t.best_b;
+				ring[slot_b * WAVE + lane] = f_b;
+				gstore(&b.f[i], f_b);
+				b.p[i] = t.arg_b < 0 ? 0 : i - t.arg_b;
+			}
+		}
+		const int now_done = ta + (t.n_b > 0 ? 2 : 1);
+		if (TRACK && lane == 0) { sh->keep[0] = keep.idx; sh->keep[1] = keep.x; sh->keep[2] = keep.hi; sh->keep[3] = keep.y; sh->keep[4] = keep.tag; sh->keep[5] = keep.f; }
+		if (lane == 0) __hip_atomic_fetch_max(&sh->done, now_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // this workgroup's waves go on
+		__builtin_amdgcn_s_setprio(0);
+		// the other workgroups: scores (and the state, at the end of a strip) are out, the publications before this one too, then the count
+		if (TRACK && wave == GANG_STRIP_PAIRS - 1 && lane == 0) {
+			gstore(&gs->keep[0], keep.idx + 1); gstore(&gs->keep[1], keep.x); gstore(&gs->keep[2], keep.hi); gstore(&gs->keep[3], keep.y); gstore(&gs->keep[4], keep.tag); gstore(&gs->keep[5], keep.f);
+		}
+		drain_stores();
+		wait_done_global(ta);
+		if (lane == 0) gstore(&gs->done, now_done);
+		known = max(known, now_done); known_global = max(known_global, now_done);
+	}
+}
+
+
 // ---- one chunk on several workgroups (SPLIT build) ------------------------------------------------------------------------
 // A team is bounded by one CU; the largest chunks of a batch that cannot fill the machine decide when it ends.  Such a chunk (one that
 // the planner gives a whole workgroup, its OWNER) is scored strip by strip, a strip being 16 tiles, one per wave.  For every strip:
@@ -1682,10 +1825,6 @@ __device__ __forceinline__ void coop_chunk_pairs(const DevBatch &b, const DevPar
 // fences, was what the first build used; it was replaced while chasing wrong results that turned out to be the compiler problem noted at
 // split_do_item_owner, and has not been tried again since.)  The slot's words are agent-scope atomics.  x, y, tag, st are not written
 // in this launch.
-#define MM2GB_AGENT __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ int  gload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, MM2GB_AGENT); }
-__device__ __forceinline__ void gstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, MM2GB_AGENT); }
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 {
 	return (unsigned long long)(unsigned)first_lane((int)(v >> 32)) << 32 | (unsigned)first_lane((int)v);
@@ -1891,7 +2030,7 @@ __device__ __forceinline__ void split_chunk(const DevBatch &b, const DevParams &
 // first: a chunk (position in the list) already pulled for team 0 by the previous phase, or -1.
 // min_cost: a chunk cheaper than this ends the phase for the team that pulled it; its position is returned (else -1) so
 // that the next phase can start with it.  Only meaningful for a one-team phase (whole workgroup).
-template <int MODE, bool SPLIT>
+template <int MODE, bool SPLIT, bool GANG>
 __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int ring_slots, CoopShared *teams,
                           const int32_t *list, const int n_list, const int cursor, const int wave, const int team_size,
                           int first = -1, const long long min_cost = 0, int *split_tab = nullptr)
@@ -1910,6 +2049,7 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 		if (c >= n_list) return -1;
 		const int ci = first_lane(list[c]);
 		if (min_cost > 0 && b.chunk_cost[ci] < min_cost) return c;
+		if (GANG && (b.chunk_track[ci] & 8)) { team_barrier(sh, team_size); continue; }   // a gang's chunk (phase 0 of k_score)
 		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
 		// whole-workgroup teams keep one tile per wave: with two, 32 tiles of one chunk would be in flight and the largest
 		// chunks -- the ones that decide when a small batch ends -- ran 6 % slower
@@ -1938,7 +2078,7 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 // table (bw + 2 entries) from P.lut_base to the end of the allocation, LUT_LDS_TOTAL (chain_dev.h)
 // --------------------------------------------------------------------------------------------------------------
 
-template <int MODE, bool SPLIT>
+template <int MODE, bool SPLIT, bool GANG>
 __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParams P, int host_mode, int ring_slots, int big_team, int whole_wg_pct)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -1949,14 +2089,15 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	// the table sweep addresses the penalty table by raw LDS offset: the dynamic allocation must start at LDS address 0, and what
 	// comes before the table must end before it
 	if (MODE == MODE_LUT && ((unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)smem != 0u ||
-	                         (size_t)ring_slots * WAVE * 4 + SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) > (size_t)LUT_LDS_BASE ||
+	                         (size_t)ring_slots * WAVE * 4 + SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) + TAB_INTS * 4 > (size_t)LUT_LDS_BASE ||
 	                         P.lut_base < LUT_LDS_BASE || P.lut_base + 4 * (P.lut_last + 1) != LUT_LDS_TOTAL)) __builtin_trap();
 	int *ring = smem;
 	int4 *stage = (int4*)(ring + ring_slots * WAVE) + (threadIdx.x / WAVE) * WAVE;   // this wave's scratch
 	CoopShared *teams = (CoopShared*)((int4*)(ring + ring_slots * WAVE) + SCORE_THREADS);   // N_SMALL_TEAMS of them
 	if (MODE == MODE_LUT) for (int k = threadIdx.x; k <= P.lut_last; k += SCORE_THREADS) lut[k] = b.lut[k];    // entry lut_last = bw + 1 is 0: reject
 	if (threadIdx.x < N_TEAM_RECORDS) { teams[threadIdx.x].bar_count = 0; teams[threadIdx.x].bar_gen = 0; }
-	int *split_tab = (int*)(teams + N_TEAM_RECORDS);           // 24 ints between the team records and the table (SPLIT build)
+	int *split_tab = (int*)(teams + N_TEAM_RECORDS);           // TAB_INTS ints between the team records and the table
+	if (threadIdx.x == 0) split_tab[24 + 8] = 0;               // a gang's turns announced so far
 	if (SPLIT && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], 1);   // this workgroup is in the whole-workgroup phase
 	__syncthreads();
 
@@ -1966,6 +2107,41 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 	const int wave = first_lane(threadIdx.x / WAVE);
 	// optional phase stamps (MM2GB_DEBUG_PHASES): 100 MHz wall clock at start / end of 1a / end of 1b / end, per workgroup
 	if (b.dbg && threadIdx.x == 0) b.dbg[blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+	// phase 0: gangs -- the chunks that would outlast the batch on one workgroup are scored by several (gang_chunk_pairs); this workgroup
+	// starts on the chunk the planner gave it, if any.
+	int gang_seq = 0;
+	int *gang_tab = split_tab + 24;
+	const int n_gang = (GANG && MODE == MODE_LUT && !SPLIT && b.gang_slots && ring_slots > 0) ? first_lane(b.counters[CNT_NGANG]) : 0;
+	if constexpr (GANG && MODE == MODE_LUT && !SPLIT) {
+	auto gang_run = [&](int e, bool late) __attribute__((always_inline)) {
+		CoopShared *sh = teams + N_SMALL_TEAMS + 2;
+		GangSlot *gs = b.gang_slots + e;
+		const int ci = first_lane(gs->chunk);
+		const int cs = first_lane(b.chunk_start[ci]), ce = first_lane(b.chunk_end[ci]);
+		if (threadIdx.x == 0) {
+			// a late helper only joins a chunk whose strips are not already handed out far ahead of what is final (those workgroups wait as it is)
+			int go = 1;
+			if (late) {
+				const int next = gload(&gs->next_strip), done = gload(&gs->done), n_tiles = (ce - cs + WAVE - 1) / WAVE;
+				go = next * 2 * GANG_STRIP_PAIRS < n_tiles && next * 2 * GANG_STRIP_PAIRS - done < 4 * 2 * GANG_STRIP_PAIRS;
+			}
+			sh->chunk = go; sh->done = 0; sh->keep[0] = -1;
+		}
+		team_barrier(sh, SCORE_THREADS / WAVE);
+		const int go = first_lane(sh->chunk);
+		if (go) {
+			if (b.chunk_track[ci] & 1) gang_chunk_pairs<true>(b, P, lut, stage, ring, ring_slots, sh, gs, gang_tab, gang_seq, cs, ce, wave);
+			else gang_chunk_pairs<false>(b, P, lut, stage, ring, ring_slots, sh, gs, gang_tab, gang_seq, cs, ce, wave);
+		}
+		team_barrier(sh, SCORE_THREADS / WAVE);
+	};
+	if (n_gang > 0) {
+		for (int e = 0; e < n_gang; ++e) {
+			const int fw = first_lane(b.gang_slots[e].first_wg), nw = first_lane(b.gang_slots[e].n_wg);
+			if ((int)blockIdx.x >= fw && (int)blockIdx.x < fw + nw) { gang_run(e, false); break; }
+		}
+	}
+	}
 	if (ring_slots > 0) {
 		// phase 1a: big teams (the whole workgroup, or two 8-wave teams) on wide-window heavy chunks; phase 1b: four 4-wave
 		// teams on narrower ones.  The ring is split hierarchically (a big team's share is made of its small teams' shares)
@@ -1980,7 +2156,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			if (whole && !(big_team < SCORE_THREADS / WAVE && whole_wg_pct > 0)) { if (SPLIT && threadIdx.x == 0) atomicAdd(&b.counters[CNT_SPLIT_OPEN], -1); continue; }
 			const long long share = whole ? max(1ll, (long long)(b.totals[2] / gridDim.x * whole_wg_pct / 100)) : 0;
 			CoopShared *records = small ? teams : whole ? teams + N_SMALL_TEAMS + 2 : teams + N_SMALL_TEAMS;
-			const int got = team_phase<MODE, SPLIT>(b, P, lut, stage, ring, ring_slots, records, small ? b.mid_list : b.long_list, small ? n_mid : n_long,
+			const int got = team_phase<MODE, SPLIT, GANG>(b, P, lut, stage, ring, ring_slots, records, small ? b.mid_list : b.long_list, small ? n_mid : n_long,
 			                                        small ? CNT_MCURSOR : CNT_LCURSOR, wave, small ? SMALL_TEAM : whole ? SCORE_THREADS / WAVE : big_team,
 			                                        whole || small ? -1 : first, share, split_tab);
 			if (whole) first = got;
@@ -2033,6 +2209,7 @@ void launch_plan(const DevBatch &b, const LaunchCfg &cfg, hipStream_t s)
 	hipLaunchKernelGGL(plan_finish, dim3(chunk_grid), dim3(256), 0, s, b, cfg);
 	hipLaunchKernelGGL(plan_bins, dim3(1), dim3(64), 0, s, b);
 	hipLaunchKernelGGL(plan_scatter, dim3(chunk_grid), dim3(256), 0, s, b);
+	if (b.gang_slots) hipLaunchKernelGGL(plan_gangs, dim3(1), dim3(256), 0, s, b, cfg);
 }
 
 void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
@@ -2042,7 +2219,7 @@ void launch_build_lut(int *d_lut, const DevParams &P, hipStream_t s)
 
 size_t score_lds_bytes(const DevParams &P, int host_mode, int ring_slots)
 {
-	const size_t front = (size_t)ring_slots * WAVE * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) + 16;
+	const size_t front = (size_t)ring_slots * WAVE * 4 + (size_t)SCORE_THREADS * sizeof(int4) + N_TEAM_RECORDS * sizeof(CoopShared) + TAB_INTS * 4;
 	if (host_mode != MODE_LUT) return front;
 	return front <= (size_t)LUT_LDS_BASE ? (size_t)LUT_LDS_TOTAL : (size_t)1 << 30;     // the table's place is fixed: what does not fit before it does not fit
 }
@@ -2059,10 +2236,11 @@ bool score_has_split_build() { return HAVE_SPLIT; }
 
 int score_set_lds_limit(size_t bytes)
 {
-	hipError_t e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-	if constexpr (HAVE_SPLIT) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, HAVE_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_FAST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_GENERAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	hipError_t e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if constexpr (HAVE_SPLIT) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_LUT, HAVE_SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_FAST, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_score<MODE_GENERAL, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 	return e == hipSuccess ? 0 : -1;
 }
 
@@ -2072,11 +2250,12 @@ void launch_score(const DevBatch &b, const DevParams &P, const LaunchCfg &cfg, h
 	const size_t lds = score_lds_bytes(P, cfg.host_mode, cfg.ring_slots);
 	const size_t lds_general = score_lds_bytes(P, MODE_GENERAL, cfg.ring_slots);
 	if (cfg.host_mode == MODE_LUT) {
-		if (HAVE_SPLIT && cfg.split && b.split_slots) hipLaunchKernelGGL((k_score<MODE_LUT, HAVE_SPLIT>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
-		else hipLaunchKernelGGL((k_score<MODE_LUT, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+		if (HAVE_SPLIT && cfg.split && b.split_slots) hipLaunchKernelGGL((k_score<MODE_LUT, HAVE_SPLIT, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+		else if (b.gang_slots) hipLaunchKernelGGL((k_score<MODE_LUT, false, true>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+		else hipLaunchKernelGGL((k_score<MODE_LUT, false, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
 	}
-	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL((k_score<MODE_FAST, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
-	hipLaunchKernelGGL((k_score<MODE_GENERAL, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	if (cfg.host_mode == MODE_FAST || cfg.host_mode == MODE_LUT) hipLaunchKernelGGL((k_score<MODE_FAST, false, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
+	hipLaunchKernelGGL((k_score<MODE_GENERAL, false, false>), dim3(cfg.score_grid), dim3(SCORE_THREADS), lds_general, s, b, P, cfg.host_mode, cfg.ring_slots, cfg.big_team, cfg.whole_wg_pct);
 }
 
 } // namespace mm2gb

@@ -72,8 +72,9 @@ struct Engine {
 		DevBuf chunk_pp, chunk_kk, chunk_blk, tile_sums, tile_base, bins;
 		DevBuf counters, totals, flags;
 		DevBuf split_slots, split_part;       // one chunk on several workgroups (k_score's SPLIT build): allocated when first used
+		DevBuf gang_slots;                    // one chunk on several workgroups (gangs, k_score's phase 0): GANG_MAX_CHUNKS slots
 		std::vector<DevBuf*> all() { return { &st, &blk_firstcut, &blk_pairs, &blk_clamped, &blk_wmax, &blk_read, &chunk_start, &chunk_end, &chunk_cost,
-		                                      &chunk_track, &order, &long_list, &mid_list, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins, &counters, &totals, &flags, &split_slots, &split_part }; }
+		                                      &chunk_track, &order, &long_list, &mid_list, &chunk_pp, &chunk_kk, &chunk_blk, &tile_sums, &tile_base, &bins, &counters, &totals, &flags, &split_slots, &split_part, &gang_slots }; }
 	};
 	WorkSet work[2];
 	DevBuf lut, dbg;
@@ -105,6 +106,8 @@ struct Engine {
 	bool misc_valid = false, coop_disabled = false, debug_phases = false, one_compute_stream = false;
 	int64_t team4_min_n = 0;        // micro-batches from this many anchors on send wide-window heavy chunks to 4-wave teams (launch.team4_share_pct)
 	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)
+	int64_t gang_max_n = 0;         // micro-batches up to this many anchors run the instantiation of k_score with the gang phase
+	int64_t last_gang_chunks = 0, last_gang_wgs = 0;        // of the last call: chunks scored by a gang of workgroups, workgroups that started in one
 	int64_t last_split_chunks = 0, last_helped_items = 0;   // of the last call: chunks scored strip by strip, items other workgroups took
 	bool rmq_tiles_last = false;    // which form the last RMQ call ran (for the debug print)
 	std::function<void(const int32_t*)> rmq_tied_ready;   // the NEXT device re-chaining call only: called on the calling thread as soon as the fill's tie counts are on the host, while the call's post-pass and copies still run

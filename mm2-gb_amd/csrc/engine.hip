@@ -229,11 +229,18 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	// Wide-window heavy chunks on 4-wave teams (chain_kernels.hip, plan_finish): pays once a micro-batch keeps the machine full for
 	// long -- 500 M anchors: 59.3 -> 47.6 ms, 300 M: 39.2 -> 36.2 -- and costs a few per cent where the largest chunks decide when the
 	// batch ends (200 M: 27.1 -> 28.5 ms), so it is tied to the batch size (profiles/r02w_ab.txt)
-	launch.team4_all = 0; launch.team4_share_pct = 150; team4_min_n = 250000000;
+	launch.team4_all = 0; launch.team4_share_pct = 60; team4_min_n = 250000000;
 	if (const char *v = getenv("MM2GB_TEAM4_ALL")) launch.team4_all = atoi(v) != 0;
 	if (const char *v = getenv("MM2GB_TEAM4_SHARE_PCT")) launch.team4_share_pct = std::max(0, atoi(v));
 	if (const char *v = getenv("MM2GB_TEAM4_MIN_ANCHORS")) team4_min_n = std::max<int64_t>(0, atoll(v));
 	if (const char *v = getenv("MM2GB_DEBUG_PHASES")) debug_phases = *v && *v != '0';
+	// Gangs: a chunk whose share of the batch's pairs is worth two workgroups or more is scored by several (chain_kernels.hip, plan_gangs):
+	// batches that cannot fill the machine end with their largest chunks.  MM2GB_GANG_MAX=0 turns them off.
+	// Large micro-batches keep the kernel without the gang code (MM2GB_GANG_MAX_ANCHORS: the largest batch that gets gangs).
+	launch.gang_max = 8; launch.gang_pct = 100; gang_max_n = 150000000;
+	if (const char *v = getenv("MM2GB_GANG_MAX")) launch.gang_max = std::max(0, std::min(64, atoi(v)));
+	if (const char *v = getenv("MM2GB_GANG_PCT")) launch.gang_pct = std::max(1, atoi(v));
+	if (const char *v = getenv("MM2GB_GANG_MAX_ANCHORS")) gang_max_n = std::max<int64_t>(0, atoll(v));
 	split_max_n = 0;                                           // off: measured slower at every batch size (profiles/r02y_split_rate.json)
 	if (const char *v = getenv("MM2GB_SPLIT_MAX_ANCHORS")) split_max_n = std::max<int64_t>(0, atoll(v));
 	if (debug_phases && dbg.ensure((size_t)launch.score_grid * 32)) return -1;
@@ -325,7 +332,7 @@ int Engine::begin_call()
 	if (n_slots > 0 && sync()) return -1;     // a previous call was never collected
 	n_slots = 0;
 	last = mm2gb_stats_t();
-	last_split_chunks = last_helped_items = 0;
+	last_split_chunks = last_helped_items = 0; last_gang_chunks = last_gang_wgs = 0;
 	return 0;
 }
 
@@ -367,6 +374,12 @@ int Engine::enqueue(int64_t n_reads, const int64_t *d_offsets, const mm2gb_ancho
 		if (w.split_slots.ensure((size_t)launch.score_grid * sizeof(SplitSlot)) || w.split_part.ensure((size_t)launch.score_grid * SPLIT_MAX_ITEMS * 2 * 64 * 8)) return -1;
 		b.split_slots = (SplitSlot*)w.split_slots.ptr; b.split_part = (unsigned long long*)w.split_part.ptr;
 		MM2GB_HIP(hipMemsetAsync(w.split_slots.ptr, 0, (size_t)launch.score_grid * sizeof(SplitSlot), stream));
+	}
+
+	b.gang_slots = nullptr;
+	if (launch.gang_max >= 2 && launch.host_mode == SCORE_MODE_LUT && launch.ring_slots > 0 && !cfg_now.split && n > 0 && n <= gang_max_n) {
+		if (w.gang_slots.ensure((size_t)GANG_MAX_CHUNKS * sizeof(GangSlot))) return -1;
+		b.gang_slots = (GangSlot*)w.gang_slots.ptr;                  // (filled by plan_gangs; CNT_NGANG says how many)
 	}
 
 	MM2GB_HIP(hipMemsetAsync(counters.ptr, 0, CNT_WORDS * sizeof(int32_t), stream));
@@ -856,6 +869,7 @@ int Engine::collect_stats()
 		last.n_tracked_chunks += c[CNT_NTRACK];
 		last.n_clamped_blocks += c[CNT_NCLAMP];
 		last_split_chunks += c[CNT_NSPLIT]; last_helped_items += c[CNT_HELPED];
+		last_gang_chunks += c[CNT_NGANG]; last_gang_wgs += c[CNT_GANG_WGS];
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, slots[k].prep0, slots[k].prep1) == hipSuccess) last.ms_prep += ms;
 		if (hipEventElapsedTime(&ms, slots[k].prep1, slots[k].score1) == hipSuccess) last.ms_score += ms;
@@ -950,8 +964,15 @@ void mm2gb_engine_split_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64
 	if (chunks) *chunks = eng ? eng->e.last_split_chunks : 0;
 	if (helped_items) *helped_items = eng ? eng->e.last_helped_items : 0;
 }
+// of the engine's last completed call: chunks that a gang of workgroups scored (k_score's phase 0) and the workgroups that started in one
+void mm2gb_engine_gang_counts(const mm2gb_engine_t *eng, int64_t *chunks, int64_t *workgroups)
+{
+	if (chunks) *chunks = eng ? eng->e.last_gang_chunks : 0;
+	if (workgroups) *workgroups = eng ? eng->e.last_gang_wgs : 0;
+}
 const char *mm2gb_version(void) { return MM2GB_VERSION; }
 int mm2gb_has_split_build(void) { return score_has_split_build() ? 1 : 0; }
+int mm2gb_has_gang_build(void) { return 1; }
 
 int mm2gb_device_count(void)
 {

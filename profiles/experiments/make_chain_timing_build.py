@@ -59,6 +59,69 @@ sub("		const long long tk1 = tick();\n", "		const long long tk1 = tick();\n		tra
 sub("		const int i = i0 + lane;\n		const int fi = arg < 0 ? T.q : best;\n		if (T.live) {\n			ring[my_slot * WAVE + lane] = fi;",
     "		trace(t, 4, ctick());\n		const int i = i0 + lane;\n		const int fi = arg < 0 ? T.q : best;\n		if (T.live) {\n			ring[my_slot * WAVE + lane] = fi;")
 sub("		if (TRACK) { chain_add(0, tk1 - tk0); chain_add(7, tick() - tk1); chain_add(8, 1); }\n", "		trace(t, 5, ctick());\n		if (TRACK) { chain_add(0, tk1 - tk0); chain_add(7, tick() - tk1); chain_add(8, 1); }\n")
+
+# ---- gangs: per PAIR of the first gang chunk: 0 before the wait for the last source block,
+# 1 before 'every earlier tile is final', 2 after it, 3 after tile A's fields are loaded, 4 after in-tile A, 5 after A is stored + published in the workgroup,
+# 6 after A is swept into B, 7 after in-tile B   (the global publication follows: stamp 0 of the next pair shows it)
+GANG = "gang_chunk_pairs(const DevBatch &b"
+def gsub(old, new):
+    global src
+    at = src.index(GANG)
+    assert src.count(old, at) >= 1, old
+    src = src[:at] + src[at:].replace(old, new, 1)
+gsub("			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);\n		}\n		const int slot_a", "			if (jb + 2 * WAVE >= i0 && jb + WAVE < i0) trace(pr, 0, ctick());\n			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);\n		}\n		trace(pr, 1, ctick());\n		const int slot_a")
+gsub("		wait_done(ta);                                               // every earlier tile is final\n		Keep keep;", "		wait_done(ta);                                               // every earlier tile is final\n		trace(pr, 2, ctick());\n		Keep keep;")
+gsub("		const Target TA = load_target(b, i0, ce, TRACK);\n		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);\n",
+     "		const Target TA = load_target(b, i0, ce, TRACK);\n		asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); trace(pr, 3, ctick());\n		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);\n		trace(pr, 4, ctick());\n")
+gsub("			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);\n", "			trace(pr, 5, ctick());\n			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);\n			trace(pr, 6, ctick());\n")
+gsub("			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);\n", "			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);\n			trace(pr, 7, ctick());\n")
+
+# ---- the plain steps alone: one wave per workgroup runs plain_steps on a made-up dense tile `iters` times; s_memtime ticks per call
+src = src.replace("} // namespace mm2gb\n", r"""
+template <int KIND>
+__global__ __launch_bounds__(64) void k_bench_steps(long long *out, int iters, DevParams P, const int *lut_g, unsigned long long need)
+{
+	extern __shared__ __attribute__((aligned(16))) int smem[];
+	int *lut = smem + P.lut_base / 4;
+	for (int k = threadIdx.x; k <= P.lut_last; k += 64) lut[k] = lut_g[k];
+	int4 *stage = (int4*)smem;
+	const int lane = threadIdx.x;
+	const int x = 1000 + 3 * lane, y = 500 + 3 * lane + (lane & 1), q = 15;
+	stage[lane] = make_int4(128 - LUT_BIAS, (q - 1) * 4, x << 2, y << 2);
+	__syncthreads();
+	TileLut tl;
+	tl.tx4 = (x - 1) << 2; tl.ty4 = (y - 1) << 2; tl.lo = 0;
+	tl.lim4 = (unsigned)P.dq_lim << 2; tl.base = (unsigned)P.lut_base; tl.last_at = tl.base + ((unsigned)P.lut_last << 2);
+	tl.stage = stage; tl.edges = false; tl.kind = KIND < 3 ? KIND : 0;
+	int bestv = (q + 1) << 7;
+	long long t0 = __builtin_amdgcn_s_memtime();
+	for (int it = 0; it < iters; ++it) { tl.tx4 += 4; tl.ty4 += 4; asm volatile("" ::: "memory"); plain_steps_impl<KIND < 3 ? KIND : 0>(tl, need, bestv); bestv = (bestv & 0xfffff) | (1 << 12); asm volatile("" : "+v"(bestv)); }
+	long long t1 = __builtin_amdgcn_s_memtime();
+	if (lane == 0) out[blockIdx.x] = t1 - t0;
+	out[1024 + blockIdx.x * 64 + lane] = bestv;
+}
+} // namespace mm2gb
+extern "C" double mm2gb_debug_bench_steps(int kind, int n_wg, int iters, unsigned long long need)
+{
+	using namespace mm2gb;
+	DevParams P; memset(&P, 0, sizeof P);
+	P.max_dist_x = P.max_dist_y = P.dq_lim = 5000; P.bw = 500; P.max_iter = 5000; P.n_seg = 1; P.gap = 0.01f * 15; P.skip = 0;
+	P.lut_last = P.bw + 1; P.lut_base = LUT_LDS_TOTAL - 4 * (P.lut_last + 1); P.lut_clamp = kind == ROWS_CLAMPED; P.free_sweep = 1;
+	int *lut; long long *out;
+	(void)hipMalloc(&lut, LUT_ENTRIES * 4); (void)hipMalloc(&out, (1024 + 2048 * 64) * 8);
+	launch_build_lut(lut, P, 0);
+	auto fn = kind == 3 ? k_bench_steps<3> : kind == ROWS_FREE ? k_bench_steps<ROWS_FREE> : kind == ROWS_CHECKED ? k_bench_steps<ROWS_CHECKED> : k_bench_steps<ROWS_CLAMPED>;
+	(void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LUT_LDS_TOTAL);
+	for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(fn, dim3(n_wg), dim3(64), LUT_LDS_TOTAL, 0, out, iters, P, lut, need);
+	(void)hipDeviceSynchronize();
+	std::vector<long long> h(n_wg);
+	(void)hipMemcpy(h.data(), out, n_wg * 8, hipMemcpyDeviceToHost);
+	double s = 0; for (auto v : h) s += (double)v;
+	(void)hipFree(lut); (void)hipFree(out);
+	return s / n_wg / iters;
+}
+""")
+src = src.replace("#include <algorithm>\n", "#include <algorithm>\n#include <vector>\n#include <string.h>\n", 1)
 src += '''
 extern "C" void mm2gb_debug_chain_ticks(unsigned long long *out, int reset)
 {
@@ -84,5 +147,5 @@ try:
     others = [os.path.join(PKG, "build", f) for f in os.listdir(os.path.join(PKG, "build")) if f.endswith(".o") and f != "chain_kernels.o"]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj] + others + ["-o", os.path.join(out_dir, "libchain.so"), "-lpthread"])
 finally:
-    os.remove(tmp)
+    os.rename(tmp, "/tmp/timing_tmp.hip")
 print(os.path.join(out_dir, "libchain.so"))

@@ -21,7 +21,7 @@ sub("constexpr int SCORE_THREADS = 1024;\n",
     "__device__ unsigned long long g_it[16];\n"
     "__device__ __forceinline__ void it_add(int k, long long v) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_it[k], (unsigned long long)v); }\n")
 sub("	if (!need) return;\n	if (tl.kind == ROWS_FREE)",
-    "	if (!need) { it_add(10, 1); return; }\n	it_add(1, 1); it_add(2, __builtin_popcountll(need)); it_add(3, 2 * ((63 - __builtin_clzll(need)) / 2 - __builtin_ctzll(need) / 2 + 1)); it_add(4 + tl.kind, 1);\n	if (tl.kind == ROWS_FREE)")
+    "	if (!need) { it_add(10, 1); return; }\n	it_add(1, 1); it_add(2, __builtin_popcountll(need)); it_add(3, 2 * __builtin_popcountll((need | need >> 1) & 0x5555555555555555ull)); it_add(4 + tl.kind, 1);\n	if (tl.kind == ROWS_FREE)")
 sub("	__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);\n	stage[lane] = make_int4(128 - LUT_BIAS,", "	it_add(0, 1); if (TRACK) it_add(9, 1);\n	__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);\n	stage[lane] = make_int4(128 - LUT_BIAS,")
 sub("			} else { bestv = bestv0; arg = arg0; }\n", "			} else { bestv = bestv0; arg = arg0; it_add(7, 1); }\n")
 sub("			const int j = i0 + t;\n			const StepPre nxt = tile_pre(tl, t + 1 < n_here ? t + 1 : t);\n", "			it_add(8, 1);\n			const int j = i0 + t;\n			const StepPre nxt = tile_pre(tl, t + 1 < n_here ? t + 1 : t);\n")

@@ -11,7 +11,7 @@ for run in ("sq1", "sq2"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % run, recursive=True):
         acc = collections.defaultdict(float); n = collections.defaultdict(int)
         for r in csv.DictReader(open(f)):
-            if "k_score<0, false>" in r["Kernel_Name"]:
+            if "k_score<0, false, false>" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
         for k in sorted(acc): print("$NAME", k, "%.4g" % (acc[k] / n[k]), "launches", n[k])
 PY

@@ -10,7 +10,7 @@ import bench as bench_mod  # noqa: E402  (kernel_sha16: which kernel build these
 tag = sys.argv[1]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-KERNEL = "k_score<0, false>"       # MODE_LUT, plain (not SPLIT) build
+KERNEL = "k_score<0, false, false>"       # MODE_LUT, plain build (not SPLIT, no gang phase)
 
 
 def one(pattern):

@@ -666,6 +666,46 @@ def test_one_chunk_on_several_workgroups(monkeypatch):
     assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
 
 
+@pytest.mark.timeout(300)
+def test_gangs_several_workgroups_on_one_chunk(monkeypatch):
+    """A batch too small to fill the GPU ends with its largest chunks, and a team is bounded by one CU: a chunk whose share of the batch's
+    pairs is worth two workgroups or more is cut into strips of 16 tile pairs that several workgroups take in turn, scores travelling
+    through global memory (chain_kernels.hip, gang_chunk_pairs; plan_gangs).  Heavy chunks of every kind -- windows cut by max_iter
+    (the rescue state crosses workgroups), wide and narrow windows, a chunk that ends inside a strip, several gangs at once -- against
+    the oracle, with the default gang size, gangs of 2 and of 64, and against the same batch with gangs switched off."""
+    parts = [sc.sort_by_x(np.concatenate([sc.repeat_block(23000, 401, xwin=4500, ywin=7000), sc.colinear(900, 402)])),
+             sc.sort_by_x(sc.repeat_block(9000, 403, xwin=9000, ywin=9000, r0=4_000_000)),
+             band_cloud(12345, 404, xwin=11000, jitter=800), sc.read_like(9000, 405),
+             sc.rescue_case(n_noise=9000, n_chain=60, seed=23),
+             sc.sort_by_x(sc.repeat_block(17000 + 64 * 3 + 7, 406, xwin=3000, ywin=4000, r0=6_000_000))]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    prm = orc.default_param()
+    results = []
+    for gang_max, pct in (("8", "100"), ("2", "100"), ("64", "400")):
+        monkeypatch.setenv("MM2GB_GANG_MAX", gang_max)
+        monkeypatch.setenv("MM2GB_GANG_PCT", pct)
+        with mm.Engine() as e:
+            st = check_batch(e, a, off, prm)
+            f1, p1, _ = e.score(a, off)
+            chunks, wgs = e.gang_counts()
+            assert chunks >= 2 and wgs >= 2 * chunks, (chunks, wgs, st)
+            for _ in range(5):                                        # which workgroup takes which strip changes from run to run; the results must not
+                f2, p2, _ = e.score(a, off)
+                assert np.array_equal(f1, f2) and np.array_equal(p1, p2)
+            check_batch(e, a, off, orc.default_param(max_iter=700))
+            check_batch(e, a, off, orc.default_param(max_dist_x=2000, max_dist_y=2000, bw=300))
+            check_batch(e, a, off, orc.default_param(max_iter=12000))   # windows wider than the LDS ring
+            results.append((f1, p1))
+    monkeypatch.setenv("MM2GB_GANG_MAX", "0")
+    with mm.Engine() as e:
+        f0, p0, _ = e.score(a, off)
+        assert e.gang_counts() == (0, 0)
+    for f1, p1 in results:
+        assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
+
+
 def test_clamped_penalty_table_build(monkeypatch):
     """MM2GB_LUT_CLAMP=1: the bw+2-entry penalty table with a clamped index (no LDS read ever leaves the table) instead of
     the wide unclamped one.  Same results on saturated windows, ties, the rescue, team and wave modes."""
