@@ -449,7 +449,7 @@ static int map_reads_body(mm2gb_engine_t *eng, const mm2gb_index_t *ix, int k, c
 		// its tree; the host form keeps that tree's rules).  rechain_on_device = 1: every read on the device first; -1: host threads only.
 		if (opt.rechain_on_device == 0) {
 			std::vector<int32_t> where(redo.size(), 0);
-			mm2gb_rmq_deal_t deal;
+			mm2gb_rmq_deal_t deal = {};
 			if (rmq_chain_parts(eng, &rp, (int64_t)redo.size(), ro.data(), ra.data(), std::max(1, opt.host_threads), parts, where.data(), &deal)) { free_matches(); return -1; }
 			for (size_t q = 0; q < redo.size(); ++q) { tied[q] = where[q] == 2; q_side[q] = (unsigned char)(2 + parts.which[q]); q_slot[q] = parts.slot[q]; }
 			if (verbose) fprintf(stderr, "[mm2gb] re-chaining deal: %lld reads on the device, %d of them a whole workgroup's (%.3f s, estimated %.3f), %lld on host threads by cost (%.3f s, estimated %.3f), %lld redone after a tie (%.3f s)\n",
@@ -647,7 +647,9 @@ int mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const 
                            int32_t n_ref, const mm2gb_map_opt_t *opt_in, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
                            int64_t chunk_bases, char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats)
 {
-	if (!engines || n_engines < 1 || !opt_in || !paf_out || !paf_len || n_reads < 0 || (n_reads > 0 && !lens)) return fail("mm2gb_map_reads_stream: null argument");
+	if (!engines || n_engines < 1 || !ix || !opt_in || !paf_out || !paf_len || n_reads < 0 || (n_reads > 0 && (!lens || !names || !seqs)) || (n_ref > 0 && (!ref_names || !ref_lens)))
+		return fail("mm2gb_map_reads_stream: null argument");
+	for (int e = 0; e < n_engines; ++e) if (!engines[e]) return fail("mm2gb_map_reads_stream: null engine");
 	*paf_out = nullptr; *paf_len = 0;
 	if (chunk_bases <= 0) chunk_bases = 48 * 1000 * 1000;
 	std::vector<int32_t> cut(1, 0);

@@ -118,12 +118,8 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	// on the mapper's batches -- windows of many hundreds of anchors, every chain of a read interleaved along x -- 2.25 s against 2.5 s for the
 	// device's share; with them the tile kernel takes 1.8 s and more of the reads, profiles/r03_rmq_teams.txt.)
 	{
-		double sum_in = 0, sum_n = 0;
-		for (size_t r = 0; r < R; ++r) { sum_in += cost[r].s_in; sum_n += (double)(offsets[r + 1] - offsets[r]); }
-		const bool steps = false;
-		(void)sum_in; (void)sum_n;
 		const char *v = getenv("MM2GB_RMQ_KERNEL");
-		const bool use_steps = v ? !strcmp(v, "steps") : steps;
+		const bool use_steps = v && !strcmp(v, "steps");
 		if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
 		// tile kernel: the reads that would set the device's pace get a whole workgroup each (there are far fewer reads than the chip holds waves)
 		// -- those whose time is the broadcasts (a team's 15 helpers idle through the serial part of every tile: a read that is mostly
@@ -155,7 +151,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			host_sum += c.host; host_max = std::max(host_max, c.host); dev_sum -= c.dev * (c.team ? 16.0 : 1.0);
 			++n_host;
 		}
-	if (deal) { const int dk = deal->device_kernel; memset(deal, 0, sizeof(*deal)); deal->device_kernel = dk; deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
+	if (deal) { memset(deal, 0, sizeof(*deal)); { const char *kv = getenv("MM2GB_RMQ_KERNEL"); deal->device_kernel = kv && !strcmp(kv, "steps") ? 1 : 0; } deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
 
 	const double s_estimate = seconds_since(t0);
 	double s_gather = 0, s_merge = 0;
@@ -217,25 +213,32 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		const auto td = std::chrono::steady_clock::now();
 		// the reads that met a tie are known when the device's fill is done: they are redone on host threads while its post-pass and its copies
 		// still run (and beside what is left of the host side's own share)
+		// (called from inside the engine, with the call's post-pass still queued: NOTHING may pass through it -- not bad_alloc from the vectors,
+		// not system_error from the thread's constructor; a failure is reported through t_rc when the device call is back)
 		eng->e.rmq_tied_ready = [&](const int32_t *tc) {
-			for (size_t q = n_host; q < R; ++q) if (tc[q - n_host]) { tie_slot[q] = (int64_t)redo.size(); redo.push_back(q); }
-			if (redo.empty()) return;
-			t_off.assign(1, 0);
-			int64_t total = 0;
-			for (size_t q : redo) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
-			try { t_a.resize((size_t)total); } catch (const std::bad_alloc&) { t_rc = -1; t_err = "mm2gb_rmq_chain: out of host memory"; return; }   // (called from inside the engine: nothing may pass through it)
-			for (size_t q : redo) {
-				const int64_t r = by_dev[q], n = offsets[r + 1] - offsets[r];
-				memcpy(t_a.data() + t_off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
-				t_off.push_back(t_off.back() + n);
-			}
-			const mm2gb_anchor_t *t_ptr = t_a.data();
-			tie_side = std::thread([&, t_ptr]() {
-				const auto tt = std::chrono::steady_clock::now();
-				t_rc = mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_ptr, nt, &t_out);
-				if (t_rc) t_err = mm2gb_last_error();
-				t_seconds = seconds_since(tt);
-			});
+			try {
+				for (size_t q = n_host; q < R; ++q) if (tc[q - n_host]) { tie_slot[q] = (int64_t)redo.size(); redo.push_back(q); }
+				if (redo.empty()) return;
+				t_off.assign(1, 0);
+				int64_t total = 0;
+				for (size_t q : redo) total += offsets[by_dev[q] + 1] - offsets[by_dev[q]];
+				t_a.resize((size_t)total);
+				for (size_t q : redo) {
+					const int64_t r = by_dev[q], n = offsets[r + 1] - offsets[r];
+					memcpy(t_a.data() + t_off.back(), anchors + offsets[r], (size_t)n * sizeof(mm2gb_anchor_t));
+					t_off.push_back(t_off.back() + n);
+				}
+				const mm2gb_anchor_t *t_ptr = t_a.data();
+				// the tie redo takes the threads the host side is not using: together they stay within the caller's n_threads (plus this one)
+				const int t_threads = n_host > 0 ? std::max(1, nt / 2) : nt;
+				tie_side = std::thread([&, t_ptr, t_threads]() {
+					const auto tt = std::chrono::steady_clock::now();
+					t_rc = mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_ptr, t_threads, &t_out);
+					if (t_rc) t_err = mm2gb_last_error();
+					t_seconds = seconds_since(tt);
+				});
+			} catch (const std::exception &ex) { t_rc = -1; t_err = std::string("mm2gb_rmq_chain: redoing the tied reads: ") + ex.what(); }
+			catch (...) { t_rc = -1; t_err = "mm2gb_rmq_chain: redoing the tied reads failed"; }
 		};
 		d_rc = mm2gb_rmq_chain_gpu(eng, prm, (int64_t)(R - n_host), d_off.data(), d_a.data(), &d_out, tied.data(), nullptr);
 		eng->e.rmq_tied_ready = nullptr;

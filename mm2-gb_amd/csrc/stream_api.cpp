@@ -297,7 +297,7 @@ int usable_cpus()
 // Engines of the synchronous single-read surface (mm2gb_lchain_dp / mm2gb_lchain_rmq): a bounded pool, leased per CALL.  A caller
 // takes a free engine (one is created while the pool is below its bound, dealt round-robin over the visible devices, MM2GB_DEVICES),
 // or waits for one; the lease's destructor hands it back.  So a host with many or short-lived threads holds at most
-// MM2GB_SINGLE_ENGINES engines (default: 2 per device, at most the CPUs the process may use) instead of one per thread id ever seen
+// MM2GB_SINGLE_ENGINES engines (default: 8 per device, at most the CPUs the process may use; made on demand) instead of one per thread id ever seen
 // -- each is 4 streams, pinned staging and two work arenas -- and a recycled thread id can never share an engine with a live thread.
 static std::mutex g_single_mu;
 static std::condition_variable g_single_cv;
@@ -314,7 +314,7 @@ struct EngineLease {
 			std::vector<int> devs;
 			if (devices_for_streams(devs)) return;
 			if (g_single_max == 0) {
-				g_single_max = std::max(1, std::min(2 * (int)devs.size(), usable_cpus()));
+				g_single_max = std::max(1, std::min(8 * (int)devs.size(), usable_cpus()));   // a call is a synchronous round trip: a host with 8-16 threads wants an engine each
 				if (const char *v = getenv("MM2GB_SINGLE_ENGINES")) g_single_max = std::max(1, atoi(v));
 			}
 			if (g_single_made < g_single_max) {
@@ -390,12 +390,16 @@ mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_
 // one read, mg_lchain_rmq's signature (lchain.c:250-369)
 // ---------------------------------------------------------------------------------------------------------------
 static std::atomic<int64_t> g_rmq_calls(0), g_rmq_tied_calls(0);
+// what the library held of a run (MM2GB_REPORT=1 prints it when the host frees the streams): nanoseconds summed over the host's threads
+static std::atomic<int64_t> g_ns_chain(0), g_ns_helper(0), g_ns_rmq(0), g_tot_batches(0), g_tot_reads(0), g_tot_anchors(0);
+static inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
                                  float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km)
 {
 	HostAlloc mem; mem.km = km; mem.use_kalloc = host_kalloc_present();
 	if (!mem.use_kalloc && km) { fprintf(stderr, "[Error] mm2gb_lchain_rmq: a kalloc arena was passed but the host allocator is not linked\n"); exit(1); }
+	struct Clock { int64_t t0 = now_ns(); ~Clock() { g_ns_rmq.fetch_add(now_ns() - t0); } } clock;
 	if (_u) *_u = 0, *n_u_ = 0;
 	if (n == 0 || a == 0) { mem.release(a); return 0; }                       // lchain.c:260-263
 	const mm2gb_rmq_param_t prm = { max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip };
@@ -465,11 +469,13 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	// batches reach 0.28-0.49 G anchors/s with 8 queues, 0.80 with 16 or more (one thread: 0.26; profiles/r03_small_batches.txt).
 	// Only effective before the runtime starts, i.e. when this is the first HIP call of the process, as it is in the minimap2 host;
 	// a value that is already set is the host's to choose, but one that is too small is worth a line.
-	const int want_queues = std::min(4 * cfg.num_streams + 2, 64);
+	// (one stream id already owns four HIP streams beside the null stream, and single-read calls lease up to two more engines per device: the
+	// runtime's default of 4 queues is too few for the default configuration too -- at least 8, whatever num_streams is)
+	const int want_queues = std::min(std::max(8, 4 * cfg.num_streams + 2), 64);
 	if (const char *q = getenv("GPU_MAX_HW_QUEUES")) {
-		if (cfg.num_streams > 1 && atoi(q) < 4 * cfg.num_streams)
+		if (atoi(q) < std::min(want_queues, 4 * cfg.num_streams + 2))
 			fprintf(stderr, "[mm2gb] GPU_MAX_HW_QUEUES=%s with num_streams=%d: streams will share hardware queues and serialise (four per stream id: %d)\n", q, cfg.num_streams, want_queues);
-	} else if (cfg.num_streams > 1) setenv("GPU_MAX_HW_QUEUES", std::to_string(want_queues).c_str(), 0);
+	} else setenv("GPU_MAX_HW_QUEUES", std::to_string(want_queues).c_str(), 0);
 	if (!(cfg.has_max_total_n && cfg.has_max_read)) {
 		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's footprint per anchor:
 		// 16 B of work arrays + two staging sets of 24 B (raw in, f and p out)
@@ -508,10 +514,16 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t **in_arr_ptr, int *n_read_ptr,
                       int thread_id, void *km)
 {
+	const int64_t t_in = now_ns();
 	StreamSlot &slot = slot_for(thread_id);
 	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;   // plchain.cu:500
 	mm2gb_chain_read_t *new_reads = *in_arr_ptr;
 	const int n_new = *n_read_ptr;
+	if (new_reads && n_new > 0) {
+		int64_t na = 0;
+		for (int i = 0; i < n_new; ++i) na += new_reads[i].n;
+		g_tot_batches.fetch_add(1); g_tot_reads.fetch_add(n_new); g_tot_anchors.fetch_add(na);
+	}
 	HostStage &prev = slot.stage[slot.cur], &next = slot.stage[slot.cur ^ 1];
 	// launch first, then finish the previous batch on the host while the GPU works (the reference does it the other way
 	// round, plchain.cu:300-305, and leaves the GPU idle during its post-pass)
@@ -523,21 +535,27 @@ void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, 
 	if (finish_stage(slot, prev, km, &done, &n_done, &done_misc)) die(mm2gb_last_error());
 	if (launched) slot.cur ^= 1;
 	*in_arr_ptr = done; *n_read_ptr = n_done;
+	const int64_t t_mid = now_ns();
 	if (done && post_chaining_helper) {
 		TraceRange range("mm2gb:post_chaining_helper");
 		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], done_misc, km);   // plchain.cu:502-507
 	}
+	const int64_t t_out = now_ns();
+	g_ns_chain.fetch_add(t_mid - t_in); g_ns_helper.fetch_add(t_out - t_mid);
 }
 
 void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t **batches, int *num_reads,
                        int num_batch, void *km)
 {
+	const int64_t t_in = now_ns();
 	StreamSlot &slot = slot_for(num_batch);
 	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
 	if (finish_stage(slot, slot.stage[slot.cur], km, &done, &n_done, &misc)) die(mm2gb_last_error());
+	const int64_t t_mid = now_ns();
 	if (done && post_chaining_helper)
 		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:539-541
+	g_ns_chain.fetch_add(t_mid - t_in); g_ns_helper.fetch_add(now_ns() - t_mid);
 	*batches = done; *num_reads = n_done;
 }
 
@@ -556,6 +574,14 @@ void free_stream_gpu(int n_threads)
 	g_streams.slots.clear();
 	g_streams.ready = false;
 	free_single_read_engines();
+	// What the library held of the run, for whoever times the drop-in (bench.py's e2e.reference_host_at_scale): seconds are summed over the
+	// host's threads; the host's own callback (post_chaining_helper, map.c:428: RMQ re-chaining, mm_gen_regs, ...) runs inside the boundary
+	// calls and is listed apart, and of it what mg_lchain_rmq calls answered by the library took (hosts linked with --wrap=mg_lchain_rmq).
+	if (const char *v = getenv("MM2GB_REPORT"))
+		if (*v && *v != '0') fprintf(stderr, "[mm2gb totals] batches %lld reads %lld anchors %lld | inside chain_stream_gpu / finish_stream_gpu without the host's callback %.3f s | "
+		                             "host callback post_chaining_helper %.3f s | of the callback: mg_lchain_rmq answered by the library %.3f s in %lld calls\n",
+		                             (long long)g_tot_batches.load(), (long long)g_tot_reads.load(), (long long)g_tot_anchors.load(), g_ns_chain.load() * 1e-9,
+		                             g_ns_helper.load() * 1e-9, g_ns_rmq.load() * 1e-9, (long long)g_rmq_calls.load());
 	if (const char *v = getenv("MM2GB_RMQ_REPORT"))
 		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls answered by the library: %lld, of which redone by the library's exact host form because of a tie (device form only): %lld; handed to the host program: 0\n",
 		                             (long long)g_rmq_calls.load(), (long long)g_rmq_tied_calls.load());
