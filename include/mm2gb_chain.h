@@ -72,6 +72,15 @@ int  mm2gb_config_load(const char *path, mm2gb_config_t *cfg);
 /* ---- engine: one per (process, device); owns streams and device arenas (replaces plmem_stream_initialize,
  *      plmem.cu:558-624, and the constant uploads plrange.cu:225-239 / plscore.cu:491-502) ---- */
 int  mm2gb_device_count(void);
+/* Node awareness (the reference uses device 0 and pins nothing, gpu/plmem.cu:426,462,499).  The NUMA node of a device's PCIe root
+ * (/sys/bus/pci/devices/<bdf>/numa_node; -1 unknown) and a move of the CALLING thread -- and of the threads it starts afterwards -- onto the
+ * CPUs of that node which the process may use: 0 when nothing changed (node unknown, none of its CPUs usable, MM2GB_NUMA=0), else the
+ * CPUs in the new mask.  Pool workers, batcher workers and bench.py's ranks call it before they allocate page-locked staging (first
+ * touch then lands on that node).  mm2gb_numa_cpus_for_bdf is the parsing alone, against a given sysfs root (tests use a made-up tree):
+ * returns the number of CPUs of the node (cpus[] filled up to max_cpus), 0 when unknown. */
+int  mm2gb_device_numa_node(int device);
+int  mm2gb_pin_thread_to_device(int device);
+int  mm2gb_numa_cpus_for_bdf(const char *bdf, const char *sysfs_root_dir, int32_t *node_out, int32_t *cpus, int32_t max_cpus);
 mm2gb_engine_t *mm2gb_engine_create(const mm2gb_config_t *cfg, const mm2gb_misc_t *misc, int device);
 void mm2gb_engine_destroy(mm2gb_engine_t *eng);
 int  mm2gb_engine_set_misc(mm2gb_engine_t *eng, const mm2gb_misc_t *misc);

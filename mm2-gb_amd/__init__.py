@@ -76,7 +76,7 @@ _lib = None
 
 # every symbol include/mm2gb_chain.h and include/mm2gb_plutils.h declare
 CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "mm2gb_config_parse", "mm2gb_config_load",
-                "mm2gb_device_count", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device", "mm2gb_engine_split_counts", "mm2gb_engine_gang_counts", "mm2gb_has_gang_build",
+                "mm2gb_device_count", "mm2gb_device_numa_node", "mm2gb_pin_thread_to_device", "mm2gb_numa_cpus_for_bdf", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device", "mm2gb_engine_split_counts", "mm2gb_engine_gang_counts", "mm2gb_has_gang_build",
                 "mm2gb_engine_reserve", "mm2gb_score_host", "mm2gb_score_device", "mm2gb_engine_sync", "mm2gb_engine_stats",
                 "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chain_gpu", "mm2gb_post_device", "mm2gb_chains_free", "mm2gb_backtrack_host",
                 "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
@@ -210,6 +210,27 @@ def load_config(path):
 
 def device_count():
     return lib().mm2gb_device_count()
+
+
+def device_numa_node(device):
+    """NUMA node of the device's PCIe root (-1: unknown)."""
+    return lib().mm2gb_device_numa_node(int(device))
+
+
+def pin_thread_to_device(device):
+    """Move the calling thread (and the threads it starts afterwards) onto the usable CPUs of the device's NUMA node; 0 = nothing changed."""
+    return lib().mm2gb_pin_thread_to_device(int(device))
+
+
+def numa_cpus_for_bdf(bdf, sysfs_root=""):
+    """(node, cpus) of a PCI device from a sysfs tree (tests hand in a made-up one)."""
+    L = lib()
+    L.mm2gb_numa_cpus_for_bdf.restype = C.c_int
+    L.mm2gb_numa_cpus_for_bdf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32]
+    node = C.c_int32(-1)
+    buf = (C.c_int32 * 4096)()
+    n = L.mm2gb_numa_cpus_for_bdf(bdf.encode(), sysfs_root.encode(), C.byref(node), buf, 4096)
+    return node.value, list(buf[:min(n, 4096)])
 
 
 class Engine:

@@ -123,6 +123,8 @@ struct mm2gb_batcher {
 	void work(int k)
 	{
 		mm2gb_engine_t *eng = engines[(size_t)k];
+		// this worker feeds one device: it, and the post-pass threads it starts, run on the CPUs next to that device (numa.cpp)
+		(void)mm2gb_pin_thread_to_device(mm2gb_engine_device(eng));
 		for (;;) {
 			Batch *b = nullptr;
 			{

@@ -112,6 +112,8 @@ int score_on_engines(const std::vector<mm2gb_engine_t*> &engines, int64_t n_read
 	std::vector<std::string> err((size_t)n_dev);
 	auto run = [&](int d) {
 		Engine &e = engines[d]->e;
+		// a device's own host thread sits on the CPUs next to it (numa.cpp; nothing happens on a one-node box or when the caller runs it itself)
+		if (n_dev > 1) (void)mm2gb_pin_thread_to_device(e.device);
 		const int64_t r0 = first[d], r1 = first[d + 1], shift = offsets[r0], share = offsets[r1] - shift;
 		int32_t *fd = f ? f + shift : nullptr, *pd = p ? p + shift : nullptr;
 		if (!f) {

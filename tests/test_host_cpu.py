@@ -174,3 +174,28 @@ def test_batch_grouping_rule_matches_the_reference_accumulator():
     # no limits: one batch
     assert mm.plan_batches(n, 0, 0, 0)[0] == 1
     assert mm.plan_batches(np.zeros(0, np.int64), 10, 10, 0)[0] == 0
+
+
+def test_numa_placement_parses_a_sysfs_tree(tmp_path):
+    """Node awareness (numa.cpp): the NUMA node of a device's PCIe root and that node's CPUs, read from a made-up sysfs tree -- the
+    parsing that decides where a rank's / pool worker's / batcher worker's host threads and page-locked buffers go on a multi-GPU node
+    (the reference: device 0, nothing pinned, gpu/plmem.cu:426,462,499)."""
+    root = tmp_path
+    dev = root / "sys" / "bus" / "pci" / "devices"
+    for bdf, node in (("0000:c1:00.0", "1\n"), ("0000:05:00.0", "0\n"), ("0000:85:00.0", "-1\n"), ("0001:0a:00.0", "3\n")):
+        (dev / bdf).mkdir(parents=True)
+        (dev / bdf / "numa_node").write_text(node)
+    nodes = root / "sys" / "devices" / "system" / "node"
+    for node, cpus in ((0, "0-31,128-159\n"), (1, "32-63,160-191\n"), (3, "7\n")):
+        (nodes / f"node{node}").mkdir(parents=True)
+        (nodes / f"node{node}" / "cpulist").write_text(cpus)
+    r = str(root)
+    assert mm.numa_cpus_for_bdf("0000:C1:00.0", r) == (1, list(range(32, 64)) + list(range(160, 192)))      # hipDeviceGetPCIBusId may answer in upper case
+    assert mm.numa_cpus_for_bdf("0000:05:00.0", r) == (0, list(range(0, 32)) + list(range(128, 160)))
+    assert mm.numa_cpus_for_bdf("0000:85:00.0", r) == (-1, [])          # the kernel's "unknown"
+    assert mm.numa_cpus_for_bdf("0000:99:00.0", r) == (-1, [])          # no such device
+    assert mm.numa_cpus_for_bdf("0001:0a:00.0", r) == (3, [7])
+    (nodes / "node3" / "cpulist").write_text("7-,9\n")                   # a list the kernel would not print: nobody is moved on a guess
+    assert mm.numa_cpus_for_bdf("0001:0a:00.0", r) == (3, [])
+    (nodes / "node3" / "cpulist").write_text("9-7\n")
+    assert mm.numa_cpus_for_bdf("0001:0a:00.0", r) == (3, [])
