@@ -228,7 +228,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_LONG_MIN_COST")) launch.long_min_cost = std::max<int64_t>(1, atoll(v));
 	// Wide-window heavy chunks on 4-wave teams (chain_kernels.hip, plan_finish): pays once a micro-batch keeps the machine full for
 	// long -- 500 M anchors: 59.3 -> 47.6 ms, 300 M: 39.2 -> 36.2 -- and costs a few per cent where the largest chunks decide when the
-	// batch ends (200 M: 27.1 -> 28.5 ms), so it is tied to the batch size (profiles/r02w_ab.txt)
+	// batch ends (200 M: 27.1 -> 28.5 ms), so it is tied to the batch size (profiles/earlier/r02w_ab.txt)
 	launch.team4_all = 0; launch.team4_share_pct = 60; team4_min_n = 250000000;
 	if (const char *v = getenv("MM2GB_TEAM4_ALL")) launch.team4_all = atoi(v) != 0;
 	if (const char *v = getenv("MM2GB_TEAM4_SHARE_PCT")) launch.team4_share_pct = std::max(0, atoi(v));
@@ -241,7 +241,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_GANG_MAX")) launch.gang_max = std::max(0, std::min(64, atoi(v)));
 	if (const char *v = getenv("MM2GB_GANG_PCT")) launch.gang_pct = std::max(1, atoi(v));
 	if (const char *v = getenv("MM2GB_GANG_MAX_ANCHORS")) gang_max_n = std::max<int64_t>(0, atoll(v));
-	split_max_n = 0;                                           // off: measured slower at every batch size (profiles/r02y_split_rate.json)
+	split_max_n = 0;                                           // off: measured slower at every batch size (profiles/earlier/r02y_split_rate.json)
 	if (const char *v = getenv("MM2GB_SPLIT_MAX_ANCHORS")) split_max_n = std::max<int64_t>(0, atoll(v));
 	if (debug_phases && dbg.ensure((size_t)launch.score_grid * 32)) return -1;
 	const char *env = getenv("MM2GB_NO_COOP");
