@@ -643,6 +643,16 @@ def backtrack_host(misc, anchors, f, p_rel):
     return u, a_out
 
 
+def synth_count(seed, first_read, n_reads, len_lo, len_hi):
+    """How many anchors synth_reads would make for these reads (no anchors are generated)."""
+    L = lib()
+    off = np.zeros(n_reads + 1, dtype=np.int64)
+    n = L.mm2gb_synth_count(seed, first_read, n_reads, len_lo, len_hi, off.ctypes.data)
+    if n < 0:
+        raise Mm2gbError(L.mm2gb_last_error().decode())
+    return int(n)
+
+
 def synth_reads(seed, first_read, n_reads, len_lo, len_hi, threads=8):
     """Deterministic synthetic reads.  Returns anchors (n,2) uint64 and offsets (R+1,) int64."""
     L = lib()

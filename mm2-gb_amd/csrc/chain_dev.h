@@ -38,6 +38,8 @@ constexpr int PLAN_BLOCK = 1024;
 constexpr int PLAN_THREADS = MM2GB_PLAN_THREADS;   // k_window: each thread owns PLAN_BLOCK / PLAN_THREADS consecutive anchors
 // cost charged per anchor on top of its pairs when ordering chunks (tile bookkeeping is not free)
 constexpr int COST_PER_ANCHOR = 16;
+// cost bins per work list of the planner (chain_kernels.hip: 16 per power of two; the engine sizes DevBatch::bins by it)
+constexpr int PLAN_COST_BINS = 1024;
 
 // A heavy chunk scored by its owner workgroup strip by strip (16 tiles = 1 024 anchors), the sweeps over the sources BEFORE the strip
 // cut into items that any idle workgroup may take (chain_kernels.hip, split_chunk).  Every word is accessed with agent-scope atomics.

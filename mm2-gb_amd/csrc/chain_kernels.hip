@@ -260,15 +260,21 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 // --------------------------------------------------------------------------------------------------------------
 constexpr int PLANNER_THREADS = 1024;
 constexpr int N_SMALL_TEAMS_PLAN = 4;                  // 4-wave teams per score workgroup (k_score: 16 waves)
-constexpr int COST_BINS = 256;
+#ifndef MM2GB_COST_BINS_PER_OCTAVE
+#define MM2GB_COST_BINS_PER_OCTAVE 16
+#endif
+constexpr int COST_SUB = MM2GB_COST_BINS_PER_OCTAVE;   // bins per power of two of a chunk's cost: the lists are served bin by bin, most expensive first
+constexpr int COST_SUB_LOG = COST_SUB == 16 ? 4 : COST_SUB == 8 ? 3 : 2;
+constexpr int COST_BINS = 64 * COST_SUB;
+static_assert(COST_BINS <= PLAN_COST_BINS, "the engine allocates PLAN_COST_BINS bins per list");
 enum { LIST_WAVE = 0, LIST_BIG = 1, LIST_TEAM4 = 2, N_LISTS = 3 };
 
 __device__ __forceinline__ int cost_bin(int64_t c)
 {
 	if (c <= 0) return 0;
 	const int msb = 63 - __clzll(c);
-	const int frac = msb >= 2 ? (int)((c >> (msb - 2)) & 3) : 0;
-	return min(COST_BINS - 1, msb * 4 + frac);
+	const int frac = msb >= COST_SUB_LOG ? (int)((c >> (msb - COST_SUB_LOG)) & (COST_SUB - 1)) : 0;
+	return min(COST_BINS - 1, msb * COST_SUB + frac);
 }
 
 template <typename T>

@@ -321,7 +321,7 @@ int Engine::reserve(int64_t n, int64_t n_reads, int set)
 		if (w.blk_firstcut.ensure(nb * 4) || w.blk_pairs.ensure(nb * 8) || w.blk_clamped.ensure(nb * 4) || w.blk_wmax.ensure(nb * 8) || w.blk_read.ensure(nb * 4)) return -1;
 		if (w.chunk_start.ensure(nb * 4) || w.chunk_end.ensure(nb * 4) || w.chunk_cost.ensure(nb * 8) || w.chunk_track.ensure(nb) ||
 		    w.order.ensure(nb * 4) || w.long_list.ensure(nb * 4) || w.mid_list.ensure(nb * 4) || w.chunk_pp.ensure(nb * 8) || w.chunk_kk.ensure(nb * 4) || w.chunk_blk.ensure(nb * 4) ||
-		    w.tile_sums.ensure((nb / 1024 + 2) * 24) || w.tile_base.ensure((nb / 1024 + 2) * 24) || w.bins.ensure(3 * 256 * 4)) return -1;
+		    w.tile_sums.ensure((nb / 1024 + 2) * 24) || w.tile_base.ensure((nb / 1024 + 2) * 24) || w.bins.ensure(3 * PLAN_COST_BINS * 4)) return -1;
 		w.cap_n = nn; w.cap_blocks = nb; w.cap_reads = std::max(had_reads, n_reads);
 	}
 	return 0;

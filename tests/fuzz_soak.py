@@ -1,4 +1,4 @@
-"""Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N] [--teams] [--post] [--big N]
+"""Soak tool (not collected by pytest): python tests/fuzz_soak.py SEED [SEED ...] [--iters N] [--teams] [--post] [--big N] [--huge N]
 Runs tests/synth_cases.fuzz_case batches through the HIP path and the oracle; the first batch that differs is written
 to gpurun_out/fuzz_fail_<seed>_<iteration>.npz (anchors, offsets, GPU f/p, parameters) and the exit code is 1.
 --teams adds three engines whose planner thresholds send every chunk that fits the LDS ring to the big (8/16-wave) teams and to
@@ -16,6 +16,8 @@ ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--teams", action="store_true")
 ap.add_argument("--post", action="store_true", help="also the device post-pass (mm2gb_chain_gpu): chains and compacted anchors against the host post-pass of the same scores")
 ap.add_argument("--big", type=int, default=0, help="per seed, also this many batches of bench-like reads (10-100 kb, ~1-2 M anchors) with random parameters")
+ap.add_argument("--huge", type=int, default=0, help="per seed, also this many batches of >= 20 M anchors (30-300 kb reads): the size at which team modes, gangs and the planner's "
+                                                    "lists carry real load; every anchor against the oracle under every engine configuration")
 args = ap.parse_args()
 out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
@@ -82,11 +84,21 @@ for seed in args.seeds:
     if failed:
         break
     # many planning blocks per read, look-back across blocks, every list of the planner in one batch
-    for it in range(args.big):
-        a, off = mm.synth_reads(seed * 1000 + it, 0, int(rng.integers(8, 40)), 10_000, 100_000, threads=8)
-        kw = dict(max_iter=int(rng.choice([100, 1000, 5000, 20000])), bw=int(rng.choice([100, 500, 2000])),
-                  max_dist_x=int(rng.choice([1000, 5000, 10000])), max_dist_y=int(rng.choice([1000, 5000, 10000])),
-                  pen_gap=np.float32(rng.choice([0.12, 0.19])), pen_skip=np.float32(0.0))
+    for it in range(args.big + args.huge):
+        huge = it >= args.big
+        if huge:
+            # >= 20 M anchors: reads are added until the batch is there (the generator is deterministic per read id)
+            n_reads = 64
+            while mm.synth_count(seed * 1000 + it, 0, n_reads, 30_000, 300_000) < 20_000_000:
+                n_reads += 32
+            a, off = mm.synth_reads(seed * 1000 + it, 0, n_reads, 30_000, 300_000, threads=16)
+            kw = dict(max_iter=int(rng.choice([5000, 5000, 2000])), bw=int(rng.choice([500, 500, 100])), max_dist_x=5000, max_dist_y=5000,
+                      pen_gap=np.float32(rng.choice([0.12, 0.19])), pen_skip=np.float32(0.0))
+        else:
+            a, off = mm.synth_reads(seed * 1000 + it, 0, int(rng.integers(8, 40)), 10_000, 100_000, threads=8)
+            kw = dict(max_iter=int(rng.choice([100, 1000, 5000, 20000])), bw=int(rng.choice([100, 500, 2000])),
+                      max_dist_x=int(rng.choice([1000, 5000, 10000])), max_dist_y=int(rng.choice([1000, 5000, 10000])),
+                      pen_gap=np.float32(rng.choice([0.12, 0.19])), pen_skip=np.float32(0.0))
         prm = orc.default_param(**kw)
         fo, po, pairs = orc.chain_fill_many(a, off, prm, threads=16)
         po_rel = np.concatenate([rel(po[off[r]:off[r + 1]]) for r in range(len(off) - 1)])
@@ -105,8 +117,8 @@ for seed in args.seeds:
         if failed:
             break
     else:
-        if args.big:
-            print("seed", seed, "clean over", args.big, "large batches", flush=True)
+        if args.big + args.huge:
+            print("seed", seed, "clean over", args.big, "large batches and", args.huge, "of >= 20 M anchors", flush=True)
     if failed:
         break
 print("chunks sent to big / 4-wave teams per engine:", seen)

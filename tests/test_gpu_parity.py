@@ -431,14 +431,15 @@ def test_fuzz_soak_five_engine_configurations():
     """tests/fuzz_soak.py inside the suite: one seed (from the kernel sources' hash) x 100 batches x the five
     engine configurations -- default planner, every chunk on 8-wave teams, on whole-workgroup teams, on 4-wave teams, on 4-wave teams
     with windows wider than the ring share -- each batch against the oracle on every anchor, the device post-pass against the host
-    post-pass, and 3 larger bench-like batches with random parameters.  The bug that mattered in round 2 (the unchecked sweep judging a
+    post-pass, 2 larger bench-like batches with random parameters, and one batch of >= 20 M anchors (30-300 kb reads: team modes, gangs and
+    the planner's lists under real load) -- every anchor of it against the oracle under all five configurations.  The bug that mattered in round 2 (the unchecked sweep judging a
     tile by an anchor of the next read) was found by exactly this tool."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     seed = fuzz_seed() ^ 0x5eed
-    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_soak.py"), str(seed), "--iters", os.environ.get("MM2GB_SOAK_ITERS", "100"), "--teams", "--post", "--big", "3"],
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_soak.py"), str(seed), "--iters", os.environ.get("MM2GB_SOAK_ITERS", "100"), "--teams", "--post", "--big", "2", "--huge", "1"],
                        capture_output=True, text=True, timeout=1500)
     print(r.stdout[-1500:])
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
