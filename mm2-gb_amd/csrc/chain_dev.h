@@ -68,11 +68,12 @@ struct GangSlot {
 	int keep[6];               // the remembered anchor (rescue state) behind tile `done`: keep[0] = index + 1 (0: none)
 	int chunk;                 // chunk id
 	int first_wg, n_wg;        // workgroups [first_wg, first_wg + n_wg) start on this chunk
-	int pad_[21];
+	int tiles_per_wave;        // 1: a wave takes one tile per turn (strips of 16 tiles); 2: a pair (strips of 32)
+	int pad_[20];
 };
 static_assert(sizeof(GangSlot) == 128, "one slot per 128-byte line");
 constexpr int GANG_MAX_CHUNKS = 64;                    // chunks per batch that may get a gang
-constexpr int GANG_STRIP_PAIRS = 16;                   // tile pairs per strip = waves of a score workgroup
+constexpr int GANG_STRIP_PAIRS = 16;                   // turns per strip = waves of a score workgroup (a turn: one tile, or a pair)
 
 // Everything one micro-batch needs in HBM: the caller's anchors (16 B each, all reads concatenated) and one array per derived field.
 struct DevBatch {
@@ -138,6 +139,7 @@ struct LaunchCfg {
 	                         // of the batch's pairs (then: a big team); 0 = wide windows always go to big teams
 	int gang_max;            // most workgroups the planner gives one chunk (0: no gangs)
 	int gang_pct;            // a chunk gets gang_pct % of the workgroups its share of the batch's pairs would give it, if that is at least two
+	int gang_pairs;          // 1: a gang's waves take pairs of tiles (as 4- and 8-wave teams do); 0: single tiles, the shorter chain per tile
 	int split;               // 1: launch the SPLIT build (such chunks strip by strip, idle workgroups help); the host's choice by batch size
 	int64_t long_min_cost;   // chunks at least this expensive ...
 	int     long_min_window; // ... whose mean window is at least this are candidates for the cooperative mode

@@ -462,7 +462,8 @@ __global__ __launch_bounds__(256) void plan_gangs(DevBatch b, LaunchCfg cfg)
 		ci = b.long_list[t];
 		const long long cost = b.chunk_cost[ci], total = b.totals[0] + (long long)b.n * COST_PER_ANCHOR;
 		const int n_tiles = (b.chunk_end[ci] - b.chunk_start[ci] + WAVE - 1) / WAVE;
-		const int n_strips = (n_tiles + 2 * GANG_STRIP_PAIRS - 1) / (2 * GANG_STRIP_PAIRS);
+		const int strip_tiles = (cfg.gang_pairs ? 2 : 1) * GANG_STRIP_PAIRS;
+		const int n_strips = (n_tiles + strip_tiles - 1) / strip_tiles;
 		const long long share = cost * cfg.score_grid * cfg.gang_pct / (max(1ll, total) * 100);
 		want = (int)min((long long)min(cfg.gang_max, n_strips), share);
 		if (want < 2) want = 0;
@@ -486,8 +487,8 @@ __global__ __launch_bounds__(256) void plan_gangs(DevBatch b, LaunchCfg cfg)
 		GangSlot g;
 		g.next_strip = 0; g.done = 0;
 		for (int k = 0; k < 6; ++k) g.keep[k] = 0;
-		g.chunk = ci; g.first_wg = s_first[t]; g.n_wg = s_want[t];
-		for (int k = 0; k < 21; ++k) g.pad_[k] = 0;
+		g.chunk = ci; g.first_wg = s_first[t]; g.n_wg = s_want[t]; g.tiles_per_wave = cfg.gang_pairs ? 2 : 1;
+		for (int k = 0; k < 20; ++k) g.pad_[k] = 0;
 		b.gang_slots[s_pos[t]] = g;
 		b.chunk_track[ci] |= 8;                       // the team phases pass it over
 	}
@@ -506,6 +507,9 @@ enum { MODE_LUT = 0, MODE_FAST = 1, MODE_GENERAL = 2 };
 constexpr int SCORE_THREADS = 1024;
 #ifndef MM2GB_POLL_SLEEP
 #define MM2GB_POLL_SLEEP 32            // x 64 cycles between two looks at a team's tile counter
+#endif
+#ifndef MM2GB_GANG_POLL_SLEEP
+#define MM2GB_GANG_POLL_SLEEP 4        // x 64 cycles, in a gang (its waves wait for the chain through the chunk's tiles and little else)
 #endif
 #ifndef MM2GB_INTILE_PRIO
 #define MM2GB_INTILE_PRIO 3
@@ -1452,12 +1456,14 @@ __device__ __forceinline__ void sweep_pair_block(const DevBatch &b, TilePair &t,
 	const bool free_a = P.free_sweep && (unsigned)(t.x_last_a - first_lane(xs)) <= free_span;
 	// ... and dr >= bw + q_span for every source too (the block's last source and the pair's first anchor give the smallest dr): the FAR
 	// build, for which the block is staged differently -- so only where both tiles take it
-	const bool far_block = free_block && nc_a && nc_b && t.x_first > bcast(xs, WAVE - 1) && __ballot(sq + P.bw > t.x_first - bcast(xs, WAVE - 1)) == 0;
+	// (a pair without a tile B -- a gang's single tiles, a chunk's last odd tile -- takes the block alone and may take it the FAR way too)
+	const bool single = t.n_b == 0;
+	const bool far_block = free_block && nc_a && (nc_b || single) && t.x_first > bcast(xs, WAVE - 1) && __ballot(sq + P.bw > t.x_first - bcast(xs, WAVE - 1)) == 0;
 	const int d0 = (first_lane(xs) - first_lane(ys)) * 4;
 	stage_block_lut(xs, ys, sf, sq, stage, far_block, d0);
 	if (nc_a && nc_b) sweep_staged_lut2(t.A, t.B, jb, free_block, far_block, d0, stage, P, t.best_a, t.arg_a, t.best_b, t.arg_b);
 	else {
-		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_a, stage, P, t.best_a, t.arg_a);
+		sweep_staged_lut(t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, nc_a, nc_a && free_a, stage, P, t.best_a, t.arg_a, far_block, d0);
 		if (use_b) sweep_staged_lut(t.B, jb, t.lo_b > jb ? t.lo_b - jb : 0, nc_b, nc_b && free_block, stage, P, t.best_b, t.arg_b);
 	}
 	__builtin_amdgcn_wave_barrier();
@@ -1704,7 +1710,11 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 {
 	const int lane = lane_id();
 	const int n_tiles = (ce - cs + WAVE - 1) / WAVE;
-	constexpr int STRIP_TILES = 2 * GANG_STRIP_PAIRS;
+	// One tile per wave and turn, or a pair (GangSlot::tiles_per_wave).  A gang exists because its chunk is bound by the chain through its
+	// tiles, and per tile a pair's chain is the longer one: it sweeps TWO fresh blocks (the previous pair's tiles) and tile A into B where a
+	// single tile sweeps one -- the pair's halved LDS broadcasts are worth nothing on workgroups that wait for the chain anyway.
+	const int tpu = first_lane(gload(&gs->tiles_per_wave)) == 2 ? 2 : 1;
+	const int STRIP_TILES = tpu * GANG_STRIP_PAIRS;
 	int known = 0, known_global = 0;                               // leading tiles known final (from anywhere / from the global counter itself)
 	auto look_global = [&]() { known_global = max(known_global, first_lane(gload(&gs->done))); known = max(known, known_global); };
 	auto wait_done = [&](int need) {
@@ -1714,10 +1724,10 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 			if (known >= need) return;
 			look_global();
 			if (known >= need) { if (lane == 0) __hip_atomic_fetch_max(&sh->done, known, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
-			__builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP);
+			__builtin_amdgcn_s_sleep(MM2GB_GANG_POLL_SLEEP);           // (a gang's workgroups wait for the chain, not for issue slots: look often)
 		}
 	};
-	auto wait_done_global = [&](int need) { while (known_global < need) { look_global(); if (known_global < need) __builtin_amdgcn_s_sleep(MM2GB_POLL_SLEEP); } };
+	auto wait_done_global = [&](int need) { while (known_global < need) { look_global(); if (known_global < need) __builtin_amdgcn_s_sleep(MM2GB_GANG_POLL_SLEEP); } };
 	int s0 = -1, s1 = -1, s2 = -1;                                  // this workgroup's strips, newest first
 	int cur = 0;
 	const lds_i32_ptr ring_l = (lds_i32_ptr)(uintptr_t)(unsigned)(uintptr_t)ring;
@@ -1743,10 +1753,10 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 		if (s * STRIP_TILES >= n_tiles) { ++seq; break; }            // no strip left (every wave of the workgroup sees the same turn)
 		s2 = s1; s1 = s0; s0 = s;
 		const int pr = s * GANG_STRIP_PAIRS + wave;
-		if (2 * pr >= n_tiles) continue;                             // the chunk's last strip is a short one
-		const int ta = 2 * pr, i0 = cs + ta * WAVE;                  // tile A = tile ta of the chunk, tile B = ta + 1
+		if (tpu * pr >= n_tiles) continue;                           // the chunk's last strip is a short one
+		const int ta = tpu * pr, i0 = cs + ta * WAVE;                // tile A = tile ta of the chunk, tile B = ta + 1 (pairs only)
 		cur = ta;
-		TilePair t = load_pair(b, i0, ce);
+		TilePair t = load_pair(b, i0, tpu == 2 ? ce : min(ce, i0 + WAVE));   // (one tile per wave: a pair whose tile B is empty)
 		int jb = cs + ((t.lo_a - cs) & ~(WAVE - 1));
 		const int eq_lo = jb < i0 ? equal_x_run_start(b, cs, i0, first_lane(t.A.x)) : i0;
 		bool have = false;
@@ -2133,7 +2143,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 			int go = 1;
 			if (late) {
 				const int next = gload(&gs->next_strip), done = gload(&gs->done), n_tiles = (ce - cs + WAVE - 1) / WAVE;
-				go = next * 2 * GANG_STRIP_PAIRS < n_tiles && next * 2 * GANG_STRIP_PAIRS - done < 4 * 2 * GANG_STRIP_PAIRS;
+				const int st_tiles = (gload(&gs->tiles_per_wave) == 2 ? 2 : 1) * GANG_STRIP_PAIRS;
+				go = next * st_tiles < n_tiles && next * st_tiles - done < 4 * st_tiles;
 			}
 			sh->chunk = go; sh->done = 0; sh->keep[0] = -1;
 		}

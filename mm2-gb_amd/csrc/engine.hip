@@ -240,6 +240,8 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	launch.gang_max = 8; launch.gang_pct = 100; gang_max_n = 150000000;
 	if (const char *v = getenv("MM2GB_GANG_MAX")) launch.gang_max = std::max(0, std::min(64, atoi(v)));
 	if (const char *v = getenv("MM2GB_GANG_PCT")) launch.gang_pct = std::max(1, atoi(v));
+	launch.gang_pairs = 0;
+	if (const char *v = getenv("MM2GB_GANG_PAIRS")) launch.gang_pairs = *v && *v != '0';
 	if (const char *v = getenv("MM2GB_GANG_MAX_ANCHORS")) gang_max_n = std::max<int64_t>(0, atoll(v));
 	split_max_n = 0;                                           // off: measured slower at every batch size (profiles/earlier/r02y_split_rate.json)
 	if (const char *v = getenv("MM2GB_SPLIT_MAX_ANCHORS")) split_max_n = std::max<int64_t>(0, atoll(v));

@@ -15,7 +15,8 @@ xwin = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
 a = sc.sort_by_x(sc.repeat_block(n, 7, xwin=xwin, ywin=6000))
 off = np.array([0, len(a)], np.int64)
 L = mm.lib()
-nt = min(8192, (len(a) + 127) // 128)
+pairs = os.environ.get("MM2GB_GANG_PAIRS", "0") not in ("", "0")
+nt = min(8192, (len(a) + 127) // 128 if pairs else (len(a) + 63) // 64)
 buf = np.zeros(nt * 8, np.int64)
 with mm.Engine() as e:
     e.score(a, off)
@@ -26,16 +27,14 @@ tr = buf.reshape(nt, 8).astype(np.float64)
 print(f"{len(a)} anchors, {nt} pairs, {st['n_pairs']} pairs of anchors, ms_score {st['ms_score']:.3f}; stamps are s_memtime ticks (~0.43 ns)")
 lo, hi = 50, nt - 2
 t = np.arange(lo + 1, hi)
-endp = tr[:, 7]
+endp = tr[:, 7] if pairs else tr[:, 4]
 step = endp[lo + 1:hi] - endp[lo:hi - 1]
-print(f"end of in-tile B to the next pair's: mean {step.mean():.0f}  median {np.median(step):.0f}  min {step.min():.0f}  max {step.max():.0f}")
+print(f"{'pairs' if pairs else 'single tiles'}: end of the last in-tile phase to the next turn's: mean {step.mean():.0f}  median {np.median(step):.0f}  min {step.min():.0f}  max {step.max():.0f}")
 parts = [("previous pair's in-tile B ends -> 'every earlier tile is final' seen", tr[t, 2] - endp[t - 1]),
          ("   sweeps done -> seen (negative = the sweeps ended after the previous pair)", tr[t, 2] - tr[t, 1]),
          ("tile A's fields loaded", tr[t, 3] - tr[t, 2]),
          ("in-tile A", tr[t, 4] - tr[t, 3]),
-         ("store + publish A", tr[t, 5] - tr[t, 4]),
-         ("A swept into B", tr[t, 6] - tr[t, 5]),
-         ("tile B's fields + in-tile B", tr[t, 7] - tr[t, 6])]
+         ] + ([("store + publish A", tr[t, 5] - tr[t, 4]), ("A swept into B", tr[t, 6] - tr[t, 5]), ("tile B's fields + in-tile B", tr[t, 7] - tr[t, 6])] if pairs else [])
 for name, v in parts:
     print(f"  {name:86s} mean {v.mean():9.0f}  median {np.median(v):9.0f}  p90 {np.percentile(v, 90):9.0f}")
 # by position of the pair in its strip (wave): the strip's first pair waits for another workgroup
