@@ -788,6 +788,42 @@ __device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int
 		asm("v_max3_i32 %0, %1, %2, %0" : "+v"(bestv) : "v"(v[2]), "v"(v[3]));
 	}
 }
+// An EDGE block -- some target windows start inside it, or it reaches into the run of anchors that share the tile's first position.
+// Two tests are left, both straight into the execution mask (v_cmpx; the second narrows the first) around a plain v_max: the query
+// distance's range and "source inside this target's window".  dr <= 0 -- a source AT the target's position (lchain.c:120), or one of
+// another read of the chunk that happens to lie right of it -- rejects through the table address, with the query distance's sign bit
+// cleared as in plain_steps; no compare-and-select chain, no scalar mask arithmetic.  11 vector instructions per source where
+// sweep_block_lut<true, .> takes 13 and three scalar ones (round 4: edge blocks are 8 % of the tile-blocks of the bench mix and most of
+// what a batch of 10-30 kb reads does).  Unclamped table only.
+__device__ __forceinline__ void sweep_block_lut_edge(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage, const DevParams &P, int &bestv)
+{
+	constexpr int G = 4;
+	const unsigned base = (unsigned)P.lut_base, lim4 = (unsigned)P.dq_lim << 2;
+	int pos = 0x7fffffff;
+	asm volatile("" : "+v"(pos));
+	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
+		int4 s4[G];
+		int dqm[G], drm[G], pen[G];
+#pragma unroll
+		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
+			pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u] & pos, base);
+		}
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
+			int v = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x;
+			asm("" : "+v"(v));
+			v += pen[u];
+			const int j = jb + kg + u;
+			unsigned long long saved;                               // (the mask on entry is saved and put back inside the statement: sweep_block_lut)
+			asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[dq]\n\tv_cmpx_ge_i32_e32 vcc, %[j], %[st]\n\tv_max_i32_e32 %[b], %[v], %[b]\n\ts_mov_b64 exec, %[sv]"
+			             : [b] "+v"(bestv), [sv] "=&s"(saved) : [lim] "s"(lim4), [dq] "v"(dqm[u]), [st] "v"(t_st), [j] "s"(j), [v] "v"(v) : "vcc");
+		}
+	}
+}
 __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, bool free_block, const int4 *stage, const DevParams &P,
                                                  int &best, int &arg, bool far_block = false, int d0 = 0)
 {
@@ -795,6 +831,7 @@ __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_
 	int bestv = best << 7;
 	if (far_block) sweep_block_lut_free<true>(tx4, ty4, stage, (unsigned)P.lut_base, d0, bestv);
 	else if (free_block) sweep_block_lut_free<false>(tx4, ty4, stage, (unsigned)P.lut_base, 0, bestv);
+	else if (!no_check && !P.lut_clamp) sweep_block_lut_edge(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 	else if (P.lut_clamp) {
 		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
@@ -1478,8 +1515,8 @@ __device__ __forceinline__ void sweep_a_into_b(const DevBatch &b, TilePair &t, i
 	// (this sweep sits on the team's critical path, between the two in-tile phases of the pair: where tile A lies inside every window of B, left
 	// of B's first position and within dq_lim - bw of its last, the unchecked sweep does it in 6.5 instead of 8 instructions per source)
 	const bool no_check = i0 >= t.hi_b && i0 + WAVE <= eq_lo;
-	const bool free_ab = no_check && P.free_sweep && (unsigned)(t.x_last - t.x_first) <= (unsigned)(P.dq_lim - P.bw);
-	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, no_check, free_ab, stage, P, t.best_b, t.arg_b);
+	const bool span_ab = P.free_sweep && (unsigned)(t.x_last - t.x_first) <= (unsigned)(P.dq_lim - P.bw);
+	sweep_staged_lut(t.B, i0, t.lo_b > i0 ? t.lo_b - i0 : 0, no_check, no_check && span_ab, stage, P, t.best_b, t.arg_b);
 	__builtin_amdgcn_wave_barrier();
 }
 
