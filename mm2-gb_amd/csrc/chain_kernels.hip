@@ -795,13 +795,13 @@ __device__ __forceinline__ void sweep_block_lut_free(int tx4, int ty4, const int
 // cleared as in plain_steps; no compare-and-select chain, no scalar mask arithmetic.  11 vector instructions per source where
 // sweep_block_lut<true, .> takes 13 and three scalar ones (round 4: edge blocks are 8 % of the tile-blocks of the bench mix and most of
 // what a batch of 10-30 kb reads does).  Unclamped table only.
-__device__ __forceinline__ void sweep_block_lut_edge(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage, const DevParams &P, int &bestv)
+__device__ __forceinline__ void sweep_block_lut_edge(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage, const DevParams &P, int &bestv, const int k_to = WAVE)
 {
 	constexpr int G = 4;
 	const unsigned base = (unsigned)P.lut_base, lim4 = (unsigned)P.dq_lim << 2;
 	int pos = 0x7fffffff;
 	asm volatile("" : "+v"(pos));
-	for (int kg = k_from & ~(G - 1); kg < WAVE; kg += G) {
+	for (int kg = k_from & ~(G - 1); kg < k_to; kg += G) {
 		int4 s4[G];
 		int dqm[G], drm[G], pen[G];
 #pragma unroll
@@ -1064,10 +1064,27 @@ __device__ __forceinline__ void tile_fin(const StepPre &pre, int t, int s_bv, in
 // tile_fin, which the rescue state machine still uses); the steps alone on a dense tile: profiles/experiments/steps_alone.py.
 // A group without a needed source is skipped; the other row of a group that holds one is computed with it (a source no later lane
 // reaches fails `lo <= t` in every lane).  Applying a row twice changes nothing (max), so a caller may ask again for rows that ran before.
+// Progressive publication (round 4): in a team whose waves take single tiles, the wave of tile t+1 needs tile t's scores for the LAST block
+// of its sweep -- a whole block sweep on the chunk's critical path, between two in-tile phases.  A lane of tile t is final long before the
+// tile is (lane L after source L - 1): the in-tile phase hands out its scores a quarter of the tile at a time (ring slot, then a counter:
+// part = 4 t + quarters), and the next wave sweeps the first three quarters of that block while the phase is still running.
+struct Progress {
+	int *ring_slot = nullptr;                               // this tile's 64 scores in the team's LDS ring; null: nothing is handed out early
+	int *part = nullptr;                                    // the team's counter
+	int base = 0;                                           // 4 * (tile of the chunk)
+	__device__ __forceinline__ void publish(const int q, const int bestv) const
+	{
+		if ((lane_id() >> 4) == q) ring_slot[lane_id()] = bestv >> 7;   // (packed value >> 7: the score, also of a lane without predecessor)
+		__builtin_amdgcn_wave_barrier();
+		if (lane_id() == 0) __hip_atomic_store(part, base + q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+};
+struct NoQuarter { __device__ __forceinline__ void operator()(int, int) const {} };
+
 enum { ROWS_FREE = 0, ROWS_CHECKED = 1, ROWS_CLAMPED = 2 };   // no test at all | dq range and window start | those and a clamped table index
 
-template <int KIND>
-__device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsigned long long need, int &bestv)
+template <int KIND, class Q>
+__device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsigned long long need, int &bestv, Q &&on_quarter)
 {
 	int negv = INT_MIN / 2, keep_hi = ~127, pos = 0x7fffffff;
 	asm volatile("" : "+v"(negv), "+v"(keep_hi), "+v"(pos));      // VGPRs, not literals per row
@@ -1099,6 +1116,7 @@ __device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsign
 	// of a typical tile's sources are needed by nobody (profiles/experiments/intile_counts.py)
 	unsigned long long gm = (need | need >> 1) & 0x5555555555555555ull;
 	auto next_group = [&]() { const int t = gm ? (int)__builtin_ctzll(gm) : -1; gm &= gm - 1; return t; };
+	int qdone = 0;                                                // quarters of the tile handed to on_quarter so far (the last one is the caller's)
 	int tc = next_group();                                        // the group whose steps run in this turn of the loop
 	int tn = next_group();                                        // the one after it: its rows are computed meanwhile
 	int4 sa = tl.stage[tc], sb = tl.stage[tc + 1];
@@ -1119,17 +1137,21 @@ __device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsign
 		__builtin_amdgcn_sched_barrier(0);                          // the reads stay HERE, a whole turn ahead of their use (the scheduler likes them next to it)
 		step(tc + 1, m1);
 		tc = tn; tn = tnn;
+		// every source before tc has been applied or needs none: the quarters that end before it are final
+		while (qdone < 3 && 16 * qdone + 15 < tc) { on_quarter(qdone, bestv); ++qdone; }
 	}
 	step(tc, finish(ra, pa));
 	step(tc + 1, finish(rb, pb));
+	while (qdone < 3) { on_quarter(qdone, bestv); ++qdone; }
 }
 
-__device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv)
+template <class Q = NoQuarter>
+__device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv, Q &&on_quarter = Q())
 {
 	if (!need) return;
-	if (tl.kind == ROWS_FREE) plain_steps_impl<ROWS_FREE>(tl, need, bestv);
-	else if (tl.kind == ROWS_CHECKED) plain_steps_impl<ROWS_CHECKED>(tl, need, bestv);
-	else plain_steps_impl<ROWS_CLAMPED>(tl, need, bestv);
+	if (tl.kind == ROWS_FREE) plain_steps_impl<ROWS_FREE>(tl, need, bestv, on_quarter);
+	else if (tl.kind == ROWS_CHECKED) plain_steps_impl<ROWS_CHECKED>(tl, need, bestv, on_quarter);
+	else plain_steps_impl<ROWS_CLAMPED>(tl, need, bestv, on_quarter);
 }
 
 // lchain.c:113-138 for one pair with every input wave-uniform (single segment, no cDNA, chn_pen_skip == 0: the MODE_LUT
@@ -1147,7 +1169,7 @@ __device__ __forceinline__ bool pair_score_uniform(const DevParams &P, int xi, i
 
 template <bool TRACK, typename FOld>
 __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, int4 *stage,
-                                            int &best, int &arg, Keep &keep, FOld f_old)
+                                            int &best, int &arg, Keep &keep, FOld f_old, const Progress &prog = Progress())
 {
 	const int lane = lane_id(), i = i0 + lane;
 	// The in-tile phase is a chain of dependent instructions, and in a team every other wave's next tile waits for it: while it lasts
@@ -1175,7 +1197,8 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
-		plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
+		if (prog.ring_slot) plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv, [&](int q, int bv) { prog.publish(q, bv); });
+		else plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
 	} else {
 		// the state machine of lchain.c:189-205 runs on the scalar side.  Anchor t's fields come by v_readlane: scalar loads
 		// would share the wave's lgkm counter with the LDS reads of every step and expose their latency
@@ -1221,7 +1244,22 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			const bool took = ((extra >> lane) & 1ull) != 0ull && ((bestv | 127) < extra_v);
 			bestv = took ? extra_v : bestv;
 			arg = took ? keep0 : arg;
-			plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
+			// (handing out a quarter early: its lanes are final, and they are RIGHT unless one of them, beyond the first anchor that beats the
+			// entry anchor, has ended with the extra candidate -- the very test made for the whole tile below, on the lanes that are final so far;
+			// once it fails nothing more is handed out, the tile is done again the long way, and what was handed out stays right: a lane's
+			// value does not depend on the lanes above it)
+			bool handed_wrong = false;
+			auto hand_out = [&](int q, int bv) {
+				if (handed_wrong) return;
+				const int last = 16 * q + 15;
+				const int f_q = lane < n_here && lane <= last ? bv >> 7 : INT_MIN;
+				const unsigned long long ab = __ballot(f_q > keep.f);
+				const int ts_q = ab ? (int)__builtin_ctzll(ab) : WAVE;
+				if (__ballot(took && lane > ts_q && lane <= last && lane < n_here && bv == extra_v) != 0ull) { handed_wrong = true; return; }
+				prog.publish(q, bv);
+			};
+			if (prog.ring_slot) plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv, hand_out);
+			else plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
 			const int f_l = lane < n_here ? bestv >> 7 : INT_MIN;
 			const unsigned long long above = __ballot(f_l > keep.f);
 			const int t_s = above ? (int)__builtin_ctzll(above) : WAVE;
@@ -1332,10 +1370,10 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 // cooperative one); only the rescue state machine needs it.
 template <int MODE, bool TRACK, typename FOld>
 __device__ __forceinline__ void in_tile(const DevBatch &b, const Target &T, int i0, int n_here, const DevParams &P, const int *lut, int4 *stage,
-                                        int &best, int &arg, Keep &keep, FOld f_old)
+                                        int &best, int &arg, Keep &keep, FOld f_old, const Progress &prog = Progress())
 {
 	if (MODE == MODE_LUT) {
-		in_tile_lut<TRACK>(b, T, i0, n_here, P, stage, best, arg, keep, f_old);
+		in_tile_lut<TRACK>(b, T, i0, n_here, P, stage, best, arg, keep, f_old, prog);
 		return;
 	}
 	const int lane = lane_id(), i = i0 + lane;
@@ -1566,7 +1604,7 @@ __device__ __forceinline__ void run_chunk_pairs(const DevBatch &b, const DevPara
 // (a tile needs ~(window/64 + 2) block sweeps, its critical dependency is 2 of them).  Final scores travel between
 // waves through an LDS ring indexed by anchor number (the sliding predecessor window, max_iter + slack entries);
 // "tiles done" is a release/acquire counter in LDS.  No block barrier inside a chunk.
-struct CoopShared { int done; int keep[6]; int chunk; int bar_count; int bar_gen; };   // one per team
+struct CoopShared { int done; int keep[6]; int chunk; int bar_count; int bar_gen; int part; };   // one per team (part: Progress)
 // Gangs (several workgroups on one chunk, gang_chunk_pairs) are an instantiation of their own, k_score<MODE_LUT, false, true>: the gang code
 // costs the plain kernel registers (250 -> 283 spilled scalars) and 1-3 % at 500 M anchors, where no chunk gets a gang anyway; the host
 // launches it for the micro-batches small enough to end with their largest chunks (Engine: gang_max_n).
@@ -1596,6 +1634,29 @@ __device__ __forceinline__ void team_barrier(CoopShared *sh, int team_size)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The last block of a single tile's sweep while the tile it holds is still in its in-tile phase (Progress): a quarter of its sources at a
+// time, as the owner hands them out; the edge sweep (window start, dq range; dr <= 0 through the table address) does every quarter.
+// sf_of(): this wave's lane of the block's scores as they stand in the ring.  wait_q(q): until quarter q is out (or the whole tile).
+template <class TT, class SF, class WQ>
+__device__ __forceinline__ void sweep_block_by_quarters(const DevBatch &b, const TT &T, const int jb, const int k_from, const int sq, int4 *stage, const DevParams &P,
+                                                        int &best, int &arg, SF &&sf_of, WQ &&wait_q)
+{
+	const int xs = a_x(b, jb + lane_id()), ys = a_y(b, jb + lane_id());
+	const int tx4 = (int)(((unsigned)T.x - 1u) << 2), ty4 = (int)(((unsigned)T.y - 1u) << 2);
+	for (int q = 0; q < 4; ++q) {
+		wait_q(q);
+		const int lo = max(k_from, 16 * q), hi = 16 * q + 16;
+		if (lo >= hi) continue;
+		stage_block_lut(xs, ys, sf_of(), sq, stage);          // (the quarters that are not out yet hold stale scores: nobody reads them)
+		int bestv = best << 7;
+		sweep_block_lut_edge(T.st, tx4, ty4, jb, lo, stage, P, bestv, hi);
+		const int won = bestv & 127;
+		arg = (unsigned)(won - 1) < (unsigned)WAVE ? jb + won - 1 : arg;
+		best = bestv >> 7;
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
 template <int MODE, bool TRACK>
 __device__ __forceinline__ void coop_chunk(const DevBatch &b, const DevParams &P, const int *lut, int4 *stage, int *ring, const int n_slots, CoopShared *sh,
                            const int cs, const int ce, const int wave, const int n_waves)
@@ -1621,10 +1682,10 @@ __device__ __forceinline__ void coop_chunk(const DevBatch &b, const DevParams &P
 		int slot = (int)((unsigned)((jb - cs) / WAVE) % (unsigned)n_slots);
 		for (; jb < i0; jb += WAVE) {
 			const int sq = MODE == MODE_LUT ? a_span(b, jb + lane) : 0;
-			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring
+			const int k = (jb - cs) / WAVE, k_from = tile_lo > jb ? tile_lo - jb : 0;
+			wait_done(k + 1);                                          // that tile's scores are in the ring
 			const int sf = ring[slot * WAVE + lane];
 			slot = slot + 1 == n_slots ? 0 : slot + 1;
-			const int k_from = tile_lo > jb ? tile_lo - jb : 0;
 			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);
 		}
 		const int my_slot = (int)((unsigned)t % (unsigned)n_slots);
@@ -1632,6 +1693,8 @@ __device__ __forceinline__ void coop_chunk(const DevBatch &b, const DevParams &P
 		Keep keep;
 		if (TRACK) { keep.idx = first_lane(sh->keep[0]); keep.x = first_lane(sh->keep[1]); keep.hi = first_lane(sh->keep[2]); keep.y = first_lane(sh->keep[3]); keep.tag = first_lane(sh->keep[4]); keep.f = first_lane(sh->keep[5]); }
 		else { keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0; }
+		// (scores are not handed out a quarter at a time here, as a gang does: a chunk on ONE workgroup is bound by what its CU can sweep, the
+		// wave that would take them is busy, and the extra code costs every other path registers -- measured: no gain, 20 M anchors 7.3 -> 8.3 ms)
 		in_tile<MODE, TRACK>(b, T, i0, n_here, P, lut, stage, best, arg, keep,
 		                     [&](int jj) { const unsigned d = (unsigned)(jj - cs); return ring[(d / WAVE) % (unsigned)n_slots * WAVE + d % WAVE]; });
 		const int i = i0 + lane;
@@ -1801,6 +1864,21 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 		for (; jb < i0; jb += WAVE) {
 			const int sq = a_span(b, jb + lane);
 			const int k = (jb - cs) / WAVE;
+			if (tpu == 1 && wave > 0 && jb + WAVE == i0 && !P.lut_clamp && known <= k) {
+				// The tile before this one is the previous wave's of this workgroup and (as far as this wave knows) still in its in-tile phase:
+				// its scores a quarter at a time as they are handed out (Progress) -- three quarters of this block's sweep leave the chain.
+				const int rs = (int)((unsigned)k % (unsigned)n_slots);
+				sweep_block_by_quarters(b, t.A, jb, t.lo_a > jb ? t.lo_a - jb : 0, sq, stage, P, t.best_a, t.arg_a, [&]() { return ring[rs * WAVE + lane]; },
+				                        [&](int q) {
+					while (known <= k) {
+						known = max(known, first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)));
+						if (known > k || first_lane(__hip_atomic_load(&sh->part, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 4 * k + q + 1) break;
+						__builtin_amdgcn_s_sleep(2);
+					}
+				});
+				have = false;
+				continue;
+			}
 			wait_done(k + 1);                                          // that tile's scores are final
 			int sf;
 			if (in_ring(k)) sf = ring[(unsigned)k % (unsigned)n_slots * WAVE + lane];
@@ -1825,7 +1903,9 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 			}
 		}
 		const Target TA = load_target(b, i0, ce, TRACK);
-		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);
+		Progress prog;
+		if (tpu == 1 && !P.lut_clamp) { prog.ring_slot = ring + slot_a * WAVE; prog.part = &sh->part; prog.base = 4 * ta; }
+		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old, prog);
 		__builtin_amdgcn_s_setprio(MM2GB_INTILE_PRIO);
 		const int f_a = t.arg_a < 0 ? TA.q : t.best_a;
 		if (TA.live) {
@@ -2099,7 +2179,7 @@ __device__ __forceinline__ int team_phase(const DevBatch &b, const DevParams &P,
 	CoopShared *sh = &teams[team];
 	while (true) {
 		const bool given = first >= 0 && team == 0;
-		if (team_wave == 0 && lane_id() == 0) { sh->chunk = given ? first : atomicAdd(&b.counters[cursor], 1); sh->done = 0; sh->keep[0] = -1; }
+		if (team_wave == 0 && lane_id() == 0) { sh->chunk = given ? first : atomicAdd(&b.counters[cursor], 1); sh->done = 0; sh->part = 0; sh->keep[0] = -1; }
 		first = -1;
 		team_barrier(sh, team_size);
 		const int c = first_lane(sh->chunk);
@@ -2183,7 +2263,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void k_score(DevBatch b, DevParam
 				const int st_tiles = (gload(&gs->tiles_per_wave) == 2 ? 2 : 1) * GANG_STRIP_PAIRS;
 				go = next * st_tiles < n_tiles && next * st_tiles - done < 4 * st_tiles;
 			}
-			sh->chunk = go; sh->done = 0; sh->keep[0] = -1;
+			sh->chunk = go; sh->done = 0; sh->part = 0; sh->keep[0] = -1;
 		}
 		team_barrier(sh, SCORE_THREADS / WAVE);
 		const int go = first_lane(sh->chunk);

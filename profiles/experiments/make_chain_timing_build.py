@@ -53,8 +53,8 @@ sub("__device__ unsigned long long g_chain[16];\n",
     "__device__ __forceinline__ void trace(int t, int k, long long v) { if ((threadIdx.x & 63) == 0 && t < 8192) g_trace[t * 8 + k] = v; }\n")
 sub("		const Target T = load_target(b, i0, ce, TRACK);\n		const int n_here = min(WAVE, ce - i0);\n		int best = T.q + 1, arg = -1;\n		const int tile_lo = first_lane(T.st);\n		const int st_hi = bcast(T.st, n_here - 1);\n		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));\n		const int eq_lo = MODE == MODE_LUT && jb < i0",
     "		trace(t, 6, ctick());\n		const Target T = load_target(b, i0, ce, TRACK);\n		const int n_here = min(WAVE, ce - i0);\n		int best = T.q + 1, arg = -1;\n		const int tile_lo = first_lane(T.st);\n		const int st_hi = bcast(T.st, n_here - 1);\n		int jb = cs + ((tile_lo - cs) & ~(WAVE - 1));\n		const int eq_lo = MODE == MODE_LUT && jb < i0")
-sub("			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring\n			const int sf = ring[slot * WAVE + lane];\n			slot = slot + 1 == n_slots ? 0 : slot + 1;\n			const int k_from = tile_lo > jb ? tile_lo - jb : 0;\n			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);\n",
-    "			const bool last_blk = jb + WAVE >= i0;\n			if (last_blk) trace(t, 0, ctick());\n			wait_done((jb - cs) / WAVE + 1);                           // that tile's scores are in the ring\n			if (last_blk) trace(t, 1, ctick());\n			const int sf = ring[slot * WAVE + lane];\n			slot = slot + 1 == n_slots ? 0 : slot + 1;\n			const int k_from = tile_lo > jb ? tile_lo - jb : 0;\n			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);\n			if (last_blk) trace(t, 2, ctick());\n")
+sub("			wait_done(k + 1);                                          // that tile's scores are in the ring\n			const int sf = ring[slot * WAVE + lane];\n			slot = slot + 1 == n_slots ? 0 : slot + 1;\n			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);\n",
+    "			const bool last_blk = jb + WAVE >= i0;\n			if (last_blk) trace(t, 0, ctick());\n			wait_done(k + 1);                                          // that tile's scores are in the ring\n			if (last_blk) trace(t, 1, ctick());\n			const int sf = ring[slot * WAVE + lane];\n			slot = slot + 1 == n_slots ? 0 : slot + 1;\n			sweep_any<MODE>(b, T, jb, k_from, sf, sq, jb >= st_hi && jb + WAVE <= eq_lo, stage, P, lut, best, arg);\n			if (last_blk) trace(t, 2, ctick());\n")
 sub("		const long long tk1 = tick();\n", "		const long long tk1 = tick();\n		trace(t, 3, ctick());\n")
 sub("		const int i = i0 + lane;\n		const int fi = arg < 0 ? T.q : best;\n		if (T.live) {\n			ring[my_slot * WAVE + lane] = fi;",
     "		trace(t, 4, ctick());\n		const int i = i0 + lane;\n		const int fi = arg < 0 ? T.q : best;\n		if (T.live) {\n			ring[my_slot * WAVE + lane] = fi;")
@@ -71,8 +71,8 @@ def gsub(old, new):
     src = src[:at] + src[at:].replace(old, new, 1)
 gsub("			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);\n		}\n		const int slot_a", "			if (jb + 2 * WAVE >= i0 && jb + WAVE < i0) trace(pr, 0, ctick());\n			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);\n		}\n		trace(pr, 1, ctick());\n		const int slot_a")
 gsub("		wait_done(ta);                                               // every earlier tile is final\n		Keep keep;", "		wait_done(ta);                                               // every earlier tile is final\n		trace(pr, 2, ctick());\n		Keep keep;")
-gsub("		const Target TA = load_target(b, i0, ce, TRACK);\n		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);\n",
-     "		const Target TA = load_target(b, i0, ce, TRACK);\n		asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); trace(pr, 3, ctick());\n		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old);\n		trace(pr, 4, ctick());\n")
+gsub("		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old, prog);\n",
+     "		asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); trace(pr, 3, ctick());\n		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old, prog);\n		trace(pr, 4, ctick());\n")
 gsub("			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);\n", "			trace(pr, 5, ctick());\n			sweep_a_into_b(b, t, cs, i0, f_a, TA.q, stage, P);\n			trace(pr, 6, ctick());\n")
 gsub("			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);\n", "			in_tile<MODE_LUT, TRACK>(b, TB, i0 + WAVE, t.n_b, P, lut, stage, t.best_b, t.arg_b, keep, f_old);\n			trace(pr, 7, ctick());\n")
 
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_bench_steps(long long *out, int iters, D
 	tl.stage = stage; tl.edges = false; tl.kind = KIND < 3 ? KIND : 0;
 	int bestv = (q + 1) << 7;
 	long long t0 = __builtin_amdgcn_s_memtime();
-	for (int it = 0; it < iters; ++it) { tl.tx4 += 4; tl.ty4 += 4; asm volatile("" ::: "memory"); plain_steps_impl<KIND < 3 ? KIND : 0>(tl, need, bestv); bestv = (bestv & 0xfffff) | (1 << 12); asm volatile("" : "+v"(bestv)); }
+	for (int it = 0; it < iters; ++it) { tl.tx4 += 4; tl.ty4 += 4; asm volatile("" ::: "memory"); plain_steps_impl<KIND < 3 ? KIND : 0>(tl, need, bestv, NoQuarter()); bestv = (bestv & 0xfffff) | (1 << 12); asm volatile("" : "+v"(bestv)); }
 	long long t1 = __builtin_amdgcn_s_memtime();
 	if (lane == 0) out[blockIdx.x] = t1 - t0;
 	out[1024 + blockIdx.x * 64 + lane] = bestv;
