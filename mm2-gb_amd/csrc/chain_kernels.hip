@@ -511,6 +511,9 @@ constexpr int SCORE_THREADS = 1024;
 #ifndef MM2GB_GANG_POLL_SLEEP
 #define MM2GB_GANG_POLL_SLEEP 4        // x 64 cycles, in a gang (its waves wait for the chain through the chunk's tiles and little else)
 #endif
+#ifndef MM2GB_QUARTER_POLL_SLEEP
+#define MM2GB_QUARTER_POLL_SLEEP 8     // x 64 cycles between two looks at the quarters a tile has handed out (every look is an LDS trip the in-tile wave waits behind)
+#endif
 #ifndef MM2GB_INTILE_PRIO
 #define MM2GB_INTILE_PRIO 3
 #endif
@@ -1074,17 +1077,20 @@ struct Progress {
 	int base = 0;                                           // 4 * (tile of the chunk)
 	__device__ __forceinline__ void publish(const int q, const int bestv) const
 	{
+		// Scores and counter are both in LDS, and the LDS executes one wave's instructions in the order they were issued: the counter's store
+		// follows the scores' without a fence (a release here waits for every LDS read the in-tile phase has asked for ahead: 2 k cycles per
+		// quarter in a gang's trace).  The reader's acquire load of the counter precedes its loads of the scores the same way.
 		if ((lane_id() >> 4) == q) ring_slot[lane_id()] = bestv >> 7;   // (packed value >> 7: the score, also of a lane without predecessor)
 		__builtin_amdgcn_wave_barrier();
-		if (lane_id() == 0) __hip_atomic_store(part, base + q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (lane_id() == 0) __hip_atomic_store(part, base + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__builtin_amdgcn_wave_barrier();
 	}
 };
-struct NoQuarter { __device__ __forceinline__ void operator()(int, int) const {} };
 
 enum { ROWS_FREE = 0, ROWS_CHECKED = 1, ROWS_CLAMPED = 2 };   // no test at all | dq range and window start | those and a clamped table index
 
-template <int KIND, class Q>
-__device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsigned long long need, int &bestv, Q &&on_quarter)
+template <int KIND>
+__device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsigned long long need, int &bestv)
 {
 	int negv = INT_MIN / 2, keep_hi = ~127, pos = 0x7fffffff;
 	asm volatile("" : "+v"(negv), "+v"(keep_hi), "+v"(pos));      // VGPRs, not literals per row
@@ -1116,7 +1122,6 @@ __device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsign
 	// of a typical tile's sources are needed by nobody (profiles/experiments/intile_counts.py)
 	unsigned long long gm = (need | need >> 1) & 0x5555555555555555ull;
 	auto next_group = [&]() { const int t = gm ? (int)__builtin_ctzll(gm) : -1; gm &= gm - 1; return t; };
-	int qdone = 0;                                                // quarters of the tile handed to on_quarter so far (the last one is the caller's)
 	int tc = next_group();                                        // the group whose steps run in this turn of the loop
 	int tn = next_group();                                        // the one after it: its rows are computed meanwhile
 	int4 sa = tl.stage[tc], sb = tl.stage[tc + 1];
@@ -1137,21 +1142,29 @@ __device__ __forceinline__ void plain_steps_impl(const TileLut &tl, const unsign
 		__builtin_amdgcn_sched_barrier(0);                          // the reads stay HERE, a whole turn ahead of their use (the scheduler likes them next to it)
 		step(tc + 1, m1);
 		tc = tn; tn = tnn;
-		// every source before tc has been applied or needs none: the quarters that end before it are final
-		while (qdone < 3 && 16 * qdone + 15 < tc) { on_quarter(qdone, bestv); ++qdone; }
 	}
 	step(tc, finish(ra, pa));
 	step(tc + 1, finish(rb, pb));
-	while (qdone < 3) { on_quarter(qdone, bestv); ++qdone; }
 }
 
-template <class Q = NoQuarter>
-__device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv, Q &&on_quarter = Q())
+__device__ __forceinline__ void plain_steps(const TileLut &tl, unsigned long long need, int &bestv)
 {
 	if (!need) return;
-	if (tl.kind == ROWS_FREE) plain_steps_impl<ROWS_FREE>(tl, need, bestv, on_quarter);
-	else if (tl.kind == ROWS_CHECKED) plain_steps_impl<ROWS_CHECKED>(tl, need, bestv, on_quarter);
-	else plain_steps_impl<ROWS_CLAMPED>(tl, need, bestv, on_quarter);
+	if (tl.kind == ROWS_FREE) plain_steps_impl<ROWS_FREE>(tl, need, bestv);
+	else if (tl.kind == ROWS_CHECKED) plain_steps_impl<ROWS_CHECKED>(tl, need, bestv);
+	else plain_steps_impl<ROWS_CLAMPED>(tl, need, bestv);
+}
+// The same a quarter of the tile at a time, on_quarter(q, bestv) after the sources of quarter q < 3 (then the lanes up to 16 q + 16 are final):
+// Progress.  Four runs of the loop rather than a test per turn inside it -- with the test the compiler spreads the callback's arithmetic over
+// every turn (a gang's in-tile phase: 11 k -> 18 k cycles).
+template <class Q>
+__device__ __forceinline__ void plain_steps_by_quarters(const TileLut &tl, const unsigned long long need, int &bestv, Q &&on_quarter)
+{
+#pragma nounroll
+	for (int q = 0; q < 4; ++q) {
+		plain_steps(tl, need & (0xffffull << (16 * q)), bestv);
+		if (q < 3) on_quarter(q, bestv);
+	}
 }
 
 // lchain.c:113-138 for one pair with every input wave-uniform (single segment, no cDNA, chn_pen_skip == 0: the MODE_LUT
@@ -1197,7 +1210,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	int bestv = (best << 7) - (arg < 0 ? 1 : 0);
 	if (!TRACK) {
 		// source t matters only if anchor t+1 reaches back to it (window starts are monotone)
-		if (prog.ring_slot) plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv, [&](int q, int bv) { prog.publish(q, bv); });
+		if (prog.ring_slot) plain_steps_by_quarters(tl, __ballot(T.live && T.st < i) >> 1, bestv, [&](int q, int bv) { prog.publish(q, bv); });
 		else plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
 	} else {
 		// the state machine of lchain.c:189-205 runs on the scalar side.  Anchor t's fields come by v_readlane: scalar loads
@@ -1249,7 +1262,9 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			// once it fails nothing more is handed out, the tile is done again the long way, and what was handed out stays right: a lane's
 			// value does not depend on the lanes above it)
 			bool handed_wrong = false;
+			const bool any_took = __ballot(took) != 0ull;               // (no lane took the entry anchor: nothing to test)
 			auto hand_out = [&](int q, int bv) {
+				if (!any_took) { prog.publish(q, bv); return; }
 				if (handed_wrong) return;
 				const int last = 16 * q + 15;
 				const int f_q = lane < n_here && lane <= last ? bv >> 7 : INT_MIN;
@@ -1258,7 +1273,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 				if (__ballot(took && lane > ts_q && lane <= last && lane < n_here && bv == extra_v) != 0ull) { handed_wrong = true; return; }
 				prog.publish(q, bv);
 			};
-			if (prog.ring_slot) plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv, hand_out);
+			if (prog.ring_slot) plain_steps_by_quarters(tl, __ballot(T.live && T.st < i) >> 1, bestv, hand_out);
 			else plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);
 			const int f_l = lane < n_here ? bestv >> 7 : INT_MIN;
 			const unsigned long long above = __ballot(f_l > keep.f);
@@ -1873,7 +1888,7 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 					while (known <= k) {
 						known = max(known, first_lane(__hip_atomic_load(&sh->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)));
 						if (known > k || first_lane(__hip_atomic_load(&sh->part, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 4 * k + q + 1) break;
-						__builtin_amdgcn_s_sleep(2);
+						__builtin_amdgcn_s_sleep(MM2GB_QUARTER_POLL_SLEEP);
 					}
 				});
 				have = false;

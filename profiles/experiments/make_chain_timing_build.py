@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_bench_steps(long long *out, int iters, D
 	tl.stage = stage; tl.edges = false; tl.kind = KIND < 3 ? KIND : 0;
 	int bestv = (q + 1) << 7;
 	long long t0 = __builtin_amdgcn_s_memtime();
-	for (int it = 0; it < iters; ++it) { tl.tx4 += 4; tl.ty4 += 4; asm volatile("" ::: "memory"); plain_steps_impl<KIND < 3 ? KIND : 0>(tl, need, bestv, NoQuarter()); bestv = (bestv & 0xfffff) | (1 << 12); asm volatile("" : "+v"(bestv)); }
+	for (int it = 0; it < iters; ++it) { tl.tx4 += 4; tl.ty4 += 4; asm volatile("" ::: "memory"); plain_steps_impl<KIND < 3 ? KIND : 0>(tl, need, bestv); bestv = (bestv & 0xfffff) | (1 << 12); asm volatile("" : "+v"(bestv)); }
 	long long t1 = __builtin_amdgcn_s_memtime();
 	if (lane == 0) out[blockIdx.x] = t1 - t0;
 	out[1024 + blockIdx.x * 64 + lane] = bestv;
