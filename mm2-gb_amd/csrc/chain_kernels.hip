@@ -26,6 +26,19 @@ namespace mm2gb {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Wave-wide maximum and the previous lane's value without the LDS crossbar: DPP row shifts and row broadcasts (six dependent vector
+// instructions where six ds_bpermute trips take ~10x as long -- they sit in the in-tile phase of the rescue build, on a team's chain)
+__device__ __forceinline__ int wave_max_i32_dpp(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of every row holds the row's maximum
+	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+	v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+	return __builtin_amdgcn_readlane(v, WAVE - 1);
+}
+__device__ __forceinline__ int prev_lane(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1 (lane 0 keeps its own)
 // An anchor's fields straight from the caller's array (mm128_t as four dwords: x.lo x.hi y.lo y.hi): reference position = x.lo, query position
 // = y.lo, q_span = y.hi & 0xff (lchain.c:125), segment id = y.hi >> 16 & 0xff (lchain.c:116).  Until round 3 k_window copied them into
 // arrays of their own (12 B written and read again per anchor: a third of that kernel's traffic) -- the score kernel reads a source block once
@@ -1198,7 +1211,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 	// "source inside this lane's window" and "dr != 0" (lchain.c:120) cannot fail when every window starts before the tile
 	// (then all its anchors share strand|rid and are sorted by position, so equal positions are neighbours) and no two
 	// neighbours are equal.  Lanes past the end of the chunk may then accept anything: they are never stored nor broadcast.
-	const int x_prev = __shfl_up(T.x, 1);
+	const int x_prev = prev_lane(T.x);
 	tl.edges = __ballot(T.live && (T.st > i0 || (lane > 0 && T.x == x_prev))) != 0;
 	// (dead lanes repeat the tile's last live anchor: what they accept is never stored nor broadcast)
 	// plain_steps: no test at all where no window starts inside the tile, the tile spans at most dq_lim - bw bases (dq > dq_lim is then
@@ -1281,8 +1294,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			if (__ballot(took && lane > t_s && lane < n_here && bestv == extra_v) == 0ull) {
 				if (above) {
 					int top = f_l;
-					for (int off = WAVE / 2; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));
-					top = first_lane(top);
+					top = wave_max_i32_dpp(top);
 					keep.idx = i0 + (int)__builtin_ctzll(__ballot(f_l == top)); keep.f = top;
 					mode = IN_TILE;                                   // (its other fields below)
 				}
@@ -1364,8 +1376,7 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 			plain_steps(tl, (__ballot(T.live && T.st < i) >> 1) & (t_from < WAVE ? ~0ull << t_from : 0ull), bestv);
 			const int f_l = (lane >= t_from && lane < n_here) ? bestv >> 7 : INT_MIN;
 			int top = f_l;
-			for (int off = WAVE / 2; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));
-			top = first_lane(top);
+			top = wave_max_i32_dpp(top);
 			if (top > keep.f) { keep.idx = i0 + __builtin_ctzll(__ballot(f_l == top)); keep.f = top; }
 		}
 		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile
@@ -1905,6 +1916,7 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 			sweep_pair_block(b, t, jb, eq_lo, sf, sq, stage, P);
 		}
 		const int slot_a = (int)((unsigned)ta % (unsigned)n_slots), slot_b = slot_a + 1 == n_slots ? 0 : slot_a + 1;
+		const Target TA = load_target(b, i0, ce, TRACK);             // (asked for before the wait: a memory round trip off the gang's chain)
 		wait_done(ta);                                               // every earlier tile is final
 		Keep keep;
 		keep.idx = -1; keep.x = keep.hi = keep.y = keep.tag = keep.f = 0;
@@ -1917,7 +1929,6 @@ __device__ __forceinline__ void gang_chunk_pairs(const DevBatch &b, const DevPar
 				keep.y = first_lane(gload(&gs->keep[3])); keep.tag = first_lane(gload(&gs->keep[4])); keep.f = first_lane(gload(&gs->keep[5]));
 			}
 		}
-		const Target TA = load_target(b, i0, ce, TRACK);
 		Progress prog;
 		if (tpu == 1 && !P.lut_clamp) { prog.ring_slot = ring + slot_a * WAVE; prog.part = &sh->part; prog.base = 4 * ta; }
 		in_tile<MODE_LUT, TRACK>(b, TA, i0, t.n_a, P, lut, stage, t.best_a, t.arg_a, keep, f_old, prog);
