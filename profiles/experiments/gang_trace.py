@@ -18,12 +18,17 @@ L = mm.lib()
 pairs = os.environ.get("MM2GB_GANG_PAIRS", "0") not in ("", "0")
 nt = min(8192, (len(a) + 127) // 128 if pairs else (len(a) + 63) // 64)
 buf = np.zeros(nt * 8, np.int64)
+c2 = (C.c_ulonglong * 8)()
 with mm.Engine() as e:
     e.score(a, off)
+    L.mm2gb_debug_chain2(c2, 1)
     st = e.score(a, off)[2]
+    L.mm2gb_debug_chain2(c2, 1)
     print("gang counts", e.gang_counts())
     L.mm2gb_debug_chain_trace(C.c_void_p(buf.ctypes.data), nt)
 tr = buf.reshape(nt, 8).astype(np.float64)
+if c2[3]:
+    print(f"rescue build in-tile phases on the fast path: {c2[3]}; per phase: before the steps {c2[0] / c2[3]:.0f}, the steps {c2[1] / c2[3]:.0f}, after them {c2[2] / c2[3]:.0f} ticks")
 print(f"{len(a)} anchors, {nt} pairs, {st['n_pairs']} pairs of anchors, ms_score {st['ms_score']:.3f}; stamps are s_memtime ticks (~0.43 ns)")
 lo, hi = 50, nt - 2
 t = np.arange(lo + 1, hi)

@@ -122,12 +122,28 @@ extern "C" double mm2gb_debug_bench_steps(int kind, int n_wg, int iters, unsigne
 }
 """)
 src = src.replace("#include <algorithm>\n", "#include <algorithm>\n#include <vector>\n#include <string.h>\n", 1)
+
+# ---- round 4: the rescue build's in-tile phase in three parts (ticks of s_memtime summed over phases): 13 from its start to the plain steps of the
+# fast path, 14 those steps (incl. the quarters handed out), 15 from their end to the end of the phase; in g_chain2[0..2], phases counted in [3]
+sub("__device__ unsigned long long g_chain[16];\n", "__device__ unsigned long long g_chain[16];\n__device__ unsigned long long g_chain2[8];\n"
+    "__device__ __forceinline__ void chain2_add(int k, long long v) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_chain2[k], (unsigned long long)v); }\n")
+sub("		enum { ENTRY = 0, IN_TILE = 1, FULL = 2 };\n", "		enum { ENTRY = 0, IN_TILE = 1, FULL = 2 };\n		const long long ck0 = (long long)__builtin_amdgcn_s_memtime();\n		long long ck1 = ck0, ck2 = ck0;\n")
+sub("			if (prog.ring_slot) plain_steps_by_quarters(tl, __ballot(T.live && T.st < i) >> 1, bestv, hand_out);\n			else plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);\n",
+    "			ck1 = (long long)__builtin_amdgcn_s_memtime();\n			if (prog.ring_slot) plain_steps_by_quarters(tl, __ballot(T.live && T.st < i) >> 1, bestv, hand_out);\n			else plain_steps(tl, __ballot(T.live && T.st < i) >> 1, bestv);\n			ck2 = (long long)__builtin_amdgcn_s_memtime();\n")
+sub("		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile\n",
+    "		if (ck2 != ck0) { const long long ck3 = (long long)__builtin_amdgcn_s_memtime(); chain2_add(0, ck1 - ck0); chain2_add(1, ck2 - ck1); chain2_add(2, ck3 - ck2); chain2_add(3, 1); }\n		if (mode == IN_TILE) {                                                   // the anchor remembered now is one of this tile\n")
 src += '''
 extern "C" void mm2gb_debug_chain_ticks(unsigned long long *out, int reset)
 {
 	(void)hipDeviceSynchronize();
 	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_chain), 128);
 	if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm2gb::g_chain), z, 128); }
+}
+extern "C" void mm2gb_debug_chain2(unsigned long long *out, int reset)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm2gb::g_chain2), 64);
+	if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm2gb::g_chain2), z, 64); }
 }
 extern "C" void mm2gb_debug_chain_trace(long long *out, int n_tiles)
 {
