@@ -1301,7 +1301,8 @@ __device__ __forceinline__ void in_tile_lut(const DevBatch &b, const Target &T, 
 				done_fast = true;
 			} else { bestv = bestv0; arg = arg0; }
 		}
-		StepPre cur = tile_pre(tl, 0);
+		StepPre cur; cur.basev = 0; cur.ok = 0ull;
+		if (!done_fast) cur = tile_pre(tl, 0);                                     // (two LDS trips nobody needs once the tile is done)
 		int t = done_fast ? n_here : 0;
 		for (; t < n_here; ++t) {
 			if (mode == IN_TILE) break;                                              // the rest of the tile: plain steps, below

@@ -2,7 +2,8 @@
 Runs tests/synth_cases.fuzz_case batches through the HIP path and the oracle; the first batch that differs is written
 to gpurun_out/fuzz_fail_<seed>_<iteration>.npz (anchors, offsets, GPU f/p, parameters) and the exit code is 1.
 --teams adds three engines whose planner thresholds send every chunk that fits the LDS ring to the big (8/16-wave) teams and to
-the 4-wave teams (normally reserved for long chunks), so the cooperative paths see the same odd shapes."""
+the 4-wave teams (normally reserved for long chunks), and one that sends every chunk of two strips or more to a gang of workgroups, so the cooperative
+paths see the same odd shapes."""
 import argparse, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
@@ -56,7 +57,11 @@ if args.teams:
     engines.append(("team4", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "100000000"})))
     # every heavy chunk on a 4-wave team, also with windows wider than the team's share of the ring (older scores from global memory)
     engines.append(("team4all", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_TEAM4_ALL": "1", "MM2GB_WHOLE_WG_PCT": "0"})))
+    # every chunk of two strips or more on a gang of workgroups (round 4): scores and the rescue state across workgroups, quarters handed out early
+    engines.append(("gangs", make_engine({"MM2GB_LONG_MIN_COST": "1", "MM2GB_LONG_MIN_WINDOW": "1", "MM2GB_WIDE_WINDOW": "1", "MM2GB_GANG_PCT": "100000", "MM2GB_GANG_MAX": "64",
+                                          "MM2GB_GANG_MAX_ANCHORS": "2000000000"})))
 seen = {name: [0, 0] for name, _ in engines}
+gang_chunks = 0
 for seed in args.seeds:
     rng = np.random.default_rng(seed)
     for it in range(args.iters):
@@ -68,6 +73,8 @@ for seed in args.seeds:
             eng.set_misc(misc_from(prm))
             f, p, st = eng.score(a, off)
             seen[name][0] += st["n_long_chunks"]; seen[name][1] += st["n_mid_chunks"]
+            if name == "gangs":
+                gang_chunks += eng.gang_counts()[0]
             if args.post and name == "default":
                 post_differs(eng, a, off, prm, f"seed {seed} iteration {it}")
             bad = np.flatnonzero((f != fo) | (p != po_rel))
@@ -121,7 +128,7 @@ for seed in args.seeds:
             print("seed", seed, "clean over", args.big, "large batches and", args.huge, "of >= 20 M anchors", flush=True)
     if failed:
         break
-print("chunks sent to big / 4-wave teams per engine:", seen)
+print("chunks sent to big / 4-wave teams per engine:", seen, "| chunks scored by gangs (engine 'gangs'):", gang_chunks)
 for _, e in engines:
     e.close()
 sys.exit(1 if failed else 0)

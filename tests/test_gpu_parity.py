@@ -427,12 +427,12 @@ def test_fuzz_random_batches_and_parameters(engine):
                 assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (it, r, kw)
 
 
-def test_fuzz_soak_five_engine_configurations():
-    """tests/fuzz_soak.py inside the suite: one seed (from the kernel sources' hash) x 100 batches x the five
+def test_fuzz_soak_six_engine_configurations():
+    """tests/fuzz_soak.py inside the suite: one seed (from the kernel sources' hash) x 100 batches x six
     engine configurations -- default planner, every chunk on 8-wave teams, on whole-workgroup teams, on 4-wave teams, on 4-wave teams
-    with windows wider than the ring share -- each batch against the oracle on every anchor, the device post-pass against the host
+    with windows wider than the ring share, on gangs of workgroups -- each batch against the oracle on every anchor, the device post-pass against the host
     post-pass, 2 larger bench-like batches with random parameters, and one batch of >= 20 M anchors (30-300 kb reads: team modes, gangs and
-    the planner's lists under real load) -- every anchor of it against the oracle under all five configurations.  The bug that mattered in round 2 (the unchecked sweep judging a
+    the planner's lists under real load) -- every anchor of it against the oracle under all six configurations.  The bug that mattered in round 2 (the unchecked sweep judging a
     tile by an anchor of the next read) was found by exactly this tool."""
     import os
     import subprocess
