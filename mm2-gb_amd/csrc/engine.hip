@@ -287,7 +287,7 @@ void Engine::shutdown()
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
-	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_mark, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -422,7 +422,7 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	cap_post_n = cap_post_reads = 0;                    // as in reserve(): only restored when every buffer has its size
 	// per-chain arrays are sized for min_cnt = 1 (a chain per anchor): min_cnt is a per-call parameter and may drop
 	const size_t chains = (size_t)(nn + nr);
-	if (post_z.ensure((size_t)nn * 8) || post_mark.ensure((size_t)nn) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
+	if (post_z.ensure((size_t)nn * 8) || post_fp.ensure((size_t)nn * 8) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
 	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_misc.ensure(2048) || post_bins.ensure(2 * N_SIZE_CLASSES * 4) || post_order.ensure((size_t)nr * 4) ||
 	    post_up4.ensure((size_t)nn * 4) || post_up16.ensure((size_t)nn * 4)) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
@@ -453,7 +453,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	PostOut &po = post_out[out_set];
 	PostBatch b;
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads; b.f = d_f; b.p = d_p;
-	b.z = (unsigned long long*)post_z.ptr; b.mark = (uint8_t*)post_mark.ptr; b.picked = (int32_t*)post_picked.ptr;
+	b.z = (unsigned long long*)post_z.ptr; b.fp = (int2*)post_fp.ptr; b.picked = (int32_t*)post_picked.ptr;
 	b.up4 = (int32_t*)post_up4.ptr; b.up16 = (int32_t*)post_up16.ptr;
 	b.u_tmp = (unsigned long long*)post_utmp.ptr; b.heads = (ulonglong2*)post_heads.ptr;
 	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)po.u_off.ptr; b.a_off = (int64_t*)po.a_off.ptr;
@@ -676,7 +676,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	float ms = 0;
 	if (n_reads > 0 && hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
 	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	if (debug_phases && n > 0 && rmq) print_post_debug(n_reads, (const int64_t*)s.offsets.ptr);
+	if (debug_phases && n > 0) print_post_debug(n_reads, (const int64_t*)s.offsets.ptr);
 	if (debug_phases && n > 0)
 		fprintf(stderr, "[mm2gb chain_gpu%s] %lld anchors in, %lld kept: enqueued at %.1f ms, device done at %.1f ms (post-pass %.1f ms), results copied at %.1f ms\n", rmq ? ", rmq" : "",
 		        (long long)n, (long long)n_a, s_enqueued * 1e3, s_synced * 1e3, ms, last.ms_total);
@@ -1038,7 +1038,7 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 			fprintf(stderr, "[mm2gb post-pass] sort level %d: %.1f ms; %lld radix passes over %lld elements: %lld cycles, %lld steps, refills of one line %lld, of all lines %lld\n",
 			        lv, t[13 + lv] / 1e5, t[24 + 6 * lv + 5], t[24 + 6 * lv + 4], t[24 + 6 * lv + 3], t[24 + 6 * lv], t[24 + 6 * lv + 1], t[24 + 6 * lv + 2]);
 	if (t[6])
-		fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld, candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[12]);
+		fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld (%lld rounds of 64 anchors), candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[20], t[12]);
 	if (t[6])
 		fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
 		        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);

@@ -17,7 +17,7 @@ struct PostBatch {
 	int64_t        n, n_reads;
 	const int32_t *f, *p;      // scores and relative predecessors, as k_score leaves them
 	unsigned long long *z;     // n: candidates (f << 32 | i), sorted in place
-	uint8_t  *mark;            // n: the host's t[] (lchain.c:43)
+	int2     *fp;              // n: (f, p | taken << 31) per anchor, written by k_post_lift: what a chain walk needs of an anchor in ONE 8-byte load; the top bit of .y is the host's t[] (lchain.c:43)
 	int32_t  *picked;          // n: the host's v[] (lchain.c:65)
 	int32_t  *up4, *up16;      // n each: distance to the anchor 4 / 16 predecessor links down the path (0 = path ends before)
 	unsigned long long *u_tmp; // n / mc + n_reads: chains in the order they were found

@@ -401,14 +401,19 @@ __global__ __launch_bounds__(256) void k_post_size_scatter(PostBatch b)
 // --------------------------------------------------------------------------------------------------------------
 // lifting tables of the predecessor links: up4[i] / up16[i] = distance from anchor i to the anchor 4 / 16 links down its path
 // (0 = the path is shorter).  p is relative and never leaves the read, so this is one pass over all anchors of the batch per level.
+// The first level also writes the walks' records fp[i] = (f[i], p[i]): a walk asks for an anchor's score, link and "taken" flag
+// together, at an address no other lane of the wave is near -- one 8-byte load instead of three loads from three arrays (the flag is
+// the top bit of .y; p is never negative).
 // --------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_post_lift(PostBatch b, int level)
 {
 	const int32_t *src = level == 0 ? b.p : b.up4;
 	int32_t *dst = level == 0 ? b.up4 : b.up16;
 	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
-		int64_t t = g;
-		for (int k = 0; k < 4 && t >= 0; ++k) { const int rj = src[t]; t = rj ? t - rj : -1; }
+		const int r0 = src[g];
+		if (level == 0) b.fp[g] = make_int2(b.f[g], r0);           // the walks' record of the anchor, nothing taken yet (lchain.c:43)
+		int64_t t = r0 ? g - r0 : -1;
+		for (int k = 1; k < 4 && t >= 0; ++k) { const int rj = src[t]; t = rj ? t - rj : -1; }
 		dst[g] = t < 0 ? 0 : (int32_t)(g - t);
 	}
 }
@@ -418,11 +423,11 @@ __global__ __launch_bounds__(256) void k_post_lift(PostBatch b, int level)
 // --------------------------------------------------------------------------------------------------------------
 namespace {
 
-struct WalkDbg { long long load = 0, longt = 0, groups = 0, open = 0, nlong = 0; };
+struct WalkDbg { long long load = 0, longt = 0, groups = 0, open = 0, nlong = 0, iters = 0; };
 
 // The chain walks of one read (lchain.c:44-74) over its sorted candidates z[0, n_z): one wave.
-__device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t off, const int n_z, const unsigned long long *z, const int32_t *f, const int32_t *p,
-                                               uint8_t *mark, int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd)
+__device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t off, const int n_z, const unsigned long long *z, int2 *fp,
+                                               int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd)
 {
 	const int l = lane();
 	long long &dbg_load = wd.load, &dbg_longt = wd.longt, &dbg_groups = wd.groups, &dbg_open = wd.open, &dbg_long = wd.nlong;
@@ -431,6 +436,8 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 	// X-drop of more than max_drop below the best prefix) is a chain of dependent loads, one memory round trip per anchor, and
 	// walks depend on each other through the marks.  Candidates are handled 64 at a time, in the host's order.
 	const int32_t *up4 = b.up4 + off, *up16 = b.up16 + off;
+	constexpr int TAKEN = INT_MIN;                           // top bit of fp[i].y
+	int *fpw = (int*)fp;                                     // fpw[2 i + 1] = fp[i].y
 	int n_u = 0, n_v = 0;
 	for (int kb = n_z - 1; kb >= 0; kb -= W) {
 		const int k_l = kb - l;
@@ -448,19 +455,19 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 			// knows -- one round trip of independent loads instead of SPEC + 1 dependent ones.
 			wave_sync();
 			const long long ta = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-			int m0 = 1, mx[SPEC];
+			int p0 = TAKEN, pn[SPEC];                            // link | taken of the candidate and of the anchors down its path
 			int own_kept = 0, own_best = 0, own_ended = 0, touched = 0;   // the lane's own walk as far as it can tell now
 #pragma unroll
-			for (int j = 0; j < SPEC; ++j) mx[j] = 1;
+			for (int j = 0; j < SPEC; ++j) pn[j] = TAKEN;
 			if (fresh) {
 #pragma unroll
 				for (int j = 0; j < SPEC; ++j) { nx[j] = -1; sx[j] = top_l; }
 			}
 			if ((pending >> l) & 1) {
-				m0 = mark[n0];
+				p0 = fpw[2 * n0 + 1];
 				if (fresh) {
-					int pc = p[n0];
-					if (m0 == 0) {
+					int pc = p0;
+					if (p0 >= 0) {
 						int cur = n0, best = 0, kept = 0;
 						bool ended = false;
 #pragma unroll
@@ -468,10 +475,10 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 							if (!ended) {
 								const int next = pc ? cur - pc : -1;
 								nx[j] = next;
-								if (next >= 0) { sx[j] = top_l - f[next]; mx[j] = mark[next]; pc = p[next]; }
+								if (next >= 0) { const int2 rec = fp[next]; sx[j] = top_l - rec.x; pn[j] = rec.y; pc = rec.y; }
 								if (sx[j] > best) { best = sx[j]; kept = j + 1; }
 								else if (best - sx[j] > b.max_drop) ended = true;
-								if (mx[j] != 0) ended = true;
+								if (pn[j] < 0) ended = true;
 								cur = next;
 							}
 						}
@@ -479,8 +486,8 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					}
 				} else {
 #pragma unroll
-					for (int j = 0; j < SPEC; ++j) if (nx[j] >= 0) mx[j] = mark[nx[j]];
-					if (m0 == 0) {
+					for (int j = 0; j < SPEC; ++j) if (nx[j] >= 0) pn[j] = fpw[2 * nx[j] + 1];
+					if (p0 >= 0) {
 						int best = 0, kept = 0;
 						bool ended = false;
 #pragma unroll
@@ -488,7 +495,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 							if (!ended) {
 								if (sx[j] > best) { best = sx[j]; kept = j + 1; }
 								else if (best - sx[j] > b.max_drop) ended = true;
-								if (mx[j] != 0) ended = true;
+								if (pn[j] < 0) ended = true;
 							}
 						}
 						own_kept = kept; own_best = best; own_ended = ended;
@@ -498,13 +505,13 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 			fresh = false;
 			// The candidates in order, on wave-uniform copies of their lane's values -- no memory round trip for a walk that ends
 			// within SPEC steps.  What an earlier walk of the group takes is set in the later lanes' copies of the marks.
-			unsigned long long open = __ballot(m0 == 0);
+			unsigned long long open = __ballot(p0 >= 0);
 			bool stale = false;
 			if (b.dbg) { dbg_load += (long long)__builtin_amdgcn_s_memrealtime() - ta; ++dbg_groups; dbg_open += __popcll(open); }
 			while (open != 0 && !stale) {
 				const int src = first_set(open);                 // lowest lane = highest k
 				open &= open - 1;
-				if (__builtin_amdgcn_readlane(m0, src) != 0) continue;   // taken by an earlier walk of this group
+				if (__builtin_amdgcn_readlane(p0, src) < 0) continue;    // taken by an earlier walk of this group
 				const int c0 = __builtin_amdgcn_readlane(n0, src);
 				if (__builtin_amdgcn_readlane(own_ended, src) != 0 && __builtin_amdgcn_readlane(touched, src) == 0) {
 					// no earlier walk of the group took any anchor this lane looked at: its own evaluation stands (most candidates:
@@ -514,12 +521,13 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					for (int j = 0; j < SPEC; ++j) {
 						if (j < kept) {
 							const int v = j == 0 ? c0 : __builtin_amdgcn_readlane(nx[j > 0 ? j - 1 : 0], src);
-							if (l == 0) { picked[n_v + j] = v; mark[v] = 1; }
+							const int link = j == 0 ? __builtin_amdgcn_readlane(p0, src) : __builtin_amdgcn_readlane(pn[j > 0 ? j - 1 : 0], src);
+							if (l == 0) { picked[n_v + j] = v; fpw[2 * v + 1] = link | TAKEN; }
 							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
 							touched |= hit;
-							m0 |= n0 == v;
+							p0 |= n0 == v ? TAKEN : 0;
 #pragma unroll
-							for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
+							for (int i = 0; i < SPEC; ++i) pn[i] |= nx[i] == v ? TAKEN : 0;
 						}
 					}
 					if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
@@ -532,7 +540,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 				int cn[SPEC], cs[SPEC], cm[SPEC];
 #pragma unroll
 				for (int j = 0; j < SPEC; ++j) {
-					cn[j] = __builtin_amdgcn_readlane(nx[j], src); cs[j] = __builtin_amdgcn_readlane(sx[j], src); cm[j] = __builtin_amdgcn_readlane(mx[j], src);
+					cn[j] = __builtin_amdgcn_readlane(nx[j], src); cs[j] = __builtin_amdgcn_readlane(sx[j], src); cm[j] = __builtin_amdgcn_readlane(pn[j], src);
 				}
 				// `kept` is how many of the visited anchors lie before the one the best prefix stops at
 				int cur = c0, kept = 0, visited = 0, best = 0;
@@ -544,7 +552,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						++visited;
 						if (cs[j] > best) { best = cs[j]; kept = visited; }
 						else if (best - cs[j] > b.max_drop) ended = true;
-						if (cm[j] != 0) ended = true;
+						if (cm[j] < 0) ended = true;
 						cur = cn[j];
 					}
 				}
@@ -553,13 +561,14 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 #pragma unroll
 					for (int j = 0; j < SPEC; ++j) {
 						if (j < kept) {
-							const int v = j == 0 ? c0 : cn[j - 1];
-							if (l == 0) mark[v] = 1;
+							const int v = j == 0 ? c0 : cn[j > 0 ? j - 1 : 0];
+							const int link = j == 0 ? __builtin_amdgcn_readlane(p0, src) : cm[j > 0 ? j - 1 : 0];
+							if (l == 0) fpw[2 * v + 1] = link | TAKEN;
 							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
 							touched |= hit;
-							m0 |= n0 == v;
+							p0 |= n0 == v ? TAKEN : 0;
 #pragma unroll
-							for (int i = 0; i < SPEC; ++i) mx[i] |= nx[i] == v;
+							for (int i = 0; i < SPEC; ++i) pn[i] |= nx[i] == v ? TAKEN : 0;
 						}
 					}
 				} else {
@@ -572,14 +581,15 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					const long long tl = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 					++dbg_long;
 					while (!ended) {
+						++wd.iters;
 						int t = cur;
 						for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
 						for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
-						for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = p[t]; t = rj ? t - rj : -1; }
+						for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = fpw[2 * t + 1] & ~TAKEN; t = rj ? t - rj : -1; }
 						const bool valid = t >= 0;
-						const int pt = valid ? p[t] : 0, next = pt ? t - pt : -1;
+						const int pt = valid ? fpw[2 * t + 1] & ~TAKEN : 0, next = pt ? t - pt : -1;
 						int s = top, m = 1;
-						if (next >= 0) { s = top - f[next]; m = mark[next]; }
+						if (next >= 0) { const int2 rec = fp[next]; s = top - rec.x; m = rec.y < 0; }
 						// best prefix BEFORE this lane's step
 						int inc = valid ? s : INT_MIN;
 						for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
@@ -600,7 +610,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						else { visited += W; cur = __shfl(next, W - 1); }
 					}
 					wave_sync();
-					for (int q = l; q < kept; q += W) mark[picked[n_v + q]] = 1;
+					for (int q = l; q < kept; q += W) { int *w = &fpw[2 * picked[n_v + q] + 1]; *w |= TAKEN; }
 					if (b.dbg) dbg_longt += (long long)__builtin_amdgcn_s_memrealtime() - tl;
 				}
 				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
@@ -615,9 +625,9 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 	n_u_out = n_u; n_v_out = n_v;
 }
 
-// candidates of anchors [i_lo, i_hi) of a read, in index order (lchain.c:35-41), appended at z[at...]; marks cleared (lchain.c:43).
+// candidates of anchors [i_lo, i_hi) of a read, in index order (lchain.c:35-41), appended at z[at...] (nothing is taken yet: k_post_lift wrote the records).
 // Returns how many; any / all: OR and AND of their keys (which key bytes differ at all).
-__device__ __forceinline__ int post_collect(const PostBatch &b, const int32_t *f, uint8_t *mark, unsigned long long *z, int i_lo, int i_hi, int at, bool write,
+__device__ __forceinline__ int post_collect(const PostBatch &b, const int32_t *f, unsigned long long *z, int i_lo, int i_hi, int at, bool write,
                                             unsigned &any, unsigned &all)
 {
 	const int l = lane();
@@ -626,7 +636,6 @@ __device__ __forceinline__ int post_collect(const PostBatch &b, const int32_t *f
 		const int i = base + l;
 		const bool in = i < i_hi;
 		const int fi = in ? f[i] : INT_MIN;
-		if (in && write) mark[i] = 0;
 		const bool take = in && fi >= b.min_sc;
 		const unsigned long long m = __ballot(take);
 		if (take) { any |= (unsigned)fi; all &= (unsigned)fi; }
@@ -668,18 +677,17 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 			const int n = (int)(b.offsets[r + 1] - off);
 			const int32_t *f = b.f + off;
 			unsigned long long *z = b.z + off;
-			uint8_t *mark = b.mark + off;
 			// candidates: every wave a quarter of the anchors (whole groups of 64), counted first, then written behind the earlier quarters'
 			const int per = ((n + 4 * W - 1) / (4 * W)) * W;
 			const int i_lo = min(n, w * per), i_hi = min(n, (w + 1) * per);
 			unsigned any = 0, all = ~0u;
-			const int mine = post_collect(b, f, mark, z, i_lo, i_hi, 0, false, any, all);
+			const int mine = post_collect(b, f, z, i_lo, i_hi, 0, false, any, all);
 			for (int o = W / 2; o > 0; o >>= 1) { any |= __shfl_xor(any, o); all &= __shfl_xor(all, o); }
 			if (l == 0) { s_team[1 + w] = mine; s_bits[2 * w] = any; s_bits[2 * w + 1] = all; }
 			__syncthreads();
 			int at = 0, n_z = 0;
 			for (int k = 0; k < POST_THREADS / W; ++k) { const int c = uni(s_team[1 + k]); if (k < w) at += c; n_z += c; any |= s_bits[2 * k]; all &= s_bits[2 * k + 1]; }
-			{ unsigned a2 = 0, b2 = ~0u; post_collect(b, f, mark, z, i_lo, i_hi, at, true, a2, b2); }
+			{ unsigned a2 = 0, b2 = ~0u; post_collect(b, f, z, i_lo, i_hi, at, true, a2, b2); }
 			__threadfence_block();
 			__syncthreads();
 			// the top pass: the highest key byte in which any two candidates differ (sort_like_host), wave 0 alone
@@ -738,16 +746,16 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 		}
 		const int64_t off = b.offsets[r];
 		const int n = (int)(b.offsets[r + 1] - off);
-		const int32_t *f = b.f + off, *p = b.p + off;
+		const int32_t *f = b.f + off;
 		unsigned long long *z = b.z + off;
-		uint8_t *mark = b.mark + off;
+		int2 *fp = b.fp + off;
 		int32_t *picked = b.picked + off;
 		unsigned long long *u_tmp = b.u_tmp + chain_slot(off, r, mc);
 		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		long long t1 = t0, t2 = t0;
 		if (!team) {
 			unsigned any = 0, all = ~0u;
-			n_z = post_collect(b, f, mark, z, 0, n, 0, true, any, all);
+			n_z = post_collect(b, f, z, 0, n, 0, true, any, all);
 			wave_sync();
 			t1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			sort_like_host<ZElem>(z, n_z, L, b.dbg);
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 		}
 		int n_u = 0, n_v = 0;
 		WalkDbg wd;
-		post_walk_read(b, off, n_z, z, f, p, mark, picked, u_tmp, n_u, n_v, wd);
+		post_walk_read(b, off, n_z, z, fp, picked, u_tmp, n_u, n_v, wd);
 		wave_sync();
 		if (l == 0) {
 			b.n_u[r] = n_u;
@@ -775,6 +783,7 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 				atomicAdd((unsigned long long*)&b.dbg[10], (unsigned long long)wd.open);
 				atomicAdd((unsigned long long*)&b.dbg[11], (unsigned long long)wd.nlong);
 				atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z);
+				atomicAdd((unsigned long long*)&b.dbg[20], (unsigned long long)wd.iters);
 			}
 		}
 		wave_sync();
