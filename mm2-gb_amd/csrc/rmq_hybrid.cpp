@@ -176,6 +176,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	std::string h_err;
 	double h_seconds = 0;
 	std::thread host_side, tie_side;
+	std::atomic<bool> host_done{ n_host == 0 };          // the host side's threads are free again (the tie redo may take all of them)
 	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } join_host{ host_side }, join_tie{ tie_side };   // (also when this thread runs out of memory)
 	if (n_host < R) {
 		// the device's share first, on every thread: its side is the longer one and cannot start before its anchors are in one piece
@@ -195,6 +196,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			h_rc = mm2gb_rmq_chain_host(prm, (int64_t)n_host, h_off.data(), h_ptr, h_threads, &h_out, nullptr);
 			if (h_rc) h_err = mm2gb_last_error();
 			h_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - th).count();
+			host_done.store(true, std::memory_order_release);
 		});
 	}
 	std::vector<int32_t> tied(R - n_host + 1, 0);
@@ -229,8 +231,9 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 					t_off.push_back(t_off.back() + n);
 				}
 				const mm2gb_anchor_t *t_ptr = t_a.data();
-				// the tie redo takes the threads the host side is not using: together they stay within the caller's n_threads (plus this one)
-				const int t_threads = n_host > 0 ? std::max(1, nt / 2) : nt;
+				// the tie redo takes the threads the host side is not using -- all of them when it is through with its share (the usual case:
+				// the deal gives it what it finishes while the device fills) --: together they stay within the caller's n_threads (plus this one)
+				const int t_threads = host_done.load(std::memory_order_acquire) ? nt : std::max(1, nt / 2);
 				tie_side = std::thread([&, t_ptr, t_threads]() {
 					const auto tt = std::chrono::steady_clock::now();
 					t_rc = mm2gb_rmq_chain_host_tied(prm, (int64_t)redo.size(), t_off.data(), t_ptr, t_threads, &t_out);
