@@ -2,9 +2,10 @@
 //
 // What the path computes is fixed by the reference's CPU code (lchain.c:113-207); how it is computed here is not
 // taken from the reference's gpu/*.cu:
-//   * k_window      mm128_t AoS -> SoA on the device (the reference does this on one CPU thread, plmem.cu:154-198) and, in the
-//                   same pass, the predecessor-window start of every anchor by bisection in LDS (role of plrange.cu:38-76)
-//                   and the planner's per-block reductions (cuts, pair counts, widest windows, max_iter clamps)
+//   * k_window      the predecessor-window start of every anchor by bisection in LDS (role of plrange.cu:38-76), the input flags and
+//                   the planner's per-block reductions (cuts, pair counts, widest windows, max_iter clamps) in one pass over the
+//                   16-byte mm128_t records, which every kernel reads IN PLACE: there is no AoS -> SoA copy (the reference makes
+//                   one on a CPU thread, plmem.cu:154-198)
 //   * plan_*        turn cuts into independent, cost-ordered work items ("chunks") without host round trips
 //                   (role of the cut/long_seg/mid_seg bookkeeping, plscore.cu:314-385, and the host pairsort, plchain.cu:30-42)
 //   * k_score<MODE> the DP: persistent workgroups; 64 anchors per tile held one-per-lane in registers; predecessors are staged
@@ -51,9 +52,9 @@ __device__ __forceinline__ int a_tag(const DevBatch &b, int i) { return tag_of((
 
 
 // --------------------------------------------------------------------------------------------------------------
-// AoS -> SoA, predecessor window start (lchain.c:172-173), planner reductions
-//   the block's own anchors are read once as mm128_t (16 B, coalesced) and leave as x / y / tag for the score kernel
-//   (role of the CPU loop plmem.cu:154-198) together with the input flags; look-back probes read the raw anchors too
+// predecessor window start (lchain.c:172-173), input flags, planner reductions
+//   the block's own anchors are read once as mm128_t (16 B, coalesced); nothing but st[] and the flags is written (the score kernel
+//   reads the same records in place: no SoA copy, role of plmem.cu:154-198 not needed); look-back probes read the raw anchors too
 //   st[i] = max( first j <= i in the same read with xhi[j]==xhi[i] and x[i] <= x[j]+max_dist_x ,  i - max_iter )
 // The CPU carries st across iterations; because validity is monotone in both i and j (anchors sorted by x) the
 // carried value equals this closed form ("window start").
