@@ -35,7 +35,7 @@ typedef struct {
 /* One read travelling through seed -> chain -> align; layout of chain_read_t (gpu/plutils.h:45-73, non-debug build).
  * The chaining step reads a/n and writes a, u, n_u (a is replaced by the compacted array, or freed and set to 0 when
  * nothing chains: plchain.cu:129-145). */
-typedef struct {
+typedef struct mm2gb_chain_read_s {
 	mm2gb_seq_meta_t seq;
 	const char **qseqs;
 	int         *qlens;
@@ -50,9 +50,25 @@ typedef struct {
 	int          n_u;
 } mm2gb_chain_read_t;
 
-/* The host's index and option records are opaque here; they are only handed back to the host callbacks below. */
+/* The host's index and option records are opaque here; they are handed back to the host callbacks below.  One exception: to answer a
+ * batch's re-chaining calls ahead of the host's callback (below, "re-chaining ahead") the library reads the LEADING fields of mm_mapopt_t
+ * (minimap.h:128-145) through this mirror -- the ones map.c:444-451 reads when it decides whether a read is re-chained and with what.
+ * tests/test_host_cpu.py compiles the reference header and compares every offset. */
 struct mm_idx_s;
 struct mm_mapopt_s;
+typedef struct {
+	int64_t flag;
+	int seed, sdust_thres, max_qlen;
+	int bw, bw_long;
+	int max_gap, max_gap_ref;
+	int max_frag_len;
+	int max_chain_skip, max_chain_iter;
+	int min_cnt, min_chain_score;
+	float chain_gap_scale, chain_skip_scale;
+	int rmq_size_cap, rmq_inner_dist;
+	int rmq_rescue_size;
+	float rmq_rescue_ratio;
+} mm2gb_mapopt_head_t;
 
 /* gpu/plutils.h:98-99, plchain.cu:470-486.  Reads gpu_config_file, creates one engine per configured stream, reports
  * the batch limits the host should accumulate to: *max_total_n = max_total_n x micro_batch anchors,
@@ -73,6 +89,23 @@ void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt,
 
 /* gpu/plutils.h:102, plchain.cu:549-557. */
 void free_stream_gpu(int n_threads);
+
+/* ---- re-chaining ahead (csrc/rechain_ahead.cpp).  post_chaining_helper (map.c:428-456), which chain_stream_gpu / finish_stream_gpu call for
+ * every read they hand back (plchain.cu:502-507, 539-541), re-chains most long reads with mg_lchain_rmq (lchain.c:250-369), one read per call on
+ * the calling thread.  In a host linked with -Wl,--wrap=mg_lchain_rmq those calls arrive at __wrap_mg_lchain_rmq below; the
+ * boundary calls then answer the whole batch's re-chaining FIRST -- map.c:444-448's trigger evaluated per read, copies of the kept anchors
+ * sorted as radix_sort_128x will sort them, one mm2gb_rmq_chain on the device beside the stream's host threads -- and a call is answered from
+ * that batch when its input equals the stored input byte for byte (it is done on the spot otherwise).  Active when the host program imports
+ * __wrap_mg_lchain_rmq (read from its ELF symbol table) and opt->max_chain_skip >= opt->rmq_size_cap (the device form is exhaustive);
+ * MM2GB_PRECHAIN=0 / 1 overrides the first condition. ---- */
+mm2gb_anchor_t *__wrap_mg_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
+                                     float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km);
+/* single-read re-chaining calls so far: all, those answered from a batch's answers made ahead, reads answered ahead in all */
+void mm2gb_rechain_ahead_counts(int64_t *calls, int64_t *answered_ahead, int64_t *reads_ahead);
+/* test hooks: offsets of the mirror's fields (order in csrc/rechain_ahead.cpp), ELF import probe, map.c:444-448's trigger */
+int  mm2gb_mapopt_head_layout(int32_t *out, int max_out);
+int  mm2gb_elf_imports_symbol(const char *path, const char *name);
+int  mm2gb_rechain_wanted(const mm2gb_mapopt_head_t *opt, const struct mm2gb_chain_read_s *read);
 
 /* ---- what the library imports from the host (resolved at link/load time; weak, so the library also loads alone) ----
  *   Misc  build_misc(const mm_idx_t*, const mm_mapopt_t*, const int64_t qlen_sum, const int n_seg);      map.c:393

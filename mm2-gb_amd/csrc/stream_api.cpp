@@ -17,6 +17,7 @@
 #include "../../include/mm2gb_plutils.h"
 #include "engine.h"
 #include "host_chain.h"
+#include "rechain_ahead.h"
 #include "trace.h"
 #include <sched.h>
 #include <map>
@@ -83,6 +84,11 @@ struct StreamSlot {
 	HostStage stage[2];
 	int  cur = 0;                          // stage of the batch in flight
 	bool live = false;
+	// re-chaining ahead (rechain_ahead.cpp): an engine of its own, made when first needed -- `eng` has the next batch in flight while the
+	// batch handed back is re-chained, and a device re-chaining call owns its engine's streams and arenas -- and the answers of the batch that
+	// is going through the host's callback
+	mm2gb_engine_t *rmq_eng = nullptr;
+	RechainAhead ahead;
 };
 
 static struct {
@@ -93,6 +99,7 @@ static struct {
 	bool post_on_device = false;           // MM2GB_POST=gpu (or MM2GB_POST_THREADS=0): no host post-pass threads at all
 	bool ready = false;
 	bool debug = false;                    // MM2GB_DEBUG_PHASES: where a batch's host time goes, on stderr
+	bool rechain_ahead = false;            // answer a batch's mg_lchain_rmq calls before the host's callback asks (host linked with --wrap, or MM2GB_PRECHAIN=1)
 } g_streams;
 
 static double now_ms()
@@ -105,6 +112,7 @@ static double now_ms()
 	fprintf(stderr, "[Error] %s\n", msg.c_str());   // the reference's style for fatal configuration problems (plmem.cu:390-412)
 	exit(1);
 }
+#define MM2GB_HIP_DIE(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) die(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 static int devices_for_streams(std::vector<int> &out)
 {
@@ -389,7 +397,10 @@ mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_
 // ---------------------------------------------------------------------------------------------------------------
 // one read, mg_lchain_rmq's signature (lchain.c:250-369)
 // ---------------------------------------------------------------------------------------------------------------
-static std::atomic<int64_t> g_rmq_calls(0), g_rmq_tied_calls(0);
+static std::atomic<int64_t> g_rmq_calls(0), g_rmq_tied_calls(0), g_rmq_from_ahead(0), g_reads_ahead(0), g_ns_ahead(0);
+// the answers of the batch whose reads the calling thread is handing to post_chaining_helper right now, and the read it is at (one call per read, map.c:450)
+static thread_local const RechainAhead *t_ahead = nullptr;
+static thread_local int32_t t_ahead_slot = -1;
 // what the library held of a run (MM2GB_REPORT=1 prints it when the host frees the streams): nanoseconds summed over the host's threads
 static std::atomic<int64_t> g_ns_chain(0), g_ns_helper(0), g_ns_rmq(0), g_tot_batches(0), g_tot_reads(0), g_tot_anchors(0);
 static inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -403,6 +414,29 @@ mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int m
 	if (_u) *_u = 0, *n_u_ = 0;
 	if (n == 0 || a == 0) { mem.release(a); return 0; }                       // lchain.c:260-263
 	const mm2gb_rmq_param_t prm = { max_dist, max_dist_inner, bw, max_chn_skip, cap_rmq_size, min_cnt, min_sc, chn_pen_gap, chn_pen_skip };
+	if (t_ahead && t_ahead_slot >= 0) {
+		// this read was re-chained with its whole batch before the callback started (rechain_ahead.cpp): the answer is the call's answer iff the
+		// call IS the one that was answered -- same parameters, same anchors in the same order, byte for byte
+		const RechainAhead &ah = *t_ahead;
+		const int32_t s = t_ahead_slot;
+		t_ahead_slot = -1;
+		if (s + 1 < (int32_t)ah.off.size() && n == ah.off[s + 1] - ah.off[s] && memcmp(&prm, &ah.prm, sizeof prm) == 0 &&
+		    memcmp(a, ah.sorted.data() + ah.off[s], (size_t)n * sizeof(mm2gb_anchor_t)) == 0) {
+			const mm2gb_chains_t &c = ah.res.c;
+			const int n_u = (int)(c.u_off[s + 1] - c.u_off[s]);
+			const int64_t n_a = c.a_off[s + 1] - c.a_off[s];
+			uint64_t *u = nullptr; mm2gb_anchor_t *res = nullptr;
+			if (n_u > 0) {
+				u = (uint64_t*)mem.alloc((size_t)n_u * 8);
+				res = (mm2gb_anchor_t*)mem.alloc((size_t)n_a * 16);
+				memcpy(u, c.u + c.u_off[s], (size_t)n_u * 8); memcpy(res, c.a + c.a_off[s], (size_t)n_a * 16);
+			}
+			mem.release(a);                                                      // input is consumed (lchain.c:357-360,109)
+			g_rmq_calls.fetch_add(1); g_rmq_from_ahead.fetch_add(1);
+			*n_u_ = n_u; *_u = u;
+			return res;
+		}
+	}
 	const int64_t off[2] = { 0, n };
 	mm2gb_chains_t out;
 	int32_t tied = 0;
@@ -456,6 +490,48 @@ void mm2gb_lchain_rmq_counts(int64_t *calls, int64_t *tied_calls)
 	if (tied_calls) *tied_calls = g_rmq_tied_calls.load();
 }
 
+void mm2gb_rechain_ahead_counts(int64_t *calls, int64_t *answered_ahead, int64_t *reads_ahead)
+{
+	if (calls) *calls = g_rmq_calls.load();
+	if (answered_ahead) *answered_ahead = g_rmq_from_ahead.load();
+	if (reads_ahead) *reads_ahead = g_reads_ahead.load();
+}
+
+// The host's callback for every read of a batch that a boundary call hands back (plchain.cu:502-507, 539-541) -- after the batch's
+// re-chaining calls have been answered together where that applies (rechain_ahead.cpp).
+static void hand_to_host_callback(StreamSlot &slot, const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *done, int n_done,
+                                  const mm2gb_misc_t &misc, void *km)
+{
+	if (!done || !post_chaining_helper) return;
+	TraceRange range("mm2gb:post_chaining_helper");
+	bool have = false;
+	if (g_streams.rechain_ahead && opt && n_done > 0) {
+		const mm2gb_mapopt_head_t &o = *(const mm2gb_mapopt_head_t*)opt;
+		if (rechain_ahead_is_exact(o)) {
+			const int64_t t0 = now_ns();
+			if (!slot.rmq_eng) {
+				MM2GB_HIP_DIE(hipSetDevice(slot.eng.device));
+				slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &misc, slot.eng.device);
+				if (!slot.rmq_eng) die(mm2gb_last_error());
+			}
+			if (rechain_ahead(slot.rmq_eng, o, misc, done, n_done, g_streams.post_threads, slot.ahead)) die(mm2gb_last_error());
+			have = slot.ahead.n_ahead() > 0;
+			g_reads_ahead.fetch_add(slot.ahead.n_ahead());
+			g_ns_ahead.fetch_add(now_ns() - t0);
+			if (g_streams.debug)
+				fprintf(stderr, "[mm2gb stream] re-chaining ahead: %lld of %d reads, %lld anchors | select %.1f ms | copy + sort %.1f ms | one call %.1f ms (device %lld reads %.1f ms || host %lld reads %.1f ms, %lld tied redone %.1f ms)\n",
+				        (long long)slot.ahead.n_ahead(), n_done, (long long)(have ? slot.ahead.off.back() : 0), slot.ahead.s_select * 1e3, slot.ahead.s_sort * 1e3, slot.ahead.s_call * 1e3,
+				        (long long)slot.ahead.deal.n_device, slot.ahead.deal.device_s * 1e3, (long long)slot.ahead.deal.n_host_cost, slot.ahead.deal.host_s * 1e3, (long long)slot.ahead.deal.n_host_tie, slot.ahead.deal.tie_s * 1e3);
+		}
+	}
+	for (int i = 0; i < n_done; ++i) {
+		if (have) { t_ahead = &slot.ahead; t_ahead_slot = slot.ahead.slot_of_read[(size_t)i]; }
+		post_chaining_helper(mi, opt, &done[i], misc, km);
+	}
+	t_ahead = nullptr; t_ahead_slot = -1;
+	if (have) slot.ahead.clear();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // the reference's boundary
 // ---------------------------------------------------------------------------------------------------------------
@@ -496,6 +572,12 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	g_streams.post_threads = pt ? std::max(1, atoi(pt)) : std::max(1, std::min(32, usable_cpus() / std::max(1, cfg.num_streams)));
 	{ const char *dbg = getenv("MM2GB_DEBUG_PHASES"); g_streams.debug = dbg && *dbg && *dbg != '0'; }
 	{ const char *pm = getenv("MM2GB_POST"); g_streams.post_on_device = (pm && strcmp(pm, "gpu") == 0) || (pt && atoi(pt) == 0); }
+	// re-chaining ahead only helps a host whose mg_lchain_rmq calls reach this library: one linked with -Wl,--wrap=mg_lchain_rmq imports
+	// __wrap_mg_lchain_rmq (an undefined dynamic symbol of the program); MM2GB_PRECHAIN=0 / 1 overrides what its symbol table says
+	{
+		const char *pc = getenv("MM2GB_PRECHAIN");
+		g_streams.rechain_ahead = pc && *pc ? atoi(pc) != 0 : elf_imports_symbol("/proc/self/exe", "__wrap_mg_lchain_rmq");
+	}
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
 	for (int s = 0; s < cfg.num_streams; ++s) {
@@ -536,10 +618,7 @@ void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, 
 	if (launched) slot.cur ^= 1;
 	*in_arr_ptr = done; *n_read_ptr = n_done;
 	const int64_t t_mid = now_ns();
-	if (done && post_chaining_helper) {
-		TraceRange range("mm2gb:post_chaining_helper");
-		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], done_misc, km);   // plchain.cu:502-507
-	}
+	hand_to_host_callback(slot, mi, opt, done, n_done, done_misc, km);                         // plchain.cu:502-507
 	const int64_t t_out = now_ns();
 	g_ns_chain.fetch_add(t_mid - t_in); g_ns_helper.fetch_add(t_out - t_mid);
 }
@@ -553,8 +632,7 @@ void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt,
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
 	if (finish_stage(slot, slot.stage[slot.cur], km, &done, &n_done, &misc)) die(mm2gb_last_error());
 	const int64_t t_mid = now_ns();
-	if (done && post_chaining_helper)
-		for (int i = 0; i < n_done; ++i) post_chaining_helper(mi, opt, &done[i], misc, km);   // plchain.cu:539-541
+	hand_to_host_callback(slot, mi, opt, done, n_done, misc, km);                              // plchain.cu:539-541
 	g_ns_chain.fetch_add(t_mid - t_in); g_ns_helper.fetch_add(now_ns() - t_mid);
 	*batches = done; *num_reads = n_done;
 }
@@ -569,6 +647,7 @@ void free_stream_gpu(int n_threads)
 			if (st.done) (void)hipEventDestroy(st.done);
 		}
 		slot->eng.shutdown();
+		if (slot->rmq_eng) mm2gb_engine_destroy(slot->rmq_eng);
 		delete slot;
 	}
 	g_streams.slots.clear();
@@ -579,9 +658,11 @@ void free_stream_gpu(int n_threads)
 	// calls and is listed apart, and of it what mg_lchain_rmq calls answered by the library took (hosts linked with --wrap=mg_lchain_rmq).
 	if (const char *v = getenv("MM2GB_REPORT"))
 		if (*v && *v != '0') fprintf(stderr, "[mm2gb totals] batches %lld reads %lld anchors %lld | inside chain_stream_gpu / finish_stream_gpu without the host's callback %.3f s | "
-		                             "host callback post_chaining_helper %.3f s | of the callback: mg_lchain_rmq answered by the library %.3f s in %lld calls\n",
+		                             "host callback post_chaining_helper %.3f s | of the callback: mg_lchain_rmq answered by the library %.3f s in %lld calls | "
+		                             "re-chaining ahead of the callback %.3f s for %lld reads, %lld calls answered from it\n",
 		                             (long long)g_tot_batches.load(), (long long)g_tot_reads.load(), (long long)g_tot_anchors.load(), g_ns_chain.load() * 1e-9,
-		                             g_ns_helper.load() * 1e-9, g_ns_rmq.load() * 1e-9, (long long)g_rmq_calls.load());
+		                             (g_ns_helper.load() - g_ns_ahead.load()) * 1e-9, g_ns_rmq.load() * 1e-9, (long long)g_rmq_calls.load(),
+		                             g_ns_ahead.load() * 1e-9, (long long)g_reads_ahead.load(), (long long)g_rmq_from_ahead.load());
 	if (const char *v = getenv("MM2GB_RMQ_REPORT"))
 		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls answered by the library: %lld, of which redone by the library's exact host form because of a tie (device form only): %lld; handed to the host program: 0\n",
 		                             (long long)g_rmq_calls.load(), (long long)g_rmq_tied_calls.load());

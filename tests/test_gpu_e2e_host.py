@@ -188,3 +188,66 @@ def test_multithreaded_host_one_stream_per_thread(tmp_path):
     want = sorted(open(os.path.join(GOLD, "sim160_inf.paf")).read().splitlines())
     got = sorted(r.stdout.decode().splitlines())
     assert got == want
+
+
+@needs_host
+@pytest.mark.parametrize("threads,post", [(1, "host"), (3, "host"), (3, "gpu")])
+def test_rechaining_answered_ahead_for_the_whole_batch(tmp_path, threads, post):
+    """The wrapped host at --max-chain-skip=2147483647 (the setting the path's results are defined at): chain_stream_gpu / finish_stream_gpu
+    answer a batch's mg_lchain_rmq calls TOGETHER on the device before the host's callback asks for them read by read
+    (csrc/rechain_ahead.cpp; map.c:444-451), and every call is then served from that batch after a byte-for-byte comparison of its input.
+    Same PAF as the reference CPU path; nearly every call must have been answered ahead (a wrong guess of map.c's trigger would show here)."""
+    import json
+    import re
+    import sim_reads
+    host_rmq = HOST + "_rmq"
+    if not os.path.exists(host_rmq):
+        pytest.fail("oracle/_ref/minimap2_gpuhost_rmq is missing (make -C oracle gpuhost_rmq where the reference checkout exists)")
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=meta["n_reads"], len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    cfg = json.load(open(CFG))
+    cfg["num_streams"] = threads
+    if threads > 1:
+        cfg["max_total_n"] = 300_000       # small batches so that every thread hands several back
+        cfg["max_read"] = 8
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg))
+    env = dict(os.environ, MM2GB_REPORT="1", MM2GB_POST=post)
+    env.pop("MM2GB_PRECHAIN", None)        # the library finds the wrap in the program's symbol table
+    r = subprocess.run([host_rmq, "-t", str(threads), "--max-chain-skip=2147483647", "--gpu-chain", "--gpu-cfg", str(p), ref, reads],
+                       capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = open(os.path.join(GOLD, "sim160_inf.paf")).read()
+    if threads == 1:
+        assert r.stdout.decode() == want
+    else:
+        assert sorted(r.stdout.decode().splitlines()) == sorted(want.splitlines())
+    m = re.search(r"mg_lchain_rmq answered by the library [0-9.]+ s in (\d+) calls \| re-chaining ahead of the callback [0-9.]+ s for (\d+) reads, (\d+) calls answered from it",
+                  r.stderr.decode())
+    assert m, r.stderr.decode()[-800:]
+    calls, ahead, served = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert calls > 50 and served >= 0.95 * calls and ahead >= served
+    # the plain host (no --wrap) never reaches the library's re-chaining entry: nothing is answered ahead for it
+    r = subprocess.run([HOST, "-t", "1", "--max-chain-skip=2147483647", "--gpu-chain", "--gpu-cfg", CFG, ref, reads], capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.decode() == want
+    m = re.search(r"re-chaining ahead of the callback [0-9.]+ s for (\d+) reads", r.stderr.decode())
+    assert m and int(m.group(1)) == 0
+
+
+@needs_host
+def test_rechaining_ahead_stays_off_at_a_finite_max_chain_skip(tmp_path):
+    """max_chain_skip below the tree's size cap: the reference's skip counter can end an inner scan early (lchain.c:329-333), which the
+    exhaustive device form does not reproduce -- the calls are answered one by one by the host form, as before."""
+    import json
+    import re
+    import sim_reads
+    host_rmq = HOST + "_rmq"
+    meta = json.load(open(os.path.join(GOLD, "sim160.json")))
+    ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=48, len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
+    env = dict(os.environ, MM2GB_REPORT="1", MM2GB_PRECHAIN="1")
+    r = subprocess.run([host_rmq, "-t", "1", "--max-chain-skip=25", "--gpu-chain", "--gpu-cfg", CFG, ref, reads], capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    m = re.search(r"in (\d+) calls \| re-chaining ahead of the callback [0-9.]+ s for (\d+) reads, (\d+) calls answered from it", r.stderr.decode())
+    assert m and int(m.group(1)) > 10 and int(m.group(2)) == 0 and int(m.group(3)) == 0

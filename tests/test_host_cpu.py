@@ -199,3 +199,108 @@ def test_numa_placement_parses_a_sysfs_tree(tmp_path):
     assert mm.numa_cpus_for_bdf("0001:0a:00.0", r) == (3, [])
     (nodes / "node3" / "cpulist").write_text("9-7\n")
     assert mm.numa_cpus_for_bdf("0001:0a:00.0", r) == (3, [])
+
+
+# ---- re-chaining ahead of the host's callback (csrc/rechain_ahead.cpp) ----
+MAPOPT_FIELDS = ["flag", "bw", "bw_long", "max_gap", "max_chain_skip", "min_cnt", "min_chain_score", "rmq_size_cap", "rmq_inner_dist",
+                 "rmq_rescue_size", "rmq_rescue_ratio"]
+# offsetof(mm_mapopt_t, field) as gcc lays minimap.h:128-145 out on x86-64 (recorded from the compiled reference header by the test below)
+MAPOPT_OFFSETS = {"flag": 0, "bw": 20, "bw_long": 24, "max_gap": 28, "max_chain_skip": 40, "min_cnt": 48, "min_chain_score": 52, "rmq_size_cap": 64,
+                  "rmq_inner_dist": 68, "rmq_rescue_size": 72, "rmq_rescue_ratio": 76}
+
+
+def _mirror_layout():
+    L = mm.lib()
+    buf = (C.c_int32 * 16)()
+    n = L.mm2gb_mapopt_head_layout(buf, 16)
+    assert n == len(MAPOPT_FIELDS) + 1
+    return dict(zip(MAPOPT_FIELDS + ["sizeof"], list(buf)[:n]))
+
+
+def test_mapopt_mirror_layout_recorded():
+    got = _mirror_layout()
+    assert {k: got[k] for k in MAPOPT_FIELDS} == MAPOPT_OFFSETS and got["sizeof"] == 80
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/minimap.h"), reason="the reference header only exists in the dev container")
+def test_mapopt_mirror_layout_matches_the_compiled_reference_header(tmp_path):
+    """The library reads opt->bw, bw_long, flag, ... through its own mirror of mm_mapopt_t's leading fields (include/mm2gb_plutils.h): every
+    offset must be the one gcc gives the reference's struct (minimap.h:128-145)."""
+    import subprocess
+    src = tmp_path / "lay.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "minimap.h"\nint main(void){' +
+                   "".join(f'printf("{f} %zu\\n", offsetof(mm_mapopt_t, {f}));' for f in MAPOPT_FIELDS) + "return 0;}\n")
+    exe = tmp_path / "lay"
+    subprocess.run(["gcc", "-I/root/reference", str(src), "-o", str(exe)], check=True)
+    want = {k: int(v) for k, v in (ln.split() for ln in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())}
+    got = _mirror_layout()
+    assert {k: got[k] for k in MAPOPT_FIELDS} == want == MAPOPT_OFFSETS
+
+
+def test_elf_import_probe_tells_a_wrapped_host_from_a_plain_one(tmp_path):
+    """A program linked with -Wl,--wrap=mg_lchain_rmq imports __wrap_mg_lchain_rmq from the library: that is how init_stream_gpu knows whether
+    answering a batch's re-chaining ahead can ever be used."""
+    import subprocess
+    L = mm.lib()
+    L.mm2gb_elf_imports_symbol.argtypes = [C.c_char_p, C.c_char_p]
+    lib_dir = os.path.join(ROOT, "mm2-gb_amd")
+    (tmp_path / "m.c").write_text("void *mg_lchain_rmq(int x); int main(void){ return mg_lchain_rmq(0) != 0; }\n")
+    (tmp_path / "d.c").write_text("void *mg_lchain_rmq(int x){ (void)x; return 0; }\n")
+    for flags, want in ((["-Wl,--wrap=mg_lchain_rmq"], 1), ([], 0)):
+        exe = tmp_path / ("wrapped" if want else "plain")
+        subprocess.run(["gcc", str(tmp_path / "m.c"), str(tmp_path / "d.c"), "-o", str(exe), *flags, "-L" + lib_dir, "-lmm2gb_chain",
+                        "-Wl,--unresolved-symbols=ignore-in-shared-libs"], check=True)
+        assert L.mm2gb_elf_imports_symbol(str(exe).encode(), b"__wrap_mg_lchain_rmq") == want
+    assert L.mm2gb_elf_imports_symbol(b"/nonexistent", b"x") == 0
+    assert L.mm2gb_elf_imports_symbol(os.path.join(ROOT, "README.md").encode(), b"x") == 0      # not an ELF file
+
+
+class _SeqMeta(C.Structure):
+    _fields_ = [("i", C.c_long), ("seg_id", C.c_int), ("name", C.c_char * 200), ("len", C.c_uint32), ("n_alt", C.c_int), ("is_alt", C.c_int), ("qlen_sum", C.c_int)]
+
+
+class _ChainRead(C.Structure):
+    _fields_ = [("seq", _SeqMeta), ("qseqs", C.c_void_p), ("qlens", C.c_void_p), ("n_seg", C.c_int), ("rep_len", C.c_int), ("frag_gap", C.c_int),
+                ("mini_pos", C.c_void_p), ("n_mini_pos", C.c_int), ("a", C.c_void_p), ("n", C.c_int64), ("u", C.c_void_p), ("n_u", C.c_int)]
+
+
+class _MapoptHead(C.Structure):
+    _fields_ = [("flag", C.c_int64), ("seed", C.c_int), ("sdust_thres", C.c_int), ("max_qlen", C.c_int), ("bw", C.c_int), ("bw_long", C.c_int),
+                ("max_gap", C.c_int), ("max_gap_ref", C.c_int), ("max_frag_len", C.c_int), ("max_chain_skip", C.c_int), ("max_chain_iter", C.c_int),
+                ("min_cnt", C.c_int), ("min_chain_score", C.c_int), ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
+                ("rmq_size_cap", C.c_int), ("rmq_inner_dist", C.c_int), ("rmq_rescue_size", C.c_int), ("rmq_rescue_ratio", C.c_float)]
+
+
+def test_rechain_trigger_follows_map_c():
+    """map.c:444-448: long-join re-chaining wanted for a single-segment read with more than one chain whose best chain leaves more than
+    rmq_rescue_size bases uncovered or covers more than rmq_rescue_ratio of the read; never in splice / sr / no-long-join modes."""
+    L = mm.lib()
+    L.mm2gb_rechain_wanted.argtypes = [C.POINTER(_MapoptHead), C.POINTER(_ChainRead)]
+    assert C.sizeof(_ChainRead) == 312 and C.sizeof(_MapoptHead) == 80
+    opt = _MapoptHead(flag=0, bw=500, bw_long=20000, rmq_rescue_size=1000, rmq_rescue_ratio=0.1, max_gap=5000, rmq_size_cap=100000, max_chain_skip=2**31 - 1)
+    a = np.zeros((10, 2), dtype=np.uint64)
+    a[:, 0] = np.arange(10) * 100 + 1000
+    a[:, 1] = (np.uint64(15) << np.uint64(32)) | (np.arange(10, dtype=np.uint64) * np.uint64(100) + np.uint64(50))     # y = 50, 150, ... 950
+    u = np.array([(100 << 32) | 6, (50 << 32) | 4], dtype=np.uint64)                  # best chain: anchors 0..5, y 50 -> 550
+    rd = _ChainRead(n_seg=1, n_u=2, n=10)
+    rd.a, rd.u = a.ctypes.data, u.ctypes.data
+
+    def wanted(qlen):
+        rd.seq.qlen_sum = qlen
+        return L.mm2gb_rechain_wanted(C.byref(opt), C.byref(rd))
+
+    assert wanted(1400) == 1                  # 500 > 1400 * 0.1
+    opt.rmq_rescue_ratio = 0.5
+    assert wanted(1400) == 0                  # 1400 - 500 = 900 <= 1000 and 500 <= 700
+    assert wanted(1600) == 1                  # 1600 - 500 > 1000
+    assert wanted(900) == 1                   # 500 > 450
+    rd.n_u = 1
+    assert wanted(1600) == 0                  # a single chain is never re-chained
+    rd.n_u = 2
+    for flag in (0x080, 0x400, 0x1000):       # MM_F_SPLICE, MM_F_NO_LJOIN, MM_F_SR
+        opt.flag = flag
+        assert wanted(1600) == 0
+    opt.flag = 0x800000000                    # MM_F_GPU_CHAIN alone does not matter
+    assert wanted(1600) == 1
+    opt.bw_long = 500
+    assert wanted(1600) == 0                  # bw_long must exceed bw
