@@ -123,8 +123,9 @@ struct mm2gb_batcher {
 	void work(int k)
 	{
 		mm2gb_engine_t *eng = engines[(size_t)k];
-		// this worker feeds one device: it, and the post-pass threads it starts, run on the CPUs next to that device (numa.cpp)
-		(void)mm2gb_pin_thread_to_device(mm2gb_engine_device(eng));
+		// this worker feeds one device: it, and the post-pass threads it starts, run on the CPUs next to that device (numa.cpp) -- when there
+		// are several workers to keep apart (as pool.cpp: a lone engine's worker and its post-pass threads keep the whole machine)
+		if (engines.size() > 1) (void)mm2gb_pin_thread_to_device(mm2gb_engine_device(eng));
 		for (;;) {
 			Batch *b = nullptr;
 			{

@@ -1095,6 +1095,10 @@ struct Progress {
 		// follows the scores' without a fence (a release here waits for every LDS read the in-tile phase has asked for ahead: 2 k cycles per
 		// quarter in a gang's trace).  The reader's acquire load of the counter precedes its loads of the scores the same way.
 		if ((lane_id() >> 4) == q) ring_slot[lane_id()] = bestv >> 7;   // (packed value >> 7: the score, also of a lane without predecessor)
+		// The hardware order is only worth something if the COMPILER keeps the two stores in program order, and a plain store followed by a
+		// relaxed atomic store to another address is nothing it has to keep: a compiler-only release fence (no instruction, no s_waitcnt)
+		// says so.  Correctness of the gang path depends on it.
+		__atomic_signal_fence(__ATOMIC_RELEASE);
 		__builtin_amdgcn_wave_barrier();
 		if (lane_id() == 0) __hip_atomic_store(part, base + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__builtin_amdgcn_wave_barrier();

@@ -29,6 +29,9 @@ struct DevBuf {
 	void release();
 };
 
+// Buffers replaced by a growth are retired, not freed (engine.hip: hipFree waits for the whole device): this frees them now.
+void flush_retired_buffers();
+
 // Page-locked host buffer that only ever grows.
 struct PinnedBuf {
 	void  *ptr = nullptr;

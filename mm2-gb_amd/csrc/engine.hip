@@ -28,6 +28,41 @@ static size_t grown(size_t need, size_t have)
 	return have == 0 ? need : std::max(need, have + have / 4);
 }
 
+// hipFree and hipHostFree wait for the WHOLE device to go idle.  One engine on its own never noticed; sixteen engines working side by side (the
+// drop-in at -t 16: a stream id and a re-chaining engine per host thread) did: an arena that had to grow in one engine waited for every kernel
+// of every other engine, and the calls of a mini-batch ran one after the other (10 s for what takes 1.6 s, profiles/r05_dropin_notes.md).  So a
+// buffer that is REPLACED because it must grow is not freed but retired: it goes to a process-wide list that is emptied when an engine shuts down,
+// when the list holds more than MM2GB_RETIRE_LIMIT_MB (default 16 GB of device memory, 4 GB page-locked), or when an allocation fails.
+// (Growth is geometric, so what a buffer retires over its life is less than its final size.)  Also safer: a retired buffer stays valid for
+// kernels of the same engine that were enqueued before the growth.
+namespace {
+struct Retired { void *ptr; size_t bytes; bool pinned; };
+std::mutex g_retired_mu;
+std::vector<Retired> g_retired;
+size_t g_retired_dev = 0, g_retired_host = 0;
+
+void flush_retired_locked()
+{
+	for (const Retired &r : g_retired) { if (r.pinned) (void)hipHostFree(r.ptr); else (void)hipFree(r.ptr); }
+	g_retired.clear();
+	g_retired_dev = g_retired_host = 0;
+}
+void retire(void *ptr, size_t bytes, bool pinned)
+{
+	if (!ptr) return;
+	static const size_t limit_mb = [] { const char *v = getenv("MM2GB_RETIRE_LIMIT_MB"); return v ? (size_t)std::max(0LL, atoll(v)) : (size_t)16384; }();
+	std::lock_guard<std::mutex> lock(g_retired_mu);
+	g_retired.push_back({ ptr, bytes, pinned });
+	(pinned ? g_retired_host : g_retired_dev) += bytes;
+	if (g_retired_dev > (limit_mb << 20) || g_retired_host > (limit_mb << 18)) flush_retired_locked();
+}
+} // namespace
+void flush_retired_buffers()
+{
+	std::lock_guard<std::mutex> lock(g_retired_mu);
+	flush_retired_locked();
+}
+
 int DevBuf::ensure(size_t need)
 {
 	if (need <= bytes) return 0;
@@ -36,9 +71,10 @@ int DevBuf::ensure(size_t need)
 	// one given up first; if even that fails the buffer is empty (ptr null, bytes 0) and the caller must treat its capacity as lost.
 	const size_t want = grown(need, bytes);
 	void *fresh = nullptr;
-	if (hipMalloc(&fresh, want) == hipSuccess) { release(); ptr = fresh; bytes = want; return 0; }
+	if (hipMalloc(&fresh, want) == hipSuccess) { retire(ptr, bytes, false); ptr = fresh; bytes = want; return 0; }
 	(void)hipGetLastError();
-	if (hipMalloc(&fresh, need) == hipSuccess) { release(); ptr = fresh; bytes = need; return 0; }
+	flush_retired_buffers();
+	if (hipMalloc(&fresh, need) == hipSuccess) { retire(ptr, bytes, false); ptr = fresh; bytes = need; return 0; }
 	(void)hipGetLastError();
 	release();
 	MM2GB_HIP(hipMalloc(&ptr, need));
@@ -56,9 +92,10 @@ int PinnedBuf::ensure(size_t need)
 	if (need <= bytes) return 0;
 	const size_t want = grown(need, bytes);
 	void *fresh = nullptr;                               // as DevBuf::ensure: a failed growth keeps the old buffer
-	if (hipHostMalloc(&fresh, want, hipHostMallocDefault) == hipSuccess) { release(); ptr = fresh; bytes = want; return 0; }
+	if (hipHostMalloc(&fresh, want, hipHostMallocDefault) == hipSuccess) { retire(ptr, bytes, true); ptr = fresh; bytes = want; return 0; }
 	(void)hipGetLastError();
-	if (hipHostMalloc(&fresh, need, hipHostMallocDefault) == hipSuccess) { release(); ptr = fresh; bytes = need; return 0; }
+	flush_retired_buffers();
+	if (hipHostMalloc(&fresh, need, hipHostMallocDefault) == hipSuccess) { retire(ptr, bytes, true); ptr = fresh; bytes = need; return 0; }
 	(void)hipGetLastError();
 	release();
 	MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
@@ -277,6 +314,7 @@ void Engine::shutdown()
 {
 	(void)hipSetDevice(device);
 	for (hipStream_t s : { s_in, work[0].stream, work[1].stream, s_out }) if (s) (void)hipStreamSynchronize(s);
+	flush_retired_buffers();
 	for (WorkSet &w : work) { for (DevBuf *b : w.all()) b->release(); w.cap_n = w.cap_reads = w.cap_blocks = 0; }
 	lut.release(); dbg.release();
 	for (IoSet &s : io) {

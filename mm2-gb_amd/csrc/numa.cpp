@@ -4,7 +4,7 @@
 // puts the pages on that node), so that H2D / D2H copies and the host post-pass do not cross the socket link.
 //   /sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node      -> node (-1: unknown / single node)
 //   /sys/devices/system/node/node<N>/cpulist                 -> "0-31,128-159"
-// Both are read through a root that tests replace with a made-up tree (MM2GB_SYSFS_ROOT).  The move is an intersection with the CPUs
+// Both are read below a root directory that the test entry point (mm2gb_numa_cpus_for_bdf) can point at a made-up tree.  The move is an intersection with the CPUs
 // the process may use already (affinity mask: a container's cpuset), and nothing happens when that is empty, when the node is
 // unknown, or with MM2GB_NUMA=0.
 #include <hip/hip_runtime.h>
@@ -23,9 +23,7 @@ namespace mm2gb {
 
 static std::string sysfs_root(const char *root)
 {
-	if (root && *root) return root;
-	if (const char *v = getenv("MM2GB_SYSFS_ROOT")) if (*v) return v;
-	return "";
+	return root && *root ? root : "";      // only the test entry point (mm2gb_numa_cpus_for_bdf) passes a root: production reads the real /sys
 }
 
 static bool read_line(const std::string &path, std::string &out)
@@ -124,7 +122,7 @@ int mm2gb_pin_thread_to_device(int device)
 	CPU_ZERO(&want);
 	int n = 0;
 	for (int c : cpus) if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) { CPU_SET(c, &want); ++n; }
-	if (n == 0 || n == CPU_COUNT(&now)) return n == 0 ? 0 : n;       // no usable CPU there, or already exactly there
+	if (n == 0 || n == CPU_COUNT(&now)) return 0;                     // no usable CPU there, or already exactly there: nothing changed
 	if (sched_setaffinity(0, sizeof want, &want) != 0) return -1;
 	return n;
 }

@@ -38,12 +38,12 @@ void for_reads(size_t n, int nt, F &&fn)
 double seconds_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
 } // namespace
 
-bool rechain_wanted(const mm2gb_mapopt_head_t &opt, const mm2gb_chain_read_t &rd)
+bool rechain_wanted(const mm2gb_mapopt_head_t &opt, const RechainRead &rd)
 {
 	if (!(opt.bw_long > opt.bw && (opt.flag & (F_SPLICE | F_SR | F_NO_LJOIN)) == 0 && rd.n_seg == 1 && rd.n_u > 1)) return false;   // map.c:444-446
 	if (!rd.a || !rd.u) return false;
 	const int32_t st = (int32_t)rd.a[0].y, en = (int32_t)rd.a[(int32_t)rd.u[0] - 1].y;                                               // map.c:447
-	const int qlen_sum = rd.seq.qlen_sum;
+	const int qlen_sum = rd.qlen_sum;
 	return qlen_sum - (en - st) > opt.rmq_rescue_size || (float)(en - st) > (float)qlen_sum * opt.rmq_rescue_ratio;                   // map.c:448
 }
 
@@ -55,7 +55,7 @@ bool rechain_ahead_is_exact(const mm2gb_mapopt_head_t &opt)
 	return opt.rmq_size_cap > 0 && opt.max_chain_skip >= opt.rmq_size_cap;
 }
 
-int rechain_ahead(mm2gb_engine_t *eng, const mm2gb_mapopt_head_t &opt, const mm2gb_misc_t &misc, const mm2gb_chain_read_t *reads, int n_reads,
+int rechain_ahead(mm2gb_engine_t *eng, const mm2gb_mapopt_head_t &opt, const mm2gb_misc_t &misc, const RechainRead *reads, int n_reads,
                   int n_threads, RechainAhead &out)
 {
 	out.clear();
@@ -80,7 +80,7 @@ int rechain_ahead(mm2gb_engine_t *eng, const mm2gb_mapopt_head_t &opt, const mm2
 	const auto t1 = std::chrono::steady_clock::now();
 	try { out.sorted.resize((size_t)out.off.back()); } catch (const std::bad_alloc&) { out.clear(); return fail("rechain_ahead: out of host memory"); }
 	for_reads(picked.size(), n_threads, [&](size_t s) {
-		const mm2gb_chain_read_t &rd = reads[picked[s]];
+		const RechainRead &rd = reads[picked[s]];
 		mm2gb_anchor_t *dst = out.sorted.data() + out.off[s];
 		const size_t n = (size_t)(out.off[s + 1] - out.off[s]);
 		memcpy(dst, rd.a, n * sizeof(mm2gb_anchor_t));
@@ -145,6 +145,11 @@ int mm2gb_mapopt_head_layout(int32_t *out, int max_out)
 
 int mm2gb_elf_imports_symbol(const char *path, const char *name) { return path && name && mm2gb::elf_imports_symbol(path, name) ? 1 : 0; }
 
-int mm2gb_rechain_wanted(const mm2gb_mapopt_head_t *opt, const mm2gb_chain_read_t *read) { return opt && read && mm2gb::rechain_wanted(*opt, *read) ? 1 : 0; }
+int mm2gb_rechain_wanted(const mm2gb_mapopt_head_t *opt, const mm2gb_chain_read_t *read)
+{
+	if (!opt || !read) return 0;
+	const mm2gb::RechainRead rd = { read->a, read->u, read->n_u, read->n_seg, read->seq.qlen_sum };
+	return mm2gb::rechain_wanted(*opt, rd) ? 1 : 0;
+}
 
 } // extern "C"

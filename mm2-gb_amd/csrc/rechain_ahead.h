@@ -23,8 +23,11 @@ struct RechainAhead {
 	void clear() { slot_of_read.clear(); off.clear(); mm2gb_chains_free(&res.c); }
 };
 
+// What map.c:444-449 looks at of a read that has been chained: its chains u[0..n_u) over the compacted anchors a[], n_seg, qlen_sum.
+struct RechainRead { const mm2gb_anchor_t *a; const uint64_t *u; int n_u, n_seg, qlen_sum; };
+
 // map.c:444-446: does post_chaining_helper re-chain this read?  (single-segment long reads whose best chain covers little of the read)
-bool rechain_wanted(const mm2gb_mapopt_head_t &opt, const mm2gb_chain_read_t &rd);
+bool rechain_wanted(const mm2gb_mapopt_head_t &opt, const RechainRead &rd);
 
 // True when the device form of the fill gives mg_lchain_rmq's answer for these options: it is exhaustive (max_chn_skip = infinity), and the
 // reference's skip counter (lchain.c:329-333) can never pass a max_chain_skip that is at least the tree's size cap.
@@ -32,7 +35,7 @@ bool rechain_ahead_is_exact(const mm2gb_mapopt_head_t &opt);
 
 // Decide, gather, sort as the host will (radix_sort_128x order, equal keys included), then ONE mm2gb_rmq_chain for the batch
 // (device || n_threads host threads, tied reads redone with the reference's tree).  Returns 0 / -1 (mm2gb_last_error).
-int rechain_ahead(mm2gb_engine_t *eng, const mm2gb_mapopt_head_t &opt, const mm2gb_misc_t &misc, const mm2gb_chain_read_t *reads, int n_reads,
+int rechain_ahead(mm2gb_engine_t *eng, const mm2gb_mapopt_head_t &opt, const mm2gb_misc_t &misc, const RechainRead *reads, int n_reads,
                   int n_threads, RechainAhead &out);
 
 // Does the ELF file at `path` import (undefined dynamic symbol) `name`?  A host linked with -Wl,--wrap=mg_lchain_rmq imports

@@ -70,25 +70,42 @@ struct HostStage {
 	std::vector<int64_t> goff;             // offsets of every read in h_raw / h_f / h_p, size n_read + 1
 	mm2gb_chain_read_t *reads = nullptr;   // owned by the host
 	mm2gb_misc_t misc = {};                // the parameters this batch was LAUNCHED with: its post-pass must use the same ones
+	const struct mm_mapopt_s *opt = nullptr;   // the host's options at launch (for re-chaining ahead; the host keeps one record for the whole run)
 	int  n_read = 0;
 	bool busy = false;
 	bool device_post = false;              // this batch's backtrack + compaction run as kernels; its chains wait in engine post set `post_set`
 	int  post_set = 0;
 	hipEvent_t done = nullptr;             // all f/p of this batch are back in h_f / h_p
+	// ---- what the stream's finisher thread makes of the batch while the host thread is back at seeding the next one (finish_compute):
+	// chains per read in libc memory (host post-pass) or one block (device post-pass), and the batch's re-chaining answered ahead ----
+	bool computed = false;                 // guarded by StreamSlot::mu
+	std::string err;                       // non-empty: the finisher failed (reported by the host thread that picks the batch up)
+	std::vector<uint64_t*> u_of;
+	std::vector<mm2gb_anchor_t*> a_of;
+	std::vector<int> nu_of;
+	mm2gb_chains_t ch = {};
+	RechainAhead ahead;
+	bool have_ahead = false;
+	double ms_wait = 0, ms_post = 0, ms_ahead = 0, t_computed_ms = 0;
 };
 
-// One stream / host thread id.  Two stages alternate: batch k is packed and launched while batch k-1's scores are still
-// being turned into chains on the host, so the GPU never waits for the host post-pass.
+// One stream / host thread id.  Two stages alternate, and each stream has a FINISHER thread: the host thread packs and launches batch k and
+// goes back to its own work (seeding batch k+1); the finisher waits for k's scores, turns them into chains (host post-pass threads, or fetches
+// the device post-pass's), answers the batch's re-chaining ahead of the host's callback (rechain_ahead.cpp) -- so that when the host thread
+// comes back with batch k+1 everything it needs of batch k is there, and what is left is the hand-over into its kalloc arena and its own callback.
+// The engine is used by one thread at a time: the host thread touches it only while no batch of the slot is with the finisher.
 struct StreamSlot {
 	Engine eng;
 	HostStage stage[2];
 	int  cur = 0;                          // stage of the batch in flight
 	bool live = false;
-	// re-chaining ahead (rechain_ahead.cpp): an engine of its own, made when first needed -- `eng` has the next batch in flight while the
-	// batch handed back is re-chained, and a device re-chaining call owns its engine's streams and arenas -- and the answers of the batch that
-	// is going through the host's callback
+	// re-chaining ahead: an engine of its own, made when first needed (a device re-chaining call owns its engine's streams and arenas)
 	mm2gb_engine_t *rmq_eng = nullptr;
-	RechainAhead ahead;
+	std::thread finisher;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<HostStage*> jobs;          // batches waiting for the finisher (at most two)
+	bool stop = false;
 };
 
 static struct {
@@ -106,6 +123,8 @@ static double now_ms()
 {
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+static inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int64_t g_t_init_ns = 0;
 
 [[noreturn]] static void die(const std::string &msg)
 {
@@ -134,26 +153,117 @@ static int devices_for_streams(std::vector<int> &out)
 	return 0;
 }
 
-// Finish the batch held by `st`: wait for its scores, extract chains per read, hand the reads back.
-static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_read_t **reads_out, int *n_out, mm2gb_misc_t *misc_out)
+static std::atomic<int64_t> g_reads_ahead(0), g_ns_ahead(0);     // reads whose re-chaining was answered ahead, and the finishers' time in it
+
+// First half of finishing the batch held by `st`, on the stream's finisher thread: wait for its scores, make the chains of every read
+// (libc memory), answer the batch's re-chaining ahead.  Touches nothing of the host's (kalloc arenas are not thread-safe).
+static int finish_compute(StreamSlot &slot, HostStage &st)
 {
-	*reads_out = nullptr; *n_out = 0;
-	if (!st.busy) return 0;
 	TraceRange range("mm2gb:finish_batch");
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
 	const double t0 = now_ms();
-	if (!st.device_post) { TraceRange wait("mm2gb:wait_scores"); MM2GB_HIP(hipEventSynchronize(st.done)); }
-	const double t_wait = now_ms();
+	const int n_read = st.n_read;
+	const int64_t *off = st.goff.data();
+	mm2gb_chain_read_t *reads = st.reads;
+	std::vector<RechainRead> view;
+	const bool want_ahead = g_streams.rechain_ahead && st.opt && n_read > 0 && rechain_ahead_is_exact(*(const mm2gb_mapopt_head_t*)st.opt);
+	if (st.device_post) {
+		// the chains were made on the device (post_kernels.hip): fetch them (exact sizes)
+		if (slot.eng.fetch_chains(st.post_set, n_read, &st.ch)) return -1;
+		st.ms_wait = now_ms() - t0; st.ms_post = 0;
+		if (want_ahead) {
+			view.resize((size_t)n_read);
+			for (int r = 0; r < n_read; ++r)
+				view[(size_t)r] = RechainRead{ st.ch.a + st.ch.a_off[r], st.ch.u + st.ch.u_off[r], (int)(st.ch.u_off[r + 1] - st.ch.u_off[r]), reads[r].n_seg, reads[r].seq.qlen_sum };
+		}
+	} else {
+		{ TraceRange wait("mm2gb:wait_scores"); MM2GB_HIP(hipEventSynchronize(st.done)); }
+		const double t_wait = now_ms();
+		const int32_t *f = (const int32_t*)st.h_f.ptr, *p = (const int32_t*)st.h_p.ptr;
+		const mm2gb_misc_t misc = st.misc;                    // not the engine's current ones: a newer batch may already be in flight
+		HostAlloc libc_mem;                                   // worker threads allocate from libc only
+		st.u_of.assign((size_t)n_read, nullptr); st.a_of.assign((size_t)n_read, nullptr); st.nu_of.assign((size_t)n_read, 0);
+		{
+			TraceRange post("mm2gb:backtrack_compact");
+			parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &ws) {
+				st.nu_of[r] = backtrack_compact(misc, reads[r].n, reads[r].a, f + off[r], p + off[r], libc_mem, ws, &st.u_of[r], &st.a_of[r]);
+			});
+		}
+		st.ms_wait = t_wait - t0; st.ms_post = now_ms() - t_wait;
+		if (want_ahead) {
+			view.resize((size_t)n_read);
+			for (int r = 0; r < n_read; ++r) view[(size_t)r] = RechainRead{ st.a_of[r], st.u_of[r], st.nu_of[r], reads[r].n_seg, reads[r].seq.qlen_sum };
+		}
+	}
+	st.have_ahead = false;
+	st.ms_ahead = 0;
+	if (want_ahead) {
+		const int64_t ta = now_ns();
+		if (!slot.rmq_eng) {
+			slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &st.misc, slot.eng.device);
+			if (!slot.rmq_eng) return -1;
+		}
+		if (rechain_ahead(slot.rmq_eng, *(const mm2gb_mapopt_head_t*)st.opt, st.misc, view.data(), n_read, g_streams.post_threads, st.ahead)) return -1;
+		st.have_ahead = st.ahead.n_ahead() > 0;
+		g_reads_ahead.fetch_add(st.ahead.n_ahead());
+		g_ns_ahead.fetch_add(now_ns() - ta);
+		st.ms_ahead = (now_ns() - ta) * 1e-6;
+		if (g_streams.debug)
+			fprintf(stderr, "[mm2gb stream] re-chaining ahead (%.3f -> %.3f s since init): %lld of %d reads, %lld anchors | select %.1f ms | copy + sort %.1f ms | one call %.1f ms (device %lld reads %.1f ms || host %lld reads %.1f ms, %lld tied redone %.1f ms)\n",
+			        (ta - g_t_init_ns) * 1e-9, (now_ns() - g_t_init_ns) * 1e-9, (long long)st.ahead.n_ahead(), n_read, (long long)(st.have_ahead ? st.ahead.off.back() : 0), st.ahead.s_select * 1e3, st.ahead.s_sort * 1e3, st.ahead.s_call * 1e3,
+			        (long long)st.ahead.deal.n_device, st.ahead.deal.device_s * 1e3, (long long)st.ahead.deal.n_host_cost, st.ahead.deal.host_s * 1e3, (long long)st.ahead.deal.n_host_tie, st.ahead.deal.tie_s * 1e3);
+	}
+	st.t_computed_ms = now_ms();
+	return 0;
+}
+
+// The stream's finisher thread: batches in launch order.
+static void finisher_main(StreamSlot *slot)
+{
+	for (;;) {
+		HostStage *st = nullptr;
+		{
+			std::unique_lock<std::mutex> lk(slot->mu);
+			slot->cv.wait(lk, [&] { return slot->stop || !slot->jobs.empty(); });
+			if (slot->jobs.empty()) return;
+			st = slot->jobs.front();
+		}
+		std::string err;
+		try { if (finish_compute(*slot, *st)) err = mm2gb_last_error(); }
+		catch (const std::exception &ex) { err = std::string("finishing a batch: ") + ex.what(); }
+		{
+			std::lock_guard<std::mutex> lk(slot->mu);
+			st->err = err;
+			st->computed = true;
+			slot->jobs.erase(slot->jobs.begin());
+		}
+		slot->cv.notify_all();
+	}
+}
+
+// Wait until the finisher is through with `st` (the host thread may then use the slot's engine again).
+static void wait_computed(StreamSlot &slot, HostStage &st)
+{
+	if (!st.busy) return;
+	std::unique_lock<std::mutex> lk(slot.mu);
+	slot.cv.wait(lk, [&] { return st.computed; });
+	if (!st.err.empty()) die(st.err);
+}
+
+// Second half, on the CALLING thread: results move into the host's kalloc arena (not thread-safe, so here), the reads go back.
+static int finish_handover(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_read_t **reads_out, int *n_out, mm2gb_misc_t *misc_out)
+{
+	*reads_out = nullptr; *n_out = 0;
+	if (!st.busy) return 0;
+	(void)slot;
+	const double t0 = now_ms();
 	mm2gb_chain_read_t *reads = st.reads;
 	const int n_read = st.n_read;
 	const int64_t *off = st.goff.data();
+	if (misc_out) *misc_out = st.misc;
+	HostAlloc host_mem; host_mem.km = km; host_mem.use_kalloc = host_kalloc_present();
 	if (st.device_post) {
-		// the chains were made on the device (post_kernels.hip): fetch them (exact sizes) and move them into the host's arena
-		mm2gb_chains_t ch;
-		if (slot.eng.fetch_chains(st.post_set, n_read, &ch)) return -1;
-		const double t_fetch = now_ms();
-		if (misc_out) *misc_out = st.misc;
-		HostAlloc host_mem; host_mem.km = km; host_mem.use_kalloc = host_kalloc_present();
+		mm2gb_chains_t &ch = st.ch;
 		for (int r = 0; r < n_read; ++r) {
 			mm2gb_chain_read_t &rd = reads[r];
 			const int n_u = (int)(ch.u_off[r + 1] - ch.u_off[r]);
@@ -168,54 +278,34 @@ static int finish_stage(StreamSlot &slot, HostStage &st, void *km, mm2gb_chain_r
 			rd.a = a_new; rd.u = u; rd.n_u = n_u;
 		}
 		mm2gb_chains_free(&ch);
-		st.busy = false; st.reads = nullptr; st.n_read = 0; st.device_post = false;
-		*reads_out = reads; *n_out = n_read;
-		if (g_streams.debug)
-			fprintf(stderr, "[mm2gb stream] finish (device post-pass): %d reads, %lld anchors | wait + fetch chains %.2f ms | hand-over %.2f ms\n",
-			        n_read, (long long)off[n_read], t_fetch - t0, now_ms() - t_fetch);
-		return 0;
-	}
-	const int32_t *f = (const int32_t*)st.h_f.ptr, *p = (const int32_t*)st.h_p.ptr;
-	const mm2gb_misc_t misc = st.misc;                    // not the engine's current ones: a newer batch may already be in flight
-	if (misc_out) *misc_out = misc;
-	HostAlloc libc_mem;                                   // worker threads allocate from libc only
-	HostAlloc host_mem; host_mem.km = km; host_mem.use_kalloc = host_kalloc_present();
-	std::vector<uint64_t*> u_of((size_t)n_read, nullptr);
-	std::vector<mm2gb_anchor_t*> a_of((size_t)n_read, nullptr);
-	std::vector<int> nu_of((size_t)n_read, 0);
-	{
-		TraceRange post("mm2gb:backtrack_compact");
-		parallel_reads(n_read, g_streams.post_threads, [&](int64_t r, BacktrackScratch &ws) {
-			nu_of[r] = backtrack_compact(misc, reads[r].n, reads[r].a, f + off[r], p + off[r], libc_mem, ws, &u_of[r], &a_of[r]);
-		});
-	}
-	const double t_post = now_ms();
-	// hand-over on the calling thread: kalloc arenas are not thread-safe, so results move into the host's arena here
-	for (int r = 0; r < n_read; ++r) {
-		mm2gb_chain_read_t &rd = reads[r];
-		uint64_t *u = u_of[r]; mm2gb_anchor_t *a_new = a_of[r];
-		if (host_mem.use_kalloc && nu_of[r] > 0) {
-			size_t na = 0;
-			for (int k = 0; k < nu_of[r]; ++k) na += (uint32_t)u[k];
-			uint64_t *ku = (uint64_t*)host_mem.alloc((size_t)nu_of[r] * 8);
-			mm2gb_anchor_t *ka = (mm2gb_anchor_t*)host_mem.alloc(na * 16);
-			memcpy(ku, u, (size_t)nu_of[r] * 8); memcpy(ka, a_new, na * 16);
-			free(u); free(a_new);
-			u = ku; a_new = ka;
+	} else {
+		for (int r = 0; r < n_read; ++r) {
+			mm2gb_chain_read_t &rd = reads[r];
+			uint64_t *u = st.u_of[r]; mm2gb_anchor_t *a_new = st.a_of[r];
+			if (host_mem.use_kalloc && st.nu_of[r] > 0) {
+				size_t na = 0;
+				for (int k = 0; k < st.nu_of[r]; ++k) na += (uint32_t)u[k];
+				uint64_t *ku = (uint64_t*)host_mem.alloc((size_t)st.nu_of[r] * 8);
+				mm2gb_anchor_t *ka = (mm2gb_anchor_t*)host_mem.alloc(na * 16);
+				memcpy(ku, u, (size_t)st.nu_of[r] * 8); memcpy(ka, a_new, na * 16);
+				free(u); free(a_new);
+				u = ku; a_new = ka;
+			}
+			host_mem.release(rd.a);                 // compact_a frees the oversized input (lchain.c:108-109, plchain.cu:135)
+			rd.a = a_new; rd.u = u; rd.n_u = st.nu_of[r];   // a = 0 when nothing chained (plchain.cu:134-137)
 		}
-		host_mem.release(rd.a);                 // compact_a frees the oversized input (lchain.c:108-109, plchain.cu:135)
-		rd.a = a_new; rd.u = u; rd.n_u = nu_of[r];   // a = 0 when nothing chained (plchain.cu:134-137)
+		st.u_of.clear(); st.a_of.clear(); st.nu_of.clear();
 	}
-	st.busy = false; st.reads = nullptr; st.n_read = 0;
-	*reads_out = reads; *n_out = n_read;
 	if (g_streams.debug)
-		fprintf(stderr, "[mm2gb stream] finish: %d reads, %lld anchors | wait for scores %.2f ms | post-pass %.2f ms | hand-over %.2f ms\n",
-		        n_read, (long long)off[n_read], t_wait - t0, t_post - t_wait, now_ms() - t_post);
+		fprintf(stderr, "[mm2gb stream] finish%s: %d reads, %lld anchors | finisher: wait %.2f ms, post-pass %.2f ms, re-chaining ahead %.2f ms, ready %.2f ms before it was asked for | hand-over %.2f ms\n",
+		        st.device_post ? " (device post-pass)" : "", n_read, (long long)off[n_read], st.ms_wait, st.ms_post, st.ms_ahead, t0 - st.t_computed_ms, now_ms() - t0);
+	st.busy = false; st.reads = nullptr; st.n_read = 0; st.device_post = false;
+	*reads_out = reads; *n_out = n_read;
 	return 0;
 }
 
 // Launch `reads` through `st`: pack anchors into pinned memory, enqueue one or more micro-batches, return at once.
-static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *reads, int n_read)
+static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *reads, int n_read, const struct mm_mapopt_s *opt)
 {
 	int64_t total = 0;
 	for (int r = 0; r < n_read; ++r) total += reads[r].n > 0 ? reads[r].n : 0;
@@ -271,7 +361,13 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)st.h_f.ptr + off[r0], (int32_t*)st.h_p.ptr + off[r0], false)) return -1;
 	}
 	if (!st.device_post && slot.eng.record_outputs_done(st.done)) return -1;
-	st.reads = reads; st.n_read = n_read; st.busy = true;
+	st.reads = reads; st.n_read = n_read; st.busy = true; st.opt = opt;
+	{
+		std::lock_guard<std::mutex> lk(slot.mu);
+		st.computed = false; st.err.clear();
+		slot.jobs.push_back(&st);                      // the finisher takes it from here
+	}
+	slot.cv.notify_all();
 	if (g_streams.debug)
 		fprintf(stderr, "[mm2gb stream] launch: %d reads, %lld anchors, %zu micro-batch(es) | pack %.2f ms | enqueue %.2f ms\n",
 		        n_read, (long long)total, n_mb, t_pack - t0, now_ms() - t_pack);
@@ -397,13 +493,12 @@ mm2gb_anchor_t *mm2gb_lchain_dp(int max_dist_x, int max_dist_y, int bw, int max_
 // ---------------------------------------------------------------------------------------------------------------
 // one read, mg_lchain_rmq's signature (lchain.c:250-369)
 // ---------------------------------------------------------------------------------------------------------------
-static std::atomic<int64_t> g_rmq_calls(0), g_rmq_tied_calls(0), g_rmq_from_ahead(0), g_reads_ahead(0), g_ns_ahead(0);
+static std::atomic<int64_t> g_rmq_calls(0), g_rmq_tied_calls(0), g_rmq_from_ahead(0);
 // the answers of the batch whose reads the calling thread is handing to post_chaining_helper right now, and the read it is at (one call per read, map.c:450)
 static thread_local const RechainAhead *t_ahead = nullptr;
 static thread_local int32_t t_ahead_slot = -1;
 // what the library held of a run (MM2GB_REPORT=1 prints it when the host frees the streams): nanoseconds summed over the host's threads
-static std::atomic<int64_t> g_ns_chain(0), g_ns_helper(0), g_ns_rmq(0), g_tot_batches(0), g_tot_reads(0), g_tot_anchors(0);
-static inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static std::atomic<int64_t> g_ns_chain(0), g_ns_helper(0), g_ns_rmq(0), g_ns_waited(0), g_tot_batches(0), g_tot_reads(0), g_tot_anchors(0);
 
 mm2gb_anchor_t *mm2gb_lchain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size, int min_cnt, int min_sc,
                                  float chn_pen_gap, float chn_pen_skip, int64_t n, mm2gb_anchor_t *a, int *n_u_, uint64_t **_u, void *km)
@@ -497,39 +592,22 @@ void mm2gb_rechain_ahead_counts(int64_t *calls, int64_t *answered_ahead, int64_t
 	if (reads_ahead) *reads_ahead = g_reads_ahead.load();
 }
 
-// The host's callback for every read of a batch that a boundary call hands back (plchain.cu:502-507, 539-541) -- after the batch's
-// re-chaining calls have been answered together where that applies (rechain_ahead.cpp).
-static void hand_to_host_callback(StreamSlot &slot, const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *done, int n_done,
+// The host's callback for every read of a batch that a boundary call hands back (plchain.cu:502-507, 539-541).  The batch's re-chaining
+// calls were answered together by the stream's finisher where that applies (rechain_ahead.cpp): each read's call finds its answer through
+// the thread-local view set here.
+static void hand_to_host_callback(HostStage &st, const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, mm2gb_chain_read_t *done, int n_done,
                                   const mm2gb_misc_t &misc, void *km)
 {
-	if (!done || !post_chaining_helper) return;
-	TraceRange range("mm2gb:post_chaining_helper");
-	bool have = false;
-	if (g_streams.rechain_ahead && opt && n_done > 0) {
-		const mm2gb_mapopt_head_t &o = *(const mm2gb_mapopt_head_t*)opt;
-		if (rechain_ahead_is_exact(o)) {
-			const int64_t t0 = now_ns();
-			if (!slot.rmq_eng) {
-				MM2GB_HIP_DIE(hipSetDevice(slot.eng.device));
-				slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &misc, slot.eng.device);
-				if (!slot.rmq_eng) die(mm2gb_last_error());
-			}
-			if (rechain_ahead(slot.rmq_eng, o, misc, done, n_done, g_streams.post_threads, slot.ahead)) die(mm2gb_last_error());
-			have = slot.ahead.n_ahead() > 0;
-			g_reads_ahead.fetch_add(slot.ahead.n_ahead());
-			g_ns_ahead.fetch_add(now_ns() - t0);
-			if (g_streams.debug)
-				fprintf(stderr, "[mm2gb stream] re-chaining ahead: %lld of %d reads, %lld anchors | select %.1f ms | copy + sort %.1f ms | one call %.1f ms (device %lld reads %.1f ms || host %lld reads %.1f ms, %lld tied redone %.1f ms)\n",
-				        (long long)slot.ahead.n_ahead(), n_done, (long long)(have ? slot.ahead.off.back() : 0), slot.ahead.s_select * 1e3, slot.ahead.s_sort * 1e3, slot.ahead.s_call * 1e3,
-				        (long long)slot.ahead.deal.n_device, slot.ahead.deal.device_s * 1e3, (long long)slot.ahead.deal.n_host_cost, slot.ahead.deal.host_s * 1e3, (long long)slot.ahead.deal.n_host_tie, slot.ahead.deal.tie_s * 1e3);
+	if (done && post_chaining_helper) {
+		TraceRange range("mm2gb:post_chaining_helper");
+		const bool have = st.have_ahead && (int)st.ahead.slot_of_read.size() == n_done;
+		for (int i = 0; i < n_done; ++i) {
+			if (have) { t_ahead = &st.ahead; t_ahead_slot = st.ahead.slot_of_read[(size_t)i]; }
+			post_chaining_helper(mi, opt, &done[i], misc, km);
 		}
+		t_ahead = nullptr; t_ahead_slot = -1;
 	}
-	for (int i = 0; i < n_done; ++i) {
-		if (have) { t_ahead = &slot.ahead; t_ahead_slot = slot.ahead.slot_of_read[(size_t)i]; }
-		post_chaining_helper(mi, opt, &done[i], misc, km);
-	}
-	t_ahead = nullptr; t_ahead_slot = -1;
-	if (have) slot.ahead.clear();
+	if (st.have_ahead) { st.ahead.clear(); st.have_ahead = false; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -538,6 +616,8 @@ static void hand_to_host_callback(StreamSlot &slot, const struct mm_idx_s *mi, c
 void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_config_file[], mm2gb_Misc misc)
 {
 	if (g_streams.ready) free_stream_gpu((int)g_streams.slots.size());
+	g_t_init_ns = now_ns();
+	const double epoch_in = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
 	if (mm2gb_config_load(gpu_config_file, &g_streams.cfg)) die(mm2gb_last_error());
 	mm2gb_config_t &cfg = g_streams.cfg;
 	// Every stream id is an engine with four HIP streams (copy in, two compute, copy out).  The HIP runtime multiplexes streams onto 4
@@ -584,9 +664,11 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 		StreamSlot *slot = new StreamSlot();
 		if (slot->eng.init(&cfg, &misc, devs[(size_t)s % devs.size()])) die(mm2gb_last_error());
 		slot->live = true;
+		slot->finisher = std::thread(finisher_main, slot);
 		g_streams.slots.push_back(slot);
 	}
 	g_streams.ready = true;
+	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] init_stream_gpu: entered at epoch %.3f, %d stream(s) ready after %.3f s\n", epoch_in, cfg.num_streams, (now_ns() - g_t_init_ns) * 1e-9);
 	// what the host accumulates to (plmem.cu:616-617)
 	*max_total_n = (size_t)cfg.max_total_n * (size_t)cfg.score_kernel.micro_batch;
 	*max_reads = (int)std::min<int64_t>((int64_t)cfg.max_read * cfg.score_kernel.micro_batch, 2147483647LL);
@@ -607,18 +689,23 @@ void chain_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt, 
 		g_tot_batches.fetch_add(1); g_tot_reads.fetch_add(n_new); g_tot_anchors.fetch_add(na);
 	}
 	HostStage &prev = slot.stage[slot.cur], &next = slot.stage[slot.cur ^ 1];
-	// launch first, then finish the previous batch on the host while the GPU works (the reference does it the other way
-	// round, plchain.cu:300-305, and leaves the GPU idle during its post-pass)
+	// The previous batch has been with the stream's finisher since it was launched (scores -> chains -> its re-chaining answered ahead),
+	// while this thread seeded the batch it brings now: normally it is through.  Wait for it -- the engine serves one thread at a time --,
+	// launch the new batch, then hand the previous one back.  (The reference finishes the previous batch on the calling thread before
+	// it launches, plchain.cu:300-305, and leaves the GPU idle during its post-pass.)
+	const int64_t t_w0 = now_ns();
+	wait_computed(slot, prev);
+	g_ns_waited.fetch_add(now_ns() - t_w0);
 	if (slot.eng.set_misc(&misc)) die(mm2gb_last_error());
 	const bool launched = new_reads && n_new > 0;
-	if (launched && launch_stage(slot, next, new_reads, n_new)) die(mm2gb_last_error());
+	if (launched && launch_stage(slot, next, new_reads, n_new, opt)) die(mm2gb_last_error());
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
 	mm2gb_misc_t done_misc = misc;                       // the batch handed back is finished with the parameters IT was launched with
-	if (finish_stage(slot, prev, km, &done, &n_done, &done_misc)) die(mm2gb_last_error());
+	if (finish_handover(slot, prev, km, &done, &n_done, &done_misc)) die(mm2gb_last_error());
 	if (launched) slot.cur ^= 1;
 	*in_arr_ptr = done; *n_read_ptr = n_done;
 	const int64_t t_mid = now_ns();
-	hand_to_host_callback(slot, mi, opt, done, n_done, done_misc, km);                         // plchain.cu:502-507
+	hand_to_host_callback(prev, mi, opt, done, n_done, done_misc, km);                         // plchain.cu:502-507
 	const int64_t t_out = now_ns();
 	g_ns_chain.fetch_add(t_mid - t_in); g_ns_helper.fetch_add(t_out - t_mid);
 }
@@ -630,9 +717,12 @@ void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt,
 	StreamSlot &slot = slot_for(num_batch);
 	mm2gb_Misc misc = build_misc ? build_misc(mi, opt, 0, 1) : g_streams.misc;
 	mm2gb_chain_read_t *done = nullptr; int n_done = 0;
-	if (finish_stage(slot, slot.stage[slot.cur], km, &done, &n_done, &misc)) die(mm2gb_last_error());
+	HostStage &st = slot.stage[slot.cur];
+	wait_computed(slot, st);
+	g_ns_waited.fetch_add(now_ns() - t_in);
+	if (finish_handover(slot, st, km, &done, &n_done, &misc)) die(mm2gb_last_error());
 	const int64_t t_mid = now_ns();
-	hand_to_host_callback(slot, mi, opt, done, n_done, misc, km);                              // plchain.cu:539-541
+	hand_to_host_callback(st, mi, opt, done, n_done, misc, km);                                // plchain.cu:539-541
 	g_ns_chain.fetch_add(t_mid - t_in); g_ns_helper.fetch_add(now_ns() - t_mid);
 	*batches = done; *num_reads = n_done;
 }
@@ -640,9 +730,16 @@ void finish_stream_gpu(const struct mm_idx_s *mi, const struct mm_mapopt_s *opt,
 void free_stream_gpu(int n_threads)
 {
 	(void)n_threads;
+	const int64_t t_free0 = now_ns();
+	const double epoch_free = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
 	for (StreamSlot *slot : g_streams.slots) {
+		{ std::lock_guard<std::mutex> lk(slot->mu); slot->stop = true; }
+		slot->cv.notify_all();
+		if (slot->finisher.joinable()) slot->finisher.join();        // (it drains what is still queued first)
 		(void)slot->eng.sync();
 		for (HostStage &st : slot->stage) {
+			mm2gb_chains_free(&st.ch);
+			for (size_t r = 0; r < st.u_of.size(); ++r) { free(st.u_of[r]); free(st.a_of[r]); }
 			st.h_raw.release(); st.h_f.release(); st.h_p.release(); st.h_off.release();
 			if (st.done) (void)hipEventDestroy(st.done);
 		}
@@ -653,16 +750,17 @@ void free_stream_gpu(int n_threads)
 	g_streams.slots.clear();
 	g_streams.ready = false;
 	free_single_read_engines();
+	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] free_stream_gpu: entered at epoch %.3f, everything released after %.3f s\n", epoch_free, (now_ns() - t_free0) * 1e-9);
 	// What the library held of the run, for whoever times the drop-in (bench.py's e2e.reference_host_at_scale): seconds are summed over the
 	// host's threads; the host's own callback (post_chaining_helper, map.c:428: RMQ re-chaining, mm_gen_regs, ...) runs inside the boundary
 	// calls and is listed apart, and of it what mg_lchain_rmq calls answered by the library took (hosts linked with --wrap=mg_lchain_rmq).
 	if (const char *v = getenv("MM2GB_REPORT"))
 		if (*v && *v != '0') fprintf(stderr, "[mm2gb totals] batches %lld reads %lld anchors %lld | inside chain_stream_gpu / finish_stream_gpu without the host's callback %.3f s | "
 		                             "host callback post_chaining_helper %.3f s | of the callback: mg_lchain_rmq answered by the library %.3f s in %lld calls | "
-		                             "re-chaining ahead of the callback %.3f s for %lld reads, %lld calls answered from it\n",
+		                             "re-chaining ahead of the callback %.3f s for %lld reads, %lld calls answered from it | of the boundary time: waiting for the stream's finisher %.3f s\n",
 		                             (long long)g_tot_batches.load(), (long long)g_tot_reads.load(), (long long)g_tot_anchors.load(), g_ns_chain.load() * 1e-9,
-		                             (g_ns_helper.load() - g_ns_ahead.load()) * 1e-9, g_ns_rmq.load() * 1e-9, (long long)g_rmq_calls.load(),
-		                             g_ns_ahead.load() * 1e-9, (long long)g_reads_ahead.load(), (long long)g_rmq_from_ahead.load());
+		                             g_ns_helper.load() * 1e-9, g_ns_rmq.load() * 1e-9, (long long)g_rmq_calls.load(),
+		                             g_ns_ahead.load() * 1e-9, (long long)g_reads_ahead.load(), (long long)g_rmq_from_ahead.load(), g_ns_waited.load() * 1e-9);
 	if (const char *v = getenv("MM2GB_RMQ_REPORT"))
 		if (*v && *v != '0') fprintf(stderr, "[mm2gb] mg_lchain_rmq calls answered by the library: %lld, of which redone by the library's exact host form because of a tie (device form only): %lld; handed to the host program: 0\n",
 		                             (long long)g_rmq_calls.load(), (long long)g_rmq_tied_calls.load());

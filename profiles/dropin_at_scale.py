@@ -27,10 +27,12 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="K=V for the host's environment")
     ap.add_argument("--debug", action="store_true", help="MM2GB_DEBUG_PHASES=1 and the library's lines on stderr")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--cfg", action="append", default=[], help="K=V: top-level key of the gpu config to override (e.g. max_total_n=1000000)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     threads = args.threads or max(1, min(32, bench.cpu_quota() or 16))
     extra = dict(kv.split("=", 1) for kv in args.env)
+    cfg_over = {k: json.loads(v) for k, v in (kv.split("=", 1) for kv in args.cfg)}
     if args.debug:
         extra["MM2GB_DEBUG_PHASES"] = "1"
     out = {}
@@ -52,7 +54,7 @@ def main():
             out["reference_cpu_whole_set"] = {"seconds": round(time.perf_counter() - t0, 1), "threads": threads, "paf_lines": want.count(b"\n"), "gbp_per_s": bases / (time.perf_counter() - t0) / 1e9}
             os.unlink(allfa)
         for k in range(args.repeat):
-            res = bench.reference_host_at_scale(td, ref, reads, bases, uniq, None, threads, legs=tuple(args.legs.split(",")), extra_env=extra, keep_stderr=True)
+            res = bench.reference_host_at_scale(td, ref, reads, bases, uniq, None, threads, legs=tuple(args.legs.split(",")), extra_env=extra, keep_stderr=True, cfg_override=cfg_over)
             for key in args.legs.split(","):
                 leg = res.get(key, {})
                 err = leg.pop("_stderr", "")
