@@ -705,11 +705,13 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb_chain_gpu: out of host memory"); }
 	out->u_off[0] = out->a_off[0] = 0;
 	if (n_reads > 0) {
-		MM2GB_HIP(hipMemcpy(out->u_off, post_uoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
-		MM2GB_HIP(hipMemcpy(out->a_off, post_aoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
-		if (n_u > 0) MM2GB_HIP(hipMemcpy(out->u, post_uout.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost));
-		if (n_a > 0) MM2GB_HIP(hipMemcpy(out->a, post_aout.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost));
-		if (rmq && n_tied) MM2GB_HIP(hipMemcpy(n_tied, rmq_tied.ptr, (size_t)n_reads * 4, hipMemcpyDeviceToHost));
+		// on the engine's own D2H stream, never the null stream: every engine of the process would queue behind the same one
+		MM2GB_HIP(hipMemcpyAsync(out->u_off, post_uoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipMemcpyAsync(out->a_off, post_aoff.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s_out));
+		if (n_u > 0) MM2GB_HIP(hipMemcpyAsync(out->u, post_uout.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost, s_out));
+		if (n_a > 0) MM2GB_HIP(hipMemcpyAsync(out->a, post_aout.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost, s_out));
+		if (rmq && n_tied) MM2GB_HIP(hipMemcpyAsync(n_tied, rmq_tied.ptr, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipStreamSynchronize(s_out));
 	}
 	float ms = 0;
 	if (n_reads > 0 && hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
@@ -794,7 +796,7 @@ int Engine::collect_seeds(int64_t opt_flag, int64_t n_reads, const int64_t *seed
 	MM2GB_HIP(hipGetLastError());
 	MM2GB_HIP(hipMemcpyAsync(anchor_off, sd_a_off.ptr, (nr + 1) * 8, hipMemcpyDeviceToHost, stream));
 	MM2GB_HIP(hipStreamSynchronize(stream));
-	if (anchor_off[n_reads] > 0) MM2GB_HIP(hipMemcpy(anchors, sd_out.ptr, (size_t)anchor_off[n_reads] * 16, hipMemcpyDeviceToHost));
+	if (anchor_off[n_reads] > 0) { MM2GB_HIP(hipMemcpyAsync(anchors, sd_out.ptr, (size_t)anchor_off[n_reads] * 16, hipMemcpyDeviceToHost, s_out)); MM2GB_HIP(hipStreamSynchronize(s_out)); }
 	return 0;
 }
 

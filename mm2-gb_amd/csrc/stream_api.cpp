@@ -66,7 +66,6 @@ static void parallel_reads(int64_t n, int n_threads, F fn)
 // ---------------------------------------------------------------------------------------------------------------
 // Host side of one batch in flight: page-locked staging and the reads it belongs to.
 struct HostStage {
-	PinnedBuf h_raw, h_f, h_p, h_off;      // h_off: per-micro-batch offsets, each from 0
 	std::vector<int64_t> goff;             // offsets of every read in h_raw / h_f / h_p, size n_read + 1
 	mm2gb_chain_read_t *reads = nullptr;   // owned by the host
 	mm2gb_misc_t misc = {};                // the parameters this batch was LAUNCHED with: its post-pass must use the same ones
@@ -99,6 +98,10 @@ struct StreamSlot {
 	HostStage stage[2];
 	int  cur = 0;                          // stage of the batch in flight
 	bool live = false;
+	// Page-locked staging, ONE set for both stages: a batch is launched only after the finisher is through with the previous one (its anchors
+	// copied in, its scores turned into chains), so the previous batch needs none of it any more -- half the memory to pin (~0.4 s per GB, and
+	// sixteen streams pin at the same moment) and to give back.
+	PinnedBuf h_raw, h_f, h_p, h_off;      // h_off: per-micro-batch offsets, each from 0
 	// re-chaining ahead: an engine of its own, made when first needed (a device re-chaining call owns its engine's streams and arenas)
 	mm2gb_engine_t *rmq_eng = nullptr;
 	std::thread finisher;
@@ -179,7 +182,7 @@ static int finish_compute(StreamSlot &slot, HostStage &st)
 	} else {
 		{ TraceRange wait("mm2gb:wait_scores"); MM2GB_HIP(hipEventSynchronize(st.done)); }
 		const double t_wait = now_ms();
-		const int32_t *f = (const int32_t*)st.h_f.ptr, *p = (const int32_t*)st.h_p.ptr;
+		const int32_t *f = (const int32_t*)slot.h_f.ptr, *p = (const int32_t*)slot.h_p.ptr;
 		const mm2gb_misc_t misc = st.misc;                    // not the engine's current ones: a newer batch may already be in flight
 		HostAlloc libc_mem;                                   // worker threads allocate from libc only
 		st.u_of.assign((size_t)n_read, nullptr); st.a_of.assign((size_t)n_read, nullptr); st.nu_of.assign((size_t)n_read, 0);
@@ -314,10 +317,10 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
 	st.misc = slot.eng.misc;
 	if (!st.done) MM2GB_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
-	if (st.h_raw.ensure((size_t)(total + 1) * 16) || st.h_f.ensure((size_t)(total + 1) * 4) || st.h_p.ensure((size_t)(total + 1) * 4)) return -1;
+	if (slot.h_raw.ensure((size_t)(total + 1) * 16)) return -1;
 	st.goff.resize((size_t)n_read + 1);
 	int64_t *off = st.goff.data();
-	mm2gb_anchor_t *raw = (mm2gb_anchor_t*)st.h_raw.ptr;
+	mm2gb_anchor_t *raw = (mm2gb_anchor_t*)slot.h_raw.ptr;
 	off[0] = 0;
 	for (int r = 0; r < n_read; ++r) off[r + 1] = off[r] + (reads[r].n > 0 ? reads[r].n : 0);
 	// pack the reads' anchor arrays into the pinned staging buffer (MM2GB_POST_THREADS host threads)
@@ -342,8 +345,8 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 	mb_first.push_back(n_read);
 	// every micro-batch needs offsets that start at 0: build them after the global ones
 	const size_t n_mb = mb_first.size() - 1;
-	if (st.h_off.ensure(((size_t)n_read + n_mb + 1) * 8)) return -1;
-	int64_t *local_off = (int64_t*)st.h_off.ptr;
+	if (slot.h_off.ensure(((size_t)n_read + n_mb + 1) * 8)) return -1;
+	int64_t *local_off = (int64_t*)slot.h_off.ptr;
 	size_t w = 0;
 	for (size_t m = 0; m < n_mb; ++m) {
 		const int64_t r0 = mb_first[m], r1 = mb_first[m + 1];
@@ -358,7 +361,8 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 			st.device_post = true;
 			continue;
 		}
-		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)st.h_f.ptr + off[r0], (int32_t*)st.h_p.ptr + off[r0], false)) return -1;
+		if (slot.h_f.ensure((size_t)(total + 1) * 4) || slot.h_p.ensure((size_t)(total + 1) * 4)) return -1;   // (scores come back only on this path)
+		if (slot.eng.enqueue_host(r1 - r0, local_off + base, raw + off[r0], n, (int32_t*)slot.h_f.ptr + off[r0], (int32_t*)slot.h_p.ptr + off[r0], false)) return -1;
 	}
 	if (!st.device_post && slot.eng.record_outputs_done(st.done)) return -1;
 	st.reads = reads; st.n_read = n_read; st.busy = true; st.opt = opt;
@@ -448,6 +452,27 @@ static void free_single_read_engines()
 	for (mm2gb_engine_t *e : g_single_free) mm2gb_engine_destroy(e);   // (engines on lease belong to calls still running: theirs to return)
 	g_single_made -= (int)g_single_free.size();
 	g_single_free.clear();
+}
+
+// streams that free_stream_gpu parked instead of releasing (see there), and the configuration they were made for
+static std::vector<StreamSlot*> g_parked;
+static mm2gb_config_t g_parked_cfg;
+
+static void destroy_slot(StreamSlot *slot)
+{
+	{ std::lock_guard<std::mutex> lk(slot->mu); slot->stop = true; }
+	slot->cv.notify_all();
+	if (slot->finisher.joinable()) slot->finisher.join();        // (it drains what is still queued first)
+	(void)slot->eng.sync();
+	for (HostStage &st : slot->stage) {
+		mm2gb_chains_free(&st.ch);
+		for (size_t r = 0; r < st.u_of.size(); ++r) { free(st.u_of[r]); free(st.a_of[r]); }
+		if (st.done) (void)hipEventDestroy(st.done);
+	}
+	slot->h_raw.release(); slot->h_f.release(); slot->h_p.release(); slot->h_off.release();
+	slot->eng.shutdown();
+	if (slot->rmq_eng) mm2gb_engine_destroy(slot->rmq_eng);
+	delete slot;
 }
 
 } // namespace mm2gb
@@ -660,7 +685,19 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	}
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
-	for (int s = 0; s < cfg.num_streams; ++s) {
+	if (!g_parked.empty()) {
+		// streams parked by free_stream_gpu: taken over as they are when they were made for this configuration and these devices
+		bool same = memcmp(&g_parked_cfg, &cfg, sizeof cfg) == 0 && (int)g_parked.size() == cfg.num_streams;
+		for (int s = 0; same && s < cfg.num_streams; ++s) same = g_parked[(size_t)s]->eng.device == devs[(size_t)s % devs.size()];
+		if (same) {
+			for (StreamSlot *slot : g_parked) { if (slot->eng.set_misc(&misc)) die(mm2gb_last_error()); slot->cur = 0; g_streams.slots.push_back(slot); }
+			g_parked.clear();
+		} else {
+			for (StreamSlot *slot : g_parked) destroy_slot(slot);
+			g_parked.clear();
+		}
+	}
+	for (int s = (int)g_streams.slots.size(); s < cfg.num_streams; ++s) {
 		StreamSlot *slot = new StreamSlot();
 		if (slot->eng.init(&cfg, &misc, devs[(size_t)s % devs.size()])) die(mm2gb_last_error());
 		slot->live = true;
@@ -732,25 +769,31 @@ void free_stream_gpu(int n_threads)
 	(void)n_threads;
 	const int64_t t_free0 = now_ns();
 	const double epoch_free = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+	// Page-locked staging is slow to give back (unpinning: ~0.2 s per GB; 16 streams of a 1 Gbp run hold 10 GB: 2.5 s of a 16 s program,
+	// profiles/r05_dropin_notes.md), and the host calls this as the last thing before it exits (main.c:465).  So the streams are PARKED:
+	// work drained, engines idle, nothing released -- a later init_stream_gpu with the same configuration takes them over as they are (no
+	// re-pinning either), another configuration or MM2GB_FREE=now releases them for real, and the process's end releases what is parked.
+	static const bool release_now = [] { const char *v = getenv("MM2GB_FREE"); return v && strcmp(v, "now") == 0; }();
 	for (StreamSlot *slot : g_streams.slots) {
-		{ std::lock_guard<std::mutex> lk(slot->mu); slot->stop = true; }
-		slot->cv.notify_all();
-		if (slot->finisher.joinable()) slot->finisher.join();        // (it drains what is still queued first)
+		{
+			std::unique_lock<std::mutex> lk(slot->mu);
+			slot->cv.wait(lk, [&] { return slot->jobs.empty(); });        // the finisher is through with what was launched
+		}
 		(void)slot->eng.sync();
 		for (HostStage &st : slot->stage) {
-			mm2gb_chains_free(&st.ch);
+			mm2gb_chains_free(&st.ch);                                    // a batch the host never came back for
 			for (size_t r = 0; r < st.u_of.size(); ++r) { free(st.u_of[r]); free(st.a_of[r]); }
-			st.h_raw.release(); st.h_f.release(); st.h_p.release(); st.h_off.release();
-			if (st.done) (void)hipEventDestroy(st.done);
+			st.u_of.clear(); st.a_of.clear(); st.nu_of.clear();
+			st.ahead.clear(); st.have_ahead = false;
+			st.busy = false; st.reads = nullptr; st.n_read = 0; st.device_post = false;
 		}
-		slot->eng.shutdown();
-		if (slot->rmq_eng) mm2gb_engine_destroy(slot->rmq_eng);
-		delete slot;
+		if (release_now) destroy_slot(slot); else g_parked.push_back(slot);
 	}
+	if (!release_now) g_parked_cfg = g_streams.cfg;
 	g_streams.slots.clear();
 	g_streams.ready = false;
-	free_single_read_engines();
-	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] free_stream_gpu: entered at epoch %.3f, everything released after %.3f s\n", epoch_free, (now_ns() - t_free0) * 1e-9);
+	if (release_now) free_single_read_engines();
+	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] free_stream_gpu: entered at epoch %.3f, streams %s after %.3f s\n", epoch_free, release_now ? "released" : "parked", (now_ns() - t_free0) * 1e-9);
 	// What the library held of the run, for whoever times the drop-in (bench.py's e2e.reference_host_at_scale): seconds are summed over the
 	// host's threads; the host's own callback (post_chaining_helper, map.c:428: RMQ re-chaining, mm_gen_regs, ...) runs inside the boundary
 	// calls and is listed apart, and of it what mg_lchain_rmq calls answered by the library took (hosts linked with --wrap=mg_lchain_rmq).
