@@ -3,6 +3,7 @@
 // plchain_cal_score_async (plchain.cu:292-464) with a design that never leaves the stream between stages:
 // split -> window(+planner reductions) -> plan -> score are all enqueued back to back, no host sort, no hipMalloc per batch.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <mutex>
 #include <algorithm>
 #include <chrono>
@@ -35,6 +36,7 @@ static size_t grown(size_t need, size_t have)
 // when the list holds more than MM2GB_RETIRE_LIMIT_MB (default 16 GB of device memory, 4 GB page-locked), or when an allocation fails.
 // (Growth is geometric, so what a buffer retires over its life is less than its final size.)  Also safer: a retired buffer stays valid for
 // kernels of the same engine that were enqueued before the growth.
+namespace { void pinned_free(void *p); }
 namespace {
 struct Retired { void *ptr; size_t bytes; bool pinned; };
 std::mutex g_retired_mu;
@@ -43,7 +45,7 @@ size_t g_retired_dev = 0, g_retired_host = 0;
 
 void flush_retired_locked()
 {
-	for (const Retired &r : g_retired) { if (r.pinned) (void)hipHostFree(r.ptr); else (void)hipFree(r.ptr); }
+	for (const Retired &r : g_retired) { if (r.pinned) pinned_free(r.ptr); else (void)hipFree(r.ptr); }
 	g_retired.clear();
 	g_retired_dev = g_retired_host = 0;
 }
@@ -87,24 +89,48 @@ void DevBuf::release()
 	ptr = nullptr; bytes = 0;
 }
 
+// Page-locked host memory.  hipHostMalloc takes ~0.16 s per GB and is serialised across threads (16 streams pinning 256 MB each at the same
+// moment: 0.77 s, and 0.79 s to give it back; profiles/ubench/pin_rate.hip), because it pins 4 KB pages one by one.  A 2 MB-aligned block
+// with MADV_HUGEPAGE, touched and then registered (hipHostRegister), is pinned in 2 MB pages: 0.06 s per GB, 0.026 s for the same 16 x 256 MB,
+// 0.16 s to give back, and copies from it run at the link's rate all the same.  MM2GB_PIN=hipmalloc keeps the runtime's allocator.
+namespace {
+bool pin_by_register() { static const bool v = [] { const char *e = getenv("MM2GB_PIN"); return !(e && strcmp(e, "hipmalloc") == 0); }(); return v; }
+void *pinned_alloc(size_t bytes)
+{
+	if (!pin_by_register()) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+	void *p = nullptr;
+	const size_t rounded = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+	if (posix_memalign(&p, (size_t)2 << 20, rounded) != 0) return nullptr;
+	(void)madvise(p, rounded, MADV_HUGEPAGE);
+	for (size_t off = 0; off < rounded; off += 4096) ((volatile char*)p)[off] = 0;       // first touch: the pages exist (as huge pages where the system grants them) before they are pinned
+	if (hipHostRegister(p, rounded, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); free(p); return nullptr; }
+	return p;
+}
+void pinned_free(void *p)
+{
+	if (!p) return;
+	if (!pin_by_register()) { (void)hipHostFree(p); return; }
+	(void)hipHostUnregister(p);
+	free(p);
+}
+} // namespace
+
 int PinnedBuf::ensure(size_t need)
 {
 	if (need <= bytes) return 0;
 	const size_t want = grown(need, bytes);
-	void *fresh = nullptr;                               // as DevBuf::ensure: a failed growth keeps the old buffer
-	if (hipHostMalloc(&fresh, want, hipHostMallocDefault) == hipSuccess) { retire(ptr, bytes, true); ptr = fresh; bytes = want; return 0; }
-	(void)hipGetLastError();
+	void *fresh = pinned_alloc(want);                    // as DevBuf::ensure: a failed growth keeps the old buffer
+	if (fresh) { retire(ptr, bytes, true); ptr = fresh; bytes = want; return 0; }
 	flush_retired_buffers();
-	if (hipHostMalloc(&fresh, need, hipHostMallocDefault) == hipSuccess) { retire(ptr, bytes, true); ptr = fresh; bytes = need; return 0; }
-	(void)hipGetLastError();
+	if ((fresh = pinned_alloc(need)) != nullptr) { retire(ptr, bytes, true); ptr = fresh; bytes = need; return 0; }
 	release();
-	MM2GB_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
+	if ((ptr = pinned_alloc(need)) == nullptr) return fail("mm2gb: cannot allocate " + std::to_string(need) + " bytes of page-locked host memory");
 	bytes = need;
 	return 0;
 }
 void PinnedBuf::release()
 {
-	if (ptr) (void)hipHostFree(ptr);
+	pinned_free(ptr);
 	ptr = nullptr; bytes = 0;
 }
 

@@ -119,6 +119,7 @@ static struct {
 	bool post_on_device = false;           // MM2GB_POST=gpu (or MM2GB_POST_THREADS=0): no host post-pass threads at all
 	bool ready = false;
 	bool debug = false;                    // MM2GB_DEBUG_PHASES: where a batch's host time goes, on stderr
+	int  ahead_threads = 1;                // host threads of a batch's re-chaining ahead (beside the device)
 	bool rechain_ahead = false;            // answer a batch's mg_lchain_rmq calls before the host's callback asks (host linked with --wrap, or MM2GB_PRECHAIN=1)
 } g_streams;
 
@@ -206,7 +207,7 @@ static int finish_compute(StreamSlot &slot, HostStage &st)
 			slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &st.misc, slot.eng.device);
 			if (!slot.rmq_eng) return -1;
 		}
-		if (rechain_ahead(slot.rmq_eng, *(const mm2gb_mapopt_head_t*)st.opt, st.misc, view.data(), n_read, g_streams.post_threads, st.ahead)) return -1;
+		if (rechain_ahead(slot.rmq_eng, *(const mm2gb_mapopt_head_t*)st.opt, st.misc, view.data(), n_read, g_streams.ahead_threads, st.ahead)) return -1;
 		st.have_ahead = st.ahead.n_ahead() > 0;
 		g_reads_ahead.fetch_add(st.ahead.n_ahead());
 		g_ns_ahead.fetch_add(now_ns() - ta);
@@ -316,6 +317,7 @@ static int launch_stage(StreamSlot &slot, HostStage &st, mm2gb_chain_read_t *rea
 	TraceRange range("mm2gb:launch_batch");
 	MM2GB_HIP(hipSetDevice(slot.eng.device));
 	st.misc = slot.eng.misc;
+	slot.eng.io_seq = 0;                                  // nothing of an earlier batch is in flight (wait_computed): start with staging set 0 again, no second set to allocate
 	if (!st.done) MM2GB_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
 	if (slot.h_raw.ensure((size_t)(total + 1) * 16)) return -1;
 	st.goff.resize((size_t)n_read + 1);
@@ -682,6 +684,9 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	{
 		const char *pc = getenv("MM2GB_PRECHAIN");
 		g_streams.rechain_ahead = pc && *pc ? atoi(pc) != 0 : elf_imports_symbol("/proc/self/exe", "__wrap_mg_lchain_rmq");
+		// the stream's post-pass threads, plus the host thread's own CPU: it waits for the finisher while the batch it just launched is finished
+		const char *at = getenv("MM2GB_AHEAD_THREADS");
+		g_streams.ahead_threads = at ? std::max(1, atoi(at)) : g_streams.post_threads + 1;
 	}
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
