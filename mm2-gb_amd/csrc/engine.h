@@ -98,6 +98,8 @@ struct Engine {
 	IoSet io[2];
 	uint64_t io_seq = 0;
 	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host
+	PinnedBuf h_slice_uoff, h_slice_aoff;  // per-slice chain / kept-anchor offsets of the sliced mm2gb_chain_gpu
+	hipEvent_t fetched[2] = { nullptr, nullptr };   // sliced mm2gb_chain_gpu: the chains of the slice that last used result set k have left it
 	PinnedBuf h_res_f, h_res_p;            // scores of whole-batch chaining calls (pool.cpp): page-locked, reused, grow-only
 	// per-slot read-back (pinned)
 	int32_t *h_counters = nullptr;         // MAX_SLOTS x CNT_WORDS
@@ -143,13 +145,14 @@ struct Engine {
 	                  const mm2gb_rmq_param_t *rmq = nullptr, int out_set = 0);   // rmq given: thresholds of the re-chaining call (lchain.c:355) instead of misc's
 	// the boundary's device post-pass: host anchors in (page-locked), H2D + score kernels + post kernels enqueued, nothing waited
 	// for; fetch_chains() waits for that batch and copies its chains out (exact sizes)
-	int  enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int out_set);
+	int  enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int out_set, bool want_stats = false);
 	int  fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out);
 	// whole batch on host buffers, chains back, nothing but the chains crosses the link on the way back
 	// rmq given: the score fill is mg_lchain_rmq's (k_rmq_fill) instead of the chaining DP; n_tied (optional, n_reads entries)
 	// receives, per read, the number of anchors whose range-minimum was tied (results for such a read are not the reference's)
 	int  chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out,
 	               const mm2gb_rmq_param_t *rmq = nullptr, int32_t *n_tied = nullptr);
+	int  chain_gpu_sliced(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out, int64_t slice);
 	int  collect_seeds(int64_t opt_flag, int64_t n_reads, const int64_t *seed_off, const mm2gb_seed_t *seeds, const int64_t *hit_off, const uint64_t *hits,
 	                   const int32_t *qlen, const int32_t *q_rank, int32_t n_ref, const int32_t *ref_len, const int32_t *ref_rank, int64_t *anchor_off, mm2gb_anchor_t *anchors);
 	int  sort_seeds(int64_t n_reads, const int64_t *offsets, mm2gb_anchor_t *anchors);

@@ -134,6 +134,57 @@ void PinnedBuf::release()
 	ptr = nullptr; bytes = 0;
 }
 
+// ---- page-locked result blocks, cached (host_chain.h) ----
+namespace {
+struct ResultBlock { void *ptr; size_t bytes; bool in_use; };
+std::mutex g_result_mu;
+std::vector<ResultBlock> g_result_blocks;
+constexpr size_t RESULT_CACHE_MIN = (size_t)8 << 20;       // smaller results are plain allocations
+} // namespace
+
+void *result_alloc_pinned(size_t bytes)
+{
+	if (bytes < RESULT_CACHE_MIN) return result_alloc(bytes);
+	{
+		std::lock_guard<std::mutex> lock(g_result_mu);
+		ResultBlock *best = nullptr;
+		for (ResultBlock &b : g_result_blocks)
+			if (!b.in_use && b.bytes >= bytes && b.bytes / 4 <= bytes && (!best || b.bytes < best->bytes)) best = &b;
+		if (best) { best->in_use = true; return best->ptr; }
+	}
+	const size_t want = bytes + bytes / 8;                      // the next batch of about this size fits too
+	void *p = pin_by_register() ? pinned_alloc(want) : nullptr;
+	if (!p) return result_alloc(bytes);
+	std::lock_guard<std::mutex> lock(g_result_mu);
+	g_result_blocks.push_back({ p, (want + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1), true });
+	return p;
+}
+
+void result_release(void *ptr)
+{
+	if (!ptr) return;
+	static const size_t cap = [] { const char *v = getenv("MM2GB_RESULT_CACHE_MB"); return (size_t)(v ? std::max(0LL, atoll(v)) : 8192) << 20; }();
+	std::vector<void*> drop;
+	{
+		std::lock_guard<std::mutex> lock(g_result_mu);
+		bool mine = false;
+		size_t idle = 0;
+		for (ResultBlock &b : g_result_blocks) { if (b.ptr == ptr) { b.in_use = false; mine = true; } if (!b.in_use) idle += b.bytes; }
+		if (!mine) { free(ptr); return; }
+		// over the cap: the largest idle blocks go first
+		while (idle > cap) {
+			size_t at = g_result_blocks.size();
+			for (size_t k = 0; k < g_result_blocks.size(); ++k)
+				if (!g_result_blocks[k].in_use && (at == g_result_blocks.size() || g_result_blocks[k].bytes > g_result_blocks[at].bytes)) at = k;
+			if (at == g_result_blocks.size()) break;
+			idle -= g_result_blocks[at].bytes;
+			drop.push_back(g_result_blocks[at].ptr);
+			g_result_blocks.erase(g_result_blocks.begin() + (std::ptrdiff_t)at);
+		}
+	}
+	for (void *p : drop) pinned_free(p);
+}
+
 static DevParams make_params(const mm2gb_misc_t &m)
 {
 	DevParams P;
@@ -350,7 +401,8 @@ void Engine::shutdown()
 	}
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-	h_slice_off.release(); h_res_f.release(); h_res_p.release();
+	h_slice_off.release(); h_slice_uoff.release(); h_slice_aoff.release(); h_res_f.release(); h_res_p.release();
+	for (hipEvent_t *e : { &fetched[0], &fetched[1] }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
@@ -555,7 +607,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	return 0;
 }
 
-int Engine::enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int out_set)
+int Engine::enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const mm2gb_anchor_t *h_anchors, int64_t n, int out_set, bool want_stats)
 {
 	MM2GB_HIP(hipSetDevice(device));
 	IoSet &s = io[io_seq++ & 1];
@@ -573,7 +625,7 @@ int Engine::enqueue_host_chains(int64_t n_reads, const int64_t *h_offsets, const
 	// the score kernels overwrite s.f / s.p: a batch that went through enqueue_host (several micro-batches) may still be copying
 	// them out of this set on the D2H stream, and its kernels may have run on the other compute stream
 	if (s.used) { MM2GB_HIP(hipStreamWaitEvent(stream, s.out_done, 0)); MM2GB_HIP(hipStreamWaitEvent(stream, s.comp_done, 0)); }
-	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, false, 0)) return -1;
+	if (enqueue(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (int32_t*)s.f.ptr, (int32_t*)s.p.ptr, want_stats, 0)) return -1;
 	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, nullptr, out_set)) return -1;
 	MM2GB_HIP(hipEventRecord(s.comp_done, stream));
 	MM2GB_HIP(hipEventRecord(s.out_done, stream));                       // (no D2H of f / p on this path: "outputs done" == kernels done)
@@ -591,8 +643,8 @@ int Engine::fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out)
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->u = (uint64_t*)malloc((size_t)(n_u + 1) * 8);
-	out->a = (mm2gb_anchor_t*)result_alloc((size_t)(n_a + 1) * 16);
-	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb: out of host memory"); }
+	out->a = (mm2gb_anchor_t*)result_alloc_pinned((size_t)(n_a + 1) * 16);
+	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); result_release(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb: out of host memory"); }
 	out->u_off[0] = out->a_off[0] = 0;
 	if (n_reads > 0) {
 		// on the D2H stream: the compute stream may already be busy with the next batch
@@ -602,6 +654,100 @@ int Engine::fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out)
 		if (n_a > 0) MM2GB_HIP(hipMemcpyAsync(out->a, po.a_out.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost, s_out));
 		MM2GB_HIP(hipStreamSynchronize(s_out));
 	}
+	return 0;
+}
+
+// The same for a LARGE batch, cut into slices of reads so that the link is never idle: the H2D of slice k+1 runs under the score and
+// post kernels of slice k, whose chains go back on the D2H stream under the H2D of slice k+2 (round 4: one H2D, then the kernels, then
+// one D2H into fresh pageable memory -- 170 ms for 200 M anchors against 55.6 ms of H2D alone, profiles/r05_host_path_timeline.md).
+// Two staging sets and two result sets alternate; the host waits only for a slice's totals (16 bytes, when its post kernels are done) to
+// know where its chains go in the caller's arrays, which are page-locked blocks out of the result cache (kept anchors <= anchors in).
+int Engine::chain_gpu_sliced(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out, int64_t slice)
+{
+	const int64_t n = offsets[n_reads];
+	if (begin_call()) return -1;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
+	io_seq = 0;
+	for (IoSet &s : io) s.used = false;
+	// slices at read boundaries; the last one small (what follows the last copy is exposed)
+	std::vector<int64_t> first(1, 0);
+	{
+		const int64_t tail = slice / 4;
+		int64_t acc = 0;
+		bool tail_cut = false;
+		for (int64_t r = 0; r + 1 < n_reads; ++r) {
+			acc += offsets[r + 1] - offsets[r];
+			const int64_t left = n - offsets[r + 1];
+			if (tail_cut) continue;
+			if (left <= tail && acc > tail) { first.push_back(r + 1); acc = 0; tail_cut = true; }
+			else if (acc >= slice && left > tail + slice / 4) { first.push_back(r + 1); acc = 0; }
+		}
+	}
+	first.push_back(n_reads);
+	const size_t n_sl = first.size() - 1;
+	// outputs: offsets per read; chains and kept anchors at their upper bounds (every chain holds >= max(1, min_cnt) anchors)
+	const int64_t mc = std::max(1, misc.min_cnt);
+	const size_t u_cap = (size_t)(n / mc + n_reads + 1), a_cap = (size_t)n + 1;
+	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->u = (uint64_t*)result_alloc_pinned(u_cap * 8);
+	out->a = (mm2gb_anchor_t*)result_alloc_pinned(a_cap * 16);
+	auto give_up = [&](const std::string &why) {
+		for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) (void)hipStreamSynchronize(q);
+		free(out->u_off); free(out->a_off); result_release(out->u); result_release(out->a); memset(out, 0, sizeof(*out));
+		n_slots = 0;
+		return fail(why);
+	};
+	if (!out->u_off || !out->a_off || !out->u || !out->a) return give_up("mm2gb_chain_gpu: out of host memory");
+	// per-slice read offsets (each from 0) in, per-slice chain / anchor offsets back: page-locked, the engine's
+	if (h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8) || h_slice_uoff.ensure(((size_t)n_reads + n_sl + 1) * 8) || h_slice_aoff.ensure(((size_t)n_reads + n_sl + 1) * 8))
+		return give_up(last_error_cstr());
+	int64_t *lo = (int64_t*)h_slice_off.ptr, *uo = (int64_t*)h_slice_uoff.ptr, *ao = (int64_t*)h_slice_aoff.ptr;
+	std::vector<size_t> at(n_sl + 1, 0);
+	for (size_t k = 0; k < n_sl; ++k) {
+		at[k + 1] = at[k] + (size_t)(first[k + 1] - first[k]) + 1;
+		for (int64_t r = first[k]; r <= first[k + 1]; ++r) lo[at[k] + (size_t)(r - first[k])] = offsets[r] - offsets[first[k]];
+	}
+	for (hipEvent_t *e : { &fetched[0], &fetched[1] }) if (!*e) MM2GB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+	std::vector<int64_t> u_base(n_sl + 1, 0), a_base(n_sl + 1, 0);
+	bool fetched_used[2] = { false, false };
+	// the chains of slice k leave on the D2H stream as soon as its totals are known; nothing is waited for but those 16 bytes
+	auto fetch = [&](size_t k) -> int {
+		const int set = (int)(k & 1);
+		PostOut &po = post_out[set];
+		MM2GB_HIP(hipEventSynchronize(po.done));
+		const int64_t nr = first[k + 1] - first[k], n_u = po.h_totals[0], n_a = po.h_totals[1];
+		u_base[k + 1] = u_base[k] + n_u; a_base[k + 1] = a_base[k] + n_a;
+		if ((size_t)u_base[k + 1] > u_cap || (size_t)a_base[k + 1] > a_cap) return fail("mm2gb_chain_gpu: a slice returned more chains than its anchors allow");
+		MM2GB_HIP(hipMemcpyAsync(uo + at[k], po.u_off.ptr, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipMemcpyAsync(ao + at[k], po.a_off.ptr, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost, s_out));
+		if (n_u > 0) MM2GB_HIP(hipMemcpyAsync(out->u + u_base[k], po.u_out.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost, s_out));
+		if (n_a > 0) MM2GB_HIP(hipMemcpyAsync(out->a + a_base[k], po.a_out.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost, s_out));
+		MM2GB_HIP(hipEventRecord(fetched[set], s_out));
+		fetched_used[set] = true;
+		return 0;
+	};
+	for (size_t k = 0; k < n_sl; ++k) {
+		const int64_t r0 = first[k], r1 = first[k + 1];
+		// the post kernels of this slice write result set k & 1: the copies of slice k-2 out of it must be through
+		if (fetched_used[k & 1]) MM2GB_HIP(hipStreamWaitEvent(stream, fetched[k & 1], 0));
+		if (enqueue_host_chains(r1 - r0, lo + at[k], anchors + offsets[r0], offsets[r1] - offsets[r0], (int)(k & 1), true)) return give_up(last_error_cstr());
+		if (k > 0 && fetch(k - 1)) return give_up(last_error_cstr());
+	}
+	if (fetch(n_sl - 1)) return give_up(last_error_cstr());
+	MM2GB_HIP(hipStreamSynchronize(s_out));
+	if (sync()) return give_up(last_error_cstr());
+	// per-slice offsets -> offsets of the whole batch
+	out->u_off[0] = out->a_off[0] = 0;
+	for (size_t k = 0; k < n_sl; ++k)
+		for (int64_t r = first[k]; r < first[k + 1]; ++r) {
+			out->u_off[r + 1] = u_base[k] + uo[at[k] + (size_t)(r - first[k]) + 1];
+			out->a_off[r + 1] = a_base[k] + ao[at[k] + (size_t)(r - first[k]) + 1];
+		}
+	last.n_anchors = n; last.n_reads = n_reads;
+	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	if (debug_phases) fprintf(stderr, "[mm2gb chain_gpu] %lld anchors in %zu slices, %lld kept, %lld chains: %.1f ms\n", (long long)n, n_sl, (long long)a_base[n_sl], (long long)u_base[n_sl], last.ms_total);
 	return 0;
 }
 
@@ -616,6 +762,11 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	const int64_t n = offsets[n_reads];
 	if (n > 0 && !anchors) return fail("mm2gb_chain_gpu: null buffer");
 	MM2GB_HIP(hipSetDevice(device));
+	if (!rmq) {
+		int64_t slice = 64 * 1000 * 1000;
+		if (const char *v = getenv("MM2GB_CHAIN_SLICE_ANCHORS")) slice = std::max<int64_t>(1, atoll(v));
+		if (n > slice + slice / 2 && n_reads > 1) return chain_gpu_sliced(n_reads, offsets, anchors, out, slice);
+	}
 	if (begin_call()) return -1;
 	const auto t0 = std::chrono::steady_clock::now();
 	IoSet &s = io[io_seq++ & 1];
@@ -727,8 +878,8 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
 	out->u = (uint64_t*)malloc((size_t)(n_u + 1) * 8);
-	out->a = (mm2gb_anchor_t*)result_alloc((size_t)(n_a + 1) * 16);
-	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); free(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb_chain_gpu: out of host memory"); }
+	out->a = (mm2gb_anchor_t*)result_alloc_pinned((size_t)(n_a + 1) * 16);
+	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); free(out->u); result_release(out->a); memset(out, 0, sizeof(*out)); return fail("mm2gb_chain_gpu: out of host memory"); }
 	out->u_off[0] = out->a_off[0] = 0;
 	if (n_reads > 0) {
 		// on the engine's own D2H stream, never the null stream: every engine of the process would queue behind the same one

@@ -61,6 +61,13 @@ inline void *result_alloc(size_t bytes)
 	return malloc(bytes ? bytes : 1);
 }
 
+// Results that the DEVICE writes (the chains of a large batch, D2H): a page-locked block out of a small process-wide cache (engine.hip) --
+// a fresh gigabyte costs its first touch and its pinning, a block that mm2gb_chains_free gave back costs nothing and is copied into at the
+// link's rate.  Falls back to result_alloc when nothing can be registered.  result_release: a cached block goes back to the cache
+// (MM2GB_RESULT_CACHE_MB, default 8192, of idle blocks are kept), anything else to free().
+void *result_alloc_pinned(size_t bytes);
+void  result_release(void *ptr);
+
 // A host thread's large scratch array, kept from call to call (static thread_local at its users): grows, never shrinks, nothing initialised.
 template <class T> struct BigBuf {
 	T *p = nullptr;

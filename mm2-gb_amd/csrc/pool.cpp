@@ -253,7 +253,7 @@ int mm2gb_chain_host(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offset
 void mm2gb_chains_free(mm2gb_chains_t *out)
 {
 	if (!out) return;
-	free(out->u_off); free(out->u); free(out->a_off); free(out->a);
+	free(out->u_off); result_release(out->u); free(out->a_off); result_release(out->a);
 	memset(out, 0, sizeof(*out));
 }
 

@@ -157,3 +157,22 @@ def test_repeated_calls_reuse_arenas(engine):
     again, _ = engine.chain_gpu(a1, off1)
     for r in range(len(off1) - 1):
         assert np.array_equal(first[r][0], again[r][0]) and np.array_equal(first[r][1], again[r][1])
+
+
+def test_sliced_call_overlaps_copies_and_kernels_same_chains(engine, monkeypatch):
+    """A large batch goes through mm2gb_chain_gpu in slices of reads (H2D of slice k+1 under the kernels of slice k, its chains back under
+    the H2D of slice k+2; results in page-locked blocks of the result cache): forced here with a tiny slice size.  Same chains as the host
+    post-pass read by read, same pair count, and a second call (which gets the first call's blocks back from the cache) the same again."""
+    a, off = mm.synth_reads(31, 0, 40, 8_000, 40_000)
+    want, st_h = engine.chain(a, off, threads=4)
+    monkeypatch.setenv("MM2GB_CHAIN_SLICE_ANCHORS", str(max(50_000, len(a) // 7)))
+    for _ in range(2):
+        got, st = engine.chain_gpu(a, off)
+        assert st["n_pairs"] == st_h["n_pairs"] and st["n_anchors"] == len(a)
+        assert len(got) == len(want)
+        for r in range(len(want)):
+            assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), r
+    monkeypatch.setenv("MM2GB_CHAIN_SLICE_ANCHORS", "1000")       # a slice per read or so, two result sets alternating many times
+    got, _ = engine.chain_gpu(a, off)
+    for r in range(len(want)):
+        assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), r
