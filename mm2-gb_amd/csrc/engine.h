@@ -98,8 +98,7 @@ struct Engine {
 	IoSet io[2];
 	uint64_t io_seq = 0;
 	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host
-	PinnedBuf h_slice_uoff, h_slice_aoff;  // per-slice chain / kept-anchor offsets of the sliced mm2gb_chain_gpu
-	hipEvent_t fetched[2] = { nullptr, nullptr };   // sliced mm2gb_chain_gpu: the chains of the slice that last used result set k have left it
+	std::vector<hipEvent_t> slice_in;      // sliced mm2gb_chain_gpu: slice k's anchors have arrived
 	PinnedBuf h_res_f, h_res_p;            // scores of whole-batch chaining calls (pool.cpp): page-locked, reused, grow-only
 	// per-slot read-back (pinned)
 	int32_t *h_counters = nullptr;         // MAX_SLOTS x CNT_WORDS

@@ -401,8 +401,9 @@ void Engine::shutdown()
 	}
 	for (BatchSlot &b : slots)
 		for (hipEvent_t *e : { &b.prep0, &b.prep1, &b.score1 }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-	h_slice_off.release(); h_slice_uoff.release(); h_slice_aoff.release(); h_res_f.release(); h_res_p.release();
-	for (hipEvent_t *e : { &fetched[0], &fetched[1] }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+	h_slice_off.release(); h_res_f.release(); h_res_p.release();
+	for (hipEvent_t &e : slice_in) if (e) (void)hipEventDestroy(e);
+	slice_in.clear();
 	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
@@ -657,20 +658,25 @@ int Engine::fetch_chains(int out_set, int64_t n_reads, mm2gb_chains_t *out)
 	return 0;
 }
 
-// The same for a LARGE batch, cut into slices of reads so that the link is never idle: the H2D of slice k+1 runs under the score and
-// post kernels of slice k, whose chains go back on the D2H stream under the H2D of slice k+2 (round 4: one H2D, then the kernels, then
-// one D2H into fresh pageable memory -- 170 ms for 200 M anchors against 55.6 ms of H2D alone, profiles/r05_host_path_timeline.md).
-// Two staging sets and two result sets alternate; the host waits only for a slice's totals (16 bytes, when its post kernels are done) to
-// know where its chains go in the caller's arrays, which are page-locked blocks out of the result cache (kept anchors <= anchors in).
+// The same for a LARGE batch: the anchors go in in slices of reads, each slice's score kernels running under the next slice's H2D (the
+// link is never idle; round 4 copied everything in, then ran the kernels, then copied the chains into fresh pageable memory: 170 ms for 200 M
+// anchors against 55.6 ms of H2D alone).  The post-pass runs ONCE, over the whole batch, when the last slice is scored: k_post_chains is as
+// long as its largest read takes (28 ms for a 64 M-anchor slice, 30 ms for the whole 200 M: four slices' post-passes one after the other were
+// no faster than the round-4 call, profiles/r05_host_path_timeline.md), so it is paid once and only the chains' D2H follows it.
+// Results land in page-locked blocks of the result cache (exact sizes: the totals are known before the copies start).
 int Engine::chain_gpu_sliced(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out, int64_t slice)
 {
 	const int64_t n = offsets[n_reads];
 	if (begin_call()) return -1;
 	const auto t0 = std::chrono::steady_clock::now();
 	for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) MM2GB_HIP(hipStreamSynchronize(q));
-	io_seq = 0;
-	for (IoSet &s : io) s.used = false;
-	// slices at read boundaries; the last one small (what follows the last copy is exposed)
+	// the whole batch resident: raw anchors, offsets, f, p in staging set 0 (sized for all of it); slices are copied into it piece by piece
+	IoSet &s = io[0];
+	io_seq = 1;
+	const size_t nn = (size_t)std::max<int64_t>(n, 1);
+	if (s.raw.ensure(nn * 16) || s.f.ensure(nn * 4) || s.p.ensure(nn * 4) || s.offsets.ensure((size_t)(n_reads + 1) * 8)) return -1;
+	if (reserve_post(n, n_reads) || reserve_post_out(0, n, n_reads)) return -1;     // before anything is in flight: growing arenas waits
+	// slices at read boundaries; the last one small (its kernels are exposed)
 	std::vector<int64_t> first(1, 0);
 	{
 		const int64_t tail = slice / 4;
@@ -686,68 +692,52 @@ int Engine::chain_gpu_sliced(int64_t n_reads, const int64_t *offsets, const mm2g
 	}
 	first.push_back(n_reads);
 	const size_t n_sl = first.size() - 1;
-	// outputs: offsets per read; chains and kept anchors at their upper bounds (every chain holds >= max(1, min_cnt) anchors)
-	const int64_t mc = std::max(1, misc.min_cnt);
-	const size_t u_cap = (size_t)(n / mc + n_reads + 1), a_cap = (size_t)n + 1;
-	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
-	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
-	out->u = (uint64_t*)result_alloc_pinned(u_cap * 8);
-	out->a = (mm2gb_anchor_t*)result_alloc_pinned(a_cap * 16);
 	auto give_up = [&](const std::string &why) {
 		for (hipStream_t q : { s_in, work[0].stream, work[1].stream, s_out }) (void)hipStreamSynchronize(q);
-		free(out->u_off); free(out->a_off); result_release(out->u); result_release(out->a); memset(out, 0, sizeof(*out));
 		n_slots = 0;
+		s.used = false;
 		return fail(why);
 	};
-	if (!out->u_off || !out->a_off || !out->u || !out->a) return give_up("mm2gb_chain_gpu: out of host memory");
-	// per-slice read offsets (each from 0) in, per-slice chain / anchor offsets back: page-locked, the engine's
-	if (h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8) || h_slice_uoff.ensure(((size_t)n_reads + n_sl + 1) * 8) || h_slice_aoff.ensure(((size_t)n_reads + n_sl + 1) * 8))
-		return give_up(last_error_cstr());
-	int64_t *lo = (int64_t*)h_slice_off.ptr, *uo = (int64_t*)h_slice_uoff.ptr, *ao = (int64_t*)h_slice_aoff.ptr;
+	// per-slice read offsets (each from 0): page-locked, the engine's; on the device they sit in a second offsets array (set 1's)
+	if (h_slice_off.ensure(((size_t)n_reads + n_sl + 1) * 8) || io[1].offsets.ensure(((size_t)n_reads + n_sl + 1) * 8)) return give_up(last_error_cstr());
+	int64_t *lo = (int64_t*)h_slice_off.ptr;
 	std::vector<size_t> at(n_sl + 1, 0);
 	for (size_t k = 0; k < n_sl; ++k) {
 		at[k + 1] = at[k] + (size_t)(first[k + 1] - first[k]) + 1;
 		for (int64_t r = first[k]; r <= first[k + 1]; ++r) lo[at[k] + (size_t)(r - first[k])] = offsets[r] - offsets[first[k]];
 	}
-	for (hipEvent_t *e : { &fetched[0], &fetched[1] }) if (!*e) MM2GB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-	std::vector<int64_t> u_base(n_sl + 1, 0), a_base(n_sl + 1, 0);
-	bool fetched_used[2] = { false, false };
-	// the chains of slice k leave on the D2H stream as soon as its totals are known; nothing is waited for but those 16 bytes
-	auto fetch = [&](size_t k) -> int {
-		const int set = (int)(k & 1);
-		PostOut &po = post_out[set];
-		MM2GB_HIP(hipEventSynchronize(po.done));
-		const int64_t nr = first[k + 1] - first[k], n_u = po.h_totals[0], n_a = po.h_totals[1];
-		u_base[k + 1] = u_base[k] + n_u; a_base[k + 1] = a_base[k] + n_a;
-		if ((size_t)u_base[k + 1] > u_cap || (size_t)a_base[k + 1] > a_cap) return fail("mm2gb_chain_gpu: a slice returned more chains than its anchors allow");
-		MM2GB_HIP(hipMemcpyAsync(uo + at[k], po.u_off.ptr, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost, s_out));
-		MM2GB_HIP(hipMemcpyAsync(ao + at[k], po.a_off.ptr, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost, s_out));
-		if (n_u > 0) MM2GB_HIP(hipMemcpyAsync(out->u + u_base[k], po.u_out.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost, s_out));
-		if (n_a > 0) MM2GB_HIP(hipMemcpyAsync(out->a + a_base[k], po.a_out.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost, s_out));
-		MM2GB_HIP(hipEventRecord(fetched[set], s_out));
-		fetched_used[set] = true;
-		return 0;
-	};
+	if (slice_in.size() < n_sl) { const size_t had = slice_in.size(); slice_in.resize(n_sl, nullptr); for (size_t k = had; k < n_sl; ++k) MM2GB_HIP(hipEventCreateWithFlags(&slice_in[k], hipEventDisableTiming)); }
+	MM2GB_HIP(hipMemcpyAsync(s.offsets.ptr, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s_in));
+	MM2GB_HIP(hipMemcpyAsync(io[1].offsets.ptr, lo, at[n_sl] * 8, hipMemcpyHostToDevice, s_in));
 	for (size_t k = 0; k < n_sl; ++k) {
-		const int64_t r0 = first[k], r1 = first[k + 1];
-		// the post kernels of this slice write result set k & 1: the copies of slice k-2 out of it must be through
-		if (fetched_used[k & 1]) MM2GB_HIP(hipStreamWaitEvent(stream, fetched[k & 1], 0));
-		if (enqueue_host_chains(r1 - r0, lo + at[k], anchors + offsets[r0], offsets[r1] - offsets[r0], (int)(k & 1), true)) return give_up(last_error_cstr());
-		if (k > 0 && fetch(k - 1)) return give_up(last_error_cstr());
+		const int64_t a0 = offsets[first[k]], na = offsets[first[k + 1]] - a0;
+		if (na > 0) MM2GB_HIP(hipMemcpyAsync((mm2gb_anchor_t*)s.raw.ptr + a0, anchors + a0, (size_t)na * 16, hipMemcpyHostToDevice, s_in));
+		MM2GB_HIP(hipEventRecord(slice_in[k], s_in));
+		MM2GB_HIP(hipStreamWaitEvent(stream, slice_in[k], 0));
+		if (enqueue(first[k + 1] - first[k], (const int64_t*)io[1].offsets.ptr + at[k], (const mm2gb_anchor_t*)s.raw.ptr + a0, na, (int32_t*)s.f.ptr + a0, (int32_t*)s.p.ptr + a0, true, 0))
+			return give_up(last_error_cstr());
 	}
-	if (fetch(n_sl - 1)) return give_up(last_error_cstr());
+	if (enqueue_post(n_reads, (const int64_t*)s.offsets.ptr, (const mm2gb_anchor_t*)s.raw.ptr, n, (const int32_t*)s.f.ptr, (const int32_t*)s.p.ptr, nullptr, 0)) return give_up(last_error_cstr());
+	PostOut &po = post_out[0];
+	MM2GB_HIP(hipEventSynchronize(po.done));
+	const int64_t n_u = po.h_totals[0], n_a = po.h_totals[1];
+	out->u_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->a_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+	out->u = (uint64_t*)result_alloc_pinned((size_t)(n_u + 1) * 8);
+	out->a = (mm2gb_anchor_t*)result_alloc_pinned((size_t)(n_a + 1) * 16);
+	if (!out->u_off || !out->a_off || !out->u || !out->a) { free(out->u_off); free(out->a_off); result_release(out->u); result_release(out->a); memset(out, 0, sizeof(*out)); return give_up("mm2gb_chain_gpu: out of host memory"); }
+	MM2GB_HIP(hipMemcpyAsync(out->u_off, po.u_off.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s_out));
+	MM2GB_HIP(hipMemcpyAsync(out->a_off, po.a_off.ptr, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s_out));
+	if (n_u > 0) MM2GB_HIP(hipMemcpyAsync(out->u, po.u_out.ptr, (size_t)n_u * 8, hipMemcpyDeviceToHost, s_out));
+	if (n_a > 0) MM2GB_HIP(hipMemcpyAsync(out->a, po.a_out.ptr, (size_t)n_a * 16, hipMemcpyDeviceToHost, s_out));
 	MM2GB_HIP(hipStreamSynchronize(s_out));
-	if (sync()) return give_up(last_error_cstr());
-	// per-slice offsets -> offsets of the whole batch
-	out->u_off[0] = out->a_off[0] = 0;
-	for (size_t k = 0; k < n_sl; ++k)
-		for (int64_t r = first[k]; r < first[k + 1]; ++r) {
-			out->u_off[r + 1] = u_base[k] + uo[at[k] + (size_t)(r - first[k]) + 1];
-			out->a_off[r + 1] = a_base[k] + ao[at[k] + (size_t)(r - first[k]) + 1];
-		}
+	if (sync()) { mm2gb_chains_free(out); return -1; }
+	s.used = false;                                     // nothing of this set is in flight once the call returns
 	last.n_anchors = n; last.n_reads = n_reads;
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, post0, post1) == hipSuccess) last.ms_post = ms;
 	last.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	if (debug_phases) fprintf(stderr, "[mm2gb chain_gpu] %lld anchors in %zu slices, %lld kept, %lld chains: %.1f ms\n", (long long)n, n_sl, (long long)a_base[n_sl], (long long)u_base[n_sl], last.ms_total);
+	if (debug_phases) fprintf(stderr, "[mm2gb chain_gpu] %lld anchors in %zu slices, %lld kept, %lld chains: %.1f ms (post-pass %.1f ms)\n", (long long)n, n_sl, (long long)n_a, (long long)n_u, last.ms_total, ms);
 	return 0;
 }
 

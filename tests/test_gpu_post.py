@@ -160,9 +160,9 @@ def test_repeated_calls_reuse_arenas(engine):
 
 
 def test_sliced_call_overlaps_copies_and_kernels_same_chains(engine, monkeypatch):
-    """A large batch goes through mm2gb_chain_gpu in slices of reads (H2D of slice k+1 under the kernels of slice k, its chains back under
-    the H2D of slice k+2; results in page-locked blocks of the result cache): forced here with a tiny slice size.  Same chains as the host
-    post-pass read by read, same pair count, and a second call (which gets the first call's blocks back from the cache) the same again."""
+    """A large batch goes into mm2gb_chain_gpu in slices of reads (the score kernels of slice k under the H2D of slice k+1, one post-pass
+    over the whole batch at the end, results in page-locked blocks of the result cache): forced here with a tiny slice size.  Same chains as
+    the host post-pass read by read, same pair count, and a second call (which gets the first call's blocks back from the cache) the same again."""
     a, off = mm.synth_reads(31, 0, 40, 8_000, 40_000)
     want, st_h = engine.chain(a, off, threads=4)
     monkeypatch.setenv("MM2GB_CHAIN_SLICE_ANCHORS", str(max(50_000, len(a) // 7)))
