@@ -62,6 +62,10 @@ static_assert(LINE_STORE_BYTES % 1024 == 0 && LINE_STORE_BYTES / 8 >= 2 * 256 + 
 #define MM2GB_POST_WAVES_PER_SIMD 3
 #endif
 constexpr int POST_WAVES_PER_SIMD = MM2GB_POST_WAVES_PER_SIMD;
+#ifndef MM2GB_POST_MARKS_IN_MEMORY
+#define MM2GB_POST_MARKS_IN_MEMORY 0            // 1: the walks' "taken" flags in the anchors' records for every read (round 4; A/B builds)
+#endif
+constexpr bool POST_MARKS_IN_MEMORY = MM2GB_POST_MARKS_IN_MEMORY != 0;
 struct alignas(16) PassLds {
 	int where[256];              // histogram first; then line start | line length << 16
 	int head[256], tail[256], anchor[256];
@@ -426,8 +430,12 @@ namespace {
 struct WalkDbg { long long load = 0, longt = 0, groups = 0, open = 0, nlong = 0, iters = 0; };
 
 // The chain walks of one read (lchain.c:44-74) over its sorted candidates z[0, n_z): one wave.
+// `bits` (round 5): one "taken" bit per anchor of the read in the wave's LDS (the sort's scratch, free by now) instead of the top bit of the
+// anchor's record in memory.  60 % of all candidates are found taken on their first probe (their chain's best end came earlier): that probe,
+// the marks of every walk and the second looks of a group become LDS traffic, and nothing but scores and links is ever loaded.  Null for a
+// read with more anchors than the scratch has bits: the flag then lives in the record as before.
 __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t off, const int n_z, const unsigned long long *z, int2 *fp,
-                                               int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd)
+                                               int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd, unsigned *bits)
 {
 	const int l = lane();
 	long long &dbg_load = wd.load, &dbg_longt = wd.longt, &dbg_groups = wd.groups, &dbg_open = wd.open, &dbg_long = wd.nlong;
@@ -438,6 +446,8 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 	const int32_t *up4 = b.up4 + off, *up16 = b.up16 + off;
 	constexpr int TAKEN = INT_MIN;                           // top bit of fp[i].y
 	int *fpw = (int*)fp;                                     // fpw[2 i + 1] = fp[i].y
+	auto taken = [&](int i) { return (int)((bits[i >> 5] >> (i & 31)) & 1u) != 0; };
+	auto take = [&](int i) { atomicOr(&bits[i >> 5], 1u << (i & 31)); };
 	int n_u = 0, n_v = 0;
 	for (int kb = n_z - 1; kb >= 0; kb -= W) {
 		const int k_l = kb - l;
@@ -464,7 +474,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 				for (int j = 0; j < SPEC; ++j) { nx[j] = -1; sx[j] = top_l; }
 			}
 			if ((pending >> l) & 1) {
-				p0 = fpw[2 * n0 + 1];
+				p0 = bits ? (taken(n0) ? TAKEN : fpw[2 * n0 + 1]) : fpw[2 * n0 + 1];
 				if (fresh) {
 					int pc = p0;
 					if (p0 >= 0) {
@@ -475,7 +485,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 							if (!ended) {
 								const int next = pc ? cur - pc : -1;
 								nx[j] = next;
-								if (next >= 0) { const int2 rec = fp[next]; sx[j] = top_l - rec.x; pn[j] = rec.y; pc = rec.y; }
+								if (next >= 0) { const int2 rec = fp[next]; sx[j] = top_l - rec.x; pn[j] = bits && taken(next) ? rec.y | TAKEN : rec.y; pc = rec.y; }
 								if (sx[j] > best) { best = sx[j]; kept = j + 1; }
 								else if (best - sx[j] > b.max_drop) ended = true;
 								if (pn[j] < 0) ended = true;
@@ -486,7 +496,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					}
 				} else {
 #pragma unroll
-					for (int j = 0; j < SPEC; ++j) if (nx[j] >= 0) pn[j] = fpw[2 * nx[j] + 1];
+					for (int j = 0; j < SPEC; ++j) if (nx[j] >= 0) pn[j] = bits ? (taken(nx[j]) ? TAKEN : 0) : fpw[2 * nx[j] + 1];   // (only the sign is looked at when the marks are bits)
 					if (p0 >= 0) {
 						int best = 0, kept = 0;
 						bool ended = false;
@@ -522,7 +532,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						if (j < kept) {
 							const int v = j == 0 ? c0 : __builtin_amdgcn_readlane(nx[j > 0 ? j - 1 : 0], src);
 							const int link = j == 0 ? __builtin_amdgcn_readlane(p0, src) : __builtin_amdgcn_readlane(pn[j > 0 ? j - 1 : 0], src);
-							if (l == 0) { picked[n_v + j] = v; fpw[2 * v + 1] = link | TAKEN; }
+							if (l == 0) { picked[n_v + j] = v; if (bits) take(v); else fpw[2 * v + 1] = link | TAKEN; }
 							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
 							touched |= hit;
 							p0 |= n0 == v ? TAKEN : 0;
@@ -563,7 +573,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						if (j < kept) {
 							const int v = j == 0 ? c0 : cn[j > 0 ? j - 1 : 0];
 							const int link = j == 0 ? __builtin_amdgcn_readlane(p0, src) : cm[j > 0 ? j - 1 : 0];
-							if (l == 0) fpw[2 * v + 1] = link | TAKEN;
+							if (l == 0) { if (bits) take(v); else fpw[2 * v + 1] = link | TAKEN; }
 							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
 							touched |= hit;
 							p0 |= n0 == v ? TAKEN : 0;
@@ -589,7 +599,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						const bool valid = t >= 0;
 						const int pt = valid ? fpw[2 * t + 1] & ~TAKEN : 0, next = pt ? t - pt : -1;
 						int s = top, m = 1;
-						if (next >= 0) { const int2 rec = fp[next]; s = top - rec.x; m = rec.y < 0; }
+						if (next >= 0) { const int2 rec = fp[next]; s = top - rec.x; m = bits ? taken(next) : rec.y < 0; }
 						// best prefix BEFORE this lane's step
 						int inc = valid ? s : INT_MIN;
 						for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
@@ -610,7 +620,8 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						else { visited += W; cur = __shfl(next, W - 1); }
 					}
 					wave_sync();
-					for (int q = l; q < kept; q += W) { int *w = &fpw[2 * picked[n_v + q] + 1]; *w |= TAKEN; }
+					if (bits) for (int q = l; q < kept; q += W) take(picked[n_v + q]);
+					else for (int q = l; q < kept; q += W) { int *w = &fpw[2 * picked[n_v + q] + 1]; *w |= TAKEN; }
 					if (b.dbg) dbg_longt += (long long)__builtin_amdgcn_s_memrealtime() - tl;
 				}
 				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
@@ -763,7 +774,11 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 		}
 		int n_u = 0, n_v = 0;
 		WalkDbg wd;
-		post_walk_read(b, off, n_z, z, fp, picked, u_tmp, n_u, n_v, wd);
+		// the marks of the walks: a bit per anchor in this wave's LDS (the sort is done with it) when the read fits
+		constexpr int MARK_WORDS = (int)(sizeof(PassLds) / 4);
+		unsigned *bits = n <= MARK_WORDS * 32 && !POST_MARKS_IN_MEMORY ? (unsigned*)&L : nullptr;
+		if (bits) { wave_sync(); for (int k = l; k < (n + 31) / 32; k += W) bits[k] = 0; wave_sync(); }
+		post_walk_read(b, off, n_z, z, fp, picked, u_tmp, n_u, n_v, wd, bits);
 		wave_sync();
 		if (l == 0) {
 			b.n_u[r] = n_u;
