@@ -92,26 +92,46 @@ void DevBuf::release()
 // Page-locked host memory.  hipHostMalloc takes ~0.16 s per GB and is serialised across threads (16 streams pinning 256 MB each at the same
 // moment: 0.77 s, and 0.79 s to give it back; profiles/ubench/pin_rate.hip), because it pins 4 KB pages one by one.  A 2 MB-aligned block
 // with MADV_HUGEPAGE, touched and then registered (hipHostRegister), is pinned in 2 MB pages: 0.06 s per GB, 0.026 s for the same 16 x 256 MB,
-// 0.16 s to give back, and copies from it run at the link's rate all the same.  MM2GB_PIN=hipmalloc keeps the runtime's allocator.
+// and copies from it run at the link's rate all the same.  MM2GB_PIN=hipmalloc keeps the runtime's allocator.
 namespace {
 bool pin_by_register() { static const bool v = [] { const char *e = getenv("MM2GB_PIN"); return !(e && strcmp(e, "hipmalloc") == 0); }(); return v; }
+// Registered blocks are never unregistered or unmapped while the process lives: a block that is given back goes to a free list and is handed
+// out again (best fit).  Unregistering is what went wrong once: the blocks came from malloc, glibc reused a freed block's addresses for
+// ordinary allocations, and a later copy from such an allocation faulted on the GPU ("Memory access fault ... Reason: Unknown", an address
+// inside a former block) -- so the blocks are also mapped directly (mmap), outside malloc's heap, at addresses nothing else will ever get.
+struct PinBlock { void *ptr; size_t bytes; };
+std::mutex g_pin_mu;
+std::vector<PinBlock> g_pin_idle, g_pin_all;
 void *pinned_alloc(size_t bytes)
 {
 	if (!pin_by_register()) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
-	void *p = nullptr;
-	const size_t rounded = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
-	if (posix_memalign(&p, (size_t)2 << 20, rounded) != 0) return nullptr;
+	constexpr size_t HUGE = (size_t)2 << 20;
+	const size_t rounded = (std::max<size_t>(bytes, 1) + (HUGE - 1)) & ~(HUGE - 1);
+	{
+		std::lock_guard<std::mutex> lock(g_pin_mu);
+		size_t best = g_pin_idle.size();
+		for (size_t k = 0; k < g_pin_idle.size(); ++k)
+			if (g_pin_idle[k].bytes >= rounded && g_pin_idle[k].bytes <= 2 * rounded + 2 * HUGE && (best == g_pin_idle.size() || g_pin_idle[k].bytes < g_pin_idle[best].bytes)) best = k;
+		if (best != g_pin_idle.size()) { void *p = g_pin_idle[best].ptr; g_pin_idle.erase(g_pin_idle.begin() + (std::ptrdiff_t)best); return p; }
+	}
+	char *raw = (char*)mmap(nullptr, rounded + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (raw == (char*)MAP_FAILED) return nullptr;
+	char *p = (char*)(((uintptr_t)raw + (HUGE - 1)) & ~(uintptr_t)(HUGE - 1));
+	if (p > raw) (void)munmap(raw, (size_t)(p - raw));
+	if (p + rounded < raw + rounded + HUGE) (void)munmap(p + rounded, (size_t)(raw + rounded + HUGE - (p + rounded)));
 	(void)madvise(p, rounded, MADV_HUGEPAGE);
 	for (size_t off = 0; off < rounded; off += 4096) ((volatile char*)p)[off] = 0;       // first touch: the pages exist (as huge pages where the system grants them) before they are pinned
-	if (hipHostRegister(p, rounded, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); free(p); return nullptr; }
+	if (hipHostRegister(p, rounded, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); (void)munmap(p, rounded); return nullptr; }
+	std::lock_guard<std::mutex> lock(g_pin_mu);
+	g_pin_all.push_back({ p, rounded });
 	return p;
 }
 void pinned_free(void *p)
 {
 	if (!p) return;
 	if (!pin_by_register()) { (void)hipHostFree(p); return; }
-	(void)hipHostUnregister(p);
-	free(p);
+	std::lock_guard<std::mutex> lock(g_pin_mu);
+	for (const PinBlock &b : g_pin_all) if (b.ptr == p) { g_pin_idle.push_back(b); return; }
 }
 } // namespace
 

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "engine.h"
@@ -21,6 +22,23 @@
 
 namespace mm2gb {
 namespace {
+
+// The cost model below is of a call that has the machine to itself.  It does not: the drop-in runs sixteen of these calls at once (a stream's
+// finisher each), the own host four, and both sides then take two to three times what the model says -- the device more than the host -- so
+// the deal left the longest reads on the device and the host threads idle (round 5, drop-in: device 1.08 s || host 0.29 s).  Each side's
+// measured / estimated ratio of the calls so far (exponential average, process-wide) scales the next call's estimates; it only steers the deal.
+struct Calibration {
+	std::mutex mu;
+	double dev = 1.0, host = 1.0;
+	void get(double &d, double &h) { std::lock_guard<std::mutex> lk(mu); d = dev; h = host; }
+	void put(double est_dev, double got_dev, double est_host, double got_host)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		auto mixin = [](double &avg, double est, double got) { if (est > 1e-3 && got > 1e-3) avg = std::min(6.0, std::max(0.5, 0.7 * avg + 0.3 * std::min(8.0, got / est))); };
+		mixin(dev, est_dev, got_dev); mixin(host, est_host, got_host);
+	}
+};
+Calibration g_calibration;
 
 // What a read costs either side, in seconds, from three sums that take one pass over its anchors (sorted by x):
 //   n      steps
@@ -131,6 +149,9 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 				if (cost[r].dev > 5e-3 && 0.07e-6 * cost[r].s_in >= 0.5 * 1.37e-6 * n && cost[r].dev_team < cost[r].dev) { cost[r].dev = cost[r].dev_team; cost[r].team = true; }
 			}
 	}
+	double cal_dev = 1.0, cal_host = 1.0;
+	if (!getenv("MM2GB_RMQ_NO_CALIBRATION")) g_calibration.get(cal_dev, cal_host);
+	for (size_t r = 0; r < R; ++r) { cost[r].dev *= cal_dev; cost[r].host *= cal_host; }
 	std::vector<int64_t> by_dev(R);
 	for (size_t r = 0; r < R; ++r) by_dev[r] = (int64_t)r;
 	std::sort(by_dev.begin(), by_dev.end(), [&](int64_t u, int64_t v) { return cost[(size_t)u].dev != cost[(size_t)v].dev ? cost[(size_t)u].dev > cost[(size_t)v].dev : u < v; });
@@ -151,6 +172,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			host_sum += c.host; host_max = std::max(host_max, c.host); dev_sum -= c.dev * (c.team ? 16.0 : 1.0);
 			++n_host;
 		}
+	const double est_host_s = std::max(host_max, host_sum / nt), est_dev_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0;
 	if (deal) { memset(deal, 0, sizeof(*deal)); { const char *kv = getenv("MM2GB_RMQ_KERNEL"); deal->device_kernel = kv && !strcmp(kv, "steps") ? 1 : 0; } deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
 
 	const double s_estimate = seconds_since(t0);
@@ -272,8 +294,10 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		if (getenv("MM2GB_DEBUG_PHASES"))
 			fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, results left in place, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, seconds_since(t0));
 		if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
+		g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
 		return 0;
 	}
+	g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
 	// ---- one result, in the caller's read order ----
 	const auto tm = std::chrono::steady_clock::now();
 	out->u_off = (int64_t*)malloc((R + 1) * 8);

@@ -702,12 +702,24 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 			g_parked.clear();
 		}
 	}
-	for (int s = (int)g_streams.slots.size(); s < cfg.num_streams; ++s) {
-		StreamSlot *slot = new StreamSlot();
-		if (slot->eng.init(&cfg, &misc, devs[(size_t)s % devs.size()])) die(mm2gb_last_error());
-		slot->live = true;
-		slot->finisher = std::thread(finisher_main, slot);
-		g_streams.slots.push_back(slot);
+	{
+		// every stream's engine is made at the same time (streams, events, the penalty table's kernel: ~40 ms each, sixteen of them 0.65 s one
+		// after the other); the first one alone, so that the runtime starts on one thread
+		const int have = (int)g_streams.slots.size();
+		std::vector<StreamSlot*> fresh;
+		for (int s = have; s < cfg.num_streams; ++s) fresh.push_back(new StreamSlot());
+		std::vector<std::string> errs(fresh.size());
+		auto make = [&](size_t k) { if (fresh[k]->eng.init(&cfg, &misc, devs[(size_t)(have + (int)k) % devs.size()])) errs[k] = mm2gb_last_error(); };
+		if (!fresh.empty()) make(0);
+		std::vector<std::thread> makers;
+		for (size_t k = 1; k < fresh.size(); ++k) makers.emplace_back(make, k);
+		for (auto &t : makers) t.join();
+		for (const std::string &e : errs) if (!e.empty()) die(e);
+		for (StreamSlot *slot : fresh) {
+			slot->live = true;
+			slot->finisher = std::thread(finisher_main, slot);
+			g_streams.slots.push_back(slot);
+		}
 	}
 	g_streams.ready = true;
 	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] init_stream_gpu: entered at epoch %.3f, %d stream(s) ready after %.3f s\n", epoch_in, cfg.num_streams, (now_ns() - g_t_init_ns) * 1e-9);
