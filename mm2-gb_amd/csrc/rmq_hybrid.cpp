@@ -150,7 +150,10 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			}
 	}
 	double cal_dev = 1.0, cal_host = 1.0;
-	if (!getenv("MM2GB_RMQ_NO_CALIBRATION")) g_calibration.get(cal_dev, cal_host);
+	// (only for callers whose host threads have nothing else to do while the call runs -- the drop-in's finishers, engine.h rmq_calibrate: where
+	// other stages compete for the host threads, as in the own host's stream of chunks, shifting reads to them made the whole run 8-10 % slower)
+	const bool calibrate = eng->e.rmq_calibrate && !getenv("MM2GB_RMQ_NO_CALIBRATION");
+	if (calibrate) g_calibration.get(cal_dev, cal_host);
 	for (size_t r = 0; r < R; ++r) { cost[r].dev *= cal_dev; cost[r].host *= cal_host; }
 	std::vector<int64_t> by_dev(R);
 	for (size_t r = 0; r < R; ++r) by_dev[r] = (int64_t)r;
@@ -294,10 +297,10 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		if (getenv("MM2GB_DEBUG_PHASES"))
 			fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, results left in place, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, seconds_since(t0));
 		if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
-		g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
+		if (calibrate) g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
 		return 0;
 	}
-	g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
+	if (calibrate) g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
 	// ---- one result, in the caller's read order ----
 	const auto tm = std::chrono::steady_clock::now();
 	out->u_off = (int64_t*)malloc((R + 1) * 8);

@@ -206,6 +206,7 @@ static int finish_compute(StreamSlot &slot, HostStage &st)
 		if (!slot.rmq_eng) {
 			slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &st.misc, slot.eng.device);
 			if (!slot.rmq_eng) return -1;
+			slot.rmq_eng->e.rmq_calibrate = true;          // the host thread waits for this finisher: its CPU, and the call's threads, are the deal's to use
 		}
 		if (rechain_ahead(slot.rmq_eng, *(const mm2gb_mapopt_head_t*)st.opt, st.misc, view.data(), n_read, g_streams.ahead_threads, st.ahead)) return -1;
 		st.have_ahead = st.ahead.n_ahead() > 0;
