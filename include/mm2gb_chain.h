@@ -141,6 +141,11 @@ int  mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offset
                      mm2gb_chains_t *out, mm2gb_stats_t *stats);
 int  mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
                        const int32_t *d_f, const int32_t *d_p, int64_t *n_chains, int64_t *n_kept, float *ms);
+/* the same, enqueued only (mm2gb_post_device_totals waits and reads the totals): the post-pass of batch k on one engine beside the score kernels of
+ * batch k+1 on another -- a stream of micro-batches pays the longer of the two, not their sum, where the kernels can share the chip */
+int  mm2gb_post_device_enqueue(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
+                               const int32_t *d_f, const int32_t *d_p);
+int  mm2gb_post_device_totals(mm2gb_engine_t *eng, int64_t *n_chains, int64_t *n_kept, float *ms);
 
 /* ---- RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369, called per read from post_chaining_helper, map.c:444-456,
  *      on the anchors the first chaining kept, sorted by x).  Parameters in the order of mg_lchain_rmq's argument list.

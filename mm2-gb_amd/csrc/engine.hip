@@ -1342,6 +1342,30 @@ int mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_off
 	return 0;
 }
 
+// the same, enqueued only: nothing is waited for (mm2gb_engine_sync does; the totals are read with mm2gb_post_device_totals afterwards).  For a
+// caller that runs the post-pass of batch k on one engine beside the score kernels of batch k+1 on another.
+int mm2gb_post_device_enqueue(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
+                              const int32_t *d_f, const int32_t *d_p)
+{
+	if (!eng) return fail("mm2gb: null engine");
+	MM2GB_HIP(hipSetDevice(eng->e.device));
+	return eng->e.enqueue_post(n_reads, d_offsets, d_anchors, n_anchors, d_f, d_p);
+}
+
+int mm2gb_post_device_totals(mm2gb_engine_t *eng, int64_t *n_chains, int64_t *n_kept, float *ms)
+{
+	if (!eng) return fail("mm2gb: null engine");
+	Engine &e = eng->e;
+	if (!e.h_post_totals) return fail("mm2gb_post_device_totals: no post-pass has run on this engine");
+	MM2GB_HIP(hipSetDevice(e.device));
+	MM2GB_HIP(hipStreamSynchronize(e.stream));
+	if (n_chains) *n_chains = e.h_post_totals[0];
+	if (n_kept) *n_kept = e.h_post_totals[1];
+	float t = 0;
+	if (ms && hipEventElapsedTime(&t, e.post0, e.post1) == hipSuccess) *ms = t;
+	return 0;
+}
+
 int mm2gb_engine_stats(mm2gb_engine_t *eng, mm2gb_stats_t *stats)
 {
 	if (!eng || !stats) return fail("mm2gb: null argument");
