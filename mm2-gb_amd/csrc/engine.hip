@@ -424,7 +424,7 @@ void Engine::shutdown()
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
 	for (hipEvent_t &e : slice_in) if (e) (void)hipEventDestroy(e);
 	slice_in.clear();
-	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -559,6 +559,7 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	cap_post_n = cap_post_reads = 0;                    // as in reserve(): only restored when every buffer has its size
 	// per-chain arrays are sized for min_cnt = 1 (a chain per anchor): min_cnt is a per-call parameter and may drop
 	const size_t chains = (size_t)(nn + nr);
+	if (post_sort_s.ensure((size_t)nn + 16384) || post_sort_perm.ensure((size_t)nn * 4) || post_sort_tmp.ensure((size_t)nn * 8)) return -1;   // radix_pass_bytes: 13 B per anchor
 	if (post_z.ensure((size_t)nn * 8) || post_fp.ensure((size_t)nn * 8) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
 	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_misc.ensure(2048) || post_bins.ensure(2 * N_SIZE_CLASSES * 4) || post_order.ensure((size_t)nr * 4) ||
 	    post_up4.ensure((size_t)nn * 4) || post_up16.ensure((size_t)nn * 4)) return -1;
@@ -592,6 +593,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.raw = (const uint4*)d_anchors; b.offsets = d_offsets; b.n = n; b.n_reads = n_reads; b.f = d_f; b.p = d_p;
 	b.z = (unsigned long long*)post_z.ptr; b.fp = (int2*)post_fp.ptr; b.picked = (int32_t*)post_picked.ptr;
 	b.up4 = (int32_t*)post_up4.ptr; b.up16 = (int32_t*)post_up16.ptr;
+	b.sort_s = (unsigned char*)post_sort_s.ptr; b.sort_perm = (int32_t*)post_sort_perm.ptr; b.sort_tmp = (unsigned long long*)post_sort_tmp.ptr;
 	b.u_tmp = (unsigned long long*)post_utmp.ptr; b.heads = (ulonglong2*)post_heads.ptr;
 	b.n_u = (int32_t*)post_nu.ptr; b.n_kept = (int32_t*)post_nkept.ptr; b.u_off = (int64_t*)po.u_off.ptr; b.a_off = (int64_t*)po.a_off.ptr;
 	b.u_out = (unsigned long long*)po.u_out.ptr; b.a_out = (uint4*)po.a_out.ptr;

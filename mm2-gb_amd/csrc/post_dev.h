@@ -19,6 +19,9 @@ struct PostBatch {
 	unsigned long long *z;     // n: candidates (f << 32 | i), sorted in place
 	int2     *fp;              // n: (f, p | taken << 31) per anchor, written by k_post_lift: what a chain walk needs of an anchor in ONE 8-byte load; the top bit of .y is the host's t[] (lchain.c:43)
 	int32_t  *picked;          // n: the host's v[] (lchain.c:65)
+	unsigned char *sort_s;     // n + slack: the sort's destination bytes; sort_perm n: its permutation; sort_tmp n: the elements' way station (radix_pass_bytes; all null: the element form)
+	int32_t  *sort_perm;
+	unsigned long long *sort_tmp;
 	int32_t  *up4, *up16;      // n each: distance to the anchor 4 / 16 predecessor links down the path (0 = path ends before)
 	unsigned long long *u_tmp; // n / mc + n_reads: chains in the order they were found
 	ulonglong2 *heads;         // n / mc + n_reads: (x of first anchor, offset << 32 | chain) for the order of compaction

@@ -78,7 +78,7 @@ struct alignas(16) PassLds {
 // H: chain heads of the compaction, key = x of the chain's first anchor, value = offset<<32 | chain (lchain.c:94-99).
 struct ZElem {
 	using T = unsigned long long;
-	static constexpr int SLOTS = LINE_STORE_BYTES / 8, LINE_MIN = 2;   // line slots of a wave; shortest line
+	[[maybe_unused]] static constexpr int SLOTS = LINE_STORE_BYTES / 8, LINE_MIN = 2;   // line slots of a wave; shortest line
 	static __device__ __forceinline__ unsigned long long key(T e) { return e >> 32; }
 };
 struct HElem {
@@ -107,7 +107,7 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 {
 	return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32;
 }
-__device__ __forceinline__ unsigned long long bcast_elem(unsigned long long e, int src) { return __shfl(e, src); }
+[[maybe_unused]] __device__ __forceinline__ unsigned long long bcast_elem(unsigned long long e, int src) { return __shfl(e, src); }
 __device__ __forceinline__ ulonglong2 bcast_elem(const ulonglong2 &e, int src) { return make_ulonglong2(__shfl(e.x, src), __shfl(e.y, src)); }
 
 // Stable sort of a run of at most 64 elements by key == what rs_insertsort leaves (ksort.h:105-115): every lane holds one
@@ -273,6 +273,235 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 	return true;
 }
 
+// ---- the same pass as a walk over BYTES (round 5; candidates' sort only) ---------------------------------------------------------------
+// What the cycle permutation does next depends on one thing only: the destination bucket of the element it has just picked up, i.e. one key
+// byte.  And a position at or beyond a bucket's head keeps its original occupant until the head gets there.  So the pass is run on the
+// sequence of destination bytes S[i] = byte of g[i] (written once, in parallel), and what the walk produces is the permutation: perm[i] = where
+// the element that was at i ends up (identity for the elements that are accepted in place); the elements are moved afterwards by all lanes.
+// The walk's state per bucket is ONE 16-byte record in LDS -- next byte of the bucket's line, next position, line end, bucket end -- and a
+// step is: read the record of the bucket the carried element goes to, read the byte of the occupant it displaces, write the record back, store
+// one perm entry; nothing else, on one lane, no scalar round trips.  A line holds BYTES: 8 positions per 8 bytes of LDS where the element form
+// holds one, so lines run out an eighth as often (level 1 of the 500 M-anchor batch: 10.8 M single-line refills in 87 M steps before).
+struct SortScratch {
+	unsigned char *S;            // one byte per position of the array being sorted
+	int *perm;                   // one entry per position
+	unsigned long long *tmp;     // the elements' way station
+};
+
+constexpr int GROUP = 8;                                   // bytes per line slot
+constexpr int GROUPS = LINE_STORE_BYTES / GROUP;           // 896 line slots per wave (PassLds::owner has one entry each)
+static_assert(GROUPS >= 2 * 256, "every bucket owns at least one slot, and there is spare to hand out");
+
+__device__ __forceinline__ unsigned long long load8_unaligned(const unsigned char *p)
+{
+	unsigned long long v;
+	__builtin_memcpy(&v, p, 8);
+	return v;
+}
+
+// every bucket's line filled with the bytes that follow its current position (all lanes, one memory round trip)
+__device__ __forceinline__ void fetch_all_byte_lines(const unsigned char *S, int used, PassLds &L)
+{
+	int4 *rec = (int4*)L.where;
+	unsigned long long *line = L.line;
+	const int l = lane();
+	constexpr int ITERS = GROUPS / W;
+	unsigned long long v[ITERS];
+	int d[ITERS], j[ITERS], l0[ITERS];
+#pragma unroll
+	for (int it = 0; it < ITERS; ++it) {
+		const int slot = min(it * W + l, used - 1);
+		d[it] = L.owner[slot];
+		const int4 r = rec[d[it]];
+		l0[it] = (int)((unsigned)r.z >> 16);
+		j[it] = slot - l0[it] / GROUP;
+		v[it] = load8_unaligned(S + r.y + GROUP * j[it]);      // (S has slack at its end: bytes past a bucket's end are read and never used)
+	}
+	wave_sync();
+#pragma unroll
+	for (int it = 0; it < ITERS; ++it) {
+		const int slot = it * W + l;
+		if (slot < used) {
+			line[slot] = v[it];
+			if (j[it] == 0) rec[d[it]].x = l0[it];
+		}
+	}
+	wave_sync();
+}
+
+// A run of at most LINE_STORE_BYTES elements (nearly every run below the top level: 1 800 elements on average at the lowest byte) keeps its
+// whole byte sequence in LDS: no lines, no refills, and the scan of a bucket for the elements that must move reads LDS instead of memory --
+// with 256 buckets and a few elements in each, those 256 dependent memory round trips were most of a small pass's time.
+__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr)
+{
+	const int l = lane();
+	const int len = hi - lo;
+	const bool resident = len <= LINE_STORE_BYTES;
+	unsigned char *lineb = (unsigned char*)L.line;
+	for (int k = l; k < 256; k += W) L.where[k] = 0;
+	wave_sync();
+	// histogram, the byte sequence, the identity permutation: one pass over the run, eight loads in flight per lane
+	for (int base = lo; base < hi; base += 8 * W) {
+		int byte[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) byte[u] = (int)(ZElem::key(g[min(base + u * W + l, hi - 1)]) >> shift) & 255;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int i = base + u * W + l;
+			if (i < hi) {
+				atomicAdd(&L.where[byte[u]], 1);
+				if (resident) lineb[i - lo] = (unsigned char)byte[u]; else sc.S[i] = (unsigned char)byte[u];
+				sc.perm[i] = i;
+			}
+		}
+	}
+	wave_sync();
+	// lane l owns buckets 4l .. 4l+3
+	const int c[4] = { L.where[4 * l], L.where[4 * l + 1], L.where[4 * l + 2], L.where[4 * l + 3] };
+	if (__ballot(c[0] == len || c[1] == len || c[2] == len || c[3] == len) != 0) return false;
+	int inc = c[0] + c[1] + c[2] + c[3];
+	const int own = inc;
+	for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(inc, off); if (l >= off) inc += o; }
+	int at = lo + inc - own;
+	// buckets that hold anything, as four masks (bucket 4 l + q: bit l of mask q): the walk only visits those
+	unsigned long long full[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) full[q] = __ballot(c[q] > 0);
+	int4 *rec = (int4*)L.where;
+	int used = 0;
+	if (resident) {
+		wave_sync();                                            // (the counts are in registers: the records take their place)
+		// record of a bucket: x = its next position, w = its end
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { rec[4 * l + q] = make_int4(at, 0, 0, at + c[q]); at += c[q]; }
+		wave_sync();
+	} else {
+		// line slots: one each, the spare ones by share of the keys
+		constexpr int SPARE = GROUPS - 256;
+		int cap[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) cap[q] = 1 + (int)((long long)c[q] * SPARE / len);
+		int cinc = cap[0] + cap[1] + cap[2] + cap[3];
+		const int cown = cinc;
+		for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(cinc, off); if (l >= off) cinc += o; }
+		used = __builtin_amdgcn_readlane(cinc, W - 1);
+		int cat = cinc - cown;
+		wave_sync();
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int l0 = cat * GROUP, lend = (cat + cap[q]) * GROUP;
+			rec[4 * l + q] = make_int4(lend, at, lend | l0 << 16, at + c[q]);      // x == lend: "line empty" until the first fetch sets x = l0
+			cat += cap[q]; at += c[q];
+		}
+		wave_sync();
+		// owner of every line slot: all lanes, by bisection over the buckets' first slots (a bucket with most of the keys owns hundreds)
+		for (int slot = l; slot < used; slot += W) {
+			int a = 0, bq = 255;
+			while (a < bq) { const int m = (a + bq + 1) >> 1; if ((int)((unsigned)rec[m].z >> 16) <= slot * GROUP) a = m; else bq = m - 1; }
+			L.owner[slot] = (unsigned char)a;
+		}
+		wave_sync();
+		fetch_all_byte_lines(sc.S, used, L);
+	}
+	int since = 0;
+	int d_steps = 0, d_one = 0, d_all = 1, d_cycles = 0;
+	for (int k = 0; k < 256; ++k) {
+		if (!((full[k & 3] >> (k >> 2)) & 1)) continue;
+		const int4 rk = rec[k];
+		int hk = uni(resident ? rk.x : rk.y);
+		const int tk = uni(rk.w);
+		for (; hk < tk; hk += W) {
+			const int i = hk + l;
+			const bool in = i < tk;
+			const int by = resident ? (int)lineb[(in ? i : hk) - lo] : (int)sc.S[in ? i : hk];
+			unsigned long long moves = __ballot(in && by != k);
+			while (((unsigned)moves | (unsigned)(moves >> 32)) != 0) {
+				const int skip = first_set(moves);
+				moves &= moves - 1;
+				++d_cycles;
+				const int home = hk + skip;
+				int d = __builtin_amdgcn_readlane(by, skip), src = home;
+				if (resident) {
+					// the cycle on lane 0: a record, a byte, a record back, a perm entry per step
+					// the cycle on lane 0: the next position of the bucket arrived at, the byte of its occupant, the position advanced, a perm
+					// entry.  (Tried: the occupant's byte kept in the bucket's record, refreshed off the dependent chain -- one dependent LDS
+					// read per step instead of two, twice the instructions: 12.0 -> 14.2 s of wave time at the lowest level.  A lone lane's
+					// step is bound by how fast one wave issues dependent instructions, not by the LDS.)
+					int steps = 0;
+					if (l == 0) {
+						for (;;) {
+							const int pos = rec[d].x;
+							const int nb = lineb[pos - lo];
+							sc.perm[src] = pos;
+							rec[d].x = pos + 1;
+							src = pos; d = nb; ++steps;
+							if (d == k) break;
+						}
+						sc.perm[src] = home;
+					}
+					d_steps += uni(steps);
+					continue;
+				}
+				for (;;) {
+					// the cycle on lane 0, until it closes or a line runs out
+					int status = 0, steps = 0;                // 0 closed, 1 line of bucket d empty
+					if (l == 0) {
+						for (;;) {
+							const int4 r = rec[d];
+							if (r.x == (r.z & 0xffff)) { status = 1; break; }
+							const int nb = lineb[r.x];
+							sc.perm[src] = r.y;
+							*(int2*)&rec[d] = make_int2(r.x + 1, r.y + 1);
+							src = r.y; d = nb; ++steps;
+							if (d == k) break;
+						}
+					}
+					status = uni(status); d = uni(d); src = uni(src); steps = uni(steps);
+					since += steps; d_steps += steps;
+					if (status == 0) break;
+					if (since >= 64) { fetch_all_byte_lines(sc.S, used, L); since = 0; ++d_all; }
+					else {
+						++d_one;
+						const int4 r = rec[d];
+						const int l0 = (int)((unsigned)r.z >> 16), ln = (r.z & 0xffff) - l0;
+						for (int j = l * GROUP; j < ln; j += W * GROUP) *(unsigned long long*)(L.line + (l0 + j) / GROUP) = load8_unaligned(sc.S + r.y + j);
+						if (l == 0) rec[d].x = l0;
+						wave_sync();
+					}
+				}
+				if (l == 0) sc.perm[src] = home;
+			}
+		}
+	}
+	wave_sync();
+	// the elements follow the permutation: out of place first, then back (all lanes, eight loads in flight each)
+	for (int base = lo; base < hi; base += 8 * W) {
+		unsigned long long e[8]; int to[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { const int i = min(base + u * W + l, hi - 1); e[u] = g[i]; to[u] = sc.perm[i]; }
+#pragma unroll
+		for (int u = 0; u < 8; ++u) if (base + u * W + l < hi) sc.tmp[to[u]] = e[u];
+	}
+	wave_sync();
+	for (int base = lo; base < hi; base += 8 * W) {
+		unsigned long long e[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) e[u] = sc.tmp[min(base + u * W + l, hi - 1)];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) if (base + u * W + l < hi) g[base + u * W + l] = e[u];
+	}
+	wave_sync();
+	if (dbg && l == 0) {
+		atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)d_steps);
+		atomicAdd((unsigned long long*)&dbg[1], (unsigned long long)d_one);
+		atomicAdd((unsigned long long*)&dbg[2], (unsigned long long)d_all);
+		atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)d_cycles);
+		atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(hi - lo));
+		atomicAdd((unsigned long long*)&dbg[5], 1ull);
+	}
+	return true;
+}
+
 // radix_sort_128x (ksort.h:147-151) of g[0, n) by key, same final element order as the host's.
 // The host recurses bucket by bucket; buckets are independent, so the same work is done here level by level: at the level of
 // key byte `shift` the array is made of runs of elements that agree on all higher key bytes; a run longer than 64 gets a
@@ -280,8 +509,18 @@ __device__ __forceinline__ bool radix_pass(typename E::T *g, int lo, int hi, int
 // one level up is seen again: a no-op).
 // Passes on bytes in which all keys of the run agree move nothing, so starting at the highest byte in which any two keys
 // differ equals the host's start at byte 7.
-template <class E>
-__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L, long long *dbg = nullptr)
+#ifndef MM2GB_POST_SORT_ELEMENTS
+#define MM2GB_POST_SORT_ELEMENTS 0              // 1: the candidates' sort moves elements step by step too (round 4; A/B builds)
+#endif
+template <class E, bool BYTES>
+__device__ __forceinline__ bool one_radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L, const SortScratch *sc, long long *dbg)
+{
+	if constexpr (BYTES && !MM2GB_POST_SORT_ELEMENTS) return radix_pass_bytes(g, lo, hi, shift, L, *sc, dbg);
+	else return radix_pass<E>(g, lo, hi, shift, L, dbg);
+}
+
+template <class E, bool BYTES = false>
+__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L, long long *dbg = nullptr, const SortScratch *sc = nullptr)
 {
 	if (n <= 1) return;
 	if (n <= SMALL_RUN) { small_run_sort<E>(g, 0, n); return; }
@@ -325,7 +564,7 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 					adv = ((unsigned)out | (unsigned)(out >> 32)) ? first_set(out) : W;
 					q += adv;
 				} while (adv == W);
-				radix_pass<E>(g, pos, q, shift, L, dbg ? dbg + 24 + 6 * min((top - shift) / 8, 2) : nullptr);
+				one_radix_pass<E, BYTES>(g, pos, q, shift, L, sc, dbg ? dbg + 24 + 6 * min((top - shift) / 8, 2) : nullptr);
 				++d_pass; d_elems += q - pos;
 				pos = q;
 				continue;
@@ -708,8 +947,9 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 				int top = 24;                                      // of the key = the score: byte 3 .. 0 (sort_like_host's `top`)
 				while (top > 0 && ((diff >> top) & 255u) == 0) top -= 8;
 				if (w == 0) {
-					radix_pass<ZElem>(z, 0, n_z, top, L, b.dbg ? b.dbg + 24 : nullptr);
-					for (int k = l; k < 256; k += W) s_bound[k + 1] = L.tail[k];
+					const SortScratch sc = { b.sort_s + off, b.sort_perm + off, b.sort_tmp + off };
+					one_radix_pass<ZElem, true>(z, 0, n_z, top, L, &sc, b.dbg ? b.dbg + 24 : nullptr);
+					for (int k = l; k < 256; k += W) s_bound[k + 1] = MM2GB_POST_SORT_ELEMENTS ? L.tail[k] : ((const int4*)L.where)[k].w;   // the buckets' ends: the byte form keeps them in its records
 					if (l == 0) s_bound[0] = 0;
 					wave_sync();
 					// buckets of more than one element are tasks, largest first (a few hold nearly everything: the scores of a read span two
@@ -737,11 +977,12 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 					if (t >= n_tasks) break;
 					const int k = uni(s_task[t]);
 					const int lo = uni(s_bound[k]), hi = uni(s_bound[k + 1]);
-					sort_like_host<ZElem>(z + lo, hi - lo, L, b.dbg);
+					const SortScratch sc = { b.sort_s + off + lo, b.sort_perm + off + lo, b.sort_tmp + off + lo };
+					sort_like_host<ZElem, true>(z + lo, hi - lo, L, b.dbg, &sc);
 				}
 				__threadfence_block();
 				__syncthreads();
-			} else if (w == 0) sort_like_host<ZElem>(z, n_z, L, b.dbg);
+			} else if (w == 0) { const SortScratch sc = { b.sort_s + off, b.sort_perm + off, b.sort_tmp + off }; sort_like_host<ZElem, true>(z, n_z, L, b.dbg, &sc); }
 			if (w == 0) { walker = true; team_r = r; team_nz = n_z; }
 		} else if (w == 0) solo_q = q;                       // not a team read (any more): wave 0's first read, on its own
 	}
@@ -769,7 +1010,8 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 			n_z = post_collect(b, f, z, 0, n, 0, true, any, all);
 			wave_sync();
 			t1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-			sort_like_host<ZElem>(z, n_z, L, b.dbg);
+			const SortScratch sc = { b.sort_s + off, b.sort_perm + off, b.sort_tmp + off };
+			sort_like_host<ZElem, true>(z, n_z, L, b.dbg, &sc);
 			t2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		}
 		int n_u = 0, n_v = 0;
