@@ -117,6 +117,7 @@ struct Engine {
 	std::function<void(const int32_t*)> rmq_tied_ready;   // the NEXT device re-chaining call only: called on the calling thread as soon as the fill's tie counts are on the host, while the call's post-pass and copies still run
 	hipEvent_t rmq_fill_done = nullptr;
 	int  rmq_team_reads = 0;        // tile form, the NEXT device call only: its first reads that get a whole workgroup each (mm2gb_rmq_chain puts the costliest first); MM2GB_RMQ_TEAM_READS overrides
+	bool rmq_abandon_tied = false;  // the NEXT device re-chaining call only: give a read up at its first tie (mm2gb_rmq_chain redoes tied reads on the host whatever the device made of them)
 	bool rmq_calibrate = false;     // mm2gb_rmq_chain on this engine scales its cost model by the measured / estimated times of earlier calls (rmq_hybrid.cpp)
 	int  rmq_kernel = 0;            // device form of the RMQ fill: 0 tiles (k_rmq_fill_tiles), 1 one anchor per step (k_rmq_fill); MM2GB_RMQ_KERNEL=steps|tiles overrides
 	bool lds_contract_ok = false;   // this device reads 0 beyond a workgroup's LDS and saturates v_sad_u32 ... clamp (probed in init)

@@ -827,6 +827,8 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		}
 		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;
 		rb.n_team = rmq_team_reads;
+		rb.abandon_tied = rmq_abandon_tied && !getenv("MM2GB_RMQ_NO_ABANDON") ? 1 : 0;
+		rmq_abandon_tied = false;
 		rmq_team_reads = 0;
 		if (const char *v = getenv("MM2GB_RMQ_TEAM_READS")) rb.n_team = std::max(0, atoi(v));
 		rb.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1536) : nullptr;

@@ -69,6 +69,7 @@ struct RmqBatch {
 	size_t   sort_tmp_bytes;
 	int      strip_shift;
 	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES), tile form: per read 8 values: anchors, waves, ticks whole / tree update / queries / broadcasts / in-tile steps, anchors broadcast (wave 0 of a team)
+	int      abandon_tied;     // tile form: a read is given up at the first tile that met a tie (its f / p are cleared: the post-pass finds nothing in it; n_tied != 0 tells the caller, who redoes the read anyway)
 	int      n_team;           // tile form: the first n_team reads of the batch are filled by a whole workgroup each (k_rmq_fill_tiles)
 };
 int  launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);   // -1: a library sort refused (nothing usable was launched after it)

@@ -1751,7 +1751,7 @@ constexpr int RMQ_MERGE_WORDS = 12;
 #endif
 constexpr int RMQ_TOP_NODES = MM2GB_RMQ_TOP_NODES;
 template <int NW>
-__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W], uint4 *s_top)
+__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W], uint4 *s_top, int *s_flag)
 {
 	const int l = lane();
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
@@ -2049,7 +2049,19 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 			}
 			}
 			wave_sync();
+			// a tie in this tile: the caller redoes the read with the reference's tree whatever comes of the rest -- stop here (abandon_tied)
+			bool give_up = false;
+			if (b.abandon_tied) {
+				if (NW == 1) give_up = __ballot(tied != 0) != 0;
+				if (NW > 1 && w == 0) { const bool any = __ballot(tied != 0) != 0; if (l == 0) *s_flag = any; }
+			}
 			if (NW > 1) { __threadfence_block(); __syncthreads(); }      // the tile's scores and its bound are out: the next tile's sweeps read them
+			if (NW > 1 && b.abandon_tied) give_up = uni(*s_flag) != 0;
+			if (give_up) {
+				if (NW > 1) __syncthreads();                              // (everybody has read the flag before the next read of the team resets it)
+				for (int i = w * W + l; i < n; i += NW * W) { f[i] = INT_MIN; p[i] = 0; }   // nothing of this read for the post-pass
+				break;
+			}
 		}
 		tied = (int)wave_sum_i32(tied);
 		if (l == 0 && (NW == 1 || w == 0)) b.n_tied[r] = tied;
@@ -2070,7 +2082,7 @@ __global__ __launch_bounds__(RMQ_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqP
 {
 	__shared__ int s_m[RMQ_TEAM - 1][RMQ_MERGE_WORDS][W];
 	__shared__ uint4 s_top[RMQ_TOP_NODES];
-	__shared__ int s_read;
+	__shared__ int s_read, s_flag;
 	const int l = lane(), w = uni(threadIdx.x / W);
 	const int n_team = (int)min((int64_t)b.n_team, b.n_reads);
 	for (;;) {
@@ -2080,14 +2092,14 @@ __global__ __launch_bounds__(RMQ_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqP
 		const int r = uni(s_read);
 		__syncthreads();
 		if (r >= n_team) break;
-		rmq_fill_read_tiles<RMQ_TEAM>(b, P, r, w, s_m, s_top);
+		rmq_fill_read_tiles<RMQ_TEAM>(b, P, r, w, s_m, s_top, &s_flag);
 	}
 	for (;;) {
 		int r = 0;
 		if (l == 0) r = atomicAdd(b.cursor, 1);
 		r = uni(r) + n_team;
 		if (r >= b.n_reads) break;
-		rmq_fill_read_tiles<1>(b, P, r, 0, nullptr, nullptr);
+		rmq_fill_read_tiles<1>(b, P, r, 0, nullptr, nullptr, nullptr);
 	}
 }
 

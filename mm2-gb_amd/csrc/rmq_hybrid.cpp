@@ -237,6 +237,9 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		for (size_t q = n_host; q < R; ++q) n_team += cost[(size_t)by_dev[q]].team;
 		if (deal) deal->n_team = (int32_t)n_team;
 		(void)mm2gb_engine_set_rmq_team_reads(eng, (int)n_team);
+		// a read that meets a tie is redone by the host form whatever the device makes of it: the kernel gives it up at that tile (the reads
+		// that tie are the largest ones -- hundreds of thousands of anchors, 0.6 s of a workgroup each -- and they were what the fill ended with)
+		eng->e.rmq_abandon_tied = true;
 		const auto td = std::chrono::steady_clock::now();
 		// the reads that met a tie are known when the device's fill is done: they are redone on host threads while its post-pass and its copies
 		// still run (and beside what is left of the host side's own share)
