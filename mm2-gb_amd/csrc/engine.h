@@ -81,7 +81,7 @@ struct Engine {
 	};
 	WorkSet work[2];
 	DevBuf lut, dbg;
-	// device post-pass (post_kernels.hip), allocated on first use: 21 B/anchor of work arrays at min_cnt = 3, + outputs
+	// device post-pass (post_kernels.hip), allocated on first use: 41 B/anchor of work arrays (candidates 8, walk records 8, picked 4, two lifting tables 8, the sort's bytes / permutation / way station 13), + chains' arrays, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
 	DevBuf post_dbg_reads, rmq_dbg_reads, rmq_skey_in, rmq_skey, rmq_sa, rmq_srange, rmq_sort_tmp, post_z, post_fp, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, post_sort_s, post_sort_perm, post_sort_tmp, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
 	DevBuf sd_seeds, sd_seed_off, sd_hit_off, sd_hits, sd_qlen, sd_q_rank, sd_ref_len, sd_ref_rank, sd_seed_read, sd_tmp, sd_n_kept, sd_a_off, sd_out;   // mm2gb_collect_seeds_gpu

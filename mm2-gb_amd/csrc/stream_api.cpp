@@ -653,19 +653,22 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	// batches reach 0.28-0.49 G anchors/s with 8 queues, 0.80 with 16 or more (one thread: 0.26; profiles/r03_small_batches.txt).
 	// Only effective before the runtime starts, i.e. when this is the first HIP call of the process, as it is in the minimap2 host;
 	// a value that is already set is the host's to choose, but one that is too small is worth a line.
-	// (one stream id already owns four HIP streams beside the null stream, and single-read calls lease up to two more engines per device: the
-	// runtime's default of 4 queues is too few for the default configuration too -- at least 8, whatever num_streams is)
-	const int want_queues = std::min(std::max(8, 4 * cfg.num_streams + 2), 64);
+	// (one stream id owns four HIP streams beside the null stream, its re-chaining engine -- rechain_ahead.cpp, made when first needed -- four
+	// more, and single-read calls lease up to eight engines per device (MM2GB_SINGLE_ENGINES): the runtime's default of 4 queues is too few for
+	// the default configuration too -- at least 8, whatever num_streams is; the runtime offers at most 64, beyond which streams share queues)
+	const int want_queues = std::min(std::max(8, 8 * cfg.num_streams + 2), 64);
 	if (const char *q = getenv("GPU_MAX_HW_QUEUES")) {
 		if (atoi(q) < std::min(want_queues, 4 * cfg.num_streams + 2))
 			fprintf(stderr, "[mm2gb] GPU_MAX_HW_QUEUES=%s with num_streams=%d: streams will share hardware queues and serialise (four per stream id: %d)\n", q, cfg.num_streams, want_queues);
 	} else setenv("GPU_MAX_HW_QUEUES", std::to_string(want_queues).c_str(), 0);
 	if (!(cfg.has_max_total_n && cfg.has_max_read)) {
 		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's footprint per anchor:
-		// 16 B of work arrays + two staging sets of 24 B (raw in, f and p out)
+		// 16 B of work arrays + two staging sets of 24 B (raw in, f and p out); with the device post-pass (MM2GB_POST=gpu) its 41 B of work
+		// arrays and two result sets of 24 B on top; a stream's re-chaining engine (rechain_ahead.cpp, ~200 B per KEPT anchor, a third of them) beside it
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) die("cannot query device memory");
-		const double per_anchor = 64.0 + 16.0 / 1024;
+		{ const char *pm = getenv("MM2GB_POST"); const char *ptz = getenv("MM2GB_POST_THREADS"); g_streams.post_on_device = (pm && strcmp(pm, "gpu") == 0) || (ptz && atoi(ptz) == 0); }
+		const double per_anchor = 64.0 + 16.0 / 1024 + (g_streams.post_on_device ? 41.0 + 48.0 : 0.0) + 70.0;
 		const double budget = (double)total_b / cfg.num_streams * 0.8;
 		int64_t n = (int64_t)(budget / per_anchor);
 		if (n > 2000000000LL) n = 2000000000LL;
