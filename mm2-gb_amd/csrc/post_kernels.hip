@@ -410,10 +410,18 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		const int4 rk = rec[k];
 		int hk = uni(resident ? rk.x : rk.y);
 		const int tk = uni(rk.w);
-		for (; hk < tk; hk += W) {
+		int by4[4];
+		for (int hq = hk; hq < tk; hq += 4 * W) {
+			// the bucket's bytes, four blocks of 64 per round trip (they never change during the pass: read ahead at will)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = min(hq + u * W + l, tk - 1); by4[u] = resident ? (int)lineb[i - lo] : (int)sc.S[i]; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			hk = hq + u * W;
+			if (hk >= tk) break;
 			const int i = hk + l;
 			const bool in = i < tk;
-			const int by = resident ? (int)lineb[(in ? i : hk) - lo] : (int)sc.S[in ? i : hk];
+			const int by = by4[u];
 			unsigned long long moves = __ballot(in && by != k);
 			while (((unsigned)moves | (unsigned)(moves >> 32)) != 0) {
 				const int skip = first_set(moves);
@@ -472,6 +480,7 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 				if (l == 0) sc.perm[src] = home;
 			}
 		}
+		}
 	}
 	wave_sync();
 	// the elements follow the permutation: out of place first, then back (all lanes, eight loads in flight each)
@@ -526,7 +535,13 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 	if (n <= SMALL_RUN) { small_run_sort<E>(g, 0, n); return; }
 	const int l = lane();
 	unsigned long long any = 0, all = ~0ull;
-	for (int i = l; i < n; i += W) { const unsigned long long k = E::key(g[i]); any |= k; all &= k; }
+	for (int base = 0; base < n; base += 8 * W) {           // (eight loads in flight per lane: a wave on its own pays every round trip in full)
+		unsigned long long k[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) k[u] = E::key(g[min(base + u * W + l, n - 1)]);
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { any |= k[u]; all &= k[u]; }
+	}
 	for (int off = W / 2; off > 0; off >>= 1) {
 		any |= (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)any, off) | (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(any >> 32), off) << 32;
 		all &= (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)all, off) | (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(all >> 32), off) << 32;
@@ -559,10 +574,20 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 				const unsigned long long pk0 = readlane64(pk, 0);
 				int q = pos + W, adv;
 				do {
-					const int i2 = q + l;
-					const unsigned long long out = __ballot(i2 >= n || (shift < 56 ? E::key(g[i2]) >> (shift + 8) : 0) != pk0);
-					adv = ((unsigned)out | (unsigned)(out >> 32)) ? first_set(out) : W;
-					q += adv;
+					// four blocks of 64 per round trip (a run of 25 000 elements is 400 of them)
+					unsigned long long pk4[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) { const int i2 = q + u * W + l; pk4[u] = i2 < n && shift < 56 ? E::key(g[i2]) >> (shift + 8) : 0; }
+					adv = W;
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						if (adv == W) {
+							const int i2 = q + l;
+							const unsigned long long out = __ballot(i2 >= n || pk4[u] != pk0);
+							adv = ((unsigned)out | (unsigned)(out >> 32)) ? first_set(out) : W;
+							q += adv;
+						}
+					}
 				} while (adv == W);
 				one_radix_pass<E, BYTES>(g, pos, q, shift, L, sc, dbg ? dbg + 24 + 6 * min((top - shift) / 8, 2) : nullptr);
 				++d_pass; d_elems += q - pos;
