@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="K=V for the host's environment")
     ap.add_argument("--debug", action="store_true", help="MM2GB_DEBUG_PHASES=1 and the library's lines on stderr")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--own-host", action="store_true", help="also the repository's own host (mm2gb_map_reads_stream, four engines) on the same reads; with --full-cpu-paf its whole PAF is compared too")
     ap.add_argument("--cfg", action="append", default=[], help="K=V: top-level key of the gpu config to override (e.g. max_total_n=1000000)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -53,6 +54,27 @@ def main():
             want = r.stdout
             out["reference_cpu_whole_set"] = {"seconds": round(time.perf_counter() - t0, 1), "threads": threads, "paf_lines": want.count(b"\n"), "gbp_per_s": bases / (time.perf_counter() - t0) / 1e9}
             os.unlink(allfa)
+        if args.own_host:
+            import mm2gb_amd as mm
+            t0 = time.perf_counter()
+            ix = mm.SeedIndex([sq for _, sq in refs], threads=threads)
+            t_index = time.perf_counter() - t0
+            engines = [mm.Engine(device=0) for _ in range(4)]
+            opt = mm.map_opt(host_threads=threads)
+            names = [n for n, _ in refs]
+            mm.map_reads_stream(engines, ix, names, reads[:24], opt=opt, chunk_bases=500_000)
+            t0 = time.perf_counter()
+            paf, st = mm.map_reads_stream(engines, ix, names, reads, opt=opt, chunk_bases=32_000_000)
+            dt = time.perf_counter() - t0
+            own = {"map_seconds": round(dt, 2), "index_seconds": round(t_index, 3), "gbp_per_s": bases / (dt + t_index) / 1e9, "paf_lines": paf.count("\n"), "engines": 4}
+            if want is not None:
+                own["whole_paf_identical_to_reference_cpu"] = paf.encode() == want
+                if paf.encode() != want:
+                    own["whole_paf_identical_as_sorted_lines"] = sorted(paf.encode().splitlines()) == sorted(want.splitlines())
+            out["own_host"] = own
+            for e in engines:
+                e.close()
+            ix.close()
         for k in range(args.repeat):
             res = bench.reference_host_at_scale(td, ref, reads, bases, uniq, None, threads, legs=tuple(args.legs.split(",")), extra_env=extra, keep_stderr=True, cfg_override=cfg_over)
             for key in args.legs.split(","):
