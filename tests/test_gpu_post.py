@@ -176,3 +176,50 @@ def test_sliced_call_overlaps_copies_and_kernels_same_chains(engine, monkeypatch
     got, _ = engine.chain_gpu(a, off)
     for r in range(len(want)):
         assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), r
+
+
+def test_post_pass_of_one_engine_beside_the_scores_of_another(engine):
+    """mm2gb_post_device_enqueue / _totals: the post-pass of a scored batch enqueued on a SECOND engine (its own stream) while the first engine
+    scores again into another pair of arrays -- what bench.py's through_backtrace_pipelined measures.  Same totals as the synchronous call
+    on the first engine, twice in a row (the second engine's arenas are reused)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dev(nbytes, src=None):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), max(nbytes, 16)) == 0
+        if src is not None:
+            assert hip.hipMemcpy(p, src.ctypes.data, nbytes, H2D) == 0
+        return p
+
+    a, off = mm.synth_reads(41, 0, 24, 8_000, 50_000)
+    a = np.ascontiguousarray(a)
+    n, nr = len(a), len(off) - 1
+    d_a, d_off = dev(n * 16, a), dev((nr + 1) * 8, off)
+    fp = [(dev(n * 4), dev(n * 4)) for _ in range(2)]
+    L = mm.lib()
+    try:
+        engine.score_device(nr, d_off.value, d_a.value, n, fp[0][0].value, fp[0][1].value)
+        engine.sync()
+        n_ch, n_kept, ms = C.c_int64(0), C.c_int64(0), C.c_float(0)
+        assert L.mm2gb_post_device(engine._h, nr, d_off, d_a, n, fp[0][0], fp[0][1], C.byref(n_ch), C.byref(n_kept), C.byref(ms)) == 0
+        want_chains, _ = engine.chain(a, off, threads=2)
+        assert n_ch.value == sum(len(u) for u, _ in want_chains) and n_kept.value == sum(len(x) for _, x in want_chains)
+        with mm.Engine(device=0) as eng_b:
+            for k in (1, 2):
+                assert L.mm2gb_post_device_enqueue(eng_b._h, nr, d_off, d_a, n, fp[(k - 1) & 1][0], fp[(k - 1) & 1][1]) == 0
+                engine.score_device(nr, d_off.value, d_a.value, n, fp[k & 1][0].value, fp[k & 1][1].value)
+                engine.sync()
+                c2, k2, m2 = C.c_int64(0), C.c_int64(0), C.c_float(0)
+                assert L.mm2gb_post_device_totals(eng_b._h, C.byref(c2), C.byref(k2), C.byref(m2)) == 0
+                assert (c2.value, k2.value) == (n_ch.value, n_kept.value) and m2.value > 0
+        f0, f1 = np.empty(n, np.int32), np.empty(n, np.int32)
+        assert hip.hipMemcpy(f0.ctypes.data, fp[0][0], n * 4, D2H) == 0 and hip.hipMemcpy(f1.ctypes.data, fp[1][0], n * 4, D2H) == 0
+        assert np.array_equal(f0, f1)
+    finally:
+        for p in [d_a, d_off] + [x for pair in fp for x in pair]:
+            hip.hipFree(p)

@@ -3,6 +3,7 @@ without a minimap2 host: batches of chain_read_t records, deferred hand-back, se
 import ctypes as C
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -205,3 +206,25 @@ def test_auto_sized_batch_limits(tmp_path):
     assert 100_000_000 <= per_mb <= 2_000_000_000          # 288 GB device: capped at 2 G anchors per micro-batch
     assert mr.value >= per_mb // 20000
     L.free_stream_gpu(1)
+
+
+def test_parked_streams_are_taken_over_by_the_next_init(tmp_path, capfd):
+    """free_stream_gpu parks the streams (nothing released: page-locked staging and arenas are seconds to give back and to make again);
+    init_stream_gpu with the same configuration takes them over as they are, another configuration replaces them.  Results are the same
+    either way, and the second run of the same configuration makes no stream anew."""
+    env_dbg = os.environ.get("MM2GB_DEBUG_PHASES")
+    os.environ["MM2GB_DEBUG_PHASES"] = "1"
+    try:
+        anchors, off = mm.synth_reads(77, 0, 12, 5_000, 30_000)
+        reads = [anchors[off[r]:off[r + 1]] for r in range(12)]
+        for cfg_edit in (None, None, {"max_read": 777}):
+            drive_boundary(tmp_path, [reads[:7], reads[7:]], cfg_edit=cfg_edit)
+        err = capfd.readouterr().err
+        inits = [float(x) for x in re.findall(r"init_stream_gpu: entered at epoch [0-9.]+, \d+ stream\(s\) ready after ([0-9.]+) s", err)]
+        assert len(inits) == 3 and err.count("streams parked") == 3
+        assert inits[1] < 0.02 and inits[1] < inits[0], inits          # taken over, not made
+    finally:
+        if env_dbg is None:
+            del os.environ["MM2GB_DEBUG_PHASES"]
+        else:
+            os.environ["MM2GB_DEBUG_PHASES"] = env_dbg
