@@ -101,6 +101,7 @@ struct Engine {
 	std::vector<hipEvent_t> slice_in;      // sliced mm2gb_chain_gpu: slice k's anchors have arrived
 	PinnedBuf h_res_f, h_res_p;            // scores of whole-batch chaining calls (pool.cpp): page-locked, reused, grow-only
 	// per-slot read-back (pinned)
+	char    *h_small = nullptr;            // one page-locked block: h_counters, h_totals, both post sets' totals
 	int32_t *h_counters = nullptr;         // MAX_SLOTS x CNT_WORDS
 	int64_t *h_totals = nullptr;           // MAX_SLOTS x 2
 	BatchSlot slots[MAX_SLOTS];

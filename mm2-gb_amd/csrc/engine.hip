@@ -390,8 +390,17 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	MM2GB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
 	for (IoSet &s : io)
 		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) MM2GB_HIP(hipEventCreate(e));
-	MM2GB_HIP(hipHostMalloc((void**)&h_counters, (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t), hipHostMallocDefault));
-	MM2GB_HIP(hipHostMalloc((void**)&h_totals, (size_t)MAX_SLOTS * 2 * sizeof(int64_t), hipHostMallocDefault));
+	{
+		// the engine's small page-locked read-back areas out of ONE registered block (hipHostMalloc is a process-wide lock: sixteen engines made at
+		// the same time spent most of their 40 ms each queueing for three of these)
+		const size_t need = (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t) + (size_t)MAX_SLOTS * 2 * sizeof(int64_t) + 2 * 64;
+		h_small = (char*)pinned_alloc(need);
+		if (!h_small) return fail("mm2gb: cannot allocate the engine's page-locked read-back block");
+		h_counters = (int32_t*)h_small;
+		h_totals = (int64_t*)(h_small + (size_t)MAX_SLOTS * CNT_WORDS * sizeof(int32_t));
+		post_out[0].h_totals = (int64_t*)((char*)h_totals + (size_t)MAX_SLOTS * 2 * sizeof(int64_t));
+		post_out[1].h_totals = post_out[0].h_totals + 8;
+	}
 	for (WorkSet &w : work) if (w.counters.ensure(CNT_WORDS * sizeof(int32_t)) || w.totals.ensure(4 * sizeof(int64_t)) || w.flags.ensure(4 * sizeof(unsigned))) return -1;
 	{
 		// once per device and process (MM2GB_LDS_PROBE=0: take the contract as broken, i.e. clamped table and every range test)
@@ -430,12 +439,12 @@ void Engine::shutdown()
 		b->release();
 	cap_post_n = cap_post_reads = 0;
 	for (PostOut &po : post_out) {
-		if (po.h_totals) { (void)hipHostFree(po.h_totals); po.h_totals = nullptr; }
+		po.h_totals = nullptr;
 		if (po.done) { (void)hipEventDestroy(po.done); po.done = nullptr; }
 	}
 	for (hipEvent_t *e : { &post0, &post1, &rmq_fill_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-	if (h_counters) (void)hipHostFree(h_counters);
-	if (h_totals) (void)hipHostFree(h_totals);
+	pinned_free(h_small);
+	h_small = nullptr;
 	for (hipStream_t *s : { &s_in, &work[0].stream, &work[1].stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
 	stream = nullptr;
 	h_counters = nullptr; h_totals = nullptr;
@@ -545,7 +554,7 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 {
 	MM2GB_HIP(hipSetDevice(device));
 	for (PostOut &po : post_out) {
-		if (!po.h_totals) MM2GB_HIP(hipHostMalloc((void**)&po.h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+		if (!po.h_totals) return fail("mm2gb: engine not initialised");
 		if (!po.done) MM2GB_HIP(hipEventCreateWithFlags(&po.done, hipEventDisableTiming));
 	}
 	for (hipEvent_t *e : { &post0, &post1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
