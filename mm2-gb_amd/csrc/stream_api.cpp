@@ -790,8 +790,8 @@ void free_stream_gpu(int n_threads)
 	(void)n_threads;
 	const int64_t t_free0 = now_ns();
 	const double epoch_free = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
-	// Page-locked staging is slow to give back (unpinning: ~0.2 s per GB; 16 streams of a 1 Gbp run hold 10 GB: 2.5 s of a 16 s program,
-	// profiles/r05_dropin_notes.md), and the host calls this as the last thing before it exits (main.c:465).  So the streams are PARKED:
+	// Giving 16 streams' engines back one by one costs 2.5 s of a 16 s program (profiles/r05_dropin_notes.md; the process's end does it in
+	// 0.6 s, profiles/r05_exit_cost.txt), and the host calls this as the last thing before it exits (main.c:465).  So the streams are PARKED:
 	// work drained, engines idle, nothing released -- a later init_stream_gpu with the same configuration takes them over as they are (no
 	// re-pinning either), another configuration or MM2GB_FREE=now releases them for real, and the process's end releases what is parked.
 	static const bool release_now = [] { const char *v = getenv("MM2GB_FREE"); return v && strcmp(v, "now") == 0; }();
@@ -814,7 +814,22 @@ void free_stream_gpu(int n_threads)
 	g_streams.slots.clear();
 	g_streams.ready = false;
 	if (release_now) free_single_read_engines();
-	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] free_stream_gpu: entered at epoch %.3f, streams %s after %.3f s\n", epoch_free, release_now ? "released" : "parked", (now_ns() - t_free0) * 1e-9);
+	if (g_streams.debug) {
+		// what the process holds when the host is about to exit (its end is not the library's to time, but most of it is memory going away)
+		long rss_kb = 0, hwm_kb = 0, huge_kb = 0;
+		if (FILE *fp = fopen("/proc/self/status", "r")) {
+			char line[256];
+			while (fgets(line, sizeof line, fp)) { (void)sscanf(line, "VmRSS: %ld", &rss_kb); (void)sscanf(line, "VmHWM: %ld", &hwm_kb); }
+			fclose(fp);
+		}
+		if (FILE *fp = fopen("/proc/self/smaps_rollup", "r")) {
+			char line[256];
+			while (fgets(line, sizeof line, fp)) (void)sscanf(line, "AnonHugePages: %ld", &huge_kb);
+			fclose(fp);
+		}
+		fprintf(stderr, "[mm2gb stream] free_stream_gpu: entered at epoch %.3f, streams %s after %.3f s; the process holds %.1f GB of memory (peak %.1f), %.1f GB of it in huge pages\n",
+		        epoch_free, release_now ? "released" : "parked", (now_ns() - t_free0) * 1e-9, rss_kb / 1048576.0, hwm_kb / 1048576.0, huge_kb / 1048576.0);
+	}
 	// What the library held of the run, for whoever times the drop-in (bench.py's e2e.reference_host_at_scale): seconds are summed over the
 	// host's threads; the host's own callback (post_chaining_helper, map.c:428: RMQ re-chaining, mm_gen_regs, ...) runs inside the boundary
 	// calls and is listed apart, and of it what mg_lchain_rmq calls answered by the library took (hosts linked with --wrap=mg_lchain_rmq).

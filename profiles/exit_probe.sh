@@ -13,6 +13,6 @@ for cfg in 1 16; do
   s=$(date +%s.%N)
   MM2GB_FREE=$mode MM2GB_DEBUG_PHASES=1 $H -t $cfg --max-chain-skip=2147483647 --gpu-chain --gpu-cfg /tmp/cfg$cfg.json $T/MT-human.fa $T/MT-orang.fa > /dev/null 2> /tmp/err.txt
   e=$(date +%s.%N)
-  echo "streams=$cfg free=$mode whole=$(echo "$e - $s" | bc) :: $(grep -E 'init_stream_gpu|free_stream_gpu' /tmp/err.txt | sed 's/.*epoch [0-9.]*, //' | tr '\n' ';') start_epoch=$s end_epoch=$e $(grep -oE 'entered at epoch [0-9.]+' /tmp/err.txt | tr '\n' ' ')"
+  echo "streams=$cfg free=$mode whole=$(python3 -c "print(round($e - $s, 3))") :: $(grep -E 'init_stream_gpu|free_stream_gpu' /tmp/err.txt | sed 's/.*epoch [0-9.]*, //' | tr '\n' ';') start_epoch=$s end_epoch=$e $(grep -oE 'entered at epoch [0-9.]+' /tmp/err.txt | tr '\n' ' ')"
  done
 done

@@ -122,6 +122,13 @@ def test_batch_call_that_is_exact_for_every_read(engine, monkeypatch, deal):
         got, where, d = engine.rmq_chain_exact(allr, o2, prm, threads=8)
         for r in range(len(reads)):
             assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), (deal, kw, r, int(where[r]))
+        if orc.ref_available():
+            # ... and the compiled reference's mg_lchain_rmq itself (oracle/_ref travels to the GPU box), read by read, ties included
+            oprm = orc.default_rmq_param(**kw)
+            for r, x in enumerate(reads):
+                if len(x):
+                    ref = orc.ref_lchain_rmq(x, oprm)
+                    assert np.array_equal(got[r][0], ref["u"]) and np.array_equal(got[r][1], ref["a_out"]), ("reference", deal, kw, r, int(where[r]))
         assert d["n_device"] + d["n_host_cost"] == len(reads) and d["n_host_tie"] == int((where == 2).sum())
         if deal == "device":
             assert d["n_host_cost"] == 0 and d["n_host_tie"] >= 1          # the clouds tie: found on the device, redone on the host
