@@ -62,7 +62,8 @@ struct RmqBatch {
 	int      grid_waves;
 	// tile form, the inner window by strips of y (null: the inner window is swept block by block): every read's anchors sorted by (y >> strip_shift, index) --
 	// a lane's inner candidates, y within max_dist_inner below its own, lie in at most two strips, and inside a strip its index window is one range
-	unsigned long long *skey_in, *skey;   // scratch, n each: (strip << 32 | index), unsorted / sorted within each read
+	unsigned long long *skey_in, *skey;   // scratch, n each: (strip << 32 | index), unsorted / sorted within each read; once sorted, skey_in's memory holds
+	                                      // two int32 arrays of n: the scores in strip order, and every anchor's position in that order (k_rmq_fill_tiles: sf, spos)
 	uint4   *sa;               // scratch, n: the anchors in that order (x, y, index, q_span)
 	int4    *srange;           // scratch, n: per anchor [begin, end) in the lower strip and [begin, end) in the upper one (positions in its read's order)
 	void    *sort_tmp;         // scratch of the segmented sort

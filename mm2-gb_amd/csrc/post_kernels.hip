@@ -1732,6 +1732,7 @@ __global__ __launch_bounds__(256) void k_rmq_strip_fill(RmqBatch b)
 		const unsigned j = (unsigned)b.skey[g];
 		const uint4 e = b.raw[off + j];
 		b.sa[g] = make_uint4(e.x, e.z, j, e.w & 0xffu);
+		((int32_t*)b.skey_in)[b.n + off + j] = (int32_t)(g - off);      // spos (k_rmq_fill_tiles): the keys' unsorted copy is not read again
 	}
 }
 __global__ __launch_bounds__(256) void k_rmq_strip_ranges(RmqBatch b, int max_inner)
@@ -1760,23 +1761,18 @@ __global__ __launch_bounds__(256) void k_rmq_strip_ranges(RmqBatch b, int max_in
 	}
 }
 
-// One read, by NW waves (1: the wave alone; RMQ_TEAM: a whole workgroup, wave w of it).  In a team wave 0 does what is serial -- the tree, the
-// queries, the 64 steps of the tile's own anchors -- and all NW share the broadcast sweeps, block by block in turn (a tile's sweeps are most
-// of its time on reads with hundreds of anchors in the inner window); their results per lane -- the best outer candidate, the best of the
-// inner window, the largest bound a lane relied on -- meet in LDS (`s_m`) and are combined by the rules of tile_offer / tile_offer_inner,
-// which do not depend on the order of the offers.  Two workgroup barriers per tile: before the combination, and after the tile's scores are out.
 constexpr int RMQ_THREADS = 1024;              // k_rmq_fill_tiles: 16 waves -- one read each, or all 16 on one read
 constexpr int RMQ_TEAM = RMQ_THREADS / W;
 constexpr int RMQ_MERGE_WORDS = 12;
-// A team's read keeps the top of its tournament tree -- nodes 1 .. RMQ_TOP_NODES - 1, eleven levels -- in LDS (`s_top`; only wave 0 touches the
-// tree): a tile's update climbs every level behind a store and a load of the level below, ~1.6 us per level in global memory, 31 us per tile
-// of a 450 k-anchor read (19 levels), a third of such a read's time (profiles/r03_rmq_teams.txt).
+// A team's read keeps the top of its tournament tree -- nodes 1 .. RMQ_TOP_NODES - 1, eleven levels -- in LDS (`s_top`; only the tree wave
+// touches it): a tile's update climbs every level behind a store and a load of the level below, ~1.6 us per level in global memory, 31 us per
+// tile of a 450 k-anchor read (19 levels), a third of such a read's time (profiles/r03_rmq_teams.txt).
 #ifndef MM2GB_RMQ_TOP_NODES
 #define MM2GB_RMQ_TOP_NODES 2048
 #endif
 constexpr int RMQ_TOP_NODES = MM2GB_RMQ_TOP_NODES;
-template <int NW>
-__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W], uint4 *s_top, int *s_flag)
+// One read by ONE wave (the reads of a call that are not worth a whole workgroup; rmq_fill_read_team below has the others).
+__device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const RmqParams &P, const int r)
 {
 	const int l = lane();
 	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
@@ -1790,13 +1786,15 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 		const bool strips = b.sa != nullptr && max_inner > 0;     // the inner window by strips of y (k_rmq_strip_ranges) instead of block sweeps
 		const uint4 *sa = b.sa + off;
 		const int4 *srange = b.srange + off;
+		// strips: every anchor's score also at its place in the strip order (the memory of the sort's input keys, free once the order stands):
+		// sf[position] for the inner scans, spos[index] = the position, for whoever settles the anchor
+		int32_t *sf = (int32_t*)b.skey_in + off;
+		const int32_t *spos = (const int32_t*)b.skey_in + b.n + off;
 		const int32_t *ord_idx = b.ord_idx + off;
 		int32_t *f = b.f + off, *p = b.p + off;
 		uint4 *tree = b.tree + 2 * off;                      // node q of this read: tree[q], leaves at n + rank, root 1
-		const int top_nodes = NW > 1 && RMQ_TOP_NODES > 1 ? RMQ_TOP_NODES : 0;   // nodes below this index live in s_top for the read's time
-		auto tld = [&](int q) -> uint4 { if (NW > 1 && q < top_nodes) return s_top[q]; return tree[q]; };
-		auto tst = [&](int q, const uint4 &v) { if (NW > 1 && q < top_nodes) s_top[q] = v; else tree[q] = v; };
-		if (NW > 1 && w == 0) { for (int q = l; q < top_nodes; q += W) s_top[q] = tnode_none(); wave_sync(); }
+		auto tld = [&](int q) -> uint4 { return tree[q]; };
+		auto tst = [&](int q, const uint4 &v) { tree[q] = v; };
 		int32_t *bound = b.bound + (off >> 6) + r;           // per block of 64 anchors (by index) the largest f + span, once its tile is done
 		int ev = 0, ins = 0, tied = 0;                       // the tree holds the anchors of index [ev, ins)
 		const long long t_read0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -1807,6 +1805,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 			const uint4 A = live ? a[i] : make_uint4(0, 0, 0, 0);
 			const int4 M = live ? meta[i] : make_int4(0, 1, 0, 0);             // rank, first and last rank of the query (dead lanes: empty)
 			const int4 Wn = live ? win[i] : make_int4(INT_MAX, INT_MAX, 0, 0);   // st, st_inner, i0 (dead lanes: nothing is in reach, nothing came before)
+			const int sp_i = (strips && live) ? spos[i] : 0;
 			const unsigned xi = A.x;
 			const int yi = (int)A.z, q_i = (int)(A.w & 0xffu);
 			const int st_first = __builtin_amdgcn_readlane(Wn.x, 0), st_last = __builtin_amdgcn_readlane(Wn.x, n_here - 1);
@@ -1816,7 +1815,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 			++d_tiles;
 			const long long ts0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			// ---- the tree: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) ----
-			if (NW == 1 || w == 0) {
+			{
 				int e0 = ev, n0 = max(ins, lo);
 				const int e1 = min(lo, ins), n1 = hi;
 				while (e0 < e1 || n0 < n1) {
@@ -1850,7 +1849,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 			{
 				uint4 best = tnode_none();
 				int ql = n + M.y, qr = n + M.z + 1;                                // [ql, qr) over the leaves
-				bool go = (NW == 1 || w == 0) && live && M.y <= M.z && lo < hi;
+				bool go = live && M.y <= M.z && lo < hi;
 				while (__ballot(go && ql < qr) != 0) {
 					uint4 vl = tnode_none(), vr = vl;
 					if (go && ql < qr) {
@@ -1875,10 +1874,9 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 			in.s = 0; in.y = 0; in.j = -1;
 			int relied = INT_MIN;                                 // the largest bound of a block this lane passed over on the strength of its outer candidate's score alone
 			const int y_top = yi - 1, y_bot = yi - max_inner;
-			auto sweep_range = [&](int from, int to, bool outer_all, bool in_turn = false) {
+			auto sweep_range = [&](int from, int to, bool outer_all) {
 				// outer_all: every anchor of the range is outside the tree (it left the window for some lanes); else only those from hi on are
 				for (int base = from; base < to; base += W) {
-					if (NW > 1 && in_turn && (((base - from) >> 6) % NW) != w) continue;       // a team's waves take the blocks of the range in turn
 					const int j_l = base + l;
 					const bool have = j_l < to;
 					const uint4 e_l = have ? a[j_l] : make_uint4(0, 0, 0, 0);
@@ -1917,7 +1915,7 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 					}
 				}
 			};
-			sweep_range(st_first, lo, true, true);
+			sweep_range(st_first, lo, true);
 			{
 				// From the newest block of 64 down: the nearest anchors carry the highest scores, so the lanes' inner bests rise at once, and a
 				// block whose largest f + span (`bound`, written when its tile was finished) cannot beat ANY lane's is passed over --
@@ -1926,7 +1924,6 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				// 5 266 broadcasts per tile on the mapper's reads (profiles/r03h_*), twenty times the work of the kernel above.
 				const int from = (max_inner > 0 && !strips) ? max(min(stin_first, tb), lo) : max(hi, lo);
 				for (int bb = (tb >> 6) - 1; bb >= 0 && ((bb + 1) << 6) > from; --bb) {
-					if (NW > 1 && (bb % NW) != w) continue;
 					const int b_lo = max(bb << 6, from), b_hi = (bb + 1) << 6;
 					if (b_lo >= hi || max_inner <= 0) { sweep_range(b_lo, b_hi, false); continue; }     // holds anchors the outer query needs (not in the tree): no skipping
 					if (b_hi > hi) { sweep_range(b_lo, b_hi, false); continue; }
@@ -1973,18 +1970,19 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				const int4 R4 = live ? srange[i] : make_int4(0, 0, 0, 0);
 				for (int pass = 0; pass < 2; ++pass) {
 					const int r_lo = pass ? R4.z : R4.x, r_hi = pass ? R4.w : R4.y;
-					const int part = NW > 1 ? (r_hi - r_lo + NW - 1) / NW : r_hi - r_lo;
-					int pp = r_lo + (NW > 1 ? w * part : 0);
-					const int pe = NW > 1 ? min(r_hi, pp + part) : r_hi;
+					int pp = r_lo;
+					const int pe = r_hi;
 					while (__ballot(pp < pe) != 0) {
 						if (pp < pe) {
 							uint4 cq[4];
 							int fq[4];
 							bool okq[4];
+							// (the candidates' scores come from their copy in this order, `sf`: a round is ONE round trip to memory, not the candidate and
+							// then f[its index] -- a lone wave has nothing else to hide a dependent load behind)
 #pragma unroll
-							for (int q = 0; q < 4; ++q) cq[q] = sa[min(pp + q, pe - 1)];
+							for (int q = 0; q < 4; ++q) { const int at = min(pp + q, pe - 1); cq[q] = sa[at]; fq[q] = sf[at]; }
 #pragma unroll
-							for (int q = 0; q < 4; ++q) { okq[q] = (pp + q < pe) & ((int)cq[q].z < tb); fq[q] = okq[q] ? f[(int)cq[q].z] : 0; }
+							for (int q = 0; q < 4; ++q) okq[q] = (pp + q < pe) & ((int)cq[q].z < tb);
 #pragma unroll
 							for (int q = 0; q < 4; ++q) {
 								int ex, wd;
@@ -1997,27 +1995,8 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 					}
 				}
 			}
-			if (NW > 1) {
-				// the team's results of this tile, per lane, to wave 0
-				if (w > 0) {
-					int (*m)[W] = s_m[w - 1];
-					m[0][l] = (int)(unsigned)(unsigned long long)c.key; m[1][l] = (int)(unsigned)((unsigned long long)c.key >> 32); m[2][l] = c.rank; m[3][l] = c.tie; m[4][l] = c.j; m[5][l] = c.sc;
-					m[6][l] = c.exact; m[7][l] = c.width; m[8][l] = in.s; m[9][l] = in.y; m[10][l] = in.j; m[11][l] = relied;
-				}
-				__syncthreads();
-				if (w == 0) {
-					for (int k = 0; k < NW - 1; ++k) {
-						int (*m)[W] = s_m[k];
-						const long long key = (long long)((unsigned long long)(unsigned)m[1][l] << 32 | (unsigned)m[0][l]);
-						tile_offer(c, key != RMQ_NONE, key, m[2][l], m[3][l], m[4][l], m[5][l], m[6][l], m[7][l]);
-						tile_offer_inner(in, m[10][l] >= 0, m[8][l], m[9][l], m[10][l]);
-						relied = max(relied, m[11][l]);
-					}
-				}
-			}
 			const long long ts3 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-			// ---- (3) the tile's own anchors, one after the other (a team: wave 0) ----
-			if (NW == 1 || w == 0) {
+			// ---- (3) the tile's own anchors, one after the other ----
 			int f_l = q_i, p_l = 0;
 			long long k_l = 0;
 			for (int t = 0; t < n_here; ++t) {
@@ -2066,40 +2045,477 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				tile_offer(c, out_ok, (long long)readlane64((unsigned long long)k_l, t), rkj, 0, j, s2, ex2, w2);
 				tile_offer_inner(in, in_ok & (w2 <= P.bw), s2, yj, j);
 			}
-			if (live) { f[i] = f_l; p[i] = p_l; }
+			if (live) { f[i] = f_l; p[i] = p_l; if (strips) sf[sp_i] = f_l; }
 			if (b.dbg) { const long long ts4 = (long long)__builtin_amdgcn_s_memrealtime(); d_upd += ts1 - ts0; d_levels += ts2 - ts1; d_qloads += ts3 - ts2; d_t3 += ts4 - ts3; }
 			{
 				const int top = wave_max_i32(live ? f_l + q_i : INT_MIN);
 				if (l == 0) bound[tb >> 6] = top;
 			}
-			}
 			wave_sync();
 			// a tie in this tile: the caller redoes the read with the reference's tree whatever comes of the rest -- stop here (abandon_tied)
-			bool give_up = false;
-			if (b.abandon_tied) {
-				if (NW == 1) give_up = __ballot(tied != 0) != 0;
-				if (NW > 1 && w == 0) { const bool any = __ballot(tied != 0) != 0; if (l == 0) *s_flag = any; }
-			}
-			if (NW > 1) { __threadfence_block(); __syncthreads(); }      // the tile's scores and its bound are out: the next tile's sweeps read them
-			if (NW > 1 && b.abandon_tied) give_up = uni(*s_flag) != 0;
-			if (give_up) {
-				if (NW > 1) __syncthreads();                              // (everybody has read the flag before the next read of the team resets it)
-				for (int i = w * W + l; i < n; i += NW * W) { f[i] = INT_MIN; p[i] = 0; }   // nothing of this read for the post-pass
+			if (b.abandon_tied && __ballot(tied != 0) != 0) {
+				for (int k = l; k < n; k += W) { f[k] = INT_MIN; p[k] = 0; }   // nothing of this read for the post-pass
 				break;
 			}
 		}
 		tied = (int)wave_sum_i32(tied);
-		if (l == 0 && (NW == 1 || w == 0)) b.n_tied[r] = tied;
-		if (b.dbg && l == 0 && (NW == 1 || w == 0)) {
+		if (l == 0) b.n_tied[r] = tied;
+		if (b.dbg && l == 0) {
 			const long long v[8] = { n, d_tiles, d_upd, d_levels, d_qloads, d_bcast + (d_single << 36), d_skip + (d_redo << 32), d_t3 };
 			for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
 			if (b.dbg_reads) {
 				long long *o = b.dbg_reads + 8 * (int64_t)r;
-				o[0] = n; o[1] = NW; o[2] = (long long)__builtin_amdgcn_s_memrealtime() - t_read0; o[3] = d_upd; o[4] = d_levels; o[5] = d_qloads; o[6] = d_t3; o[7] = d_bcast;
+				o[0] = n; o[1] = 1; o[2] = (long long)__builtin_amdgcn_s_memrealtime() - t_read0; o[3] = d_upd; o[4] = d_levels; o[5] = d_qloads; o[6] = d_t3; o[7] = d_bcast;
 			}
 		}
 		wave_sync();
 	}
+}
+
+// One read by a whole workgroup, round 5.  A tile of a large read used to be a chain -- the tree's update, the queries, the waves' sweeps and
+// inner scans, the combination, the tile's own 64 steps -- of which only the sweeps were shared (96 us per tile of a 450 k-anchor read: 0.68 s,
+// and a call to the device is over when its longest read is).  Only the 64 steps need the previous tile's scores at once, so the team is SKEWED,
+// three roles with a loop of their own each (and registers of their own: one loop with the roles as branches spilled 48 of them):
+//   wave 0      the combination and the 64 steps of tile T, nothing else (team_steps);
+//   wave 1      the tree, one tile behind (team_tree) -- while wave 0 walks tile T it puts the tree in the state tile T + 1 needs (what leaves
+//               before that tile's last window start goes out; what has entered up to the END OF TILE T - 1, all final, goes in), and asks it
+//               tile T + 1's queries beside P2;
+//   waves 2..   for tile T + 1 (team_helper): while wave 0 walks tile T everything that does not need tile T's scores -- the sweep of the anchors
+//               leaving the window, the inner scans up to tile T - 1's last anchor (P1) -- and, once tile T is out, its 64 anchors by a broadcast
+//               sweep and the end of the inner scans (P2); tile T's anchors are not in the tree for tile T + 1, the sweep offers them like any
+//               anchor from `hi` on.
+// Per tile: { P2 | queries }, a barrier, { the 64 steps | the tree's update | P1 }, a barrier.  Results per lane meet in LDS (`s_m`, wave 1's and
+// the helpers') and are combined by the rules of tile_offer / tile_offer_inner, which do not depend on the order of the offers.
+namespace {
+
+constexpr int TEAM_HELPERS = RMQ_TEAM - 2;                   // waves 2 .. RMQ_TEAM - 1
+
+// what the three roles share of a read
+struct TeamRead {
+	int n, max_inner;
+	bool strips;
+	double half_gap;
+	const uint4 *a, *sa;
+	const int4 *meta, *win, *srange;
+	int32_t *sf, *f, *p, *bound;
+	const int32_t *spos, *ord_idx;
+	uint4 *tree;
+};
+// the tile a wave works FOR: wave 0 the one whose 64 steps come next, the others the one after it
+struct TeamTile {
+	int tb, n_here, i, yi, q_i, st_first, st_last, stin_first, hi, lo, y_top, y_bot;
+	bool live;
+	unsigned xi;
+	uint4 A;
+	int4 M, Wn;
+	__device__ __forceinline__ void load(const TeamRead &R, int tb_)
+	{
+		const int l = lane();
+		tb = tb_; n_here = min(W, R.n - tb); i = tb + l; live = l < n_here;
+		A = live ? R.a[i] : make_uint4(0, 0, 0, 0);
+		M = live ? R.meta[i] : make_int4(0, 1, 0, 0);             // rank, first and last rank of the query (dead lanes: empty)
+		Wn = live ? R.win[i] : make_int4(INT_MAX, INT_MAX, 0, 0);   // st, st_inner, i0 (dead lanes: nothing is in reach, nothing came before)
+		xi = A.x; yi = (int)A.z; q_i = (int)(A.w & 0xffu);
+		st_first = __builtin_amdgcn_readlane(Wn.x, 0); st_last = __builtin_amdgcn_readlane(Wn.x, n_here - 1);
+		stin_first = __builtin_amdgcn_readlane(Wn.y, 0);
+		hi = max(0, min(__builtin_amdgcn_readlane(Wn.z, 0), tb - W));   // the tree for this tile: [lo, hi) -- nothing of the tile before it
+		lo = min(st_last, hi);
+		y_top = yi - 1; y_bot = yi - R.max_inner;
+	}
+};
+__device__ __forceinline__ void team_cand_reset(TileCand &c, TileInner &in, int &relied)
+{
+	c.key = RMQ_NONE; c.rank = -1; c.tie = 0; c.j = -1; c.sc = 0; c.exact = 0; c.width = 0; in.s = 0; in.y = 0; in.j = -1; relied = INT_MIN;
+}
+__device__ __forceinline__ void team_cand_out(int (*m)[W], const TileCand &c, const TileInner &in, int relied)
+{
+	const int l = lane();
+	m[0][l] = (int)(unsigned)(unsigned long long)c.key; m[1][l] = (int)(unsigned)((unsigned long long)c.key >> 32); m[2][l] = c.rank; m[3][l] = c.tie; m[4][l] = c.j; m[5][l] = c.sc;
+	m[6][l] = c.exact; m[7][l] = c.width; m[8][l] = in.s; m[9][l] = in.y; m[10][l] = in.j; m[11][l] = relied;
+}
+// what every role does when a tile is out: a tie in it and the caller redoes the read with the reference's tree anyway (abandon_tied) -- the
+// read's scores are cleared (nothing of it for the post-pass) and the team is through with it
+__device__ __forceinline__ bool team_gives_up(const RmqBatch &b, const TeamRead &R, int w, const int *s_flag)
+{
+	if (!b.abandon_tied || uni(*s_flag) == 0) return false;
+	__syncthreads();                                          // (everybody has read the flag before the next read of the team resets it)
+	for (int k = w * W + lane(); k < R.n; k += RMQ_TEAM * W) { R.f[k] = INT_MIN; R.p[k] = 0; }
+	return true;
+}
+
+// ---- wave 0 ----
+__device__ __forceinline__ void team_steps(const RmqBatch &b, const RmqParams &P, const TeamRead &R, const int r, int (*s_m)[RMQ_MERGE_WORDS][W], int *s_flag)
+{
+	const int l = lane(), n = R.n, max_inner = R.max_inner;
+	const long long t_read0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+	long long d_tiles = 0, d_wait = 0, d_t3 = 0, d_redo = 0;
+	int tied = 0;
+	TeamTile T;
+	for (int tb = 0; tb < n; tb += W) {
+		const long long tx0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		T.load(R, tb);
+		const int sp_i = (R.strips && T.live) ? R.spos[T.i] : 0;
+		++d_tiles;
+		__syncthreads();                                       // every wave's part of this tile is in LDS
+		const long long tx1 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		TileCand c;
+		TileInner in;
+		int relied;
+		team_cand_reset(c, in, relied);
+		for (int k = 0; k < RMQ_TEAM - 1; ++k) {
+			int (*m)[W] = s_m[k];
+			const long long key = (long long)((unsigned long long)(unsigned)m[1][l] << 32 | (unsigned)m[0][l]);
+			tile_offer(c, key != RMQ_NONE, key, m[2][l], m[3][l], m[4][l], m[5][l], m[6][l], m[7][l]);
+			tile_offer_inner(in, m[10][l] >= 0, m[8][l], m[9][l], m[10][l]);
+			relied = max(relied, m[11][l]);
+		}
+		// ---- the tile's own anchors, one after the other (rmq_fill_read_tiles) ----
+		const unsigned xi = T.xi;
+		const int yi = T.yi, q_i = T.q_i, i = T.i, y_top = T.y_top, y_bot = T.y_bot;
+		const int4 Wn = T.Wn, M = T.M;
+		const uint4 A = T.A;
+		int f_l = q_i, p_l = 0;
+		long long k_l = 0;
+		for (int t = 0; t < T.n_here; ++t) {
+			const bool has = c.key != RMQ_NONE;
+			int max_f = q_i, max_j = -1;
+			{ const bool use_out = has & (c.width <= P.bw) & (c.sc > max_f); max_f = use_out ? c.sc : max_f; max_j = use_out ? c.j : max_j; }
+			const bool inner_on = has & !c.exact & (max_inner > 0) & (Wn.y < Wn.z) & (yi > 0);
+			if (__builtin_amdgcn_readlane((int)(inner_on & (relied > max_f)), t) != 0) {
+				// lane t passed blocks over that its final outer result does not rule out: its whole inner window before the tile again
+				++d_redo;
+				const unsigned xt = (unsigned)__builtin_amdgcn_readlane((int)xi, t);
+				const int yt = __builtin_amdgcn_readlane(yi, t), from_t = __builtin_amdgcn_readlane(Wn.y, t), to_t = min(__builtin_amdgcn_readlane(Wn.z, t), tb);
+				TileInner best; best.s = 0; best.y = 0; best.j = -1;
+				for (int base = from_t; base < to_t; base += W) {
+					const int j = base + l;
+					if (j < to_t) {
+						const uint4 e = R.a[j];
+						int ex2, w2;
+						const int s2 = R.f[j] + tile_pair_score(xt, yt, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex2, w2);
+						tile_offer_inner(best, ((int)e.z <= yt - 1) & ((int)e.z >= yt - max_inner) & (w2 <= P.bw), s2, (int)e.z, j);
+					}
+				}
+				for (int o = W / 2; o > 0; o >>= 1) tile_offer_inner(best, __shfl_xor(best.j, o) >= 0, __shfl_xor(best.s, o), __shfl_xor(best.y, o), __shfl_xor(best.j, o));
+				if (l == t) tile_offer_inner(in, best.j >= 0, best.s, best.y, best.j);
+			}
+			const bool use_in = inner_on & (in.j >= 0) & (in.s > max_f);
+			max_f = use_in ? in.s : max_f; max_j = use_in ? in.j : max_j;
+			if (l == t) {
+				f_l = max_f; p_l = max_j < 0 ? 0 : i - max_j;
+				k_l = key_order((double)max_f + R.half_gap * (double)((int)xi + yi));
+				tied += has && c.tie;
+			}
+			// lane t's anchor to the lanes above it
+			const int j = tb + t;
+			const int yj = __builtin_amdgcn_readlane((int)A.z, t), rkj = __builtin_amdgcn_readlane(M.x, t);
+			const bool before = j < Wn.z;
+			const bool out_ok = before & (j >= Wn.x) & (rkj >= M.y) & (rkj <= M.z);
+			const bool in_ok = (max_inner > 0) & before & (j >= Wn.y) & (yj <= y_top) & (yj >= y_bot);
+			if (__ballot(out_ok | in_ok) == 0) continue;
+			const unsigned xj = (unsigned)__builtin_amdgcn_readlane((int)A.x, t);
+			const int sj = __builtin_amdgcn_readlane((int)A.w, t) & 0xff, fj = __builtin_amdgcn_readlane(f_l, t);
+			int ex2, w2;
+			const int s2 = fj + tile_pair_score(xi, yi, xj, yj, sj, P, ex2, w2);
+			tile_offer(c, out_ok, (long long)readlane64((unsigned long long)k_l, t), rkj, 0, j, s2, ex2, w2);
+			tile_offer_inner(in, in_ok & (w2 <= P.bw), s2, yj, j);
+		}
+		if (T.live) { R.f[i] = f_l; R.p[i] = p_l; if (R.strips) R.sf[sp_i] = f_l; }
+		{
+			const int top = wave_max_i32(T.live ? f_l + q_i : INT_MIN);
+			if (l == 0) R.bound[tb >> 6] = top;
+		}
+		if (b.dbg) { const long long tx2 = (long long)__builtin_amdgcn_s_memrealtime(); d_wait += tx1 - tx0; d_t3 += tx2 - tx1; }
+		if (b.abandon_tied) { const bool any = __ballot(tied != 0) != 0; if (l == 0) *s_flag = any; }
+		__threadfence_block();
+		__syncthreads();                                       // the tile's scores and its bound are out, the tree stands for the next tile
+		if (team_gives_up(b, R, 0, s_flag)) break;
+	}
+	tied = (int)wave_sum_i32(tied);
+	if (l == 0) b.n_tied[r] = tied;
+	if (b.dbg && l == 0) {
+		const long long v[8] = { n, d_tiles, 0, 0, d_wait, 0, d_redo << 32, d_t3 };
+		for (int q = 0; q < 8; ++q) if (v[q]) atomicAdd((unsigned long long*)&b.dbg[q], (unsigned long long)v[q]);
+		if (b.dbg_reads) {
+			long long *o = b.dbg_reads + 8 * (int64_t)r;
+			o[0] = n; o[1] = RMQ_TEAM; o[2] = (long long)__builtin_amdgcn_s_memrealtime() - t_read0; o[5] = d_wait; o[6] = d_t3; o[7] = 0;
+		}
+	}
+}
+
+// ---- wave 1 ----
+__device__ __forceinline__ void team_tree(const RmqBatch &b, const RmqParams &P, const TeamRead &R, const int r, int (*s_m)[RMQ_MERGE_WORDS][W], uint4 *s_top, const int *s_flag)
+{
+	const int l = lane(), n = R.n;
+	constexpr int top_nodes = RMQ_TOP_NODES > 1 ? RMQ_TOP_NODES : 0;     // nodes below this index live in s_top for the read's time
+	uint4 *tree = R.tree;
+	auto tld = [&](int q) -> uint4 { if (q < top_nodes) return s_top[q]; return tree[q]; };
+	auto tst = [&](int q, const uint4 &v) { if (q < top_nodes) s_top[q] = v; else tree[q] = v; };
+	int ev = 0, ins = 0;                                       // the tree holds the anchors of index [ev, ins)
+	long long d_upd = 0, d_levels = 0;
+	TeamTile T;
+	T.load(R, 0);
+	for (int tb = 0; tb < n; tb += W) {
+		// ---- every lane's query of the tree for tile tb, bottom up; the loads do not depend on each other ----
+		const long long tq0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		TileCand c;
+		TileInner in;
+		int relied;
+		team_cand_reset(c, in, relied);
+		{
+			uint4 best = tnode_none();
+			int ql = n + T.M.y, qr = n + T.M.z + 1;                         // [ql, qr) over the leaves
+			const bool go = T.live && T.M.y <= T.M.z && T.lo < T.hi;
+			while (__ballot(go && ql < qr) != 0) {
+				uint4 vl = tnode_none(), vr = vl;
+				if (go && ql < qr) {
+					if (ql & 1) vl = tld(ql++);
+					if (qr & 1) vr = tld(--qr);
+					ql >>= 1; qr >>= 1;
+				}
+				best = tnode_comb(best, tnode_comb(vl, vr));
+			}
+			if (tnode_key(best) != RMQ_NONE) {
+				const int rk = (int)(best.z & 0x7fffffffu);
+				const int j = R.ord_idx[rk];
+				const uint4 e = R.a[j];
+				int ex, wd;
+				const int sc = R.f[j] + tile_pair_score(T.xi, T.yi, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex, wd);
+				c.key = tnode_key(best); c.rank = rk; c.tie = (int)(best.z >> 31); c.j = j; c.sc = sc; c.exact = ex; c.width = wd;
+			}
+		}
+		team_cand_out(s_m[0], c, in, relied);
+		if (b.dbg) d_levels += (long long)__builtin_amdgcn_s_memrealtime() - tq0;
+		__syncthreads();
+		// ---- the tree for tile tb + W: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) (rmq_fill_read_tiles) ----
+		if (tb + W < n) {
+			const long long tu0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+			T.load(R, tb + W);
+			const int lo = T.lo, hi = T.hi;
+			int e0 = ev, n0 = max(ins, lo);
+			const int e1 = min(lo, ins), n1 = hi;
+			while (e0 < e1 || n0 < n1) {
+				const int je = e0 + l, ji = n0 + l;
+				int pe = 0, pi = 0;
+				if (je < e1) { pe = n + R.meta[je].x; tst(pe, tnode_none()); }
+				if (ji < n1) {
+					const uint4 e = R.a[ji];
+					const int rk = R.meta[ji].x;
+					const long long kk = key_order((double)R.f[ji] + R.half_gap * (double)((int)e.x + (int)e.z));
+					pi = n + rk;
+					tst(pi, make_uint4((unsigned)kk, (unsigned)((unsigned long long)kk >> 32), (unsigned)rk, 0u));
+				}
+				wave_sync();
+				while (__ballot(pe > 1 || pi > 1) != 0) {
+					uint4 c0 = tnode_none(), c1 = c0, c2 = c0, c3 = c0;
+					if (pe > 1) { pe >>= 1; c0 = tld(2 * pe); c1 = tld(2 * pe + 1); } else pe = 0;
+					if (pi > 1) { pi >>= 1; c2 = tld(2 * pi); c3 = tld(2 * pi + 1); } else pi = 0;
+					if (pe > 0) tst(pe, tnode_comb(c0, c1));
+					if (pi > 0 && pi != pe) tst(pi, tnode_comb(c2, c3));
+					wave_sync();
+				}
+				e0 += W; n0 += W;
+			}
+			ev = lo; ins = hi;
+			if (b.dbg) d_upd += (long long)__builtin_amdgcn_s_memrealtime() - tu0;
+		}
+		__threadfence_block();
+		__syncthreads();
+		if (team_gives_up(b, R, 1, s_flag)) break;
+	}
+	if (b.dbg && l == 0) {
+		atomicAdd((unsigned long long*)&b.dbg[2], (unsigned long long)d_upd);
+		atomicAdd((unsigned long long*)&b.dbg[3], (unsigned long long)d_levels);
+		if (b.dbg_reads) { b.dbg_reads[8 * (int64_t)r + 3] = d_upd; b.dbg_reads[8 * (int64_t)r + 4] = d_levels; }
+	}
+}
+
+// ---- waves 2 .. ----
+__device__ __forceinline__ void team_helper(const RmqBatch &b, const RmqParams &P, const TeamRead &R, const int w, int (*s_m)[RMQ_MERGE_WORDS][W], const int *s_flag)
+{
+	constexpr int NH = TEAM_HELPERS;
+	const int l = lane(), h = w - 2, n = R.n, max_inner = R.max_inner;
+	const bool strips = R.strips;
+	const uint4 *a = R.a;
+	const int32_t *f = R.f;
+	long long d_bcast = 0, d_single = 0, d_skip = 0;
+	TeamTile T;
+	TileCand c;
+	TileInner in;
+	int relied;
+	int spp[2] = { 0, 0 }, spe[2] = { 0, 0 };                  // this wave's part of the lane's two strip ranges: where the walk stands, where it ends
+	// anchors broadcast one by one to all lanes (rmq_fill_read_tiles); in_turn: the helpers take eighths of a block of 64 in turn
+	auto sweep_range = [&](int from, int to, bool outer_all, bool in_turn, int blk0) {
+		for (int base = from; base < to; base += W) {
+			const int blk = blk0 + ((base - from) >> 6);
+			if (in_turn && ((h - blk * 8) % NH + NH) % NH >= 8) continue;    // none of this block's eight turns is this wave's
+			const int j_l = base + l;
+			const bool have = j_l < to;
+			const uint4 e_l = have ? a[j_l] : make_uint4(0, 0, 0, 0);
+			const int f_l = have ? f[j_l] : 0, rk_l = have ? R.meta[j_l].x : 0;
+			const long long k_l = key_order((double)f_l + R.half_gap * (double)((int)e_l.x + (int)e_l.z));
+			const int cnt = min(W, to - base);
+			for (int k = 0; k < cnt; k += 2) {
+				if (in_turn && (blk * 8 + (k >> 3)) % NH != h) continue;
+				const int ja = base + k, jb2 = ja + 1;
+				const bool two = k + 1 < cnt;
+				const int kb = two ? k + 1 : k;
+				const bool outer_a = outer_all || ja >= T.hi, outer_b = two && (outer_all || jb2 >= T.hi);     // wave-uniform: in the tree otherwise
+				const bool inner_a = !strips && max_inner > 0 && ja >= T.stin_first, inner_b = !strips && two && max_inner > 0 && jb2 >= T.stin_first;   // wave-uniform
+				d_bcast += two ? 2 : 1;
+				if (!(outer_a || outer_b || inner_a || inner_b)) continue;
+				const int ya = __builtin_amdgcn_readlane((int)e_l.z, k), yb = __builtin_amdgcn_readlane((int)e_l.z, kb);
+				const int rka = __builtin_amdgcn_readlane(rk_l, k), rkb = __builtin_amdgcn_readlane(rk_l, kb);
+				const bool out_a = outer_a & (ja < T.Wn.z) & (ja >= T.Wn.x) & (rka >= T.M.y) & (rka <= T.M.z);
+				const bool out_b = outer_b & (jb2 < T.Wn.z) & (jb2 >= T.Wn.x) & (rkb >= T.M.y) & (rkb <= T.M.z);
+				const bool in_a = inner_a & (ja < T.Wn.z) & (ja >= T.Wn.y) & (ya <= T.y_top) & (ya >= T.y_bot);
+				const bool in_b = inner_b & (jb2 < T.Wn.z) & (jb2 >= T.Wn.y) & (yb <= T.y_top) & (yb >= T.y_bot);
+				const unsigned long long any_out = __ballot(out_a | out_b);
+				if ((any_out | __ballot(in_a | in_b)) == 0) continue;
+				const unsigned xa = (unsigned)__builtin_amdgcn_readlane((int)e_l.x, k), xb = (unsigned)__builtin_amdgcn_readlane((int)e_l.x, kb);
+				const int sa2 = __builtin_amdgcn_readlane((int)e_l.w, k) & 0xff, sb2 = __builtin_amdgcn_readlane((int)e_l.w, kb) & 0xff;
+				const int fa = __builtin_amdgcn_readlane(f_l, k), fb = __builtin_amdgcn_readlane(f_l, kb);
+				int exa, wa, exb, wb;
+				const int s2a = fa + tile_pair_score(T.xi, T.yi, xa, ya, sa2, P, exa, wa);     // the same pair score serves the outer query and the inner scan
+				const int s2b = fb + tile_pair_score(T.xi, T.yi, xb, yb, sb2, P, exb, wb);
+				if (any_out != 0) {
+					tile_offer(c, out_a, (long long)readlane64((unsigned long long)k_l, k), rka, 0, ja, s2a, exa, wa);
+					tile_offer(c, out_b, (long long)readlane64((unsigned long long)k_l, kb), rkb, 0, jb2, s2b, exb, wb);
+				}
+				tile_offer_inner(in, in_a & (wa <= P.bw), s2a, ya, ja);
+				tile_offer_inner(in, in_b & (wb <= P.bw), s2b, yb, jb2);
+			}
+		}
+	};
+	// the blocks of 64 from bb_top down to `from` (rmq_fill_read_tiles: bounds, lanes one at a time where few need a block)
+	auto sweep_blocks = [&](int bb_top, int from) {
+		for (int bb = bb_top; bb >= 0 && ((bb + 1) << 6) > from; --bb) {
+			const int b_lo = max(bb << 6, from), b_hi = (bb + 1) << 6;
+			if (b_lo >= T.hi || max_inner <= 0) { sweep_range(b_lo, b_hi, false, true, bb); continue; }     // holds anchors the outer query needs (not in the tree): no skipping
+			if (bb % NH != h) continue;
+			if (b_hi > T.hi) { sweep_range(b_lo, b_hi, false, false, bb); continue; }
+			const int bnd = uni(R.bound[bb]);
+			const bool sure = !T.live || bnd <= T.q_i || (in.j >= 0 && bnd < in.s) || b_hi <= T.Wn.y || b_lo >= T.Wn.z;
+			const int spec = (c.key != RMQ_NONE && c.width <= P.bw) ? c.sc : INT_MIN;
+			const bool idle = sure || bnd <= spec;
+			const unsigned long long need = __ballot(!idle);
+			if (need == 0) { ++d_skip; relied = (!sure && bnd > relied) ? bnd : relied; continue; }
+			if (__popcll(need) >= 24) { sweep_range(b_lo, b_hi, false, false, bb); continue; }
+			relied = (idle && !sure && bnd > relied) ? bnd : relied;
+			const int j_c = (bb << 6) + l;
+			const bool have = j_c >= b_lo && j_c < b_hi;
+			const uint4 e_c = have ? a[j_c] : make_uint4(0, 0, 0, 0);
+			const int f_c = have ? f[j_c] : 0;
+			for (unsigned long long m = need; m != 0; m &= m - 1) {
+				const int u = first_set(m);
+				const unsigned xu = (unsigned)__builtin_amdgcn_readlane((int)T.xi, u);
+				const int yu = __builtin_amdgcn_readlane(T.yi, u), from_u = __builtin_amdgcn_readlane(T.Wn.y, u), to_u = __builtin_amdgcn_readlane(T.Wn.z, u);
+				int ex2, w2;
+				const int s2 = f_c + tile_pair_score(xu, yu, e_c.x, (int)e_c.z, (int)(e_c.w & 0xffu), P, ex2, w2);
+				const bool ok = have & (j_c >= from_u) & (j_c < to_u) & ((int)e_c.z <= yu - 1) & ((int)e_c.z >= yu - max_inner) & (w2 <= P.bw);
+				const unsigned long long oks = __ballot(ok);
+				++d_single;
+				if (oks == 0) continue;
+				const int bs = wave_max_i32(ok ? s2 : INT_MIN);
+				const int by = wave_max_i32((ok & (s2 == bs)) ? (int)e_c.z : INT_MIN);
+				const int bj = wave_max_i32((ok & (s2 == bs) & ((int)e_c.z == by)) ? j_c : -1);
+				if (l == u) tile_offer_inner(in, true, bs, by, bj);
+			}
+		}
+	};
+	// the inner window lane by lane over the (strip, index) order, this wave's part of either range, as far as index `upto` (indices rise along a
+	// range: the walk stops at the first candidate that is not final yet and goes on from there in the next phase)
+	auto strips_walk = [&](int upto) {
+		constexpr int G = 4;                                   // candidates per round: a round is one round trip to memory, and the wave waits it out
+#pragma unroll
+		for (int pass = 0; pass < 2; ++pass) {
+			bool act = spp[pass] < spe[pass];
+			while (__ballot(act) != 0) {
+				if (act) {
+					const int pp = spp[pass], pe = spe[pass];
+					uint4 cq[G];
+					int fq[G];
+#pragma unroll
+					for (int q = 0; q < G; ++q) { const int at = min(pp + q, pe - 1); cq[q] = R.sa[at]; fq[q] = R.sf[at]; }
+					int adv = 0;
+					bool run = true;
+#pragma unroll
+					for (int q = 0; q < G; ++q) {
+						const bool ok = run & (pp + q < pe) & ((int)cq[q].z < upto);
+						int ex, wd;
+						const int s2 = fq[q] + tile_pair_score(T.xi, T.yi, cq[q].x, (int)cq[q].y, (int)cq[q].w, P, ex, wd);
+						tile_offer_inner(in, ok & ((int)cq[q].y <= T.y_top) & ((int)cq[q].y >= T.y_bot) & (wd <= P.bw), s2, (int)cq[q].y, (int)cq[q].z);
+						adv += ok; run = ok;
+					}
+					++d_single;
+					spp[pass] = pp + adv;
+					act = (adv == G) & (pp + G < pe);
+				}
+			}
+		}
+	};
+	auto next_tile = [&](int tb) {
+		T.load(R, tb);
+		team_cand_reset(c, in, relied);
+		if (strips) {
+			const int4 R4 = T.live ? R.srange[T.i] : make_int4(0, 0, 0, 0);
+#pragma unroll
+			for (int pass = 0; pass < 2; ++pass) {
+				const int r_lo = pass ? R4.z : R4.x, r_hi = pass ? R4.w : R4.y;
+				const int part = (r_hi - r_lo + NH - 1) / NH;   // a helper's part of the lane's range
+				spp[pass] = r_lo + h * part; spe[pass] = min(r_hi, spp[pass] + part);
+			}
+		}
+	};
+	next_tile(0);                                             // tile 0 has nothing before it
+	for (int tb = 0; tb < n; tb += W) {
+		// P2: the tile that has just been finished -- its anchors for the outer query (and the inner window where it is swept), the inner scans' end
+		if (tb > 0) sweep_range(tb - W, tb, false, true, (tb >> 6) - 1);
+		if (strips) strips_walk(tb);
+		team_cand_out(s_m[w - 1], c, in, relied);
+		__syncthreads();
+		if (tb + W < n) {
+			// P1 for the next tile, beside wave 0's 64 steps: what does not need this tile's scores
+			next_tile(tb + W);
+			sweep_range(T.st_first, T.lo, true, true, 0);
+			// (everything from `hi` on is outside the tree and swept for the outer query, wherever the inner windows start)
+			const int from = max((max_inner > 0 && !strips) ? min(min(T.stin_first, T.tb), T.hi) : T.hi, T.lo);
+			sweep_blocks((T.tb >> 6) - 2, from);
+			if (strips) strips_walk(tb);
+		}
+		__threadfence_block();
+		__syncthreads();
+		if (team_gives_up(b, R, w, s_flag)) break;
+	}
+	if (b.dbg && l == 0) atomicAdd((unsigned long long*)&b.dbg[5], (unsigned long long)(d_bcast + (d_single << 36)));
+	if (b.dbg && l == 0 && d_skip) atomicAdd((unsigned long long*)&b.dbg[6], (unsigned long long)d_skip);
+}
+
+} // namespace
+
+__device__ __forceinline__ void rmq_fill_read_team(const RmqBatch &b, const RmqParams &P, const int r, const int w, int (*s_m)[RMQ_MERGE_WORDS][W], uint4 *s_top, int *s_flag)
+{
+	TeamRead R;
+	const int max_dist = P.max_dist < P.bw ? P.bw : P.max_dist;                                       // lchain.c:264
+	R.max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;      // lchain.c:265
+	R.half_gap = 0.5 * (double)P.pen_gap;
+	const int64_t off = b.offsets[r];
+	R.n = (int)(b.offsets[r + 1] - off);
+	R.a = b.raw + off; R.meta = b.meta + off; R.win = b.win + off;
+	R.strips = b.sa != nullptr && R.max_inner > 0;
+	R.sa = b.sa + off; R.srange = b.srange + off;
+	R.sf = (int32_t*)b.skey_in + off;                         // the scores in strip order, and every anchor's place in it (rmq_fill_read_tiles)
+	R.spos = (const int32_t*)b.skey_in + b.n + off;
+	R.ord_idx = b.ord_idx + off;
+	R.f = b.f + off; R.p = b.p + off;
+	R.tree = b.tree + 2 * off;
+	R.bound = b.bound + (off >> 6) + r;
+	if (w == 0) for (int q = lane(); q < (RMQ_TOP_NODES > 1 ? RMQ_TOP_NODES : 0); q += W) s_top[q] = tnode_none();
+	__syncthreads();
+	if (w == 0) team_steps(b, P, R, r, s_m, s_flag);
+	else if (w == 1) team_tree(b, P, R, r, s_m, s_top, s_flag);
+	else team_helper(b, P, R, w, s_m, s_flag);
+	wave_sync();
 }
 
 // The first b.n_team reads of the batch (the caller puts the most expensive first) are a whole workgroup's each, the rest one wave's.
@@ -2117,14 +2533,14 @@ __global__ __launch_bounds__(RMQ_THREADS) void k_rmq_fill_tiles(RmqBatch b, RmqP
 		const int r = uni(s_read);
 		__syncthreads();
 		if (r >= n_team) break;
-		rmq_fill_read_tiles<RMQ_TEAM>(b, P, r, w, s_m, s_top, &s_flag);
+		rmq_fill_read_team(b, P, r, w, s_m, s_top, &s_flag);
 	}
 	for (;;) {
 		int r = 0;
 		if (l == 0) r = atomicAdd(b.cursor, 1);
 		r = uni(r) + n_team;
 		if (r >= b.n_reads) break;
-		rmq_fill_read_tiles<1>(b, P, r, 0, nullptr, nullptr, nullptr);
+		rmq_fill_read_tiles(b, P, r);
 	}
 }
 

@@ -76,7 +76,11 @@ ReadCost estimate(const mm2gb_rmq_param_t &P, const mm2gb_anchor_t *a, int64_t n
 	// 0.07 us per anchor of window on the mapper's densest reads, profiles/r03_rmq_teams.txt)
 	c.dev = 1.37e-6 * (double)n + 0.07e-6 * s_in;                         // tile kernel
 	c.dev_steps = 4.0e-6 * (double)n + 0.42e-6 * (s_in + s_out);          // one anchor per step
-	// a whole workgroup on the read (tile kernel): the serial part of a tile (tree, queries, its own 64 steps: ~48 us) stays, the broadcasts are shared by its 16 waves
+	// a whole workgroup on the read (rmq_fill_read_team, round 5): per tile the longer of the serial wave's part (queries beside the last tile's
+	// sweep, the combination, the 64 steps: ~40 us) and the helpers' (~22 us + their share of the inner scans) -- the 455 k-anchor read of
+	// profiles/mapper_rate.py 3000: 0.41 s (0.68 s when the tree's update and the queries were in front of the steps)
+	// (the figures below are the round-4 team's: as steering values they deal better than the new team's own -- with 0.35 us per anchor the
+	// largest reads no longer head the list the host threads take from, stay on the device, and the mapper's call takes 1.06 s instead of 0.93)
 	c.dev_team = 0.95e-6 * (double)n + 0.0045e-6 * s_in;
 	c.team = false;
 	c.s_in = s_in;
@@ -140,9 +144,12 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		const bool use_steps = v && !strcmp(v, "steps");
 		if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
 		// tile kernel: the reads that would set the device's pace get a whole workgroup each (there are far fewer reads than the chip holds waves)
-		// -- those whose time is the broadcasts (a team's 15 helpers idle through the serial part of every tile: a read that is mostly
-		// serial would hold 16 wave slots for the work of one).  Measured on the mapper's reads: the slowest single-wave reads spend 1.5-1.9 s
-		// of 1.6-1.9 s in broadcasts (2-4 M anchors each, profiles/r03_rmq_teams.txt)
+		// -- those whose time is the sweeps and inner scans, which a team's helpers share.  Measured on the mapper's reads: the slowest
+		// single-wave reads spend 1.5-1.9 s of 1.6-1.9 s in them (2-4 M anchors each, profiles/r03_rmq_teams.txt).  (Round 5: a team also
+		// overlaps the serial part of a tile with the rest, so every long read would gain; but a team holds 16 wave slots for the work of three or
+		// four, sixteen calls at once share the chip in the drop-in, and a rule built on comparing the two estimates read by read -- a team only
+		// where one wave would take longer than the call's longest team read -- left reads to single waves that then took 1.0-1.2 s: the
+		// single-wave estimate is not that good.  The rule stays.)
 		else if (!getenv("MM2GB_RMQ_NO_TEAMS"))
 			for (size_t r = 0; r < R; ++r) {
 				const double n = (double)(offsets[r + 1] - offsets[r]);

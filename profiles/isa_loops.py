@@ -7,7 +7,7 @@ spill traffic inside it (scratch_load / scratch_store, v_readlane / v_writelane 
 Needs hipcc (cross-compiles without a GPU)."""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "mm2-gb_amd", "csrc", "chain_kernels.hip")
+SRC = os.path.join(ROOT, "mm2-gb_amd", "csrc", os.environ.get("MM2GB_ISA_SRC", "chain_kernels.hip"))      # MM2GB_ISA_SRC=post_kernels.hip for the post-pass / RMQ kernels
 want = sys.argv[1] if len(sys.argv) > 1 else "k_scoreILi0ELb0ELb0E"
 min_len = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 HALF = re.compile(r"^v_(sad_u32|min3|max3|lshl_add|add3|and_or|min_|max_|cmp|cmpx|readlane|readfirstlane|writelane|cvt_|mul_lo|mul_hi|mad_|bfe|perm|lshl_or|or3|xad|add_lshl|med3)")
