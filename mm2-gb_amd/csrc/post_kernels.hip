@@ -2079,12 +2079,13 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 //   wave 0      the combination and the 64 steps of tile T, nothing else (team_steps);
 //   wave 1      the tree, one tile behind (team_tree) -- while wave 0 walks tile T it puts the tree in the state tile T + 1 needs (what leaves
 //               before that tile's last window start goes out; what has entered up to the END OF TILE T - 1, all final, goes in), and asks it
-//               tile T + 1's queries beside P2;
+//               tile T + 1's queries;
 //   waves 2..   for tile T + 1 (team_helper): while wave 0 walks tile T everything that does not need tile T's scores -- the sweep of the anchors
 //               leaving the window, the inner scans up to tile T - 1's last anchor (P1) -- and, once tile T is out, its 64 anchors by a broadcast
 //               sweep and the end of the inner scans (P2); tile T's anchors are not in the tree for tile T + 1, the sweep offers them like any
 //               anchor from `hi` on.
-// Per tile: { P2 | queries }, a barrier, { the 64 steps | the tree's update | P1 }, a barrier.  Results per lane meet in LDS (`s_m`, wave 1's and
+// Per tile: P2, a barrier, { the 64 steps | the tree's update and queries | P1 }, a barrier (measured on the mapper's largest reads: 4 us, then
+// 26 | 35 | 47 us -- the helpers' inner scans are what a tile waits for now).  Results per lane meet in LDS (`s_m`, wave 1's and
 // the helpers') and are combined by the rules of tile_offer / tile_offer_inner, which do not depend on the order of the offers.
 namespace {
 
@@ -2254,41 +2255,15 @@ __device__ __forceinline__ void team_tree(const RmqBatch &b, const RmqParams &P,
 	int ev = 0, ins = 0;                                       // the tree holds the anchors of index [ev, ins)
 	long long d_upd = 0, d_levels = 0;
 	TeamTile T;
-	T.load(R, 0);
+	TileCand c;
+	TileInner in;
+	int relied;
+	team_cand_reset(c, in, relied);                            // (tile 0 has nothing before it: nothing in the tree to ask for)
 	for (int tb = 0; tb < n; tb += W) {
-		// ---- every lane's query of the tree for tile tb, bottom up; the loads do not depend on each other ----
-		const long long tq0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-		TileCand c;
-		TileInner in;
-		int relied;
-		team_cand_reset(c, in, relied);
-		{
-			uint4 best = tnode_none();
-			int ql = n + T.M.y, qr = n + T.M.z + 1;                         // [ql, qr) over the leaves
-			const bool go = T.live && T.M.y <= T.M.z && T.lo < T.hi;
-			while (__ballot(go && ql < qr) != 0) {
-				uint4 vl = tnode_none(), vr = vl;
-				if (go && ql < qr) {
-					if (ql & 1) vl = tld(ql++);
-					if (qr & 1) vr = tld(--qr);
-					ql >>= 1; qr >>= 1;
-				}
-				best = tnode_comb(best, tnode_comb(vl, vr));
-			}
-			if (tnode_key(best) != RMQ_NONE) {
-				const int rk = (int)(best.z & 0x7fffffffu);
-				const int j = R.ord_idx[rk];
-				const uint4 e = R.a[j];
-				int ex, wd;
-				const int sc = R.f[j] + tile_pair_score(T.xi, T.yi, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex, wd);
-				c.key = tnode_key(best); c.rank = rk; c.tie = (int)(best.z >> 31); c.j = j; c.sc = sc; c.exact = ex; c.width = wd;
-			}
-		}
-		team_cand_out(s_m[0], c, in, relied);
-		if (b.dbg) d_levels += (long long)__builtin_amdgcn_s_memrealtime() - tq0;
+		team_cand_out(s_m[0], c, in, relied);                     // tile tb's queries, answered beside the previous tile's 64 steps
 		__syncthreads();
-		// ---- the tree for tile tb + W: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) (rmq_fill_read_tiles) ----
 		if (tb + W < n) {
+			// ---- the tree for tile tb + W: out with [ev, min(lo, ins)), in with [max(ins, lo), hi) (rmq_fill_read_tiles) ----
 			const long long tu0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 			T.load(R, tb + W);
 			const int lo = T.lo, hi = T.hi;
@@ -2317,7 +2292,30 @@ __device__ __forceinline__ void team_tree(const RmqBatch &b, const RmqParams &P,
 				e0 += W; n0 += W;
 			}
 			ev = lo; ins = hi;
-			if (b.dbg) d_upd += (long long)__builtin_amdgcn_s_memrealtime() - tu0;
+			// ---- every lane's query of it, bottom up; the loads do not depend on each other ----
+			const long long tq0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+			team_cand_reset(c, in, relied);
+			uint4 best = tnode_none();
+			int ql = n + T.M.y, qr = n + T.M.z + 1;                         // [ql, qr) over the leaves
+			const bool go = T.live && T.M.y <= T.M.z && lo < hi;
+			while (__ballot(go && ql < qr) != 0) {
+				uint4 vl = tnode_none(), vr = vl;
+				if (go && ql < qr) {
+					if (ql & 1) vl = tld(ql++);
+					if (qr & 1) vr = tld(--qr);
+					ql >>= 1; qr >>= 1;
+				}
+				best = tnode_comb(best, tnode_comb(vl, vr));
+			}
+			if (tnode_key(best) != RMQ_NONE) {
+				const int rk = (int)(best.z & 0x7fffffffu);
+				const int j = R.ord_idx[rk];
+				const uint4 e = R.a[j];
+				int ex, wd;
+				const int sc = R.f[j] + tile_pair_score(T.xi, T.yi, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex, wd);
+				c.key = tnode_key(best); c.rank = rk; c.tie = (int)(best.z >> 31); c.j = j; c.sc = sc; c.exact = ex; c.width = wd;
+			}
+			if (b.dbg) { d_upd += tq0 - tu0; d_levels += (long long)__builtin_amdgcn_s_memrealtime() - tq0; }
 		}
 		__threadfence_block();
 		__syncthreads();
