@@ -121,6 +121,12 @@ static struct {
 	bool debug = false;                    // MM2GB_DEBUG_PHASES: where a batch's host time goes, on stderr
 	int  ahead_threads = 1;                // host threads of a batch's re-chaining ahead (beside the device)
 	bool rechain_ahead = false;            // answer a batch's mg_lchain_rmq calls before the host's callback asks (host linked with --wrap, or MM2GB_PRECHAIN=1)
+	// The streams' engines are made by a thread of their own while the host reads and seeds its first batch (init_stream_gpu returns once
+	// the sizes are known): a slot is `live` when its engine and its finisher are there; whoever needs it waits for that (slot_for).
+	std::thread *maker = nullptr;          // (on the heap: a process that ends without free_stream_gpu must not run a joinable thread's destructor)
+	std::mutex mk_mu;
+	std::condition_variable mk_cv;
+	std::string mk_err;
 } g_streams;
 
 static double now_ms()
@@ -387,7 +393,19 @@ static StreamSlot &slot_for(int thread_id)
 	if (thread_id < 0 || thread_id >= (int)g_streams.slots.size())
 		die("thread id " + std::to_string(thread_id) + " has no GPU stream: raise num_streams in the gpu config (have " +
 		    std::to_string(g_streams.slots.size()) + ")");
-	return *g_streams.slots[thread_id];
+	StreamSlot &slot = *g_streams.slots[thread_id];
+	{
+		std::unique_lock<std::mutex> lk(g_streams.mk_mu);
+		g_streams.mk_cv.wait(lk, [&] { return slot.live || !g_streams.mk_err.empty(); });
+		if (!slot.live) die(g_streams.mk_err);
+	}
+	return slot;
+}
+// every stream is there (or the process ends with what went wrong making one)
+static void wait_for_all_streams()
+{
+	if (g_streams.maker) { g_streams.maker->join(); delete g_streams.maker; g_streams.maker = nullptr; }
+	if (!g_streams.mk_err.empty()) die(g_streams.mk_err);
 }
 
 // CPUs this process may use at once: affinity mask and cgroup quota, whichever is smaller (containers give 16 of 128 here)
@@ -707,26 +725,42 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 		}
 	}
 	{
-		// every stream's engine is made at the same time (streams, events, the penalty table's kernel: ~40 ms each, sixteen of them 0.65 s one
-		// after the other); the first one alone, so that the runtime starts on one thread
+		// The engines that are not there yet -- streams, events, the penalty table's kernel, ~40 ms each and one after the other inside the
+		// runtime whoever asks (sixteen: 0.6 s) -- are made by a thread of their own, in stream order: the host goes on to read and seed its first
+		// batch (seconds), and a stream's first boundary call waits for its engine only if it comes earlier than that.  MM2GB_INIT=wait keeps
+		// init_stream_gpu until every engine stands (tests that time the call; a host that wants configuration errors from init itself).
 		const int have = (int)g_streams.slots.size();
 		std::vector<StreamSlot*> fresh;
-		for (int s = have; s < cfg.num_streams; ++s) fresh.push_back(new StreamSlot());
-		std::vector<std::string> errs(fresh.size());
-		auto make = [&](size_t k) { if (fresh[k]->eng.init(&cfg, &misc, devs[(size_t)(have + (int)k) % devs.size()])) errs[k] = mm2gb_last_error(); };
-		if (!fresh.empty()) make(0);
-		std::vector<std::thread> makers;
-		for (size_t k = 1; k < fresh.size(); ++k) makers.emplace_back(make, k);
-		for (auto &t : makers) t.join();
-		for (const std::string &e : errs) if (!e.empty()) die(e);
-		for (StreamSlot *slot : fresh) {
-			slot->live = true;
-			slot->finisher = std::thread(finisher_main, slot);
-			g_streams.slots.push_back(slot);
+		for (int s = have; s < cfg.num_streams; ++s) { fresh.push_back(new StreamSlot()); g_streams.slots.push_back(fresh.back()); }
+		for (int s = 0; s < have; ++s) g_streams.slots[(size_t)s]->live = true;
+		g_streams.mk_err.clear();
+		if (!fresh.empty()) {
+			const mm2gb_config_t cfg_copy = cfg;
+			const mm2gb_misc_t misc_copy = misc;
+			g_streams.maker = new std::thread([fresh, devs, have, cfg_copy, misc_copy]() {
+				for (size_t k = 0; k < fresh.size(); ++k) {
+					std::string err;
+					try {
+						if (fresh[k]->eng.init(&cfg_copy, &misc_copy, devs[(size_t)(have + (int)k) % devs.size()])) err = mm2gb_last_error();
+						else fresh[k]->finisher = std::thread(finisher_main, fresh[k]);
+					} catch (const std::exception &ex) { err = std::string("init_stream_gpu: making a stream: ") + ex.what(); }
+					std::lock_guard<std::mutex> lk(g_streams.mk_mu);
+					if (err.empty()) fresh[k]->live = true; else g_streams.mk_err = err;
+					g_streams.mk_cv.notify_all();
+					if (!err.empty()) return;
+				}
+			});
+			const char *iw = getenv("MM2GB_INIT");
+			if (iw && strcmp(iw, "wait") == 0) wait_for_all_streams();
 		}
 	}
 	g_streams.ready = true;
-	if (g_streams.debug) fprintf(stderr, "[mm2gb stream] init_stream_gpu: entered at epoch %.3f, %d stream(s) ready after %.3f s\n", epoch_in, cfg.num_streams, (now_ns() - g_t_init_ns) * 1e-9);
+	if (g_streams.debug) {
+		int n_new = 0;
+		{ std::lock_guard<std::mutex> lk(g_streams.mk_mu); for (StreamSlot *slot : g_streams.slots) n_new += !slot->live; }
+		fprintf(stderr, "[mm2gb stream] init_stream_gpu: entered at epoch %.3f, returns after %.3f s: %d stream(s), %d of them still being made (beside the host's first batch)\n",
+		        epoch_in, (now_ns() - g_t_init_ns) * 1e-9, cfg.num_streams, n_new);
+	}
 	// what the host accumulates to (plmem.cu:616-617)
 	*max_total_n = (size_t)cfg.max_total_n * (size_t)cfg.score_kernel.micro_batch;
 	*max_reads = (int)std::min<int64_t>((int64_t)cfg.max_read * cfg.score_kernel.micro_batch, 2147483647LL);
@@ -795,6 +829,7 @@ void free_stream_gpu(int n_threads)
 	// work drained, engines idle, nothing released -- a later init_stream_gpu with the same configuration takes them over as they are (no
 	// re-pinning either), another configuration or MM2GB_FREE=now releases them for real, and the process's end releases what is parked.
 	static const bool release_now = [] { const char *v = getenv("MM2GB_FREE"); return v && strcmp(v, "now") == 0; }();
+	wait_for_all_streams();                                       // (a host with nothing to map gets here before the engines stand)
 	for (StreamSlot *slot : g_streams.slots) {
 		{
 			std::unique_lock<std::mutex> lk(slot->mu);
