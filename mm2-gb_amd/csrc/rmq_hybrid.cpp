@@ -27,6 +27,8 @@ namespace {
 // finisher each), the own host four, and both sides then take two to three times what the model says -- the device more than the host -- so
 // the deal left the longest reads on the device and the host threads idle (round 5, drop-in: device 1.08 s || host 0.29 s).  Each side's
 // measured / estimated ratio of the calls so far (exponential average, process-wide) scales the next call's estimates; it only steers the deal.
+// (Sixteen calls at once settle at x 6 -- the clamp -- for the device and x 1.9-2.4 for the host; starting there instead of at 1 / 1 was tried:
+// the first mini-batch's calls got a host side of 1.0-1.25 s for a device side of 1.0 s, no better than 1.1 s || 0.2-0.5 s, and the run no faster.)
 struct Calibration {
 	std::mutex mu;
 	double dev = 1.0, host = 1.0;
@@ -304,8 +306,8 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			if (where) where[r] = q < n_host ? 1 : tie_slot[q] >= 0 ? 2 : 0;
 		}
 		parts->chains[0] = h_own.release(); parts->chains[1] = d_own.release(); parts->chains[2] = t_own.release();      // (theirs to free now)
-		if (getenv("MM2GB_DEBUG_PHASES"))
-			fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, results left in place, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, seconds_since(t0));
+		if (getenv("MM2GB_DEBUG_PHASES") || getenv("MM2GB_RMQ_CALLS"))      // MM2GB_RMQ_CALLS=1: this line alone (the engines' own debugging copies wait for the whole device)
+			fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, results left in place, whole %.3f s (estimates scaled x %.2f device, x %.2f host)\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, seconds_since(t0), cal_dev, cal_host);
 		if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
 		if (calibrate) g_calibration.put(est_dev_s / cal_dev, d_seconds, est_host_s / cal_host, h_seconds);
 		return 0;
@@ -340,8 +342,8 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	});
 	mm2gb_chains_free(&h_out); mm2gb_chains_free(&d_out); mm2gb_chains_free(&t_out);
 	s_merge = seconds_since(tm);
-	if (getenv("MM2GB_DEBUG_PHASES"))
-		fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, merge %.3f s, whole %.3f s\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, s_merge, seconds_since(t0));
+	if (getenv("MM2GB_DEBUG_PHASES") || getenv("MM2GB_RMQ_CALLS"))
+		fprintf(stderr, "[mm2gb rmq call] %zu reads: estimate + deal %.3f s, gathers %.3f s, device %.3f s || host %.3f s, ties %.3f s, merge %.3f s, whole %.3f s (estimates scaled x %.2f device, x %.2f host)\n", R, s_estimate, s_gather, d_seconds, h_seconds, t_seconds, s_merge, seconds_since(t0), cal_dev, cal_host);
 	if (deal) { deal->host_s = h_seconds; deal->device_s = d_seconds; deal->tie_s = t_seconds; deal->total_s = seconds_since(t0); }
 	return 0;
 }

@@ -80,7 +80,7 @@ def main():
             for key in args.legs.split(","):
                 leg = res.get(key, {})
                 err = leg.pop("_stderr", "")
-                if args.debug:
+                if args.debug or any(e.startswith("MM2GB_RMQ_CALLS=") for e in args.env):
                     sys.stderr.write(f"---- {key} ----\n" + "\n".join(l for l in err.splitlines() if "mm2gb" in l or "M::" in l) + "\n")
                 if want is not None and "seconds_whole_program" in leg:
                     got = open(os.path.join(td, key + ".paf"), "rb").read()
