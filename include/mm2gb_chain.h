@@ -276,7 +276,7 @@ int  mm2gb_map_reads_multi(mm2gb_engine_t *const *engines, int n_engines, const 
                            int32_t n_ref, const mm2gb_map_opt_t *opt, int32_t n_reads, const char *const *names, const char *const *seqs, const int32_t *lens,
                            char **paf_out, int64_t *paf_len, mm2gb_map_stats_t *stats);
 /* A run of any size as a stream of batches (role of worker_for's batch rotation, map.c:924-1153): reads cut into chunks of about
- * chunk_bases bases (<= 0: 48 Mbp), every engine's host thread takes the next chunk and maps it from seeding to PAF.  Several engines
+ * chunk_bases bases (<= 0: 96 Mbp), every engine's host thread takes the next chunk and maps it from seeding to PAF.  Several engines
  * per device overlap one chunk's host stages with another's kernels; engines on several devices shard the reads.  PAF in read order;
  * stats->s_*: seconds per stage summed over chunks (stages overlap: not wall time). */
 int  mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const mm2gb_index_t *ix, int k, const char *const *ref_names, const int32_t *ref_lens,

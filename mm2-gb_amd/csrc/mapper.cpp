@@ -651,7 +651,7 @@ int mm2gb_map_reads_stream(mm2gb_engine_t *const *engines, int n_engines, const 
 		return fail("mm2gb_map_reads_stream: null argument");
 	for (int e = 0; e < n_engines; ++e) if (!engines[e]) return fail("mm2gb_map_reads_stream: null engine");
 	*paf_out = nullptr; *paf_len = 0;
-	if (chunk_bases <= 0) chunk_bases = 48 * 1000 * 1000;
+	if (chunk_bases <= 0) chunk_bases = 96 * 1000 * 1000;
 	std::vector<int32_t> cut(1, 0);
 	{ int64_t acc = 0; for (int32_t r = 0; r < n_reads; ++r) { acc += lens[r]; if (acc >= chunk_bases && r + 1 < n_reads) { cut.push_back(r + 1); acc = 0; } } }
 	cut.push_back(n_reads);

@@ -64,7 +64,7 @@ def main():
             names = [n for n, _ in refs]
             mm.map_reads_stream(engines, ix, names, reads[:24], opt=opt, chunk_bases=500_000)
             t0 = time.perf_counter()
-            paf, st = mm.map_reads_stream(engines, ix, names, reads, opt=opt, chunk_bases=32_000_000)
+            paf, st = mm.map_reads_stream(engines, ix, names, reads, opt=opt, chunk_bases=bench.OWN_HOST_CHUNK_BASES)
             dt = time.perf_counter() - t0
             own = {"map_seconds": round(dt, 2), "index_seconds": round(t_index, 3), "gbp_per_s": bases / (dt + t_index) / 1e9, "paf_lines": paf.count("\n"), "engines": 4}
             if want is not None:
