@@ -666,18 +666,19 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	const double epoch_in = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
 	if (mm2gb_config_load(gpu_config_file, &g_streams.cfg)) die(mm2gb_last_error());
 	mm2gb_config_t &cfg = g_streams.cfg;
-	// Every stream id is an engine with four HIP streams (copy in, two compute, copy out).  The HIP runtime multiplexes streams onto 4
-	// hardware queues unless told otherwise, and streams that share a queue run one after the other: four host threads driving 64-read
-	// batches reach 0.28-0.49 G anchors/s with 8 queues, 0.80 with 16 or more (one thread: 0.26; profiles/r03_small_batches.txt).
-	// Only effective before the runtime starts, i.e. when this is the first HIP call of the process, as it is in the minimap2 host;
-	// a value that is already set is the host's to choose, but one that is too small is worth a line.
-	// (one stream id owns four HIP streams beside the null stream, its re-chaining engine -- rechain_ahead.cpp, made when first needed -- four
-	// more, and single-read calls lease up to eight engines per device (MM2GB_SINGLE_ENGINES): the runtime's default of 4 queues is too few for
-	// the default configuration too -- at least 8, whatever num_streams is; the runtime offers at most 64, beyond which streams share queues)
-	const int want_queues = std::min(std::max(8, 8 * cfg.num_streams + 2), 64);
+	// Every stream id is an engine with four HIP streams (copy in, two compute, copy out), its re-chaining engine (rechain_ahead.cpp) four more,
+	// and single-read calls lease up to eight engines per device.  The HIP runtime multiplexes streams onto 4 hardware queues unless told
+	// otherwise, and streams that share a queue run one after the other: four host threads driving 64-read batches reach 0.28-0.49 G anchors/s
+	// with 8 queues, 0.80 with 16 (one thread: 0.26; profiles/r03_small_batches.txt).  But MORE is not better: past what the device has slots for
+	// the queues themselves are time-sliced -- the drop-in at -t 16 (128 HIP streams) maps 1.05 Gbp in 11.8-12.0 s with 8, 11.1-11.3 with 12,
+	// 10.2 with 16, 10.1-10.9 with 20, 10.4-10.6 with 24, 11.1-11.6 with 32, 11.6-12.4 with 64 (which rounds 4-5 asked for), and the own host's
+	// four engines are fastest at 16 too.  So: 8 for a single stream, 16 from two streams on.  Only effective before the runtime starts, i.e. when
+	// this is the first HIP call of the process, as it is in the minimap2 host; a value that is already set is the host's to choose, but one
+	// below 8 is worth a line.
+	const int want_queues = cfg.num_streams > 1 ? 16 : 8;
 	if (const char *q = getenv("GPU_MAX_HW_QUEUES")) {
-		if (atoi(q) < std::min(want_queues, 4 * cfg.num_streams + 2))
-			fprintf(stderr, "[mm2gb] GPU_MAX_HW_QUEUES=%s with num_streams=%d: streams will share hardware queues and serialise (four per stream id: %d)\n", q, cfg.num_streams, want_queues);
+		if (atoi(q) < 8)
+			fprintf(stderr, "[mm2gb] GPU_MAX_HW_QUEUES=%s with num_streams=%d: streams will share hardware queues and serialise (this library would ask for %d)\n", q, cfg.num_streams, want_queues);
 	} else setenv("GPU_MAX_HW_QUEUES", std::to_string(want_queues).c_str(), 0);
 	if (!(cfg.has_max_total_n && cfg.has_max_read)) {
 		// auto-size from avg_read_n like plmem.cu:497-539, against this device's memory and this engine's footprint per anchor:

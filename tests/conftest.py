@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before any HIP runtime starts: see mm2-gb_amd/csrc/engine.hip, Engine::init
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before any HIP runtime starts: see mm2-gb_amd/csrc/engine.hip, Engine::init
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
