@@ -60,6 +60,8 @@ struct Engine {
 	LaunchCfg      launch;
 	hipStream_t    stream = nullptr;       // kernels (== work[0].stream)
 	hipStream_t    s_in = nullptr, s_out = nullptr;   // H2D / D2H of the host-buffer paths
+	bool           lean_streams = false;   // two HIP streams instead of four: kernels and H2D share one (Engine::init: every engine but the first on its device)
+	bool           counted_on_device = false;
 	int            n_cu = 256;
 
 	// Work arenas of the kernels of one micro-batch (sized by cap_n / cap_blocks, grow-only).  Two sets, each with its own

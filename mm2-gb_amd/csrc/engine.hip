@@ -2,6 +2,7 @@
 // Replaces plmem_stream_initialize / plmem_*_memcpy (plmem.cu:12-359, 558-641) and the kernel sequencing of
 // plchain_cal_score_async (plchain.cu:292-464) with a design that never leaves the stream between stages:
 // split -> window(+planner reductions) -> plan -> score are all enqueued back to back, no host sort, no hipMalloc per batch.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <mutex>
@@ -322,6 +323,9 @@ int Engine::configure_score()
 	return 0;
 }
 
+constexpr int MAX_COUNTED_DEVICES = 64;
+static std::atomic<int> g_engines_on_device[MAX_COUNTED_DEVICES];      // engines alive per device (Engine::init: how many HIP streams an engine gets)
+
 int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 {
 	// An engine has up to four HIP streams (H2D, two compute, D2H) whose whole point is to run at the same time.  The HIP runtime
@@ -382,11 +386,23 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (debug_phases && dbg.ensure((size_t)launch.score_grid * 32)) return -1;
 	const char *env = getenv("MM2GB_NO_COOP");
 	coop_disabled = env && *env && *env != '0';
-	for (WorkSet &w : work) MM2GB_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+	// Four HIP streams -- H2D, two compute, D2H -- let ONE engine overlap its copies with its kernels (the host-buffer paths).  Where several
+	// engines share a device they overlap each other, and every stream more is one more thing the runtime multiplexes onto the hardware queues:
+	// the drop-in at -t 16 (32 engines) maps 1.05 Gbp in 9.2-10.3 s with two streams per engine against 10.7-10.9 s with four, the own host's four
+	// engines 4.3-4.5 s against 4.6-4.8 s (profiles/r05_hw_queues.txt).  So the first engine alive on a device gets four, every further one two:
+	// kernels and H2D on one, D2H on the other.  MM2GB_LEAN_STREAMS=0 / 1 forces either.
+	{
+		const int before = dev >= 0 && dev < MAX_COUNTED_DEVICES ? g_engines_on_device[dev].fetch_add(1) : 0;
+		counted_on_device = dev >= 0 && dev < MAX_COUNTED_DEVICES;
+		const char *v = getenv("MM2GB_LEAN_STREAMS");
+		lean_streams = v && *v ? *v != '0' : before > 0;
+	}
+	MM2GB_HIP(hipStreamCreateWithFlags(&work[0].stream, hipStreamNonBlocking));
+	if (lean_streams) work[1].stream = work[0].stream; else MM2GB_HIP(hipStreamCreateWithFlags(&work[1].stream, hipStreamNonBlocking));
 	stream = work[0].stream;
 	{ const char *v = getenv("MM2GB_ONE_COMPUTE_STREAM"); one_compute_stream = v && *v && *v != '0'; }
 	if (const char *v = getenv("MM2GB_DUAL_STREAM_MAX")) dual_stream_max_n = std::max<int64_t>(0, atoll(v));
-	MM2GB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+	if (lean_streams) s_in = work[0].stream; else MM2GB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
 	MM2GB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
 	for (IoSet &s : io)
 		for (hipEvent_t *e : { &s.in_start, &s.in_done, &s.comp_done, &s.out_start, &s.out_done }) MM2GB_HIP(hipEventCreate(e));
@@ -418,6 +434,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 
 void Engine::shutdown()
 {
+	if (counted_on_device) { g_engines_on_device[device].fetch_sub(1); counted_on_device = false; }
 	(void)hipSetDevice(device);
 	for (hipStream_t s : { s_in, work[0].stream, work[1].stream, s_out }) if (s) (void)hipStreamSynchronize(s);
 	flush_retired_buffers();
@@ -445,6 +462,7 @@ void Engine::shutdown()
 	for (hipEvent_t *e : { &post0, &post1, &rmq_fill_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	pinned_free(h_small);
 	h_small = nullptr;
+	if (lean_streams) { s_in = nullptr; work[1].stream = nullptr; }
 	for (hipStream_t *s : { &s_in, &work[0].stream, &work[1].stream, &s_out }) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
 	stream = nullptr;
 	h_counters = nullptr; h_totals = nullptr;
