@@ -104,6 +104,7 @@ struct StreamSlot {
 	PinnedBuf h_raw, h_f, h_p, h_off;      // h_off: per-micro-batch offsets, each from 0
 	// re-chaining ahead: an engine of its own, made when first needed (a device re-chaining call owns its engine's streams and arenas)
 	mm2gb_engine_t *rmq_eng = nullptr;
+	std::mutex rmq_mu;                     // whoever makes rmq_eng (the maker thread ahead of time, else the finisher at its first need)
 	std::thread finisher;
 	std::mutex mu;
 	std::condition_variable cv;
@@ -209,10 +210,14 @@ static int finish_compute(StreamSlot &slot, HostStage &st)
 	st.ms_ahead = 0;
 	if (want_ahead) {
 		const int64_t ta = now_ns();
-		if (!slot.rmq_eng) {
-			slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &st.misc, slot.eng.device);
-			if (!slot.rmq_eng) return -1;
-			slot.rmq_eng->e.rmq_calibrate = true;          // the host thread waits for this finisher: its CPU, and the call's threads, are the deal's to use
+		{
+			// (normally there already: init_stream_gpu's maker makes the re-chaining engines too, beside the host's first batch)
+			std::lock_guard<std::mutex> lk(slot.rmq_mu);
+			if (!slot.rmq_eng) {
+				slot.rmq_eng = mm2gb_engine_create(&g_streams.cfg, &st.misc, slot.eng.device);
+				if (!slot.rmq_eng) return -1;
+				slot.rmq_eng->e.rmq_calibrate = true;          // the host thread waits for this finisher: its CPU, and the call's threads, are the deal's to use
+			}
 		}
 		if (rechain_ahead(slot.rmq_eng, *(const mm2gb_mapopt_head_t*)st.opt, st.misc, view.data(), n_read, g_streams.ahead_threads, st.ahead)) return -1;
 		st.have_ahead = st.ahead.n_ahead() > 0;
@@ -750,6 +755,17 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 					g_streams.mk_cv.notify_all();
 					if (!err.empty()) return;
 				}
+				// ... and the streams' re-chaining engines (rechain_ahead.cpp), which the finishers would otherwise all make at the same moment -- the end
+				// of the first batch's chaining, one after the other inside the runtime, 40 ms each.  A failure here is not fatal: the finisher tries again.
+				const char *ra = getenv("MM2GB_RMQ_ENGINES_AHEAD");
+				if (g_streams.rechain_ahead && !(ra && *ra == '0'))
+					for (StreamSlot *slot : fresh) {
+						std::lock_guard<std::mutex> lk(slot->rmq_mu);
+						if (!slot->rmq_eng) {
+							slot->rmq_eng = mm2gb_engine_create(&cfg_copy, &misc_copy, slot->eng.device);
+							if (slot->rmq_eng) slot->rmq_eng->e.rmq_calibrate = true;
+						}
+					}
 			});
 			const char *iw = getenv("MM2GB_INIT");
 			if (iw && strcmp(iw, "wait") == 0) wait_for_all_streams();
