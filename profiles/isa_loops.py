@@ -56,7 +56,7 @@ for i in range(start + 1, end):
     ln = lines[i]
     m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", ln)
     if m:
-        cur = (int(m.group(2)), file_ids.get(int(m.group(1)), "").endswith("chain_kernels.hip"))
+        cur = (int(m.group(2)), file_ids.get(int(m.group(1)), "").endswith(os.path.basename(SRC)))
         continue
     m = re.match(r"^(\.LBB\d+_\d+):", ln)
     if m:
