@@ -178,6 +178,31 @@ def test_sliced_call_overlaps_copies_and_kernels_same_chains(engine, monkeypatch
         assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), r
 
 
+def test_a_further_engine_on_the_device_has_two_streams_and_the_same_chains(engine, monkeypatch):
+    """Every engine but the first alive on a device gets two HIP streams instead of four (kernels and H2D on one, D2H on the other:
+    Engine::init, profiles/r05_hw_queues.txt).  The host-buffer paths are written for four -- copies in on one stream, kernels on another,
+    events between them -- and must give the same chains when two of those streams are one: the sliced call and the plain one on a second
+    engine, against the first engine's host post-pass."""
+    a, off = mm.synth_reads(33, 0, 30, 8_000, 40_000)
+    want, st_h = engine.chain(a, off, threads=4)
+    second = mm.Engine(device=engine.device)
+    try:
+        for slice_anchors in (str(max(50_000, len(a) // 5)), "1000", None):
+            if slice_anchors is None:
+                monkeypatch.delenv("MM2GB_CHAIN_SLICE_ANCHORS", raising=False)
+            else:
+                monkeypatch.setenv("MM2GB_CHAIN_SLICE_ANCHORS", slice_anchors)
+            got, st = second.chain_gpu(a, off)
+            assert st["n_pairs"] == st_h["n_pairs"] and len(got) == len(want)
+            for r in range(len(want)):
+                assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), (slice_anchors, r)
+        got, _ = second.chain(a, off, threads=4)                # scores through the host buffers, host post-pass
+        for r in range(len(want)):
+            assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), r
+    finally:
+        second.close()
+
+
 def test_post_pass_of_one_engine_beside_the_scores_of_another(engine):
     """mm2gb_post_device_enqueue / _totals: the post-pass of a scored batch enqueued on a SECOND engine (its own stream) while the first engine
     scores again into another pair of arrays -- what bench.py's through_backtrace_pipelined measures.  Same totals as the synchronous call
