@@ -146,6 +146,9 @@ int  mm2gb_post_device(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_of
 int  mm2gb_post_device_enqueue(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *d_offsets, const mm2gb_anchor_t *d_anchors, int64_t n_anchors,
                                const int32_t *d_f, const int32_t *d_p);
 int  mm2gb_post_device_totals(mm2gb_engine_t *eng, int64_t *n_chains, int64_t *n_kept, float *ms);
+/* a digest of the chains the last post-pass on this engine left on the device (offsets of chains, offsets of anchors, chains, anchors: four
+ * position-dependent sums folded on the host), for comparing two settings or builds on batches too large for the oracle */
+int  mm2gb_post_device_digest(mm2gb_engine_t *eng, int64_t n_reads, uint64_t *digest);
 
 /* ---- RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369, called per read from post_chaining_helper, map.c:444-456,
  *      on the anchors the first chaining kept, sorted by x).  Parameters in the order of mg_lchain_rmq's argument list.

@@ -82,7 +82,7 @@ _lib = None
 CORE_SYMBOLS = ["mm2gb_last_error", "mm2gb_version", "mm2gb_config_defaults", "mm2gb_config_parse", "mm2gb_config_load",
                 "mm2gb_device_count", "mm2gb_device_numa_node", "mm2gb_pin_thread_to_device", "mm2gb_numa_cpus_for_bdf", "mm2gb_engine_create", "mm2gb_engine_destroy", "mm2gb_engine_set_misc", "mm2gb_engine_device", "mm2gb_engine_split_counts", "mm2gb_engine_gang_counts", "mm2gb_has_gang_build",
                 "mm2gb_engine_reserve", "mm2gb_score_host", "mm2gb_score_device", "mm2gb_engine_sync", "mm2gb_engine_stats",
-                "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chain_gpu", "mm2gb_post_device", "mm2gb_post_device_enqueue", "mm2gb_post_device_totals", "mm2gb_chains_free", "mm2gb_backtrack_host",
+                "mm2gb_engine_stream", "mm2gb_engine_last_kernel_ms", "mm2gb_chain_host", "mm2gb_chain_gpu", "mm2gb_post_device", "mm2gb_post_device_enqueue", "mm2gb_post_device_totals", "mm2gb_post_device_digest", "mm2gb_chains_free", "mm2gb_backtrack_host",
                 "mm2gb_free", "mm2gb_lchain_dp", "mm2gb_synth_count", "mm2gb_synth_fill",
                 "mm2gb_pool_create", "mm2gb_pool_destroy", "mm2gb_pool_size", "mm2gb_pool_device", "mm2gb_pool_set_misc",
                 "mm2gb_pool_score_host", "mm2gb_pool_chain_host",
@@ -126,6 +126,7 @@ def lib():
         L.mm2gb_chain_gpu.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(Chains), C.POINTER(Stats)]
         L.mm2gb_post_device_enqueue.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.mm2gb_post_device_totals.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+        L.mm2gb_post_device_digest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.mm2gb_post_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.mm2gb_chains_free.argtypes = [C.POINTER(Chains)]

@@ -372,6 +372,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_TEAM4_SHARE_PCT")) launch.team4_share_pct = std::max(0, atoi(v));
 	if (const char *v = getenv("MM2GB_TEAM4_MIN_ANCHORS")) team4_min_n = std::max<int64_t>(0, atoll(v));
 	if (const char *v = getenv("MM2GB_DEBUG_PHASES")) debug_phases = *v && *v != '0';
+	if (const char *v = getenv("MM2GB_POST_FORM")) post_split = strcmp(v, "fused") != 0;
 	// Gangs: a chunk whose share of the batch's pairs is worth two workgroups or more is scored by several (chain_kernels.hip, plan_gangs):
 	// batches that cannot fill the machine end with their largest chunks.  MM2GB_GANG_MAX=0 turns them off.
 	// Large micro-batches keep the kernel without the gang code (MM2GB_GANG_MAX_ANCHORS: the largest batch that gets gangs).
@@ -450,7 +451,7 @@ void Engine::shutdown()
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
 	for (hipEvent_t &e : slice_in) if (e) (void)hipEventDestroy(e);
 	slice_in.clear();
-	for (DevBuf *b : { &post_dbg_reads, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &post_dbg_tasks, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &post_cls, &post_cls_cnt, &post_cls_nz, &post_read_nz, &post_uloc, &post_wtask, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -590,6 +591,9 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	if (post_z.ensure((size_t)nn * 8) || post_fp.ensure((size_t)nn * 8) || post_picked.ensure((size_t)nn * 4) || post_utmp.ensure(chains * 8) ||
 	    post_heads.ensure(chains * 16) || post_nu.ensure((size_t)nr * 4) || post_nkept.ensure((size_t)nr * 4) || post_misc.ensure(2048) || post_bins.ensure(2 * N_SIZE_CLASSES * 4) || post_order.ensure((size_t)nr * 4) ||
 	    post_up4.ensure((size_t)nn * 4) || post_up16.ensure((size_t)nn * 4)) return -1;
+	// split form: a class per anchor, per read and class the anchors / candidates, per chain slot where its anchors are, the walk tasks and their order
+	if (post_cls.ensure((size_t)nn) || post_cls_cnt.ensure((size_t)nr * N_TREE_CLASSES * 4) || post_cls_nz.ensure((size_t)nr * N_TREE_CLASSES * 4) || post_read_nz.ensure((size_t)nr * 4) ||
+	    post_uloc.ensure(chains * 4) || post_wtask.ensure((size_t)nr * N_TREE_CLASSES * 4 * 2)) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
 	return 0;
 }
@@ -626,14 +630,23 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.u_out = (unsigned long long*)po.u_out.ptr; b.a_out = (uint4*)po.a_out.ptr;
 	b.totals = (int64_t*)post_misc.ptr; b.cursor = (int32_t*)((char*)post_misc.ptr + 16);
 	b.order = (int32_t*)post_order.ptr; b.size_bins = (int32_t*)post_bins.ptr;
+	b.cls = post_split ? (unsigned char*)post_cls.ptr : nullptr;
+	b.cls_cnt = (int32_t*)post_cls_cnt.ptr; b.cls_nz = (int32_t*)post_cls_nz.ptr; b.read_nz = (int32_t*)post_read_nz.ptr;
+	b.zc = (unsigned long long*)post_sort_tmp.ptr; b.kpos = (int32_t*)post_sort_perm.ptr; b.u_loc = (int32_t*)post_uloc.ptr;
+	b.wtask = (int32_t*)post_wtask.ptr; b.wtask_order = b.wtask + (size_t)std::max<int64_t>(cap_post_reads, 16) * N_TREE_CLASSES;
+	b.walk_grid_waves = n_cu * 4 * 8;
+	if (const char *v = getenv("MM2GB_WALK_WAVES")) b.walk_grid_waves = std::max(4, atoi(v));
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
-	if (debug_phases) MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream));
+	if (debug_phases) { MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream)); MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024 + 22 * 8, 0xff, 8, stream)); }   // ([22]: a minimum)
 	b.dbg_reads = nullptr;
 	if (debug_phases) {
 		if (post_dbg_reads.ensure((size_t)std::max<int64_t>(n_reads, 1) * 32)) return -1;
 		MM2GB_HIP(hipMemsetAsync(post_dbg_reads.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * 32, stream));
 		b.dbg_reads = (long long*)post_dbg_reads.ptr;
+		if (post_dbg_tasks.ensure((size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 32)) return -1;
+		MM2GB_HIP(hipMemsetAsync(post_dbg_tasks.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 32, stream));
 	}
+	b.dbg_tasks = debug_phases ? (long long*)post_dbg_tasks.ptr : nullptr;
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
 	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
 	if (rmq) { b.min_cnt = rmq->min_cnt; b.min_sc = rmq->min_sc; b.max_drop = rmq->bw; }   // lchain.c:253,355
@@ -1295,9 +1308,12 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 		for (int lv = 0; lv < 3; ++lv)
 			fprintf(stderr, "[mm2gb post-pass] sort level %d: %.1f ms; %lld radix passes over %lld elements: %lld cycles, %lld steps, refills of one line %lld, of all lines %lld\n",
 			        lv, t[13 + lv] / 1e5, t[24 + 6 * lv + 5], t[24 + 6 * lv + 4], t[24 + 6 * lv + 3], t[24 + 6 * lv], t[24 + 6 * lv + 1], t[24 + 6 * lv + 2]);
+	if (t[21])
+		fprintf(stderr, "[mm2gb post-pass] split form: %lld walk tasks, first starts at 0, last ends at %.2f ms; summed %.1f ms, longest task %.2f ms; spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld (%lld rounds)\n",
+		        t[21], (t[23] - t[22]) / 1e5, t[2] / 1e5, t[5] / 1e5, t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[20]);
 	if (t[6])
 		fprintf(stderr, "[mm2gb post-pass] walks: spec loads %.1f ms, long walks %.1f ms; groups %lld, open %lld, long %lld (%lld rounds of 64 anchors), candidates %lld\n", t[7] / 1e5, t[8] / 1e5, t[9], t[10], t[11], t[20], t[12]);
-	if (t[6])
+	if (t[6] || t[21])
 		fprintf(stderr, "[mm2gb post-pass] wave-time summed over reads: collect %.1f ms | sort %.1f ms | chain walks %.1f ms | emit %.1f ms  (%lld reads) | slowest read: sort %.2f ms, walks %.2f ms, whole %.2f ms\n",
 		        t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, (long long)n_reads, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5);
 	// the schedule: when the reads that finish last were started, and how long their parts took
@@ -1323,6 +1339,27 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 			const double span = std::max(1.0, (double)(t_last - t_first));
 			for (int64_t r : idx) for (int k = 0; k < n_bins; ++k) { const double at = t_first + span * (k + 0.5) / n_bins; if (tr[4 * r] <= at && at < tr[4 * r + 3]) ++busy[k]; }
 			fprintf(stderr, "    reads in flight at %d points of the kernel's time:", n_bins);
+			for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
+			fprintf(stderr, "\n");
+		}
+	}
+	if (t[21] > 0 && post_dbg_tasks.ptr) {
+		const size_t n_t = (size_t)t[21];
+		std::vector<long long> tk(n_t * 4);
+		if (hipMemcpy(tk.data(), post_dbg_tasks.ptr, tk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			std::vector<size_t> idx(n_t);
+			for (size_t k = 0; k < n_t; ++k) idx[k] = k;
+			std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b2) { return tk[4 * a + 1] - tk[4 * a] > tk[4 * b2 + 1] - tk[4 * b2]; });
+			fprintf(stderr, "[mm2gb post-pass] k_post_walk: the longest tasks (taken as | read | class | candidates | start | ms):\n");
+			for (size_t k = 0; k < std::min<size_t>(n_t, 16); ++k) {
+				const size_t q = idx[k];
+				fprintf(stderr, "    %6zu | %6lld | %2lld | %7lld | %6.2f | %6.2f\n", q, tk[4 * q + 2] >> 4, tk[4 * q + 2] & 15, tk[4 * q + 3], (tk[4 * q] - t[22]) / 1e5, (tk[4 * q + 1] - tk[4 * q]) / 1e5);
+			}
+			const int n_bins = 14;
+			std::vector<int> busy(n_bins, 0);
+			const double span = std::max(1.0, (double)(t[23] - t[22]));
+			for (size_t q = 0; q < n_t; ++q) for (int k = 0; k < n_bins; ++k) { const double at = t[22] + span * (k + 0.5) / n_bins; if (tk[4 * q] <= at && at < tk[4 * q + 1]) ++busy[k]; }
+			fprintf(stderr, "    tasks in flight at %d points of the kernel's time:", n_bins);
 			for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
 			fprintf(stderr, "\n");
 		}
@@ -1394,6 +1431,30 @@ int mm2gb_post_device_totals(mm2gb_engine_t *eng, int64_t *n_chains, int64_t *n_
 	if (n_kept) *n_kept = e.h_post_totals[1];
 	float t = 0;
 	if (ms && hipEventElapsedTime(&t, e.post0, e.post1) == hipSuccess) *ms = t;
+	return 0;
+}
+
+// A digest of what the last post-pass on this engine left on the device (u_off, a_off, u[], a[] of result set 0), for comparing two builds or two
+// settings of the post-pass on batches too large to take through the oracle: copied to the host and folded there (position-dependent, so a
+// permutation of chains or anchors changes it).  digest[0..3]: offsets of chains, offsets of anchors, chains, anchors.
+int mm2gb_post_device_digest(mm2gb_engine_t *eng, int64_t n_reads, uint64_t *digest)
+{
+	if (!eng || !digest) return fail("mm2gb: null argument");
+	Engine &e = eng->e;
+	if (!e.h_post_totals) return fail("mm2gb_post_device_digest: no post-pass has run on this engine");
+	MM2GB_HIP(hipSetDevice(e.device));
+	MM2GB_HIP(hipStreamSynchronize(e.stream));
+	const int64_t n_u = e.h_post_totals[0], n_a = e.h_post_totals[1];
+	auto fold = [](const void *dev, size_t words, uint64_t &out) -> int {
+		std::vector<uint64_t> h(words ? words : 1);
+		if (words) MM2GB_HIP(hipMemcpy(h.data(), dev, words * 8, hipMemcpyDeviceToHost));
+		uint64_t acc = 0x9E3779B97F4A7C15ULL;
+		for (size_t k = 0; k < words; ++k) { uint64_t v = h[k] + 0x9E3779B97F4A7C15ULL * (k + 1); v ^= v >> 29; v *= 0xBF58476D1CE4E5B9ULL; v ^= v >> 32; acc += v; }
+		out = acc;
+		return 0;
+	};
+	if (fold(e.post_uoff.ptr, (size_t)n_reads + 1, digest[0]) || fold(e.post_aoff.ptr, (size_t)n_reads + 1, digest[1]) ||
+	    fold(e.post_uout.ptr, (size_t)n_u, digest[2]) || fold(e.post_aout.ptr, (size_t)n_a * 2, digest[3])) return -1;
 	return 0;
 }
 

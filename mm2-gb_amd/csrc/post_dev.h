@@ -30,7 +30,7 @@ struct PostBatch {
 	unsigned long long *u_out; // chains, read by read, in output order (lchain.c:145: score << 32 | count)
 	uint4    *a_out;           // compacted anchors, read by read (lchain.c:78-111)
 	int64_t  *totals;          // [0] chains [1] anchors kept
-	int32_t  *cursor;          // two work cursors
+	int32_t  *cursor;          // work cursors: [0] reads of the sort [1] of the emit [2] of the classes [3] of the partition [4] walk tasks taken [5] walk tasks made
 	int32_t  *order;           // n_reads: reads, largest first (the kernel ends with its longest read: start those first)
 	int32_t  *size_bins;       // 2 x N_SIZE_CLASSES: reads per size class (eight classes per power of two), and the fill cursors of the scatter
 	int       min_cnt, min_sc, max_drop;
@@ -38,7 +38,23 @@ struct PostBatch {
 	int       team_reads;      // the largest reads of the batch that a whole workgroup starts on together (k_post_chains)
 	long long *dbg;            // optional (MM2GB_DEBUG_PHASES): summed 100 MHz ticks of [0] candidate collection [1] sort [2] chain walks [3] emit
 	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES): per read 4 ticks: start, end of collection, end of sort, end of walks (k_post_chains)
+	// The walks of a read shared out by TREE (round 6; null: one wave sorts and walks a read, k_post_chains).  p[] is a forest and a walk never
+	// leaves its tree (lchain.c:9-25 follows p; marks are only ever set along it), so walks that start in different trees never meet: every tree
+	// gets a class -- a hash of its root --, a read's sorted candidates are dealt to their classes in order, and (read, class) pairs are walked by
+	// different waves.  What the host appends to u[] / v[] candidate by candidate is put together again from the candidates' sorted positions.
+	unsigned char *cls;        // n: class of every anchor's tree
+	int32_t  *cls_cnt;         // n_reads x N_TREE_CLASSES: anchors per class (a class's share of the read's slots in picked / zc / kpos; of u_tmp / u_loc: count / mc)
+	int32_t  *cls_nz;          // n_reads x N_TREE_CLASSES: candidates per class
+	int32_t  *read_nz;         // n_reads: candidates
+	unsigned long long *zc;    // n: the sorted candidates class by class (aliases sort_tmp: the sort is over)
+	int32_t  *kpos;            // n: their positions in the read's sorted order (aliases sort_perm)
+	                           // (endslot: by sorted position, the chain slot of the chain that candidate ended, -1 none: n entries of 4 bytes in the read's own part of z, whose candidates live in zc by then)
+	int32_t  *u_loc;           // per chain slot: where the chain's anchors start in the read's picked[]
+	int32_t  *wtask, *wtask_order;   // up to n_reads x N_TREE_CLASSES each: read << 4 | class of every pair with candidates; the same, most candidates first
+	int       walk_grid_waves; // waves of k_post_walk (it holds no LDS: more fit than of the sort)
+	long long *dbg_tasks;      // optional (MM2GB_DEBUG_PHASES): per walk task (in the order taken) 4 values: start tick, end tick, read << 4 | class, candidates
 };
+constexpr int N_TREE_CLASSES = 16;
 void launch_post(const PostBatch &b, hipStream_t s);
 
 // RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369) of reads whose anchors are already chained once: score fill on the device.

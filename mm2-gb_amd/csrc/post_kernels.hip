@@ -698,8 +698,13 @@ struct WalkDbg { long long load = 0, longt = 0, groups = 0, open = 0, nlong = 0,
 // anchor's record in memory.  60 % of all candidates are found taken on their first probe (their chain's best end came earlier): that probe,
 // the marks of every walk and the second looks of a group become LDS traffic, and nothing but scores and links is ever loaded.  Null for a
 // read with more anchors than the scratch has bits: the flag then lives in the record as before.
+// Split form (round 6, k_post_walk): z is ONE CLASS of the read's sorted candidates (the trees whose roots hash to it; sorted order kept), kp
+// their positions in the whole read's order; a chain that is kept is recorded under its end's position (what.endslot: its chain slot, read-relative,
+// what.u_loc: where its anchors start in the read's picked[]), so that the read's chains can be put in the host's order afterwards.
+struct WalkSplit { const int32_t *kp = nullptr; int32_t *endslot = nullptr; int32_t *u_loc = nullptr; int picked_base = 0, slot_base = 0; };
 __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t off, const int n_z, const unsigned long long *z, int2 *fp,
-                                               int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd, unsigned *bits)
+                                               int32_t *picked, unsigned long long *u_tmp, int &n_u_out, int &n_v_out, WalkDbg &wd, unsigned *bits,
+                                               const WalkSplit &what = WalkSplit())
 {
 	const int l = lane();
 	long long &dbg_load = wd.load, &dbg_longt = wd.longt, &dbg_groups = wd.groups, &dbg_open = wd.open, &dbg_long = wd.nlong;
@@ -716,6 +721,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 	for (int kb = n_z - 1; kb >= 0; kb -= W) {
 		const int k_l = kb - l;
 		const unsigned long long z_l = k_l >= 0 ? z[k_l] : 0;
+		const int kp_l = what.kp && k_l >= 0 ? what.kp[k_l] : 0;
 		const int n0 = (int)(unsigned)z_l, top_l = (int)(z_l >> 32);
 		unsigned long long pending = __ballot(k_l >= 0);
 		int nx[SPEC], sx[SPEC];                                 // the group's look-ahead: anchors SPEC steps down every candidate's path, and their score drops
@@ -806,6 +812,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					}
 					if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
 						if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
+						if (what.kp) { const int kp = __builtin_amdgcn_readlane(kp_l, src); if (l == 0) { what.u_loc[n_u] = what.picked_base + n_v; what.endslot[kp] = what.slot_base + n_u; } }
 						++n_u; n_v += kept;
 					}
 					continue;
@@ -854,9 +861,12 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					wave_sync();
 					const long long tl = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 					++dbg_long;
+					// the first round looks at 16 anchors only: most walks that go on end within a dozen steps (the chains of a repeat), and a lane
+					// beyond the walk's end costs its loads all the same -- divergent loads are what this kernel is made of
+					int rw = W / 4;
 					while (!ended) {
 						++wd.iters;
-						int t = cur;
+						int t = l < rw ? cur : -1;
 						for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
 						for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
 						for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = fpw[2 * t + 1] & ~TAKEN; t = rj ? t - rj : -1; }
@@ -871,8 +881,8 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						before = l == 0 ? best : max(best, before);
 						const bool newmax = valid && s > before;
 						const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
-						const unsigned long long endm = __ballot(ends);
-						const int jb = endm ? first_set(endm) : W;             // the step that ends the walk (all of it is still taken)
+						const unsigned long long endm = __ballot(ends && l < rw);
+						const int jb = endm ? first_set(endm) : rw;            // the step that ends the walk (all of it is still taken)
 						if (valid && l <= jb) picked[n_v + visited + l] = t;
 						const unsigned long long nm = __ballot(newmax && l <= jb);
 						if (nm) {
@@ -880,8 +890,8 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 							best = __shfl(s, last);
 							kept = visited + last + 1;
 						}
-						if (jb < W) { visited += jb + 1; ended = true; }
-						else { visited += W; cur = __shfl(next, W - 1); }
+						if (jb < rw) { visited += jb + 1; ended = true; }
+						else { visited += rw; cur = __shfl(next, rw - 1); rw = W; }
 					}
 					wave_sync();
 					if (bits) for (int q = l; q < kept; q += W) take(picked[n_v + q]);
@@ -891,6 +901,7 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
 				if (best >= b.min_sc && kept > 0 && kept >= b.min_cnt) {
 					if (l == 0) u_tmp[n_u] = (unsigned long long)(unsigned)best << 32 | (unsigned)kept;
+					if (what.kp) { const int kp = __builtin_amdgcn_readlane(kp_l, src); if (l == 0) { what.u_loc[n_u] = what.picked_base + n_v; what.endslot[kp] = what.slot_base + n_u; } }
 					++n_u; n_v += kept;
 				}
 			}
@@ -929,7 +940,9 @@ __device__ __forceinline__ int post_collect(const PostBatch &b, const int32_t *f
 // through 256 bucket heads, inherently serial (ksort.h:116-146) -- is wave 0's, and its buckets, which the host sorts independently of each
 // other (rs_sort's recursion, ksort.h:140-145), are dealt to the four waves, largest first.  The chain walks are wave 0's again (they
 // depend on each other through the marks); the other three waves go on to reads of their own.
-__global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chains(PostBatch b, int team_reads)
+// SORT_ONLY (round 6): the same up to the sorted candidates, whose number goes to read_nz[]; the walks are k_post_walk's.
+template <bool SORT_ONLY>
+__device__ __forceinline__ void post_chains_body(const PostBatch &b, int team_reads)
 {
 	__shared__ PassLds lds[POST_THREADS / W];
 	__shared__ int s_team[8];                                // [0] the team's read (position in the order), [1..4] candidates per wave, [5] next task
@@ -1039,6 +1052,20 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 			sort_like_host<ZElem, true>(z, n_z, L, b.dbg, &sc);
 			t2 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		}
+		if constexpr (SORT_ONLY) {
+			if (l == 0) {
+				b.read_nz[r] = n_z;
+				if (b.dbg) {
+					if (b.dbg_reads) { b.dbg_reads[4 * r] = t0; b.dbg_reads[4 * r + 1] = t1; b.dbg_reads[4 * r + 2] = t2; b.dbg_reads[4 * r + 3] = team ? (long long)__builtin_amdgcn_s_memrealtime() : t2; }
+					atomicAdd((unsigned long long*)&b.dbg[0], (unsigned long long)(t1 - t0));
+					atomicAdd((unsigned long long*)&b.dbg[1], (unsigned long long)(t2 - t1));
+					atomicMax((unsigned long long*)&b.dbg[4], (unsigned long long)(t2 - t1));
+					atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z);
+				}
+			}
+			wave_sync();
+			continue;
+		}
 		int n_u = 0, n_v = 0;
 		WalkDbg wd;
 		// the marks of the walks: a bit per anchor in this wave's LDS (the sort is done with it) when the read fits
@@ -1066,6 +1093,198 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 				atomicAdd((unsigned long long*)&b.dbg[11], (unsigned long long)wd.nlong);
 				atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z);
 				atomicAdd((unsigned long long*)&b.dbg[20], (unsigned long long)wd.iters);
+			}
+		}
+		wave_sync();
+	}
+}
+
+__global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chains(PostBatch b, int team_reads) { post_chains_body<false>(b, team_reads); }
+__global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort(PostBatch b, int team_reads) { post_chains_body<true>(b, team_reads); }
+
+// --------------------------------------------------------------------------------------------------------------
+// The walks shared out by tree (round 6).  k_post_classes: every anchor's class -- a hash of the root of its tree -- by one pass over the read in
+// index order (a predecessor always lies before its anchor): 64 anchors per step, predecessors inside the 64 resolved by pointer jumping
+// between lanes, the most recent classes kept in LDS (most predecessors are near), older ones read back from memory.  k_post_partition: a read's
+// sorted candidates dealt to their classes, order kept.  k_post_walk: one wave per (read, class).
+// --------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int CLS_RING = 1024;                  // most recent classes kept in LDS, per wave
+__device__ __forceinline__ int tree_class(int root) { return (int)(((unsigned)root * 0x9E3779B1u) >> 28); }
+static_assert(N_TREE_CLASSES == 16, "tree_class takes the top four bits of the hash; tasks pack the class into four bits");
+} // namespace
+
+__global__ __launch_bounds__(POST_THREADS) void k_post_classes(PostBatch b)
+{
+	__shared__ unsigned char s_ring[POST_THREADS / W][CLS_RING];
+	__shared__ int s_cnt[POST_THREADS / W][N_TREE_CLASSES];
+	const int l = lane(), w = uni(threadIdx.x / W);
+	unsigned char *ring = s_ring[w];
+	int *cnt = s_cnt[w];
+	for (;;) {
+		int q = 0;
+		if (l == 0) q = atomicAdd(b.cursor + 2, 1);
+		q = uni(q);
+		if (q >= b.n_reads) break;
+		const int r = uni(b.order[q]);
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const int32_t *p = b.p + off;
+		unsigned char *cls = b.cls + off;
+		if (l < N_TREE_CLASSES) cnt[l] = 0;
+		wave_sync();
+		for (int base = 0; base < n; base += W) {
+			const int i = base + l;
+			const bool in = i < n;
+			const int pl = in ? p[i] : 0;
+			const int pred = i - pl;
+			int c = tree_class(i);                                 // a root's own
+			bool known = !in || pl == 0;
+			const bool far = !known && pred < base - CLS_RING;       // (the ring holds the CLS_RING anchors before this block; it is read before the block's own classes go in)
+			if (__ballot(far) != 0) {
+				wave_sync();                                       // what this wave stored blocks ago has landed
+				if (far) { c = cls[pred]; known = true; }
+			}
+			if (!known && pred < base) { c = ring[pred & (CLS_RING - 1)]; known = true; }
+			// predecessors inside the block: pointer jumping between lanes (a chain of at most 64 links: six rounds)
+			int ptr = known ? l : pred - base;
+			for (int it = 0; it < 6; ++it) {
+				if (__ballot(!known) == 0) break;
+				const int c2 = __shfl(c, ptr), k2 = __shfl((int)known, ptr), p2 = __shfl(ptr, ptr);
+				if (!known) { if (k2) { c = c2; known = true; } else ptr = p2; }
+			}
+			wave_sync();                                           // the ring's reads before its writes
+			if (in) { cls[i] = (unsigned char)c; ring[i & (CLS_RING - 1)] = (unsigned char)c; atomicAdd(&cnt[c], 1); }
+			wave_sync();
+		}
+		if (l < N_TREE_CLASSES) b.cls_cnt[(int64_t)r * N_TREE_CLASSES + l] = cnt[l];
+		wave_sync();
+	}
+}
+
+__global__ __launch_bounds__(POST_THREADS) void k_post_partition(PostBatch b)
+{
+	const int l = lane();
+	for (;;) {
+		int q = 0;
+		if (l == 0) q = atomicAdd(b.cursor + 3, 1);
+		q = uni(q);
+		if (q >= b.n_reads) break;
+		const int r = uni(b.order[q]);
+		const int64_t off = b.offsets[r];
+		const int n_z = b.read_nz[r];
+		const unsigned long long *z = b.z + off;
+		const unsigned char *cls = b.cls + off;
+		unsigned long long *zc = b.zc + off;
+		int32_t *kpos = b.kpos + off, *endslot = (int32_t*)(b.z + off);     // (endslot takes the place of the read's own z: n entries of 4 bytes in its 8 n bytes)
+		// a class's candidates go where its anchors' share of the read's slots begins (candidates of a class <= anchors of a class)
+		int inc = l < N_TREE_CLASSES ? b.cls_cnt[(int64_t)r * N_TREE_CLASSES + l] : 0;
+		const int own = inc;
+		for (int o = 1; o < N_TREE_CLASSES; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc += v; }
+		const int sub_l = inc - own;
+		int sub[N_TREE_CLASSES], cur[N_TREE_CLASSES];
+#pragma unroll
+		for (int c = 0; c < N_TREE_CLASSES; ++c) { sub[c] = __builtin_amdgcn_readlane(sub_l, c); cur[c] = 0; }
+		for (int base = 0; base < n_z; base += 4 * W) {
+			// four blocks of 64 per round trip (one wave streams a read: every round trip is paid in full)
+			unsigned long long e4[4];
+			int c4[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) e4[u] = z[min(base + u * W + l, n_z - 1)];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) c4[u] = base + u * W + l < n_z ? (int)cls[(int)(unsigned)e4[u]] : -1;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int k = base + u * W + l;
+				const unsigned long long e = e4[u];
+				const int c = c4[u];
+#pragma unroll
+				for (int cc = 0; cc < N_TREE_CLASSES; ++cc) {
+					const unsigned long long m = __ballot(c == cc);
+					if (c == cc) { const int at = sub[cc] + cur[cc] + __popcll(m & ((1ull << l) - 1)); zc[at] = e; kpos[at] = k; }
+					cur[cc] += __popcll(m);
+				}
+			}
+			// (endslot lives in z's memory: entries [base, base + 256) lie inside z[0, base / 2 + 128), which has been read)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) if (base + u * W + l < n_z) endslot[base + u * W + l] = -1;
+		}
+		int mine = 0;
+#pragma unroll
+		for (int c = 0; c < N_TREE_CLASSES; ++c) if (l == c) mine = cur[c];
+		if (l < N_TREE_CLASSES) {
+			b.cls_nz[(int64_t)r * N_TREE_CLASSES + l] = mine;
+			if (mine > 0) b.wtask[atomicAdd(b.cursor + 5, 1)] = r << 4 | l;
+		}
+	}
+}
+
+// walk tasks by number of candidates, most first (the same classes of sizes as the reads')
+__global__ __launch_bounds__(256) void k_post_task_count(PostBatch b)
+{
+	const int n_t = b.cursor[5];
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) {
+		const int task = b.wtask[t];
+		atomicAdd(&b.size_bins[size_class(b.cls_nz[(int64_t)(task >> 4) * N_TREE_CLASSES + (task & 15)])], 1);
+	}
+}
+__global__ __launch_bounds__(256) void k_post_task_scatter(PostBatch b)
+{
+	const int n_t = b.cursor[5];
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) {
+		const int task = b.wtask[t];
+		const int c = size_class(b.cls_nz[(int64_t)(task >> 4) * N_TREE_CLASSES + (task & 15)]);
+		b.wtask_order[atomicAdd(&b.size_bins[N_SIZE_CLASSES + c], 1)] = task;
+	}
+}
+
+#ifndef MM2GB_WALK_WAVES_PER_SIMD
+#define MM2GB_WALK_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(POST_THREADS, MM2GB_WALK_WAVES_PER_SIMD) void k_post_walk(PostBatch b)
+{
+	const int l = lane();
+	const int mc = b.min_cnt > 1 ? b.min_cnt : 1;
+	const int n_t = b.cursor[5];
+	for (;;) {
+		int q = 0;
+		if (l == 0) q = atomicAdd(b.cursor + 4, 1);
+		q = uni(q);
+		if (q >= n_t) break;
+		const int task = uni(b.wtask_order[q]);
+		const int r = task >> 4, c = task & 15;
+		const int64_t off = b.offsets[r];
+		// this class's share of the read's slots
+		const int cc = l < N_TREE_CLASSES ? b.cls_cnt[(int64_t)r * N_TREE_CLASSES + l] : 0;
+		int inc = cc, uinc = cc / mc;
+		for (int o = 1; o < N_TREE_CLASSES; o <<= 1) { const int v = __shfl_up(inc, o), uv = __shfl_up(uinc, o); if (l >= o) { inc += v; uinc += uv; } }
+		const int sub = __builtin_amdgcn_readlane(inc - cc, c), usub = __builtin_amdgcn_readlane(uinc - cc / mc, c);
+		const int n_zc = b.cls_nz[(int64_t)r * N_TREE_CLASSES + c];
+		const int64_t slot0 = chain_slot(off, r, mc);
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		WalkSplit what;
+		what.kp = b.kpos + off + sub; what.endslot = (int32_t*)(b.z + off); what.u_loc = b.u_loc + slot0 + usub; what.picked_base = sub; what.slot_base = usub;
+		int n_u = 0, n_v = 0;
+		WalkDbg wd;
+		post_walk_read(b, off, n_zc, b.zc + off + sub, b.fp + off, b.picked + off + sub, b.u_tmp + slot0 + usub, n_u, n_v, wd, nullptr, what);
+		wave_sync();
+		if (l == 0) {
+			if (n_u) atomicAdd(&b.n_u[r], n_u);
+			if (n_v) atomicAdd(&b.n_kept[r], n_v);
+			if (b.dbg) {
+				const long long t3 = (long long)__builtin_amdgcn_s_memrealtime();
+				atomicAdd((unsigned long long*)&b.dbg[2], (unsigned long long)(t3 - t0));
+				atomicMax((unsigned long long*)&b.dbg[5], (unsigned long long)(t3 - t0));
+				atomicAdd((unsigned long long*)&b.dbg[7], (unsigned long long)wd.load);
+				atomicAdd((unsigned long long*)&b.dbg[8], (unsigned long long)wd.longt);
+				atomicAdd((unsigned long long*)&b.dbg[9], (unsigned long long)wd.groups);
+				atomicAdd((unsigned long long*)&b.dbg[10], (unsigned long long)wd.open);
+				atomicAdd((unsigned long long*)&b.dbg[11], (unsigned long long)wd.nlong);
+				atomicAdd((unsigned long long*)&b.dbg[20], (unsigned long long)wd.iters);
+				atomicAdd((unsigned long long*)&b.dbg[21], 1ull);
+				atomicMin((unsigned long long*)&b.dbg[22], (unsigned long long)t0);      // first task's start (the slot is set to ~0 before the launch)
+				atomicMax((unsigned long long*)&b.dbg[23], (unsigned long long)t3);
+				if (b.dbg_tasks) { b.dbg_tasks[4 * q] = t0; b.dbg_tasks[4 * q + 1] = t3; b.dbg_tasks[4 * q + 2] = task; b.dbg_tasks[4 * q + 3] = n_zc; }
 			}
 		}
 		wave_sync();
@@ -1126,6 +1345,29 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_emit(PostBatch b)
 		uint4 *a_out = b.a_out + b.a_off[r];
 		// (x of the chain's first anchor, offset << 32 | chain): the first anchor is the last one picked (lchain.c:88-99)
 		int k_at = 0;
+		if (b.cls) {
+			// split form: the chains in the order the host finds them = the candidates from the best one down; endslot[] says which of them ended a
+			// chain that was kept, and where k_post_walk left it (its slot in u_tmp / u_loc; u_loc: its anchors in picked)
+			const int32_t *endslot = (const int32_t*)(b.z + off);
+			const int32_t *u_loc = b.u_loc + chain_slot(off, r, mc);
+			const int n_z = b.read_nz[r];
+			for (int kb = n_z - 1; kb >= 0; kb -= 4 * W) {
+				int slot[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) { const int k = kb - q * W - l; slot[q] = k >= 0 ? endslot[k] : -1; }
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const unsigned long long m = __ballot(slot[q] >= 0);
+					if (slot[q] >= 0) {
+						const int c = k_at + __popcll(m & ((1ull << l) - 1));
+						const int cnt = (int)(unsigned)u_tmp[slot[q]], k0 = u_loc[slot[q]];
+						const uint4 first = raw[picked[k0 + cnt - 1]];
+						heads[c] = make_ulonglong2((unsigned long long)first.y << 32 | first.x, (unsigned long long)(unsigned)k0 << 32 | (unsigned)slot[q]);
+					}
+					k_at += __popcll(m);
+				}
+			}
+		} else
 		for (int base = 0; base < n_u; base += W) {
 			const int c = base + l;
 			const int cnt = c < n_u ? (int)(unsigned)u_tmp[c] : 0;
@@ -2792,7 +3034,7 @@ void launch_gen_regs(const RegBatch &b, hipStream_t s)
 void launch_post(const PostBatch &b, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;
-	(void)hipMemsetAsync(b.cursor, 0, 2 * sizeof(int32_t), s);
+	(void)hipMemsetAsync(b.cursor, 0, 8 * sizeof(int32_t), s);
 	(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
 	const unsigned rgrid = (unsigned)((b.n_reads + 255) / 256);
 	hipLaunchKernelGGL(k_post_size_count, dim3(rgrid), dim3(256), 0, s, b);
@@ -2804,6 +3046,22 @@ void launch_post(const PostBatch &b, hipStream_t s)
 	const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n + 255) / 256, 256 * 64));
 	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0);
 	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1);
+	if (b.cls) {
+		// split form (round 6): sort | classes of the trees | candidates dealt to their classes | walks per (read, class)
+		(void)hipMemsetAsync(b.n_u, 0, (size_t)b.n_reads * sizeof(int32_t), s);
+		(void)hipMemsetAsync(b.n_kept, 0, (size_t)b.n_reads * sizeof(int32_t), s);
+		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b);
+		hipLaunchKernelGGL(k_post_sort, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads);
+		hipLaunchKernelGGL(k_post_partition, dim3(grid), dim3(POST_THREADS), 0, s, b);
+		(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
+		const unsigned tgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + 255) / 256, 1024));
+		hipLaunchKernelGGL(k_post_task_count, dim3(tgrid), dim3(256), 0, s, b);
+		hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b);
+		hipLaunchKernelGGL(k_post_task_scatter, dim3(tgrid), dim3(256), 0, s, b);
+		const int64_t wwaves = std::max<int64_t>(b.walk_grid_waves, 4);
+		const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + POST_THREADS / W - 1) / (POST_THREADS / W), (wwaves + POST_THREADS / W - 1) / (POST_THREADS / W)));
+		hipLaunchKernelGGL(k_post_walk, dim3(wgrid), dim3(POST_THREADS), 0, s, b);
+	} else
 	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads);
 	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b);
 	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);

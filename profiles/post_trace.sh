@@ -1,0 +1,13 @@
+#!/bin/bash
+# kernel trace of the device post-pass alone (profiles/post_only.py): per-kernel average durations -> gpurun_out/<tag>/post_kernel_stats.csv
+# usage: profiles/post_trace.sh <tag> [post_only.py arguments]
+tag=${1:-trace}; shift
+root=$PWD
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o post -- python3 $root/profiles/post_only.py --runs 3 "$@" > $out/post_trace.log 2>&1
+f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $out/post_kernel_stats.csv && grep -E "k_post|Name" $out/post_kernel_stats.csv | cut -c1-200
+tail -2 $out/post_trace.log
+rm -rf $out/prof
