@@ -85,7 +85,7 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 41 B/anchor of work arrays (candidates 8, walk records 8, picked 4, two lifting tables 8, the sort's bytes / permutation / way station 13), + chains' arrays, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_dbg_reads, post_dbg_tasks, rmq_dbg_reads, rmq_skey_in, rmq_skey, rmq_sa, rmq_srange, rmq_sort_tmp, post_z, post_fp, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, post_sort_s, post_sort_perm, post_sort_tmp, post_cls, post_cls_cnt, post_cls_nz, post_read_nz, post_uloc, post_wtask, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
+	DevBuf post_dbg_reads, post_dbg_tasks, rmq_dbg_reads, rmq_skey_in, rmq_skey, rmq_sa, rmq_srange, rmq_sort_tmp, post_z, post_fp, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, post_sort_s, post_sort_perm, post_sort_tmp, post_cls, post_cls_cnt, post_cls_nz, post_read_nz, post_uloc, post_wtask, post_stask, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
 	DevBuf sd_seeds, sd_seed_off, sd_hit_off, sd_hits, sd_qlen, sd_q_rank, sd_ref_len, sd_ref_rank, sd_seed_read, sd_tmp, sd_n_kept, sd_a_off, sd_out;   // mm2gb_collect_seeds_gpu
 	// what the post-pass leaves for the host, two sets: the boundary keeps two batches in flight (the results of batch k are
 	// fetched after batch k+1 has been launched)
@@ -111,6 +111,7 @@ struct Engine {
 
 	mm2gb_stats_t last = {};
 	bool misc_valid = false, coop_disabled = false, debug_phases = false, one_compute_stream = false;
+	bool post_levels = true;        // the split form's sort level by level over the whole batch, a task per run (MM2GB_POST_SORT=reads: one wave sorts a read from top to bottom)
 	bool post_split = true;         // device post-pass: a read's walks shared out by tree over several waves (MM2GB_POST_FORM=fused: one wave sorts and walks a read)
 	int64_t team4_min_n = 0;        // micro-batches from this many anchors on send wide-window heavy chunks to 4-wave teams (launch.team4_share_pct)
 	int64_t split_max_n = 0;        // micro-batches up to this many anchors run the SPLIT build of k_score (0: never)

@@ -373,6 +373,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	if (const char *v = getenv("MM2GB_TEAM4_MIN_ANCHORS")) team4_min_n = std::max<int64_t>(0, atoll(v));
 	if (const char *v = getenv("MM2GB_DEBUG_PHASES")) debug_phases = *v && *v != '0';
 	if (const char *v = getenv("MM2GB_POST_FORM")) post_split = strcmp(v, "fused") != 0;
+	if (const char *v = getenv("MM2GB_POST_SORT")) post_levels = strcmp(v, "reads") != 0;
 	// Gangs: a chunk whose share of the batch's pairs is worth two workgroups or more is scored by several (chain_kernels.hip, plan_gangs):
 	// batches that cannot fill the machine end with their largest chunks.  MM2GB_GANG_MAX=0 turns them off.
 	// Large micro-batches keep the kernel without the gang code (MM2GB_GANG_MAX_ANCHORS: the largest batch that gets gangs).
@@ -451,7 +452,7 @@ void Engine::shutdown()
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
 	for (hipEvent_t &e : slice_in) if (e) (void)hipEventDestroy(e);
 	slice_in.clear();
-	for (DevBuf *b : { &post_dbg_reads, &post_dbg_tasks, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &post_cls, &post_cls_cnt, &post_cls_nz, &post_read_nz, &post_uloc, &post_wtask, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &post_dbg_tasks, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &post_cls, &post_cls_cnt, &post_cls_nz, &post_read_nz, &post_uloc, &post_wtask, &post_stask, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -594,6 +595,8 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 	// split form: a class per anchor, per read and class the anchors / candidates, per chain slot where its anchors are, the walk tasks and their order
 	if (post_cls.ensure((size_t)nn) || post_cls_cnt.ensure((size_t)nr * N_TREE_CLASSES * 4) || post_cls_nz.ensure((size_t)nr * N_TREE_CLASSES * 4) || post_read_nz.ensure((size_t)nr * 4) ||
 	    post_uloc.ensure(chains * 4) || post_wtask.ensure((size_t)nr * N_TREE_CLASSES * 4 * 2)) return -1;
+	// the sort's tasks: runs of more than 64 candidates, at most n / 65 of them at a level (+ a read's first): two lists and an order
+	if (post_stask.ensure(((size_t)nn / 64 + (size_t)nr + 64) * (16 + 16 + 4))) return -1;
 	cap_post_n = nn; cap_post_reads = nr;
 	return 0;
 }
@@ -634,6 +637,11 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.cls_cnt = (int32_t*)post_cls_cnt.ptr; b.cls_nz = (int32_t*)post_cls_nz.ptr; b.read_nz = (int32_t*)post_read_nz.ptr;
 	b.zc = (unsigned long long*)post_sort_tmp.ptr; b.kpos = (int32_t*)post_sort_perm.ptr; b.u_loc = (int32_t*)post_uloc.ptr;
 	b.wtask = (int32_t*)post_wtask.ptr; b.wtask_order = b.wtask + (size_t)std::max<int64_t>(cap_post_reads, 16) * N_TREE_CLASSES;
+	{
+		const size_t cap = (size_t)cap_post_n / 64 + (size_t)cap_post_reads + 64;
+		b.stask[0] = post_levels ? (int4*)post_stask.ptr : nullptr; b.stask[1] = b.stask[0] ? b.stask[0] + cap : nullptr;
+		b.stask_order = b.stask[0] ? (int32_t*)(b.stask[0] + 2 * cap) : nullptr;
+	}
 	b.walk_grid_waves = n_cu * 4 * 8;
 	if (const char *v = getenv("MM2GB_WALK_WAVES")) b.walk_grid_waves = std::max(4, atoi(v));
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;

@@ -30,7 +30,7 @@ struct PostBatch {
 	unsigned long long *u_out; // chains, read by read, in output order (lchain.c:145: score << 32 | count)
 	uint4    *a_out;           // compacted anchors, read by read (lchain.c:78-111)
 	int64_t  *totals;          // [0] chains [1] anchors kept
-	int32_t  *cursor;          // work cursors: [0] reads of the sort [1] of the emit [2] of the classes [3] of the partition [4] walk tasks taken [5] walk tasks made
+	int32_t  *cursor;          // work cursors: [0] reads of the sort [1] of the emit [2] of the classes [3] of the partition [4] walk tasks taken [5] walk tasks made [6] of the collection [8 + level] sort tasks of a level [16 + level] taken (32 words)
 	int32_t  *order;           // n_reads: reads, largest first (the kernel ends with its longest read: start those first)
 	int32_t  *size_bins;       // 2 x N_SIZE_CLASSES: reads per size class (eight classes per power of two), and the fill cursors of the scatter
 	int       min_cnt, min_sc, max_drop;
@@ -51,6 +51,10 @@ struct PostBatch {
 	                           // (endslot: by sorted position, the chain slot of the chain that candidate ended, -1 none: n entries of 4 bytes in the read's own part of z, whose candidates live in zc by then)
 	int32_t  *u_loc;           // per chain slot: where the chain's anchors start in the read's picked[]
 	int32_t  *wtask, *wtask_order;   // up to n_reads x N_TREE_CLASSES each: read << 4 | class of every pair with candidates; the same, most candidates first
+	// The sort by LEVELS (round 6): every run of more than 64 candidates that needs a radix pass is a task of its level's launch (k_post_sort_level)
+	// -- the host's recursion bucket by bucket (ksort.h:140-145), breadth first over the whole batch -- instead of one wave sorting a read from top to bottom
+	int4     *stask[2];        // two lists (a level reads one and fills the other): read, first candidate, length, key byte's shift; counts in cursor[8 + level], work cursors in cursor[16 + level]
+	int32_t  *stask_order;     // the tasks of the level that runs, longest first
 	int       walk_grid_waves; // waves of k_post_walk (it holds no LDS: more fit than of the sort)
 	long long *dbg_tasks;      // optional (MM2GB_DEBUG_PHASES): per walk task (in the order taken) 4 values: start tick, end tick, read << 4 | class, candidates
 };

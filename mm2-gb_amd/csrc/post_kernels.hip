@@ -17,6 +17,8 @@
 //                   compacted anchors written to their final place
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <limits.h>
 #include <algorithm>
 #include <rocprim/device/device_segmented_radix_sort.hpp>   // the (strip, index) order of the RMQ fill's inner windows: a plain segmented key sort
@@ -528,11 +530,78 @@ __device__ __forceinline__ bool one_radix_pass(typename E::T *g, int lo, int hi,
 	else return radix_pass<E>(g, lo, hi, shift, L, dbg);
 }
 
-template <class E, bool BYTES = false>
-__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L, long long *dbg = nullptr, const SortScratch *sc = nullptr)
+// One level of the sort over g[0, n): runs of equal key >> (shift + 8) (at the top level the whole array is one run by construction).  The
+// array is taken 64 elements at a time from the start of a run: a run that does not end within them is a LONG run -- long_run(first, end) is
+// called for it (the radix pass on this byte, now or as a task of its own) --; otherwise ALL the runs that end within the 64 are
+// insertion-sorted together -- every lane ranks its element among those of its own run -- with one load and one store for the lot (short runs
+// are many: one round trip each would be the whole cost).  Returns the number of such groups that had to be reordered.
+template <class E, class LongRun>
+__device__ __forceinline__ int sort_level(typename E::T *g, int n, int shift, LongRun &&long_run)
 {
-	if (n <= 1) return;
-	if (n <= SMALL_RUN) { small_run_sort<E>(g, 0, n); return; }
+	const int l = lane();
+	int d_small = 0;
+	int pos = 0;
+	while (pos < n) {
+		const int i = pos + l, n_in = min(W, n - pos);
+		const bool in = i < n;
+		const typename E::T e = g[in ? i : n - 1];
+		const unsigned long long k = E::key(e);
+		const unsigned long long pk = shift < 56 ? k >> (shift + 8) : 0;
+		const bool has_after = pos + W < n;
+		const unsigned long long pk_after = has_after && shift < 56 ? E::key(g[pos + W]) >> (shift + 8) : 0;
+		const unsigned long long pk_prev = shfl_up64(pk, 1), k_prev = shfl_up64(k, 1);
+		const bool start = in && (l == 0 || pk != pk_prev);
+		const unsigned long long starts = __ballot(start);
+		const bool tail_open = has_after && pk_after == readlane64(pk, n_in - 1);   // the last run goes on beyond these 64
+		if (tail_open && (starts & (starts - 1)) == 0) {
+			// a single run of more than 64 elements: where it ends
+			const unsigned long long pk0 = readlane64(pk, 0);
+			int q = pos + W, adv;
+			do {
+				// four blocks of 64 per round trip (a run of 25 000 elements is 400 of them)
+				unsigned long long pk4[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const int i2 = q + u * W + l; pk4[u] = i2 < n && shift < 56 ? E::key(g[i2]) >> (shift + 8) : 0; }
+				adv = W;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					if (adv == W) {
+						const int i2 = q + l;
+						const unsigned long long out = __ballot(i2 >= n || pk4[u] != pk0);
+						adv = ((unsigned)out | (unsigned)(out >> 32)) ? first_set(out) : W;
+						q += adv;
+					}
+				}
+			} while (adv == W);
+			long_run(pos, q);
+			pos = q;
+			continue;
+		}
+		const int end_c = tail_open ? 63 - first_set_from_top(starts) : n_in;   // the open run (if any) starts the next 64
+		const int rs = 63 - __clzll(starts & ((2ull << l) - 1));                // where this lane's run starts
+		const bool act = l < end_c;
+		if (__ballot(act && !start && k < k_prev) != 0) {
+			int rank = 0;
+			for (int m = 0; m < end_c; ++m) {
+				const unsigned long long km = readlane64(k, m);
+				const int rsm = __builtin_amdgcn_readlane(rs, m);
+				rank += (rsm == rs) & ((km < k) | ((km == k) & (m < l)));
+			}
+			wave_sync();
+			if (act) g[pos + rs + rank] = e;
+			++d_small;
+		}
+		wave_sync();
+		pos += end_c;
+	}
+	wave_sync();
+	return d_small;
+}
+
+// the highest key byte in which any two of g[0, n) differ (the sort starts there: passes on bytes in which all keys agree move nothing), -8 if none
+template <class E>
+__device__ __forceinline__ int top_byte_shift(const typename E::T *g, int n)
+{
 	const int l = lane();
 	unsigned long long any = 0, all = ~0ull;
 	for (int base = 0; base < n; base += 8 * W) {           // (eight loads in flight per lane: a wave on its own pays every round trip in full)
@@ -547,71 +616,25 @@ __device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds 
 		all &= (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)all, off) | (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(all >> 32), off) << 32;
 	}
 	const unsigned long long diff = any ^ all;
-	if (diff == 0) return;
+	if (diff == 0) return -8;
 	int top = 56;
 	while (top > 0 && ((diff >> top) & 255) == 0) top -= 8;
+	return top;
+}
+
+template <class E, bool BYTES = false>
+__device__ __forceinline__ void sort_like_host(typename E::T *g, int n, PassLds &L, long long *dbg = nullptr, const SortScratch *sc = nullptr)
+{
+	if (n <= 1) return;
+	if (n <= SMALL_RUN) { small_run_sort<E>(g, 0, n); return; }
+	const int top = top_byte_shift<E>(g, n);
+	if (top < 0) return;
 	long long tlev = dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0, d_pass = 0, d_elems = 0, d_small = 0;
 	for (int shift = top; shift >= 0; shift -= 8) {
-		// runs of equal key >> (shift + 8); at the top level the whole array is one run by construction.  The array is taken 64
-		// elements at a time from the start of a run: a run that does not end within them gets its radix pass; otherwise ALL the
-		// runs that end within them are insertion-sorted together -- every lane ranks its element among those of its own run --
-		// with one load and one store for the lot (short runs are many: one round trip each would be the whole cost).
-		int pos = 0;
-		while (pos < n) {
-			const int i = pos + l, n_in = min(W, n - pos);
-			const bool in = i < n;
-			const typename E::T e = g[in ? i : n - 1];
-			const unsigned long long k = E::key(e);
-			const unsigned long long pk = shift < 56 ? k >> (shift + 8) : 0;
-			const bool has_after = pos + W < n;
-			const unsigned long long pk_after = has_after && shift < 56 ? E::key(g[pos + W]) >> (shift + 8) : 0;
-			const unsigned long long pk_prev = shfl_up64(pk, 1), k_prev = shfl_up64(k, 1);
-			const bool start = in && (l == 0 || pk != pk_prev);
-			const unsigned long long starts = __ballot(start);
-			const bool tail_open = has_after && pk_after == readlane64(pk, n_in - 1);   // the last run goes on beyond these 64
-			if (tail_open && (starts & (starts - 1)) == 0) {
-				// a single run of more than 64 elements: where it ends
-				const unsigned long long pk0 = readlane64(pk, 0);
-				int q = pos + W, adv;
-				do {
-					// four blocks of 64 per round trip (a run of 25 000 elements is 400 of them)
-					unsigned long long pk4[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) { const int i2 = q + u * W + l; pk4[u] = i2 < n && shift < 56 ? E::key(g[i2]) >> (shift + 8) : 0; }
-					adv = W;
-#pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						if (adv == W) {
-							const int i2 = q + l;
-							const unsigned long long out = __ballot(i2 >= n || pk4[u] != pk0);
-							adv = ((unsigned)out | (unsigned)(out >> 32)) ? first_set(out) : W;
-							q += adv;
-						}
-					}
-				} while (adv == W);
-				one_radix_pass<E, BYTES>(g, pos, q, shift, L, sc, dbg ? dbg + 24 + 6 * min((top - shift) / 8, 2) : nullptr);
-				++d_pass; d_elems += q - pos;
-				pos = q;
-				continue;
-			}
-			const int end_c = tail_open ? 63 - first_set_from_top(starts) : n_in;   // the open run (if any) starts the next 64
-			const int rs = 63 - __clzll(starts & ((2ull << l) - 1));                // where this lane's run starts
-			const bool act = l < end_c;
-			if (__ballot(act && !start && k < k_prev) != 0) {
-				int rank = 0;
-				for (int m = 0; m < end_c; ++m) {
-					const unsigned long long km = readlane64(k, m);
-					const int rsm = __builtin_amdgcn_readlane(rs, m);
-					rank += (rsm == rs) & ((km < k) | ((km == k) & (m < l)));
-				}
-				wave_sync();
-				if (act) g[pos + rs + rank] = e;
-				++d_small;
-			}
-			wave_sync();
-			pos += end_c;
-		}
-		wave_sync();
+		d_small += sort_level<E>(g, n, shift, [&](int first, int end) {
+			one_radix_pass<E, BYTES>(g, first, end, shift, L, sc, dbg ? dbg + 24 + 6 * min((top - shift) / 8, 2) : nullptr);
+			++d_pass; d_elems += end - first;
+		});
 		if (dbg && lane() == 0) {
 			const long long tn = (long long)__builtin_amdgcn_s_memrealtime();
 			const int lvl = (top - shift) / 8;
@@ -1103,6 +1126,101 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort(PostBatch b, int team_reads) { post_chains_body<true>(b, team_reads); }
 
 // --------------------------------------------------------------------------------------------------------------
+// The sort by levels (round 6).  k_post_collect: a read's candidates, in index order (lchain.c:35-41); a read of more than 64 candidates whose
+// scores differ becomes the first task.  k_post_sort_level: one wave per task -- the radix pass of a run on its key byte (on the next byte down
+// while all keys share it: such a pass moves nothing), then the run's buckets: those of more than 64 elements are the next level's tasks, the
+// others are insertion-sorted on the spot (rs_sort's recursion, ksort.h:140-145: buckets are sorted independently of each other, so any order
+// of the tasks gives the host's result).  Tasks are taken longest first.
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(POST_THREADS) void k_post_collect(PostBatch b)
+{
+	const int l = lane();
+	for (;;) {
+		int q = 0;
+		if (l == 0) q = atomicAdd(b.cursor + 6, 1);
+		q = uni(q);
+		if (q >= b.n_reads) break;
+		const int r = uni(b.order[q]);
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		unsigned long long *z = b.z + off;
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		unsigned any = 0, all = ~0u;
+		const int n_z = post_collect(b, b.f + off, z, 0, n, 0, true, any, all);
+		for (int o = W / 2; o > 0; o >>= 1) { any |= __shfl_xor(any, o); all &= __shfl_xor(all, o); }
+		wave_sync();
+		if (l == 0) {
+			b.read_nz[r] = n_z;
+			if (b.dbg) { atomicAdd((unsigned long long*)&b.dbg[0], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - t0)); atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z); }
+		}
+		const unsigned diff = uni((int)(any ^ all));
+		if (n_z > SMALL_RUN) {
+			if (diff != 0) {
+				int top = 24;                                      // of the key = the score: byte 3 .. 0 (sort_like_host's `top`)
+				while (top > 0 && ((diff >> top) & 255u) == 0) top -= 8;
+				if (l == 0) b.stask[0][atomicAdd(b.cursor + 8, 1)] = make_int4(r, 0, n_z, top);
+			}
+		} else if (n_z > 1) small_run_sort<ZElem>(z, 0, n_z);
+		wave_sync();
+	}
+}
+
+__global__ __launch_bounds__(256) void k_post_stask_count(PostBatch b, int level)
+{
+	const int n_t = b.cursor[8 + level];
+	const int4 *list = b.stask[level & 1];
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) atomicAdd(&b.size_bins[size_class(list[t].z)], 1);
+}
+__global__ __launch_bounds__(256) void k_post_stask_scatter(PostBatch b, int level)
+{
+	const int n_t = b.cursor[8 + level];
+	const int4 *list = b.stask[level & 1];
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) b.stask_order[atomicAdd(&b.size_bins[N_SIZE_CLASSES + size_class(list[t].z)], 1)] = t;
+}
+
+__global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort_level(PostBatch b, int level)
+{
+	__shared__ PassLds lds[POST_THREADS / W];
+	PassLds &L = lds[threadIdx.x / W];
+	const int l = lane();
+	const int n_t = b.cursor[8 + level];
+	const int4 *list = b.stask[level & 1];
+	int4 *next = b.stask[(level + 1) & 1];
+	const int lvl = level < 3 ? level : 2;
+	for (;;) {
+		int q = 0;
+		if (l == 0) q = atomicAdd(b.cursor + 16 + level, 1);
+		q = uni(q);
+		if (q >= n_t) break;
+		const int4 t = list[uni(b.stask_order[q])];
+		const int r = uni(t.x), lo = uni(t.y), len = uni(t.z);
+		const int64_t off = b.offsets[r];
+		unsigned long long *g = b.z + off + lo;
+		const SortScratch sc = { b.sort_s + off + lo, b.sort_perm + off + lo, b.sort_tmp + off + lo };
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+		int shift = uni(t.w);
+		bool moved = false;
+		for (; shift >= 0 && !moved; shift -= 8) moved = one_radix_pass<ZElem, true>(g, 0, len, shift, L, &sc, b.dbg ? b.dbg + 24 + 6 * lvl : nullptr);
+		// (shift is now one byte below the pass that moved the run)
+		int d_small = 0;
+		if (moved && shift >= 0)
+			d_small = sort_level<ZElem>(g, len, shift, [&](int first, int end) {
+				if (l == 0) next[atomicAdd(b.cursor + 8 + level + 1, 1)] = make_int4(r, lo + first, end - first, shift);
+			});
+		if (b.dbg && l == 0) {
+			const long long t1 = (long long)__builtin_amdgcn_s_memrealtime();
+			atomicAdd((unsigned long long*)&b.dbg[13 + lvl], (unsigned long long)(t1 - t0));
+			atomicAdd((unsigned long long*)&b.dbg[1], (unsigned long long)(t1 - t0));
+			atomicMax((unsigned long long*)&b.dbg[4], (unsigned long long)(t1 - t0));
+			atomicAdd((unsigned long long*)&b.dbg[17], 1ull);
+			atomicAdd((unsigned long long*)&b.dbg[18], (unsigned long long)len);
+			atomicAdd((unsigned long long*)&b.dbg[19], (unsigned long long)d_small);
+		}
+		wave_sync();
+	}
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // The walks shared out by tree (round 6).  k_post_classes: every anchor's class -- a hash of the root of its tree -- by one pass over the read in
 // index order (a predecessor always lies before its anchor): 64 anchors per step, predecessors inside the 64 resolved by pointer jumping
 // between lanes, the most recent classes kept in LDS (most predecessors are near), older ones read back from memory.  k_post_partition: a read's
@@ -1382,16 +1500,51 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_emit(PostBatch b)
 		}
 		wave_sync();
 		sort_like_host<HElem>(heads, n_u, L);
-		// chains in that order; each chain's anchors from its first to its last (picked[] holds them last to first)
+		// chains in that order; each chain's anchors from its first to its last (picked[] holds them last to first).  64 chains at a time: their
+		// records and counts with all lanes (one round trip for the lot, not one per chain); chains of 64 anchors or more are then copied by the
+		// whole wave, four blocks of 64 in flight; the others -- a repeat's chains of a dozen anchors, hundreds per read -- share the wave: output
+		// positions are dealt to the lanes in order, a lane finds its chain by bisection over the lanes' running counts
+		wave_sync();
 		int out_at = 0;
-		for (int c = 0; c < n_u; ++c) {
-			const ulonglong2 h = heads[c];
+		for (int cb = 0; cb < n_u; cb += W) {
+			const int c = cb + l;
+			const bool in = c < n_u;
+			const ulonglong2 h = heads[in ? c : n_u - 1];
 			const int k0 = (int)(h.y >> 32), ci = (int)(unsigned)h.y;
 			const unsigned long long u = u_tmp[ci];
-			const int cnt = (int)(unsigned)u;
-			if (l == 0) u_out[c] = u;
-			for (int j = l; j < cnt; j += W) a_out[out_at + j] = raw[picked[k0 + (cnt - 1 - j)]];
-			out_at += cnt;
+			const int cnt = in ? (int)(unsigned)u : 0, small = cnt < W ? cnt : 0;
+			if (in) u_out[c] = u;
+			int inc = cnt, sinc = small;
+			for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o), sv = __shfl_up(sinc, o); if (l >= o) { inc += v; sinc += sv; } }
+			const int at = out_at + inc - cnt;                       // where this lane's chain goes
+			// the long ones
+			unsigned long long big = __ballot(cnt >= W);
+			while (((unsigned)big | (unsigned)(big >> 32)) != 0) {
+				const int src = first_set(big);
+				big &= big - 1;
+				const int bk = __builtin_amdgcn_readlane(k0, src), bc = __builtin_amdgcn_readlane(cnt, src), ba = __builtin_amdgcn_readlane(at, src);
+				for (int j0 = 0; j0 < bc; j0 += 4 * W) {
+					int from[4];
+					uint4 a4[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { const int j = j0 + q * W + l; from[q] = picked[bk + (bc - 1 - min(j, bc - 1))]; }
+#pragma unroll
+					for (int q = 0; q < 4; ++q) a4[q] = raw[from[q]];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { const int j = j0 + q * W + l; if (j < bc) a_out[ba + j] = a4[q]; }
+				}
+			}
+			// the short ones
+			const int total_small = __builtin_amdgcn_readlane(sinc, W - 1);
+			for (int p0 = 0; p0 < total_small; p0 += W) {
+				const int pp = p0 + l;
+				int lo = 0, hi = W - 1;                               // first lane whose running count of short-chain anchors exceeds pp
+#pragma unroll
+				for (int it = 0; it < 6; ++it) { const int mid = (lo + hi) >> 1; const int v = __shfl(sinc, mid); if (v <= pp) lo = mid + 1; else hi = mid; }
+				const int sk = __shfl(k0, lo), sc2 = __shfl(small, lo), sa = __shfl(at, lo), before = __shfl(sinc, lo) - sc2;
+				if (pp < total_small) { const int j = pp - before; a_out[sa + j] = raw[picked[sk + (sc2 - 1 - j)]]; }
+			}
+			out_at += __builtin_amdgcn_readlane(inc, W - 1);
 		}
 		if (b.dbg && l == 0) atomicAdd((unsigned long long*)&b.dbg[3], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - t0));
 	}
@@ -3034,37 +3187,50 @@ void launch_gen_regs(const RegBatch &b, hipStream_t s)
 void launch_post(const PostBatch &b, hipStream_t s)
 {
 	if (b.n_reads <= 0) return;
-	(void)hipMemsetAsync(b.cursor, 0, 8 * sizeof(int32_t), s);
+	// MM2GB_DEBUG_LAUNCH=1: wait after every launch and say which one it was (finding a kernel that does not come back)
+	static const bool step = [] { const char *v = getenv("MM2GB_DEBUG_LAUNCH"); return v && *v && *v != '0'; }();
+	auto done = [&](const char *what) { if (step) { fprintf(stderr, "[mm2gb post-pass] %s ...", what); const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e)); } };
+	(void)hipMemsetAsync(b.cursor, 0, 32 * sizeof(int32_t), s);
 	(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
 	const unsigned rgrid = (unsigned)((b.n_reads + 255) / 256);
-	hipLaunchKernelGGL(k_post_size_count, dim3(rgrid), dim3(256), 0, s, b);
-	hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b);
-	hipLaunchKernelGGL(k_post_size_scatter, dim3(rgrid), dim3(256), 0, s, b);
+	hipLaunchKernelGGL(k_post_size_count, dim3(rgrid), dim3(256), 0, s, b); done("k_post_size_count");
+	hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b); done("k_post_size_bases");
+	hipLaunchKernelGGL(k_post_size_scatter, dim3(rgrid), dim3(256), 0, s, b); done("k_post_size_scatter");
 	const int64_t waves = (int64_t)b.grid_waves;
 	unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
 	if (b.team_reads > 0) grid = (unsigned)std::max<int64_t>(grid, std::min<int64_t>(b.team_reads, (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));   // a workgroup per team read
 	const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n + 255) / 256, 256 * 64));
-	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0);
-	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1);
+	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0); done("k_post_lift");
+	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1); done("k_post_lift");
 	if (b.cls) {
 		// split form (round 6): sort | classes of the trees | candidates dealt to their classes | walks per (read, class)
 		(void)hipMemsetAsync(b.n_u, 0, (size_t)b.n_reads * sizeof(int32_t), s);
 		(void)hipMemsetAsync(b.n_kept, 0, (size_t)b.n_reads * sizeof(int32_t), s);
-		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b);
-		hipLaunchKernelGGL(k_post_sort, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads);
-		hipLaunchKernelGGL(k_post_partition, dim3(grid), dim3(POST_THREADS), 0, s, b);
+		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_classes");
+		if (b.stask[0]) {
+			hipLaunchKernelGGL(k_post_collect, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_collect");
+			for (int level = 0; level < 4; ++level) {           // key bytes 3 .. 0 of the score
+				(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
+				hipLaunchKernelGGL(k_post_stask_count, dim3(256), dim3(256), 0, s, b, level); done("k_post_stask_count");
+				hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b); done("k_post_size_bases");
+				hipLaunchKernelGGL(k_post_stask_scatter, dim3(256), dim3(256), 0, s, b, level); done("k_post_stask_scatter");
+				hipLaunchKernelGGL(k_post_sort_level, dim3((unsigned)std::max<int64_t>(1, ((int64_t)b.grid_waves + POST_THREADS / W - 1) / (POST_THREADS / W))), dim3(POST_THREADS), 0, s, b, level); done("k_post_sort_level");
+			}
+		} else
+		hipLaunchKernelGGL(k_post_sort, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads); done("k_post_sort");
+		hipLaunchKernelGGL(k_post_partition, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_partition");
 		(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
 		const unsigned tgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + 255) / 256, 1024));
-		hipLaunchKernelGGL(k_post_task_count, dim3(tgrid), dim3(256), 0, s, b);
-		hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b);
-		hipLaunchKernelGGL(k_post_task_scatter, dim3(tgrid), dim3(256), 0, s, b);
+		hipLaunchKernelGGL(k_post_task_count, dim3(tgrid), dim3(256), 0, s, b); done("k_post_task_count");
+		hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b); done("k_post_size_bases");
+		hipLaunchKernelGGL(k_post_task_scatter, dim3(tgrid), dim3(256), 0, s, b); done("k_post_task_scatter");
 		const int64_t wwaves = std::max<int64_t>(b.walk_grid_waves, 4);
 		const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + POST_THREADS / W - 1) / (POST_THREADS / W), (wwaves + POST_THREADS / W - 1) / (POST_THREADS / W)));
-		hipLaunchKernelGGL(k_post_walk, dim3(wgrid), dim3(POST_THREADS), 0, s, b);
+		hipLaunchKernelGGL(k_post_walk, dim3(wgrid), dim3(POST_THREADS), 0, s, b); done("k_post_walk");
 	} else
-	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads);
-	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b);
-	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b);
+	hipLaunchKernelGGL(k_post_chains, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads); done("k_post_chains");
+	hipLaunchKernelGGL(k_post_scan, dim3(1), dim3(1024), 0, s, b); done("k_post_scan");
+	hipLaunchKernelGGL(k_post_emit, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_emit");
 }
 
 size_t rmq_strip_sort_temp_bytes(int64_t n, int64_t n_reads)
