@@ -85,7 +85,7 @@ struct Engine {
 	DevBuf lut, dbg;
 	// device post-pass (post_kernels.hip), allocated on first use: 41 B/anchor of work arrays (candidates 8, walk records 8, picked 4, two lifting tables 8, the sort's bytes / permutation / way station 13), + chains' arrays, + outputs
 	int64_t cap_post_n = 0, cap_post_reads = 0;
-	DevBuf post_dbg_reads, post_dbg_tasks, rmq_dbg_reads, rmq_skey_in, rmq_skey, rmq_sa, rmq_srange, rmq_sort_tmp, post_z, post_fp, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, post_sort_s, post_sort_perm, post_sort_tmp, post_cls, post_cls_cnt, post_cls_nz, post_read_nz, post_uloc, post_wtask, post_stask, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
+	DevBuf post_dbg_reads, post_dbg_tasks, post_dbg_stasks, rmq_dbg_reads, rmq_skey_in, rmq_skey, rmq_sa, rmq_srange, rmq_sort_tmp, post_z, post_fp, post_picked, post_utmp, post_heads, post_nu, post_nkept, post_misc, post_bins, post_order, post_up4, post_up16, post_sort_s, post_sort_perm, post_sort_tmp, post_cls, post_cls_cnt, post_cls_nz, post_read_nz, post_uloc, post_wtask, post_stask, rmq_tied, rmq_sum, rmq_by_y, rmq_ord, rmq_meta, rmq_win, rmq_tree, reg_out;
 	DevBuf sd_seeds, sd_seed_off, sd_hit_off, sd_hits, sd_qlen, sd_q_rank, sd_ref_len, sd_ref_rank, sd_seed_read, sd_tmp, sd_n_kept, sd_a_off, sd_out;   // mm2gb_collect_seeds_gpu
 	// what the post-pass leaves for the host, two sets: the boundary keeps two batches in flight (the results of batch k are
 	// fetched after batch k+1 has been launched)
@@ -97,6 +97,7 @@ struct Engine {
 	DevBuf &post_uoff = post_out[0].u_off, &post_aoff = post_out[0].a_off, &post_uout = post_out[0].u_out, &post_aout = post_out[0].a_out;
 	int64_t *&h_post_totals = post_out[0].h_totals;
 	hipEvent_t post0 = nullptr, post1 = nullptr;
+	hipEvent_t post_fork = nullptr, post_join = nullptr;   // the classes' pass on the second compute stream beside the lifting tables' (engines with streams of their own)
 	IoSet io[2];
 	uint64_t io_seq = 0;
 	PinnedBuf h_slice_off;                 // per-slice read offsets of mm2gb_score_host

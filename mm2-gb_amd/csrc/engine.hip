@@ -452,7 +452,7 @@ void Engine::shutdown()
 	h_slice_off.release(); h_res_f.release(); h_res_p.release();
 	for (hipEvent_t &e : slice_in) if (e) (void)hipEventDestroy(e);
 	slice_in.clear();
-	for (DevBuf *b : { &post_dbg_reads, &post_dbg_tasks, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &post_cls, &post_cls_cnt, &post_cls_nz, &post_read_nz, &post_uloc, &post_wtask, &post_stask, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
+	for (DevBuf *b : { &post_dbg_reads, &post_dbg_tasks, &post_dbg_stasks, &rmq_dbg_reads, &rmq_skey_in, &rmq_skey, &rmq_sa, &rmq_srange, &rmq_sort_tmp, &post_z, &post_fp, &post_picked, &post_utmp, &post_heads, &post_nu, &post_nkept, &post_misc, &post_bins, &post_order, &post_up4, &post_up16, &post_sort_s, &post_sort_perm, &post_sort_tmp, &post_cls, &post_cls_cnt, &post_cls_nz, &post_read_nz, &post_uloc, &post_wtask, &post_stask, &rmq_tied, &rmq_sum, &rmq_by_y, &rmq_ord, &rmq_meta, &rmq_win, &rmq_tree, &reg_out,
 	                   &sd_seeds, &sd_seed_off, &sd_hit_off, &sd_hits, &sd_qlen, &sd_q_rank, &sd_ref_len, &sd_ref_rank, &sd_seed_read, &sd_tmp, &sd_n_kept, &sd_a_off, &sd_out,
 	                   &post_out[0].u_off, &post_out[0].a_off, &post_out[0].u_out, &post_out[0].a_out, &post_out[1].u_off, &post_out[1].a_off, &post_out[1].u_out, &post_out[1].a_out })
 		b->release();
@@ -461,7 +461,7 @@ void Engine::shutdown()
 		po.h_totals = nullptr;
 		if (po.done) { (void)hipEventDestroy(po.done); po.done = nullptr; }
 	}
-	for (hipEvent_t *e : { &post0, &post1, &rmq_fill_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+	for (hipEvent_t *e : { &post0, &post1, &post_fork, &post_join, &rmq_fill_done }) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
 	pinned_free(h_small);
 	h_small = nullptr;
 	if (lean_streams) { s_in = nullptr; work[1].stream = nullptr; }
@@ -578,6 +578,7 @@ int Engine::reserve_post(int64_t n, int64_t n_reads)
 		if (!po.done) MM2GB_HIP(hipEventCreateWithFlags(&po.done, hipEventDisableTiming));
 	}
 	for (hipEvent_t *e : { &post0, &post1 }) if (!*e) MM2GB_HIP(hipEventCreate(e));
+	for (hipEvent_t *e : { &post_fork, &post_join }) if (!*e) MM2GB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
 	if (n <= cap_post_n && n_reads <= cap_post_reads) return 0;
 	// Only the WORK arrays of the post kernels live here: they are dead once the kernels of the batch that used them have run, so
 	// waiting for the compute stream is all it takes to move them.  What a batch leaves for the host (PostOut) is sized by
@@ -655,6 +656,8 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 		MM2GB_HIP(hipMemsetAsync(post_dbg_tasks.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 32, stream));
 	}
 	b.dbg_tasks = debug_phases ? (long long*)post_dbg_tasks.ptr : nullptr;
+	if (debug_phases && post_dbg_stasks.ensure((size_t)262144 * 32)) return -1;
+	b.dbg_stasks = debug_phases ? (long long*)post_dbg_stasks.ptr : nullptr;
 	b.min_cnt = misc.min_cnt; b.min_sc = misc.min_score;
 	b.max_drop = misc.is_cdna ? INT_MAX : misc.bw;                    // lchain.c:151,162
 	if (rmq) { b.min_cnt = rmq->min_cnt; b.min_sc = rmq->min_sc; b.max_drop = rmq->bw; }   // lchain.c:253,355
@@ -670,7 +673,7 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	b.team_reads = n_reads <= (int64_t)n_cu * 3 ? (int)n_reads : 64;
 	if (const char *v = getenv("MM2GB_POST_TEAM_READS")) b.team_reads = std::max(0, atoi(v));
 	MM2GB_HIP(hipEventRecord(post0, stream));
-	launch_post(b, stream);
+	launch_post(b, stream, !lean_streams && work[1].stream && work[1].stream != stream ? work[1].stream : nullptr, post_fork, post_join);
 	MM2GB_HIP(hipEventRecord(post1, stream));
 	MM2GB_HIP(hipMemcpyAsync(po.h_totals, post_misc.ptr, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 	MM2GB_HIP(hipEventRecord(po.done, stream));
@@ -1311,7 +1314,7 @@ int mm2gb_chain_gpu(mm2gb_engine_t *eng, int64_t n_reads, const int64_t *offsets
 // MM2GB_DEBUG_PHASES: what the last post-pass kernel recorded (to stderr)
 void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 {
-	long long t[48] = { 0 };
+	long long t[64] = { 0 };
 	if (hipMemcpy(t, (char*)post_misc.ptr + 1024, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
 		for (int lv = 0; lv < 3; ++lv)
 			fprintf(stderr, "[mm2gb post-pass] sort level %d: %.1f ms; %lld radix passes over %lld elements: %lld cycles, %lld steps, refills of one line %lld, of all lines %lld\n",
@@ -1349,6 +1352,24 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 			fprintf(stderr, "    reads in flight at %d points of the kernel's time:", n_bins);
 			for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
 			fprintf(stderr, "\n");
+		}
+	}
+	if (t[42] > 0 && post_dbg_stasks.ptr) {
+		const size_t n_t = (size_t)std::min<long long>(t[42], 262144);
+		std::vector<long long> tk(n_t * 4);
+		if (hipMemcpy(tk.data(), post_dbg_stasks.ptr, tk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			for (int lv = 0; lv < 4; ++lv) {
+				std::vector<size_t> idx;
+				long long first = LLONG_MAX, last = 0, sum = 0;
+				for (size_t k = 0; k < n_t; ++k) if ((int)(tk[4 * k + 2] >> 32) == lv) { idx.push_back(k); first = std::min(first, tk[4 * k]); last = std::max(last, tk[4 * k + 1]); sum += tk[4 * k + 1] - tk[4 * k]; }
+				if (idx.empty()) continue;
+				std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b2) { return tk[4 * a + 1] - tk[4 * a] > tk[4 * b2 + 1] - tk[4 * b2]; });
+				fprintf(stderr, "[mm2gb post-pass] k_post_sort_level %d: %zu tasks, %.2f ms from the first start to the last end, %.1f ms summed; the longest (elements | start | ms):", lv, idx.size(), (last - first) / 1e5, sum / 1e5);
+				for (size_t k = 0; k < std::min<size_t>(idx.size(), 6); ++k) fprintf(stderr, "  %lld | %.2f | %.2f", tk[4 * idx[k] + 2] & 0xffffffffLL, (tk[4 * idx[k]] - first) / 1e5, (tk[4 * idx[k] + 1] - tk[4 * idx[k]]) / 1e5);
+				fprintf(stderr, "\n    tasks in flight at 14 points of its time:");
+				for (int kb = 0; kb < 14; ++kb) { const double at = first + (double)(last - first) * (kb + 0.5) / 14; int busy = 0; for (size_t k : idx) if (tk[4 * k] <= at && at < tk[4 * k + 1]) ++busy; fprintf(stderr, " %d", busy); }
+				fprintf(stderr, "\n");
+			}
 		}
 	}
 	if (t[21] > 0 && post_dbg_tasks.ptr) {

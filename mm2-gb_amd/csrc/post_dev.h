@@ -56,10 +56,12 @@ struct PostBatch {
 	int4     *stask[2];        // two lists (a level reads one and fills the other): read, first candidate, length, key byte's shift; counts in cursor[8 + level], work cursors in cursor[16 + level]
 	int32_t  *stask_order;     // the tasks of the level that runs, longest first
 	int       walk_grid_waves; // waves of k_post_walk (it holds no LDS: more fit than of the sort)
+	long long *dbg_stasks;     // optional (MM2GB_DEBUG_PHASES): per sort task (up to 262144, in the order finished; count in dbg[40]) 4 values: start tick, end tick, level << 32 | length, steps of its pass
 	long long *dbg_tasks;      // optional (MM2GB_DEBUG_PHASES): per walk task (in the order taken) 4 values: start tick, end tick, read << 4 | class, candidates
 };
 constexpr int N_TREE_CLASSES = 16;
-void launch_post(const PostBatch &b, hipStream_t s);
+// aux (may be null): a second stream for the pass that gives the anchors their classes, beside the lifting tables' (both only read the scores); fork / join: its events
+void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 
 // RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369) of reads whose anchors are already chained once: score fill on the device.
 struct RmqParams { int max_dist, max_dist_inner, bw, cap_rmq_size; float pen_gap, pen_skip; };

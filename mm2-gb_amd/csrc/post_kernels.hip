@@ -40,6 +40,13 @@ static_assert(SPEC == 4, "the walk resolution spells out four look-ahead steps")
 
 __device__ __forceinline__ int lane() { return threadIdx.x & (W - 1); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the same for LDS alone: a wave's LDS instructions execute in order, so all it takes is that the compiler keeps them in order (and that what was
+// read has arrived); outstanding global stores are NOT waited for
+__device__ __forceinline__ void lds_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void wave_sync()
 {
 	// LDS and global accesses of one wave are issued in order; the fence keeps the compiler from moving them across phases
@@ -1126,45 +1133,12 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_chai
 __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort(PostBatch b, int team_reads) { post_chains_body<true>(b, team_reads); }
 
 // --------------------------------------------------------------------------------------------------------------
-// The sort by levels (round 6).  k_post_collect: a read's candidates, in index order (lchain.c:35-41); a read of more than 64 candidates whose
-// scores differ becomes the first task.  k_post_sort_level: one wave per task -- the radix pass of a run on its key byte (on the next byte down
+// The sort by levels (round 6).  A read's candidates are collected in index order (lchain.c:35-41) by the pass over its anchors that also gives
+// them their classes (k_post_classes, below); a read of more than 64 candidates whose scores differ becomes the first task.  k_post_sort_level: one wave per task -- the radix pass of a run on its key byte (on the next byte down
 // while all keys share it: such a pass moves nothing), then the run's buckets: those of more than 64 elements are the next level's tasks, the
 // others are insertion-sorted on the spot (rs_sort's recursion, ksort.h:140-145: buckets are sorted independently of each other, so any order
 // of the tasks gives the host's result).  Tasks are taken longest first.
 // --------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(POST_THREADS) void k_post_collect(PostBatch b)
-{
-	const int l = lane();
-	for (;;) {
-		int q = 0;
-		if (l == 0) q = atomicAdd(b.cursor + 6, 1);
-		q = uni(q);
-		if (q >= b.n_reads) break;
-		const int r = uni(b.order[q]);
-		const int64_t off = b.offsets[r];
-		const int n = (int)(b.offsets[r + 1] - off);
-		unsigned long long *z = b.z + off;
-		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-		unsigned any = 0, all = ~0u;
-		const int n_z = post_collect(b, b.f + off, z, 0, n, 0, true, any, all);
-		for (int o = W / 2; o > 0; o >>= 1) { any |= __shfl_xor(any, o); all &= __shfl_xor(all, o); }
-		wave_sync();
-		if (l == 0) {
-			b.read_nz[r] = n_z;
-			if (b.dbg) { atomicAdd((unsigned long long*)&b.dbg[0], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - t0)); atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z); }
-		}
-		const unsigned diff = uni((int)(any ^ all));
-		if (n_z > SMALL_RUN) {
-			if (diff != 0) {
-				int top = 24;                                      // of the key = the score: byte 3 .. 0 (sort_like_host's `top`)
-				while (top > 0 && ((diff >> top) & 255u) == 0) top -= 8;
-				if (l == 0) b.stask[0][atomicAdd(b.cursor + 8, 1)] = make_int4(r, 0, n_z, top);
-			}
-		} else if (n_z > 1) small_run_sort<ZElem>(z, 0, n_z);
-		wave_sync();
-	}
-}
-
 __global__ __launch_bounds__(256) void k_post_stask_count(PostBatch b, int level)
 {
 	const int n_t = b.cursor[8 + level];
@@ -1215,6 +1189,10 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort
 			atomicAdd((unsigned long long*)&b.dbg[17], 1ull);
 			atomicAdd((unsigned long long*)&b.dbg[18], (unsigned long long)len);
 			atomicAdd((unsigned long long*)&b.dbg[19], (unsigned long long)d_small);
+			if (b.dbg_stasks) {
+				const unsigned long long at = atomicAdd((unsigned long long*)&b.dbg[42], 1ull);
+				if (at < 262144) { b.dbg_stasks[4 * at] = t0; b.dbg_stasks[4 * at + 1] = t1; b.dbg_stasks[4 * at + 2] = (long long)level << 32 | len; b.dbg_stasks[4 * at + 3] = 0; }
+			}
 		}
 		wave_sync();
 	}
@@ -1247,14 +1225,34 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_classes(PostBatch b)
 		const int r = uni(b.order[q]);
 		const int64_t off = b.offsets[r];
 		const int n = (int)(b.offsets[r + 1] - off);
-		const int32_t *p = b.p + off;
+		const int32_t *p = b.p + off, *f = b.f + off;
 		unsigned char *cls = b.cls + off;
+		// the same pass collects the read's candidates for the sort by levels (lchain.c:35-41: z[k] = (f[i], i) for f[i] >= min_sc, in index order)
+		const bool collect = b.stask[0] != nullptr;
+		unsigned long long *z = b.z + off;
+		int n_z = 0;
+		unsigned any = 0, all = ~0u;
+		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		if (l < N_TREE_CLASSES) cnt[l] = 0;
 		wave_sync();
-		for (int base = 0; base < n; base += W) {
+		// (the links of four blocks per round trip, asked for four blocks ahead: a block's classes wait for the block before it, its links need
+		// not -- and a wait for loads that were issued BEFORE the last blocks' stores does not wait for those stores)
+		int pn4[4], fn4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { pn4[u] = u * W + l < n ? p[u * W + l] : 0; fn4[u] = collect && u * W + l < n ? f[u * W + l] : INT_MIN; }
+		for (int base0 = 0; base0 < n; base0 += 4 * W) {
+		int pl4[4], fl4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { pl4[u] = pn4[u]; fl4[u] = fn4[u]; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const int i2 = base0 + (4 + u) * W + l; pn4[u] = i2 < n ? p[i2] : 0; fn4[u] = collect && i2 < n ? f[i2] : INT_MIN; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int base = base0 + u * W;
+			if (base >= n) break;
 			const int i = base + l;
 			const bool in = i < n;
-			const int pl = in ? p[i] : 0;
+			const int pl = pl4[u];
 			const int pred = i - pl;
 			int c = tree_class(i);                                 // a root's own
 			bool known = !in || pl == 0;
@@ -1271,11 +1269,33 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_classes(PostBatch b)
 				const int c2 = __shfl(c, ptr), k2 = __shfl((int)known, ptr), p2 = __shfl(ptr, ptr);
 				if (!known) { if (k2) { c = c2; known = true; } else ptr = p2; }
 			}
-			wave_sync();                                           // the ring's reads before its writes
+			lds_sync();                                            // the ring's reads before its writes (the stores to memory drain behind: nothing near reads them back)
 			if (in) { cls[i] = (unsigned char)c; ring[i & (CLS_RING - 1)] = (unsigned char)c; atomicAdd(&cnt[c], 1); }
-			wave_sync();
+			lds_sync();
+			const int fi = fl4[u];
+			const bool take = in && fi >= b.min_sc;                // (never when nothing is collected: fl4 is INT_MIN then)
+			const unsigned long long m = __ballot(take);
+			if (take) { any |= (unsigned)fi; all &= (unsigned)fi; z[n_z + __popcll(m & ((1ull << l) - 1))] = (unsigned long long)(unsigned)fi << 32 | (unsigned)i; }
+			n_z += __popcll(m);
 		}
+		}
+		wave_sync();
 		if (l < N_TREE_CLASSES) b.cls_cnt[(int64_t)r * N_TREE_CLASSES + l] = cnt[l];
+		if (collect) {
+			for (int o = W / 2; o > 0; o >>= 1) { any |= __shfl_xor(any, o); all &= __shfl_xor(all, o); }
+			if (l == 0) {
+				b.read_nz[r] = n_z;
+				if (b.dbg) { atomicAdd((unsigned long long*)&b.dbg[0], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - t0)); atomicAdd((unsigned long long*)&b.dbg[12], (unsigned long long)n_z); }
+			}
+			const unsigned diff = uni((int)(any ^ all));
+			if (n_z > SMALL_RUN) {
+				if (diff != 0) {
+					int top = 24;                                  // of the key = the score: byte 3 .. 0 (sort_like_host's `top`)
+					while (top > 0 && ((diff >> top) & 255u) == 0) top -= 8;
+					if (l == 0) b.stask[0][atomicAdd(b.cursor + 8, 1)] = make_int4(r, 0, n_z, top);
+				}
+			} else if (n_z > 1) small_run_sort<ZElem>(z, 0, n_z);
+		}
 		wave_sync();
 	}
 }
@@ -3184,7 +3204,7 @@ void launch_gen_regs(const RegBatch &b, hipStream_t s)
 	hipLaunchKernelGGL(k_gen_regs, dim3(grid), dim3(POST_THREADS), 0, s, b);
 }
 
-void launch_post(const PostBatch &b, hipStream_t s)
+void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux, hipEvent_t fork, hipEvent_t join)
 {
 	if (b.n_reads <= 0) return;
 	// MM2GB_DEBUG_LAUNCH=1: wait after every launch and say which one it was (finding a kernel that does not come back)
@@ -3200,15 +3220,21 @@ void launch_post(const PostBatch &b, hipStream_t s)
 	unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
 	if (b.team_reads > 0) grid = (unsigned)std::max<int64_t>(grid, std::min<int64_t>(b.team_reads, (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));   // a workgroup per team read
 	const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n + 255) / 256, 256 * 64));
+	// split form: the classes' pass (one wave per read, as long as its longest read) runs beside the lifting tables' (bandwidth) where a second stream is given
+	const bool beside = b.cls && aux && fork && join && !step && hipEventRecord(fork, s) == hipSuccess && hipStreamWaitEvent(aux, fork, 0) == hipSuccess;
+	if (beside) {
+		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, aux, b);
+		(void)hipEventRecord(join, aux);
+	}
 	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0); done("k_post_lift");
 	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1); done("k_post_lift");
 	if (b.cls) {
 		// split form (round 6): sort | classes of the trees | candidates dealt to their classes | walks per (read, class)
 		(void)hipMemsetAsync(b.n_u, 0, (size_t)b.n_reads * sizeof(int32_t), s);
 		(void)hipMemsetAsync(b.n_kept, 0, (size_t)b.n_reads * sizeof(int32_t), s);
-		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_classes");
+		if (beside) (void)hipStreamWaitEvent(s, join, 0);
+		else { hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_classes"); }
 		if (b.stask[0]) {
-			hipLaunchKernelGGL(k_post_collect, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_collect");
 			for (int level = 0; level < 4; ++level) {           // key bytes 3 .. 0 of the score
 				(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
 				hipLaunchKernelGGL(k_post_stask_count, dim3(256), dim3(256), 0, s, b, level); done("k_post_stask_count");
