@@ -652,8 +652,8 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 		if (post_dbg_reads.ensure((size_t)std::max<int64_t>(n_reads, 1) * 32)) return -1;
 		MM2GB_HIP(hipMemsetAsync(post_dbg_reads.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * 32, stream));
 		b.dbg_reads = (long long*)post_dbg_reads.ptr;
-		if (post_dbg_tasks.ensure((size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 32)) return -1;
-		MM2GB_HIP(hipMemsetAsync(post_dbg_tasks.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 32, stream));
+		if (post_dbg_tasks.ensure((size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 64)) return -1;
+		MM2GB_HIP(hipMemsetAsync(post_dbg_tasks.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * N_TREE_CLASSES * 64, stream));
 	}
 	b.dbg_tasks = debug_phases ? (long long*)post_dbg_tasks.ptr : nullptr;
 	if (debug_phases && post_dbg_stasks.ensure((size_t)262144 * 32)) return -1;
@@ -1374,20 +1374,20 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 	}
 	if (t[21] > 0 && post_dbg_tasks.ptr) {
 		const size_t n_t = (size_t)t[21];
-		std::vector<long long> tk(n_t * 4);
+		std::vector<long long> tk(n_t * 8);
 		if (hipMemcpy(tk.data(), post_dbg_tasks.ptr, tk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
 			std::vector<size_t> idx(n_t);
 			for (size_t k = 0; k < n_t; ++k) idx[k] = k;
-			std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b2) { return tk[4 * a + 1] - tk[4 * a] > tk[4 * b2 + 1] - tk[4 * b2]; });
-			fprintf(stderr, "[mm2gb post-pass] k_post_walk: the longest tasks (taken as | read | class | candidates | start | ms):\n");
+			std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b2) { return tk[8 * a + 1] - tk[8 * a] > tk[8 * b2 + 1] - tk[8 * b2]; });
+			fprintf(stderr, "[mm2gb post-pass] k_post_walk: the longest tasks (taken as | read | class | candidates | start | ms | of which look-ahead loads | long walks | how many | rounds):\n");
 			for (size_t k = 0; k < std::min<size_t>(n_t, 16); ++k) {
 				const size_t q = idx[k];
-				fprintf(stderr, "    %6zu | %6lld | %2lld | %7lld | %6.2f | %6.2f\n", q, tk[4 * q + 2] >> 4, tk[4 * q + 2] & 15, tk[4 * q + 3], (tk[4 * q] - t[22]) / 1e5, (tk[4 * q + 1] - tk[4 * q]) / 1e5);
+				fprintf(stderr, "    %6zu | %6lld | %2lld | %7lld | %6.2f | %6.2f | %6.2f | %6.2f | %lld | %lld\n", q, tk[8 * q + 2] >> 4, tk[8 * q + 2] & 15, tk[8 * q + 3], (tk[8 * q] - t[22]) / 1e5, (tk[8 * q + 1] - tk[8 * q]) / 1e5, tk[8 * q + 4] / 1e5, tk[8 * q + 5] / 1e5, tk[8 * q + 6], tk[8 * q + 7]);
 			}
 			const int n_bins = 14;
 			std::vector<int> busy(n_bins, 0);
 			const double span = std::max(1.0, (double)(t[23] - t[22]));
-			for (size_t q = 0; q < n_t; ++q) for (int k = 0; k < n_bins; ++k) { const double at = t[22] + span * (k + 0.5) / n_bins; if (tk[4 * q] <= at && at < tk[4 * q + 1]) ++busy[k]; }
+			for (size_t q = 0; q < n_t; ++q) for (int k = 0; k < n_bins; ++k) { const double at = t[22] + span * (k + 0.5) / n_bins; if (tk[8 * q] <= at && at < tk[8 * q + 1]) ++busy[k]; }
 			fprintf(stderr, "    tasks in flight at %d points of the kernel's time:", n_bins);
 			for (int k = 0; k < n_bins; ++k) fprintf(stderr, " %d", busy[k]);
 			fprintf(stderr, "\n");

@@ -886,22 +886,23 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 					// a walk that goes on: 64 anchors at a time, lane j finds the j-th anchor down the path through the lifting tables
 					// (p, p^4, p^16: at most 9 dependent loads instead of j); what the sequential loop decides step by step -- the running
 					// best prefix, the first step that ends the walk -- becomes a prefix maximum and a ballot over the wave.  It may take
-					// anchors the other lanes have looked at: they look again afterwards.
-					stale = true;
+					// anchors the other lanes have looked at: they look again afterwards -- unless the walk ended within its first round (most do):
+					// then everything it took is in registers, and the later lanes' copies of the marks are set from there as after a short walk.
 					wave_sync();
 					const long long tl = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 					++dbg_long;
 					// the first round looks at 16 anchors only: most walks that go on end within a dozen steps (the chains of a repeat), and a lane
 					// beyond the walk's end costs its loads all the same -- divergent loads are what this kernel is made of
-					int rw = W / 4;
+					int rw = W / 4, n_rounds = 0, t_first = -1, pt_first = 0;
 					while (!ended) {
-						++wd.iters;
+						++wd.iters; ++n_rounds;
 						int t = l < rw ? cur : -1;
 						for (int k = 0; k < 3; ++k) if (k < (l >> 4) && t >= 0) { const int rj = up16[t]; t = rj ? t - rj : -1; }
 						for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
 						for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = fpw[2 * t + 1] & ~TAKEN; t = rj ? t - rj : -1; }
 						const bool valid = t >= 0;
 						const int pt = valid ? fpw[2 * t + 1] & ~TAKEN : 0, next = pt ? t - pt : -1;
+						if (n_rounds == 1) { t_first = t; pt_first = pt; }
 						int s = top, m = 1;
 						if (next >= 0) { const int2 rec = fp[next]; s = top - rec.x; m = bits ? taken(next) : rec.y < 0; }
 						// best prefix BEFORE this lane's step
@@ -924,8 +925,35 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						else { visited += rw; cur = __shfl(next, rw - 1); rw = W; }
 					}
 					wave_sync();
-					if (bits) for (int q = l; q < kept; q += W) take(picked[n_v + q]);
-					else for (int q = l; q < kept; q += W) { int *w = &fpw[2 * picked[n_v + q] + 1]; *w |= TAKEN; }
+					if (n_rounds == 1 && !bits) {
+						// the first SPEC anchors it took are the look-ahead's, the others the round's (one per lane)
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							if (j < kept) {
+								const int v = j == 0 ? c0 : cn[j > 0 ? j - 1 : 0];
+								const int link = j == 0 ? __builtin_amdgcn_readlane(p0, src) : cm[j > 0 ? j - 1 : 0];
+								if (l == 0) fpw[2 * v + 1] = link | TAKEN;
+								const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
+								touched |= hit;
+								p0 |= n0 == v ? TAKEN : 0;
+#pragma unroll
+								for (int i = 0; i < SPEC; ++i) pn[i] |= nx[i] == v ? TAKEN : 0;
+							}
+						}
+						if (l < kept - SPEC) fpw[2 * t_first + 1] = pt_first | TAKEN;
+						for (int q = SPEC; q < kept; ++q) {
+							const int v = __builtin_amdgcn_readlane(t_first, q - SPEC);
+							const bool hit = (n0 == v) | (nx[0] == v) | (nx[1] == v) | (nx[2] == v) | (nx[3] == v);
+							touched |= hit;
+							p0 |= n0 == v ? TAKEN : 0;
+#pragma unroll
+							for (int i = 0; i < SPEC; ++i) pn[i] |= nx[i] == v ? TAKEN : 0;
+						}
+					} else {
+						stale = true;
+						if (bits) for (int q = l; q < kept; q += W) take(picked[n_v + q]);
+						else for (int q = l; q < kept; q += W) { int *w = &fpw[2 * picked[n_v + q] + 1]; *w |= TAKEN; }
+					}
 					if (b.dbg) dbg_longt += (long long)__builtin_amdgcn_s_memrealtime() - tl;
 				}
 				// the chain's score is the best prefix itself (lchain.c:66: f of the end minus f of where it stops)
@@ -1422,7 +1450,7 @@ __global__ __launch_bounds__(POST_THREADS, MM2GB_WALK_WAVES_PER_SIMD) void k_pos
 				atomicAdd((unsigned long long*)&b.dbg[21], 1ull);
 				atomicMin((unsigned long long*)&b.dbg[22], (unsigned long long)t0);      // first task's start (the slot is set to ~0 before the launch)
 				atomicMax((unsigned long long*)&b.dbg[23], (unsigned long long)t3);
-				if (b.dbg_tasks) { b.dbg_tasks[4 * q] = t0; b.dbg_tasks[4 * q + 1] = t3; b.dbg_tasks[4 * q + 2] = task; b.dbg_tasks[4 * q + 3] = n_zc; }
+				if (b.dbg_tasks) { b.dbg_tasks[8 * q] = t0; b.dbg_tasks[8 * q + 1] = t3; b.dbg_tasks[8 * q + 2] = task; b.dbg_tasks[8 * q + 3] = n_zc; b.dbg_tasks[8 * q + 4] = wd.load; b.dbg_tasks[8 * q + 5] = wd.longt; b.dbg_tasks[8 * q + 6] = wd.nlong; b.dbg_tasks[8 * q + 7] = wd.iters; }
 			}
 		}
 		wave_sync();
