@@ -3248,20 +3248,21 @@ void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux, hipEvent_t 
 	unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads + POST_THREADS / W - 1) / (POST_THREADS / W), (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));
 	if (b.team_reads > 0) grid = (unsigned)std::max<int64_t>(grid, std::min<int64_t>(b.team_reads, (waves + POST_THREADS / W - 1) / (POST_THREADS / W)));   // a workgroup per team read
 	const unsigned lgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n + 255) / 256, 256 * 64));
-	// split form: the classes' pass (one wave per read, as long as its longest read) runs beside the lifting tables' (bandwidth) where a second stream is given
+	// split form: only the WALKS need the lifting tables and the walks' records -- where a second stream is given, the two passes that make them
+	// (bandwidth: 24 bytes per anchor) run beside the classes' pass and the sort (waves that wait for LDS and for each other: the sort's levels
+	// end with a few long tasks and an idle chip)
 	const bool beside = b.cls && aux && fork && join && !step && hipEventRecord(fork, s) == hipSuccess && hipStreamWaitEvent(aux, fork, 0) == hipSuccess;
-	if (beside) {
-		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, aux, b);
-		(void)hipEventRecord(join, aux);
+	{
+		hipStream_t ls = beside ? aux : s;
+		hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, ls, b, 0); done("k_post_lift");
+		hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, ls, b, 1); done("k_post_lift");
+		if (beside) (void)hipEventRecord(join, aux);
 	}
-	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 0); done("k_post_lift");
-	hipLaunchKernelGGL(k_post_lift, dim3(lgrid), dim3(256), 0, s, b, 1); done("k_post_lift");
 	if (b.cls) {
 		// split form (round 6): sort | classes of the trees | candidates dealt to their classes | walks per (read, class)
 		(void)hipMemsetAsync(b.n_u, 0, (size_t)b.n_reads * sizeof(int32_t), s);
 		(void)hipMemsetAsync(b.n_kept, 0, (size_t)b.n_reads * sizeof(int32_t), s);
-		if (beside) (void)hipStreamWaitEvent(s, join, 0);
-		else { hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_classes"); }
+		hipLaunchKernelGGL(k_post_classes, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_classes");
 		if (b.stask[0]) {
 			for (int level = 0; level < 4; ++level) {           // key bytes 3 .. 0 of the score
 				(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
@@ -3278,6 +3279,7 @@ void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux, hipEvent_t 
 		hipLaunchKernelGGL(k_post_task_count, dim3(tgrid), dim3(256), 0, s, b); done("k_post_task_count");
 		hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b); done("k_post_size_bases");
 		hipLaunchKernelGGL(k_post_task_scatter, dim3(tgrid), dim3(256), 0, s, b); done("k_post_task_scatter");
+		if (beside) (void)hipStreamWaitEvent(s, join, 0);            // the tables are there
 		const int64_t wwaves = std::max<int64_t>(b.walk_grid_waves, 4);
 		const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + POST_THREADS / W - 1) / (POST_THREADS / W), (wwaves + POST_THREADS / W - 1) / (POST_THREADS / W)));
 		hipLaunchKernelGGL(k_post_walk, dim3(wgrid), dim3(POST_THREADS), 0, s, b); done("k_post_walk");
