@@ -248,3 +248,51 @@ def test_post_pass_of_one_engine_beside_the_scores_of_another(engine):
     finally:
         for p in [d_a, d_off] + [x for pair in fp for x in pair]:
             hip.hipFree(p)
+
+
+def _chains_under(env, a, off, prm):
+    """The device post-pass of a fresh engine made under these environment settings (the form is read when an engine is made)."""
+    import os
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with mm.Engine() as e:
+            e.set_misc(misc_from(prm))
+            res, _ = e.chain_gpu(a, off)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return res
+
+
+def test_the_forms_of_the_post_pass_agree(engine):
+    """Round 6 split the post-pass: the sort level by level over the whole batch (a task per run), the walks per (read, class of trees) on
+    waves of their own, the chains put back in the host's order from their ends' sorted positions.  The earlier forms are still in the
+    library (MM2GB_POST_SORT=reads: one wave sorts a read from top to bottom; MM2GB_POST_FORM=fused: one wave sorts AND walks a read):
+    all three must give the same chains, element for element, on reads of every shape -- equal scores (the sort's order decides), repeats
+    (hundreds of trees per read), forests of single anchors, reads with one tree only."""
+    prm = orc.default_param()
+    rng = np.random.default_rng(2026)
+    parts = [sc.read_like(60_000, 3), sc.grid_ties(), sc.sort_by_x(sc.repeat_block(9000, 5, xwin=2500, ywin=3000)), sc.colinear(7000, 21), sc.noise(3000, 4),
+             sc.sort_by_x(np.concatenate([sc.repeat_block(3000, 6, xwin=300, ywin=300), sc.colinear(4000, 7)])), sc.colinear(3, 5), sc.colinear(70, 6)]
+    for _ in range(12):                                     # the fuzz batches' reads (their own parameters are not used here)
+        fa, foff, _ = sc.fuzz_case(rng)
+        parts += [fa[foff[r]:foff[r + 1]] for r in range(len(foff) - 1)]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    for kw in (dict(), dict(min_cnt=1, min_sc=15), dict(bw=100)):
+        p2 = orc.default_param(**kw)
+        engine.set_misc(misc_from(p2))
+        want, _ = engine.chain(a, off, threads=4)          # the host post-pass
+        for env in ({}, {"MM2GB_POST_SORT": "reads"}, {"MM2GB_POST_FORM": "fused"}):
+            got = _chains_under(env, a, off, p2)
+            for r in range(len(parts)):
+                assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), f"{env} {kw}: read {r}"
+    for r in (0, 1, 2, 5):
+        o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
+        got = _chains_under({}, a[off[r]:off[r + 1]], np.array([0, off[r + 1] - off[r]], dtype=np.int64), prm)
+        assert np.array_equal(got[0][0], o["u"]) and np.array_equal(got[0][1], o["a_out"])
