@@ -1365,7 +1365,11 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 				if (idx.empty()) continue;
 				std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b2) { return tk[4 * a + 1] - tk[4 * a] > tk[4 * b2 + 1] - tk[4 * b2]; });
 				fprintf(stderr, "[mm2gb post-pass] k_post_sort_level %d: %zu tasks, %.2f ms from the first start to the last end, %.1f ms summed; the longest (elements | start | ms):", lv, idx.size(), (last - first) / 1e5, sum / 1e5);
-				for (size_t k = 0; k < std::min<size_t>(idx.size(), 6); ++k) fprintf(stderr, "  %lld | %.2f | %.2f", tk[4 * idx[k] + 2] & 0xffffffffLL, (tk[4 * idx[k]] - first) / 1e5, (tk[4 * idx[k] + 1] - tk[4 * idx[k]]) / 1e5);
+				for (size_t k = 0; k < std::min<size_t>(idx.size(), 6); ++k) {
+					const long long phv = tk[4 * idx[k] + 3];
+					fprintf(stderr, "  %lld | %.2f | %.2f (histogram %.2f, set-up %.2f, walk %.2f of %lld steps, move %.2f)", tk[4 * idx[k] + 2] & 0xffffffffLL, (tk[4 * idx[k]] - first) / 1e5, (tk[4 * idx[k] + 1] - tk[4 * idx[k]]) / 1e5,
+					        (phv & 4095) * 0.01024, (phv >> 12 & 4095) * 0.01024, (phv >> 24 & 4095) * 0.01024, phv >> 48 & 0xfffff, (phv >> 36 & 4095) * 0.01024);
+				}
 				fprintf(stderr, "\n    tasks in flight at 14 points of its time:");
 				for (int kb = 0; kb < 14; ++kb) { const double at = first + (double)(last - first) * (kb + 0.5) / 14; int busy = 0; for (size_t k : idx) if (tk[4 * k] <= at && at < tk[4 * k + 1]) ++busy; fprintf(stderr, " %d", busy); }
 				fprintf(stderr, "\n");

@@ -341,8 +341,10 @@ __device__ __forceinline__ void fetch_all_byte_lines(const unsigned char *S, int
 // A run of at most LINE_STORE_BYTES elements (nearly every run below the top level: 1 800 elements on average at the lowest byte) keeps its
 // whole byte sequence in LDS: no lines, no refills, and the scan of a bucket for the elements that must move reads LDS instead of memory --
 // with 256 buckets and a few elements in each, those 256 dependent memory round trips were most of a small pass's time.
-__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr)
+__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr, long long *ph = nullptr)
 {
+	long long tp = ph ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+	auto phase = [&](int k) { if (ph) { const long long tn = (long long)__builtin_amdgcn_s_memrealtime(); ph[k] += tn - tp; tp = tn; } };
 	const int l = lane();
 	const int len = hi - lo;
 	const bool resident = len <= LINE_STORE_BYTES;
@@ -365,6 +367,7 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		}
 	}
 	wave_sync();
+	phase(0);
 	// lane l owns buckets 4l .. 4l+3
 	const int c[4] = { L.where[4 * l], L.where[4 * l + 1], L.where[4 * l + 2], L.where[4 * l + 3] };
 	if (__ballot(c[0] == len || c[1] == len || c[2] == len || c[3] == len) != 0) return false;
@@ -378,6 +381,77 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 	for (int q = 0; q < 4; ++q) full[q] = __ballot(c[q] > 0);
 	int4 *rec = (int4*)L.where;
 	int used = 0;
+	int since = 0;
+	int d_steps = 0, d_one = 0, d_all = 1, d_cycles = 0;
+	// A run too long for LDS whose keys take at most four values of this byte -- the top pass of a read: its scores span two to four values of
+	// their highest byte that differs -- needs no records and no lines: the walk's whole state is four positions, and what it reads are four
+	// sequences of bytes that it consumes front to back.  Positions live in scalar registers, the next 64 bytes of every sequence across the
+	// lanes of one vector register (a step reads one with v_readlane; 64 more are loaded when they run out): a step is a handful of scalar
+	// instructions instead of two trips to LDS behind each other (0.33 us a step before, and such passes were what a level's launch ended with).
+	const int n_full = __popcll(full[0]) + __popcll(full[1]) + __popcll(full[2]) + __popcll(full[3]);
+	const bool few = !resident && n_full <= 4;
+	if (few) {
+		int v0 = -1, v1 = -1, v2 = -1, v3 = -1, h0 = 0, h1 = 0, h2 = 0, h3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, nf = 0;
+		{
+			const int st_q[4] = { at, at + c[0], at + c[0] + c[1], at + c[0] + c[1] + c[2] };
+			unsigned long long lanes = full[0] | full[1] | full[2] | full[3];
+			while (((unsigned)lanes | (unsigned)(lanes >> 32)) != 0) {
+				const int src_l = first_set(lanes);
+				lanes &= lanes - 1;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int cq = __builtin_amdgcn_readlane(c[q], src_l), sq = __builtin_amdgcn_readlane(st_q[q], src_l);
+					if (cq > 0) {
+						const int val = 4 * src_l + q;
+						if (nf == 0) { v0 = val; h0 = sq; e0 = sq + cq; } else if (nf == 1) { v1 = val; h1 = sq; e1 = sq + cq; }
+						else if (nf == 2) { v2 = val; h2 = sq; e2 = sq + cq; } else { v3 = val; h3 = sq; e3 = sq + cq; }
+						++nf;
+					}
+				}
+			}
+		}
+		phase(1);
+		// the sequences of buckets 1 .. 3 (a cycle never goes to the first one: nothing that belongs below the bucket being done is left)
+		int w1 = 0, w2 = 0, w3 = 0, b1 = INT_MIN / 2, b2 = INT_MIN / 2, b3 = INT_MIN / 2;
+		int d = 0, src = 0;
+		// (where the elements go is collected 64 entries at a time across the lanes of two registers and stored by all lanes at once: a store per
+		// step would be waited for by the next load of bytes -- loads and stores are counted together, in order)
+		int out_src = 0, out_pos = 0, n_out = 0;
+#define MM2GB_FEW_PUT(SRC, POS) { if (l == n_out) { out_src = SRC; out_pos = POS; } \
+                                  if (++n_out == W) { sc.perm[out_src] = out_pos; n_out = 0; } }
+#define MM2GB_FEW_STEP(J) { int off_ = h##J - b##J; if (off_ < 0 || off_ >= W) { w##J = (int)sc.S[h##J + l]; b##J = h##J; off_ = 0; } \
+                            const int nb_ = __builtin_amdgcn_readlane(w##J, off_); MM2GB_FEW_PUT(src, h##J) src = h##J; ++h##J; d = nb_; }
+#define MM2GB_FEW_BUCKET(K) if (K < nf) { \
+			const int tk = e##K, vk = v##K; \
+			for (int hq = h##K; hq < tk; hq += 4 * W) { \
+				int by4[4]; \
+				_Pragma("unroll") for (int u = 0; u < 4; ++u) by4[u] = (int)sc.S[min(hq + u * W + l, tk - 1)]; \
+				_Pragma("unroll") for (int u = 0; u < 4; ++u) { \
+					const int hk = hq + u * W; \
+					if (hk < tk) { \
+						unsigned long long moves = __ballot(hk + l < tk && by4[u] != vk); \
+						while (((unsigned)moves | (unsigned)(moves >> 32)) != 0) { \
+							const int skip = first_set(moves); \
+							moves &= moves - 1; \
+							++d_cycles; \
+							const int home = hk + skip; \
+							d = __builtin_amdgcn_readlane(by4[u], skip); src = home; \
+							do { if (d == v1) MM2GB_FEW_STEP(1) else if (d == v2) MM2GB_FEW_STEP(2) else MM2GB_FEW_STEP(3) ++d_steps; } while (d != vk); \
+							MM2GB_FEW_PUT(src, home) \
+						} \
+					} \
+				} \
+			} \
+		}
+		MM2GB_FEW_BUCKET(0)
+		MM2GB_FEW_BUCKET(1)
+		MM2GB_FEW_BUCKET(2)
+		MM2GB_FEW_BUCKET(3)
+		if (l < n_out) sc.perm[out_src] = out_pos;
+#undef MM2GB_FEW_BUCKET
+#undef MM2GB_FEW_STEP
+#undef MM2GB_FEW_PUT
+	} else {
 	if (resident) {
 		wave_sync();                                            // (the counts are in registers: the records take their place)
 		// record of a bucket: x = its next position, w = its end
@@ -412,8 +486,7 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		wave_sync();
 		fetch_all_byte_lines(sc.S, used, L);
 	}
-	int since = 0;
-	int d_steps = 0, d_one = 0, d_all = 1, d_cycles = 0;
+	phase(1);
 	for (int k = 0; k < 256; ++k) {
 		if (!((full[k & 3] >> (k >> 2)) & 1)) continue;
 		const int4 rk = rec[k];
@@ -491,7 +564,9 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		}
 		}
 	}
+	}
 	wave_sync();
+	phase(2);
 	// the elements follow the permutation: out of place first, then back (all lanes, eight loads in flight each)
 	for (int base = lo; base < hi; base += 8 * W) {
 		unsigned long long e[8]; int to[8];
@@ -509,6 +584,8 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		for (int u = 0; u < 8; ++u) if (base + u * W + l < hi) g[base + u * W + l] = e[u];
 	}
 	wave_sync();
+	phase(3);
+	if (ph) ph[5] += d_steps;
 	if (dbg && l == 0) {
 		atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)d_steps);
 		atomicAdd((unsigned long long*)&dbg[1], (unsigned long long)d_one);
@@ -531,9 +608,9 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 #define MM2GB_POST_SORT_ELEMENTS 0              // 1: the candidates' sort moves elements step by step too (round 4; A/B builds)
 #endif
 template <class E, bool BYTES>
-__device__ __forceinline__ bool one_radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L, const SortScratch *sc, long long *dbg)
+__device__ __forceinline__ bool one_radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L, const SortScratch *sc, long long *dbg, long long *ph = nullptr)
 {
-	if constexpr (BYTES && !MM2GB_POST_SORT_ELEMENTS) return radix_pass_bytes(g, lo, hi, shift, L, *sc, dbg);
+	if constexpr (BYTES && !MM2GB_POST_SORT_ELEMENTS) return radix_pass_bytes(g, lo, hi, shift, L, *sc, dbg, ph);
 	else return radix_pass<E>(g, lo, hi, shift, L, dbg);
 }
 
@@ -1202,7 +1279,8 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort
 		const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 		int shift = uni(t.w);
 		bool moved = false;
-		for (; shift >= 0 && !moved; shift -= 8) moved = one_radix_pass<ZElem, true>(g, 0, len, shift, L, &sc, b.dbg ? b.dbg + 24 + 6 * lvl : nullptr);
+		long long ph[6] = { 0, 0, 0, 0, 0, 0 };
+		for (; shift >= 0 && !moved; shift -= 8) moved = one_radix_pass<ZElem, true>(g, 0, len, shift, L, &sc, b.dbg ? b.dbg + 24 + 6 * lvl : nullptr, b.dbg_stasks ? ph : nullptr);
 		// (shift is now one byte below the pass that moved the run)
 		int d_small = 0;
 		if (moved && shift >= 0)
@@ -1219,7 +1297,10 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort
 			atomicAdd((unsigned long long*)&b.dbg[19], (unsigned long long)d_small);
 			if (b.dbg_stasks) {
 				const unsigned long long at = atomicAdd((unsigned long long*)&b.dbg[42], 1ull);
-				if (at < 262144) { b.dbg_stasks[4 * at] = t0; b.dbg_stasks[4 * at + 1] = t1; b.dbg_stasks[4 * at + 2] = (long long)level << 32 | len; b.dbg_stasks[4 * at + 3] = 0; }
+				// [3]: ticks of the pass's phases, 12 bits of 10.24 us each: histogram | set-up | walk | the elements' move; the rest: the children
+				auto q12 = [](long long v) { const long long u = v >> 10; return u > 4095 ? 4095LL : u; };
+				if (at < 262144) { b.dbg_stasks[4 * at] = t0; b.dbg_stasks[4 * at + 1] = t1; b.dbg_stasks[4 * at + 2] = (long long)level << 32 | len;
+				                   b.dbg_stasks[4 * at + 3] = q12(ph[0]) | q12(ph[1]) << 12 | q12(ph[2]) << 24 | q12(ph[3]) << 36 | (ph[5] & 0xfffff) << 48; }
 			}
 		}
 		wave_sync();
