@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # An engine's copy and compute streams must not share a hardware queue (csrc/engine.hip, Engine::init): the HIP runtime reads this once, when
-# it starts, so a Python user who imports the package before torch / before the first HIP call gets 8 queues without doing anything.  A value
+# it starts, so a Python user who imports the package before torch / before the first HIP call gets 16 queues without doing anything.  A value
 # that is already set is the user's.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("MM2GB_LIB_PATH") or os.path.join(_HERE, "libmm2gb_chain.so")   # override: A/B runs of kernel builds

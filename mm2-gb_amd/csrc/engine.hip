@@ -35,10 +35,12 @@ static size_t grown(size_t need, size_t have)
 // of every other engine, and the calls of a mini-batch ran one after the other (10 s for what takes 1.6 s, profiles/r05_dropin_notes.md).  So a
 // buffer that is REPLACED because it must grow is not freed but retired: it goes to a process-wide list that is emptied when an engine shuts down,
 // when the list holds more than MM2GB_RETIRE_LIMIT_MB (default 16 GB of device memory, 4 GB page-locked), or when an allocation fails.
-// (Growth is geometric, so what a buffer retires over its life is less than its final size.)  Also safer: a retired buffer stays valid for
-// kernels of the same engine that were enqueued before the growth.
+// (Growth is geometric, by a quarter: what a buffer retires over its life is a geometric series of its earlier sizes -- up to four times its
+// final size if nothing flushed the list in between; the limits above bound it.)  A retired DEVICE buffer stays valid for work enqueued
+// before the growth (hipFree waits for the device); retired page-locked blocks are recycled only after every device has gone idle (below).
 namespace { void pinned_free(void *p); }
 namespace {
+std::atomic<unsigned long long> g_devices_with_engines{0};   // bit d: an engine was made on device d
 struct Retired { void *ptr; size_t bytes; bool pinned; };
 std::mutex g_retired_mu;
 std::vector<Retired> g_retired;
@@ -46,6 +48,19 @@ size_t g_retired_dev = 0, g_retired_host = 0;
 
 void flush_retired_locked()
 {
+	// a page-locked block on the list may still be the source or target of a copy some engine enqueued before it grew: nothing is handed out again
+	// before those copies are through (the list is process-wide: every device that is in use)
+	bool any_pinned = false;
+	for (const Retired &r : g_retired) any_pinned |= r.pinned;
+	if (any_pinned) {
+		int cur = 0;
+		const unsigned long long used = g_devices_with_engines.load();        // (only devices this process has engines on: touching another one would make a context there)
+		if (hipGetDevice(&cur) == hipSuccess) {
+			for (int d = 0; d < 64; ++d) if ((used >> d) & 1ull) if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+			(void)hipSetDevice(cur);
+		}
+		(void)hipGetLastError();
+	}
 	for (const Retired &r : g_retired) { if (r.pinned) pinned_free(r.ptr); else (void)hipFree(r.ptr); }
 	g_retired.clear();
 	g_retired_dev = g_retired_host = 0;
@@ -96,13 +111,39 @@ void DevBuf::release()
 // and copies from it run at the link's rate all the same.  MM2GB_PIN=hipmalloc keeps the runtime's allocator.
 namespace {
 bool pin_by_register() { static const bool v = [] { const char *e = getenv("MM2GB_PIN"); return !(e && strcmp(e, "hipmalloc") == 0); }(); return v; }
-// Registered blocks are never unregistered or unmapped while the process lives: a block that is given back goes to a free list and is handed
-// out again (best fit).  Unregistering is what went wrong once: the blocks came from malloc, glibc reused a freed block's addresses for
-// ordinary allocations, and a later copy from such an allocation faulted on the GPU ("Memory access fault ... Reason: Unknown", an address
-// inside a former block) -- so the blocks are also mapped directly (mmap), outside malloc's heap, at addresses nothing else will ever get.
+// A block that is given back goes to a free list and is handed out again (best fit, any idle block that is large enough).  What the list holds
+// beyond MM2GB_PIN_IDLE_MB (default 2048) is really let go, largest first: unregistered, and its pages returned to the system -- but its
+// ADDRESS RANGE stays reserved (mapped again PROT_NONE, no memory behind it) for as long as the process lives.  Unregistering is what went
+// wrong once: the blocks came from malloc, glibc reused a freed block's addresses for ordinary allocations, and a later copy from such an
+// allocation faulted on the GPU ("Memory access fault ... Reason: Unknown", an address inside a former block).  So the blocks are mapped
+// directly (mmap), outside malloc's heap, and an address that once was page-locked is never handed to anybody again.
 struct PinBlock { void *ptr; size_t bytes; };
 std::mutex g_pin_mu;
 std::vector<PinBlock> g_pin_idle, g_pin_all;
+size_t g_pin_idle_bytes = 0;
+// idle blocks over the cap: out of the lists under the lock, let go outside it (hipHostUnregister may wait for the device)
+void trim_idle_locked(std::vector<PinBlock> &out)
+{
+	static const size_t cap = [] { const char *v = getenv("MM2GB_PIN_IDLE_MB"); return (size_t)(v && *v ? std::max(0LL, atoll(v)) : 2048LL) << 20; }();
+	while (g_pin_idle_bytes > cap && !g_pin_idle.empty()) {
+		size_t big = 0;
+		for (size_t k = 1; k < g_pin_idle.size(); ++k) if (g_pin_idle[k].bytes > g_pin_idle[big].bytes) big = k;
+		const PinBlock blk = g_pin_idle[big];
+		g_pin_idle.erase(g_pin_idle.begin() + (std::ptrdiff_t)big);
+		g_pin_idle_bytes -= blk.bytes;
+		for (size_t k = 0; k < g_pin_all.size(); ++k) if (g_pin_all[k].ptr == blk.ptr) { g_pin_all.erase(g_pin_all.begin() + (std::ptrdiff_t)k); break; }
+		out.push_back(blk);
+	}
+}
+void let_go(const std::vector<PinBlock> &blocks)
+{
+	for (const PinBlock &blk : blocks) {
+		(void)hipHostUnregister(blk.ptr);
+		(void)hipGetLastError();
+		// the pages go back to the system, the addresses stay taken: a fresh PROT_NONE mapping over the same range
+		if (mmap(blk.ptr, blk.bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED | MAP_NORESERVE, -1, 0) == MAP_FAILED) (void)madvise(blk.ptr, blk.bytes, MADV_DONTNEED);
+	}
+}
 void *pinned_alloc(size_t bytes)
 {
 	if (!pin_by_register()) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
@@ -112,8 +153,8 @@ void *pinned_alloc(size_t bytes)
 		std::lock_guard<std::mutex> lock(g_pin_mu);
 		size_t best = g_pin_idle.size();
 		for (size_t k = 0; k < g_pin_idle.size(); ++k)
-			if (g_pin_idle[k].bytes >= rounded && g_pin_idle[k].bytes <= 2 * rounded + 2 * HUGE && (best == g_pin_idle.size() || g_pin_idle[k].bytes < g_pin_idle[best].bytes)) best = k;
-		if (best != g_pin_idle.size()) { void *p = g_pin_idle[best].ptr; g_pin_idle.erase(g_pin_idle.begin() + (std::ptrdiff_t)best); return p; }
+			if (g_pin_idle[k].bytes >= rounded && (best == g_pin_idle.size() || g_pin_idle[k].bytes < g_pin_idle[best].bytes)) best = k;
+		if (best != g_pin_idle.size()) { void *p = g_pin_idle[best].ptr; g_pin_idle_bytes -= g_pin_idle[best].bytes; g_pin_idle.erase(g_pin_idle.begin() + (std::ptrdiff_t)best); return p; }
 	}
 	char *raw = (char*)mmap(nullptr, rounded + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
 	if (raw == (char*)MAP_FAILED) return nullptr;
@@ -131,8 +172,13 @@ void pinned_free(void *p)
 {
 	if (!p) return;
 	if (!pin_by_register()) { (void)hipHostFree(p); return; }
-	std::lock_guard<std::mutex> lock(g_pin_mu);
-	for (const PinBlock &b : g_pin_all) if (b.ptr == p) { g_pin_idle.push_back(b); return; }
+	std::vector<PinBlock> over;
+	{
+		std::lock_guard<std::mutex> lock(g_pin_mu);
+		for (const PinBlock &b : g_pin_all) if (b.ptr == p) { g_pin_idle.push_back(b); g_pin_idle_bytes += b.bytes; break; }
+		trim_idle_locked(over);
+	}
+	let_go(over);
 }
 } // namespace
 
@@ -347,6 +393,7 @@ int Engine::init(const mm2gb_config_t *c, const mm2gb_misc_t *m, int dev)
 	MM2GB_HIP(hipGetDeviceCount(&n_dev));
 	if (dev < 0 || dev >= n_dev) return fail("mm2gb: device " + std::to_string(dev) + " not present (" + std::to_string(n_dev) + " visible)");
 	device = dev;
+	if (dev >= 0 && dev < 64) g_devices_with_engines.fetch_or(1ull << dev);
 	MM2GB_HIP(hipSetDevice(device));
 	hipDeviceProp_t prop;
 	MM2GB_HIP(hipGetDeviceProperties(&prop, device));

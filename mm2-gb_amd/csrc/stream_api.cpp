@@ -483,6 +483,44 @@ static void free_single_read_engines()
 // streams that free_stream_gpu parked instead of releasing (see there), and the configuration they were made for
 static std::vector<StreamSlot*> g_parked;
 static mm2gb_config_t g_parked_cfg;
+// Parked streams do not stay parked for ever: a reaper thread releases them -- arenas, page-locked staging, re-chaining engines,
+// finisher threads, the leased single-read engines -- when no init_stream_gpu has taken them over within MM2GB_PARK_SECONDS (default 3) of the
+// free_stream_gpu that parked them.  A host that exits right after free_stream_gpu (minimap2 does) never pays for the release; a process that
+// goes on using the GPU gets the memory back.  MM2GB_FREE=now: released inside free_stream_gpu; MM2GB_FREE=park: kept until the process ends.
+static std::mutex g_park_mu;                    // g_parked, g_parked_cfg, g_park_epoch
+static std::condition_variable g_park_cv;
+static uint64_t g_park_epoch = 0;
+static bool g_reaper_started = false, g_reaper_stop = false;
+static std::thread g_reaper;
+static void destroy_slot(StreamSlot *slot);
+static void free_single_read_engines();
+static double g_grace_s = 3.0;
+static void reaper_main()
+{
+	std::unique_lock<std::mutex> lk(g_park_mu);
+	for (;;) {
+		g_park_cv.wait(lk, [] { return g_reaper_stop || !g_parked.empty(); });
+		if (g_reaper_stop) return;
+		const uint64_t seen = g_park_epoch;
+		if (g_park_cv.wait_for(lk, std::chrono::duration<double>(g_grace_s), [&] { return g_reaper_stop || g_park_epoch != seen || g_parked.empty(); })) {
+			if (g_reaper_stop) return;
+			continue;                               // taken over, or parked anew: the clock starts again
+		}
+		std::vector<StreamSlot*> mine;
+		mine.swap(g_parked);
+		lk.unlock();
+		for (StreamSlot *slot : mine) destroy_slot(slot);
+		free_single_read_engines();
+		if (g_streams.debug) fprintf(stderr, "[mm2gb stream] %zu parked stream(s) released: nobody took them over within the grace period\n", mine.size());
+		lk.lock();
+	}
+}
+static void stop_reaper_at_exit()
+{
+	{ std::lock_guard<std::mutex> lk(g_park_mu); g_reaper_stop = true; }
+	g_park_cv.notify_all();
+	if (g_reaper.joinable()) g_reaper.join();       // (what is still parked goes with the process)
+}
 
 static void destroy_slot(StreamSlot *slot)
 {
@@ -718,6 +756,8 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 	}
 	std::vector<int> devs;
 	if (devices_for_streams(devs)) die(mm2gb_last_error());
+	std::unique_lock<std::mutex> park_lk(g_park_mu);
+	++g_park_epoch;
 	if (!g_parked.empty()) {
 		// streams parked by free_stream_gpu: taken over as they are when they were made for this configuration and these devices
 		bool same = memcmp(&g_parked_cfg, &cfg, sizeof cfg) == 0 && (int)g_parked.size() == cfg.num_streams;
@@ -730,6 +770,8 @@ void init_stream_gpu(size_t *max_total_n, int *max_reads, int *min_n, char gpu_c
 			g_parked.clear();
 		}
 	}
+	park_lk.unlock();
+	g_park_cv.notify_all();
 	{
 		// The engines that are not there yet -- streams, events, the penalty table's kernel, ~40 ms each and one after the other inside the
 		// runtime whoever asks (sixteen: 0.6 s) -- are made by a thread of their own, in stream order: the host goes on to read and seed its first
@@ -846,6 +888,8 @@ void free_stream_gpu(int n_threads)
 	// work drained, engines idle, nothing released -- a later init_stream_gpu with the same configuration takes them over as they are (no
 	// re-pinning either), another configuration or MM2GB_FREE=now releases them for real, and the process's end releases what is parked.
 	static const bool release_now = [] { const char *v = getenv("MM2GB_FREE"); return v && strcmp(v, "now") == 0; }();
+	static const bool park_for_ever = [] { const char *v = getenv("MM2GB_FREE"); return v && strcmp(v, "park") == 0; }();
+	const double grace_s = [] { const char *v = getenv("MM2GB_PARK_SECONDS"); return v && *v ? std::max(0.0, atof(v)) : 3.0; }();
 	wait_for_all_streams();                                       // (a host with nothing to map gets here before the engines stand)
 	for (StreamSlot *slot : g_streams.slots) {
 		{
@@ -860,9 +904,21 @@ void free_stream_gpu(int n_threads)
 			st.ahead.clear(); st.have_ahead = false;
 			st.busy = false; st.reads = nullptr; st.n_read = 0; st.device_post = false;
 		}
-		if (release_now) destroy_slot(slot); else g_parked.push_back(slot);
+		if (release_now) destroy_slot(slot);
+		else { std::lock_guard<std::mutex> lk(g_park_mu); g_parked.push_back(slot); }
 	}
-	if (!release_now) g_parked_cfg = g_streams.cfg;
+	if (!release_now) {
+		std::lock_guard<std::mutex> lk(g_park_mu);
+		g_parked_cfg = g_streams.cfg;
+		++g_park_epoch;
+		g_grace_s = grace_s;
+		if (!park_for_ever && !g_reaper_started) {
+			g_reaper_started = true;
+			g_reaper = std::thread(reaper_main);
+			atexit(stop_reaper_at_exit);                              // registered after the runtime's own handlers: runs before them
+		}
+	}
+	g_park_cv.notify_all();
 	g_streams.slots.clear();
 	g_streams.ready = false;
 	if (release_now) free_single_read_engines();
@@ -880,7 +936,7 @@ void free_stream_gpu(int n_threads)
 			fclose(fp);
 		}
 		fprintf(stderr, "[mm2gb stream] free_stream_gpu: entered at epoch %.3f, streams %s after %.3f s; the process holds %.1f GB of memory (peak %.1f), %.1f GB of it in huge pages\n",
-		        epoch_free, release_now ? "released" : "parked", (now_ns() - t_free0) * 1e-9, rss_kb / 1048576.0, hwm_kb / 1048576.0, huge_kb / 1048576.0);
+		        epoch_free, release_now ? "released" : park_for_ever ? "parked" : "parked (released if not taken over within the grace period)", (now_ns() - t_free0) * 1e-9, rss_kb / 1048576.0, hwm_kb / 1048576.0, huge_kb / 1048576.0);
 	}
 	// What the library held of the run, for whoever times the drop-in (bench.py's e2e.reference_host_at_scale): seconds are summed over the
 	// host's threads; the host's own callback (post_chaining_helper, map.c:428: RMQ re-chaining, mm_gen_regs, ...) runs inside the boundary

@@ -222,9 +222,35 @@ def test_parked_streams_are_taken_over_by_the_next_init(tmp_path, capfd):
         err = capfd.readouterr().err
         made = [int(x) for x in re.findall(r"init_stream_gpu: entered at epoch [0-9.]+, returns after [0-9.]+ s: \d+ stream\(s\), (\d+) of them still being made", err)]
         assert len(made) == 3 and err.count("streams parked") == 3
-        assert made[0] >= 1 and made[1] == 0 and made[2] == made[0], made          # made | taken over as they were | another configuration: made anew
+        # made | taken over as they were | another configuration: made anew.  (How many engines of a fresh set are still being made when
+        # init returns depends on how fast their maker thread is, and is none under MM2GB_INIT=wait: only the takeover is a fixed number.)
+        assert made[1] == 0, made
     finally:
         if env_dbg is None:
             del os.environ["MM2GB_DEBUG_PHASES"]
         else:
             os.environ["MM2GB_DEBUG_PHASES"] = env_dbg
+
+
+def test_parked_streams_are_released_after_the_grace_period(tmp_path, capfd):
+    """Parked streams do not stay for ever: with nobody taking them over within MM2GB_PARK_SECONDS the library releases them (arenas, page-locked
+    staging, engines); the next init_stream_gpu makes its streams anew and the results are the same."""
+    import time
+    saved = {k: os.environ.get(k) for k in ("MM2GB_DEBUG_PHASES", "MM2GB_PARK_SECONDS")}
+    os.environ["MM2GB_DEBUG_PHASES"] = "1"
+    os.environ["MM2GB_PARK_SECONDS"] = "0.2"
+    try:
+        anchors, off = mm.synth_reads(78, 0, 8, 5_000, 20_000)
+        reads = [anchors[off[r]:off[r + 1]] for r in range(8)]
+        first = drive_boundary(tmp_path, [reads[:5], reads[5:]])
+        time.sleep(1.5)                                      # the grace period passes: the reaper lets everything go
+        second = drive_boundary(tmp_path, [reads[:5], reads[5:]])
+        assert first is None or first == second
+        err = capfd.readouterr().err
+        assert "parked stream(s) released: nobody took them over" in err
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
