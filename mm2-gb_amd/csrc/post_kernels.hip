@@ -751,6 +751,33 @@ __device__ __forceinline__ int size_class(int64_t n)
 	return min(N_SIZE_CLASSES - 1, 1 + msb * 8 + frac);
 }
 
+// Items into bins with the bins' counters in memory: a workgroup first counts its own items per bin in LDS and then takes a range of every bin it
+// needs with ONE atomic (atomics on one address are served one after the other, ~30 ns each: a level's tens of thousands of tasks crowd a few
+// dozen bins).  count: bins[c] += the workgroup's items of bin c.  scatter: returns the item's slot (bins[c] is the bin's cursor).
+// Every thread of the workgroup calls; `active` says whether it has an item.  s_cnt / s_base: N_SIZE_CLASSES ints of LDS each.
+__device__ __forceinline__ void block_bin_count(int32_t *bins, int c, bool active, int *s_cnt)
+{
+	for (int k = threadIdx.x; k < N_SIZE_CLASSES; k += blockDim.x) s_cnt[k] = 0;
+	__syncthreads();
+	if (active) atomicAdd(&s_cnt[c], 1);
+	__syncthreads();
+	for (int k = threadIdx.x; k < N_SIZE_CLASSES; k += blockDim.x) if (s_cnt[k]) atomicAdd(&bins[k], s_cnt[k]);
+	__syncthreads();
+}
+__device__ __forceinline__ int block_bin_slot(int32_t *bins, int c, bool active, int *s_cnt, int *s_base)
+{
+	for (int k = threadIdx.x; k < N_SIZE_CLASSES; k += blockDim.x) s_cnt[k] = 0;
+	__syncthreads();
+	int mine = 0;
+	if (active) mine = atomicAdd(&s_cnt[c], 1);
+	__syncthreads();
+	for (int k = threadIdx.x; k < N_SIZE_CLASSES; k += blockDim.x) if (s_cnt[k]) s_base[k] = atomicAdd(&bins[k], s_cnt[k]);
+	__syncthreads();
+	const int at = active ? s_base[c] + mine : 0;
+	__syncthreads();
+	return at;
+}
+
 __global__ __launch_bounds__(256) void k_post_size_count(PostBatch b)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1248,13 +1275,22 @@ __global__ __launch_bounds__(256) void k_post_stask_count(PostBatch b, int level
 {
 	const int n_t = b.cursor[8 + level];
 	const int4 *list = b.stask[level & 1];
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) atomicAdd(&b.size_bins[size_class(list[t].z)], 1);
+	__shared__ int s_cnt[N_SIZE_CLASSES];
+	for (int t0 = blockIdx.x * blockDim.x; t0 < n_t; t0 += gridDim.x * blockDim.x) {
+		const int t = t0 + threadIdx.x;
+		block_bin_count(b.size_bins, t < n_t ? size_class(list[t].z) : 0, t < n_t, s_cnt);
+	}
 }
 __global__ __launch_bounds__(256) void k_post_stask_scatter(PostBatch b, int level)
 {
 	const int n_t = b.cursor[8 + level];
 	const int4 *list = b.stask[level & 1];
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) b.stask_order[atomicAdd(&b.size_bins[N_SIZE_CLASSES + size_class(list[t].z)], 1)] = t;
+	__shared__ int s_cnt[N_SIZE_CLASSES], s_base[N_SIZE_CLASSES];
+	for (int t0 = blockIdx.x * blockDim.x; t0 < n_t; t0 += gridDim.x * blockDim.x) {
+		const int t = t0 + threadIdx.x;
+		const int at = block_bin_slot(b.size_bins + N_SIZE_CLASSES, t < n_t ? size_class(list[t].z) : 0, t < n_t, s_cnt, s_base);
+		if (t < n_t) b.stask_order[at] = t;
+	}
 }
 
 __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort_level(PostBatch b, int level)
@@ -1470,18 +1506,22 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_partition(PostBatch b)
 __global__ __launch_bounds__(256) void k_post_task_count(PostBatch b)
 {
 	const int n_t = b.cursor[5];
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) {
-		const int task = b.wtask[t];
-		atomicAdd(&b.size_bins[size_class(b.cls_nz[(int64_t)(task >> 4) * N_TREE_CLASSES + (task & 15)])], 1);
+	__shared__ int s_cnt[N_SIZE_CLASSES];
+	for (int t0 = blockIdx.x * blockDim.x; t0 < n_t; t0 += gridDim.x * blockDim.x) {
+		const int t = t0 + threadIdx.x;
+		const int task = t < n_t ? b.wtask[t] : 0;
+		block_bin_count(b.size_bins, t < n_t ? size_class(b.cls_nz[(int64_t)(task >> 4) * N_TREE_CLASSES + (task & 15)]) : 0, t < n_t, s_cnt);
 	}
 }
 __global__ __launch_bounds__(256) void k_post_task_scatter(PostBatch b)
 {
 	const int n_t = b.cursor[5];
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_t; t += gridDim.x * blockDim.x) {
-		const int task = b.wtask[t];
-		const int c = size_class(b.cls_nz[(int64_t)(task >> 4) * N_TREE_CLASSES + (task & 15)]);
-		b.wtask_order[atomicAdd(&b.size_bins[N_SIZE_CLASSES + c], 1)] = task;
+	__shared__ int s_cnt[N_SIZE_CLASSES], s_base[N_SIZE_CLASSES];
+	for (int t0 = blockIdx.x * blockDim.x; t0 < n_t; t0 += gridDim.x * blockDim.x) {
+		const int t = t0 + threadIdx.x;
+		const int task = t < n_t ? b.wtask[t] : 0;
+		const int at = block_bin_slot(b.size_bins + N_SIZE_CLASSES, t < n_t ? size_class(b.cls_nz[(int64_t)(task >> 4) * N_TREE_CLASSES + (task & 15)]) : 0, t < n_t, s_cnt, s_base);
+		if (t < n_t) b.wtask_order[at] = task;
 	}
 }
 
@@ -3356,7 +3396,7 @@ void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux, hipEvent_t 
 		hipLaunchKernelGGL(k_post_sort, dim3(grid), dim3(POST_THREADS), 0, s, b, b.team_reads); done("k_post_sort");
 		hipLaunchKernelGGL(k_post_partition, dim3(grid), dim3(POST_THREADS), 0, s, b); done("k_post_partition");
 		(void)hipMemsetAsync(b.size_bins, 0, 2 * N_SIZE_CLASSES * sizeof(int32_t), s);
-		const unsigned tgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + 255) / 256, 1024));
+		const unsigned tgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((b.n_reads * N_TREE_CLASSES + 255) / 256, 512));
 		hipLaunchKernelGGL(k_post_task_count, dim3(tgrid), dim3(256), 0, s, b); done("k_post_task_count");
 		hipLaunchKernelGGL(k_post_size_bases, dim3(1), dim3(64), 0, s, b); done("k_post_size_bases");
 		hipLaunchKernelGGL(k_post_task_scatter, dim3(tgrid), dim3(256), 0, s, b); done("k_post_task_scatter");
