@@ -341,7 +341,9 @@ __device__ __forceinline__ void fetch_all_byte_lines(const unsigned char *S, int
 // A run of at most LINE_STORE_BYTES elements (nearly every run below the top level: 1 800 elements on average at the lowest byte) keeps its
 // whole byte sequence in LDS: no lines, no refills, and the scan of a bucket for the elements that must move reads LDS instead of memory --
 // with 256 buckets and a few elements in each, those 256 dependent memory round trips were most of a small pass's time.
-__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr, long long *ph = nullptr)
+// (few-bucket passes, below, report their buckets: the run's children are known without another look at the elements)
+struct FewBuckets { int n = 0; int start[4] = { 0, 0, 0, 0 }, end[4] = { 0, 0, 0, 0 }; };
+__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr, long long *ph = nullptr, FewBuckets *fb = nullptr)
 {
 	long long tp = ph ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 	auto phase = [&](int k) { if (ph) { const long long tn = (long long)__builtin_amdgcn_s_memrealtime(); ph[k] += tn - tp; tp = tn; } };
@@ -410,8 +412,10 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 				}
 			}
 		}
+		if (fb) { fb->n = nf; fb->start[0] = h0; fb->end[0] = e0; fb->start[1] = h1; fb->end[1] = e1; fb->start[2] = h2; fb->end[2] = e2; fb->start[3] = h3; fb->end[3] = e3; }
 		phase(1);
-		// the sequences of buckets 1 .. 3 (a cycle never goes to the first one: nothing that belongs below the bucket being done is left)
+		// the sequences of buckets 1 .. 3 (a cycle never goes to the first one: nothing that belongs below the bucket being done is left): 64 bytes
+		// across the lanes.  (Tried: the next 64 asked for when the first are half used -- the extra test per step cost more than the waits it saved.)
 		int w1 = 0, w2 = 0, w3 = 0, b1 = INT_MIN / 2, b2 = INT_MIN / 2, b3 = INT_MIN / 2;
 		int d = 0, src = 0;
 		// (where the elements go is collected 64 entries at a time across the lanes of two registers and stored by all lanes at once: a store per
@@ -419,13 +423,17 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		int out_src = 0, out_pos = 0, n_out = 0;
 #define MM2GB_FEW_PUT(SRC, POS) { if (l == n_out) { out_src = SRC; out_pos = POS; } \
                                   if (++n_out == W) { sc.perm[out_src] = out_pos; n_out = 0; } }
-#define MM2GB_FEW_STEP(J) { int off_ = h##J - b##J; if (off_ < 0 || off_ >= W) { w##J = (int)sc.S[h##J + l]; b##J = h##J; off_ = 0; } \
-                            const int nb_ = __builtin_amdgcn_readlane(w##J, off_); MM2GB_FEW_PUT(src, h##J) src = h##J; ++h##J; d = nb_; }
+// (Tried: a run of J's own elements that moves up by one found with a ballot and moved with one store -- the runs are short, a step each is faster.)
+#define MM2GB_FEW_STEP(J) { unsigned off_ = (unsigned)(h##J - b##J); if (off_ >= (unsigned)W) { w##J = (int)sc.S[h##J + l]; b##J = h##J; off_ = 0; } \
+                            const int nb_ = __builtin_amdgcn_readlane(w##J, (int)off_); MM2GB_FEW_PUT(src, h##J) src = h##J; ++h##J; d = nb_; }
 #define MM2GB_FEW_BUCKET(K) if (K < nf) { \
 			const int tk = e##K, vk = v##K; \
+			int nx4[4]; \
+			_Pragma("unroll") for (int u = 0; u < 4; ++u) nx4[u] = (int)sc.S[min(h##K + u * W + l, max(tk - 1, h##K))]; \
 			for (int hq = h##K; hq < tk; hq += 4 * W) { \
 				int by4[4]; \
-				_Pragma("unroll") for (int u = 0; u < 4; ++u) by4[u] = (int)sc.S[min(hq + u * W + l, tk - 1)]; \
+				_Pragma("unroll") for (int u = 0; u < 4; ++u) by4[u] = nx4[u]; \
+				if (hq + 4 * W < tk) { _Pragma("unroll") for (int u = 0; u < 4; ++u) nx4[u] = (int)sc.S[min(hq + (4 + u) * W + l, tk - 1)]; }   /* the next four blocks, under this one's cycles */ \
 				_Pragma("unroll") for (int u = 0; u < 4; ++u) { \
 					const int hk = hq + u * W; \
 					if (hk < tk) { \
@@ -608,9 +616,9 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 #define MM2GB_POST_SORT_ELEMENTS 0              // 1: the candidates' sort moves elements step by step too (round 4; A/B builds)
 #endif
 template <class E, bool BYTES>
-__device__ __forceinline__ bool one_radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L, const SortScratch *sc, long long *dbg, long long *ph = nullptr)
+__device__ __forceinline__ bool one_radix_pass(typename E::T *g, int lo, int hi, int shift, PassLds &L, const SortScratch *sc, long long *dbg, long long *ph = nullptr, FewBuckets *fb = nullptr)
 {
-	if constexpr (BYTES && !MM2GB_POST_SORT_ELEMENTS) return radix_pass_bytes(g, lo, hi, shift, L, *sc, dbg, ph);
+	if constexpr (BYTES && !MM2GB_POST_SORT_ELEMENTS) return radix_pass_bytes(g, lo, hi, shift, L, *sc, dbg, ph, fb);
 	else return radix_pass<E>(g, lo, hi, shift, L, dbg);
 }
 
@@ -1316,10 +1324,21 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort
 		int shift = uni(t.w);
 		bool moved = false;
 		long long ph[6] = { 0, 0, 0, 0, 0, 0 };
-		for (; shift >= 0 && !moved; shift -= 8) moved = one_radix_pass<ZElem, true>(g, 0, len, shift, L, &sc, b.dbg ? b.dbg + 24 + 6 * lvl : nullptr, b.dbg_stasks ? ph : nullptr);
+		FewBuckets fb;
+		for (; shift >= 0 && !moved; shift -= 8) { fb.n = 0; moved = one_radix_pass<ZElem, true>(g, 0, len, shift, L, &sc, b.dbg ? b.dbg + 24 + 6 * lvl : nullptr, b.dbg_stasks ? ph : nullptr, &fb); }
 		// (shift is now one byte below the pass that moved the run)
 		int d_small = 0;
-		if (moved && shift >= 0)
+		if (moved && shift >= 0 && fb.n > 0) {
+			// the pass knew its (at most four) buckets: they are the run's children
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (j < fb.n) {
+					const int first = fb.start[j], n_j = fb.end[j] - fb.start[j];
+					if (n_j > SMALL_RUN) { if (l == 0) next[atomicAdd(b.cursor + 8 + level + 1, 1)] = make_int4(r, lo + first, n_j, shift); }
+					else if (n_j > 1) small_run_sort<ZElem>(g, first, n_j);
+				}
+			}
+		} else if (moved && shift >= 0)
 			d_small = sort_level<ZElem>(g, len, shift, [&](int first, int end) {
 				if (l == 0) next[atomicAdd(b.cursor + 8 + level + 1, 1)] = make_int4(r, lo + first, end - first, shift);
 			});
