@@ -343,15 +343,18 @@ __device__ __forceinline__ void fetch_all_byte_lines(const unsigned char *S, int
 // with 256 buckets and a few elements in each, those 256 dependent memory round trips were most of a small pass's time.
 // (few-bucket passes, below, report their buckets: the run's children are known without another look at the elements)
 struct FewBuckets { int n = 0; int start[4] = { 0, 0, 0, 0 }, end[4] = { 0, 0, 0, 0 }; };
-__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr, long long *ph = nullptr, FewBuckets *fb = nullptr)
+// FEW_ONLY: only the few-bucket form (below) and nothing of PassLds but 256 words for the histogram -- the pass a read's candidates get right where
+// they were collected (k_post_classes).  Returns 0: every key has the same byte (nothing moved), 1: done, 2 (FEW_ONLY): more than four values, not done.
+template <bool FEW_ONLY>
+__device__ __forceinline__ int radix_pass_bytes_t(unsigned long long *g, int lo, int hi, int shift, PassLds *Lp, int *where, const SortScratch &sc, long long *dbg, long long *ph, FewBuckets *fb)
 {
 	long long tp = ph ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 	auto phase = [&](int k) { if (ph) { const long long tn = (long long)__builtin_amdgcn_s_memrealtime(); ph[k] += tn - tp; tp = tn; } };
 	const int l = lane();
 	const int len = hi - lo;
-	const bool resident = len <= LINE_STORE_BYTES;
-	unsigned char *lineb = (unsigned char*)L.line;
-	for (int k = l; k < 256; k += W) L.where[k] = 0;
+	const bool resident = !FEW_ONLY && len <= LINE_STORE_BYTES;
+	unsigned char *lineb = FEW_ONLY ? nullptr : (unsigned char*)Lp->line;
+	for (int k = l; k < 256; k += W) where[k] = 0;
 	wave_sync();
 	// histogram, the byte sequence, the identity permutation: one pass over the run, eight loads in flight per lane
 	for (int base = lo; base < hi; base += 8 * W) {
@@ -362,7 +365,7 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		for (int u = 0; u < 8; ++u) {
 			const int i = base + u * W + l;
 			if (i < hi) {
-				atomicAdd(&L.where[byte[u]], 1);
+				atomicAdd(&where[byte[u]], 1);
 				if (resident) lineb[i - lo] = (unsigned char)byte[u]; else sc.S[i] = (unsigned char)byte[u];
 				sc.perm[i] = i;
 			}
@@ -371,8 +374,8 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 	wave_sync();
 	phase(0);
 	// lane l owns buckets 4l .. 4l+3
-	const int c[4] = { L.where[4 * l], L.where[4 * l + 1], L.where[4 * l + 2], L.where[4 * l + 3] };
-	if (__ballot(c[0] == len || c[1] == len || c[2] == len || c[3] == len) != 0) return false;
+	const int c[4] = { where[4 * l], where[4 * l + 1], where[4 * l + 2], where[4 * l + 3] };
+	if (__ballot(c[0] == len || c[1] == len || c[2] == len || c[3] == len) != 0) return 0;
 	int inc = c[0] + c[1] + c[2] + c[3];
 	const int own = inc;
 	for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(inc, off); if (l >= off) inc += o; }
@@ -381,7 +384,7 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 	unsigned long long full[4];
 #pragma unroll
 	for (int q = 0; q < 4; ++q) full[q] = __ballot(c[q] > 0);
-	int4 *rec = (int4*)L.where;
+	int4 *rec = (int4*)where;
 	int used = 0;
 	int since = 0;
 	int d_steps = 0, d_one = 0, d_all = 1, d_cycles = 0;
@@ -392,6 +395,7 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 	// instructions instead of two trips to LDS behind each other (0.33 us a step before, and such passes were what a level's launch ended with).
 	const int n_full = __popcll(full[0]) + __popcll(full[1]) + __popcll(full[2]) + __popcll(full[3]);
 	const bool few = !resident && n_full <= 4;
+	if (FEW_ONLY && !few) return 2;
 	if (few) {
 		int v0 = -1, v1 = -1, v2 = -1, v3 = -1, h0 = 0, h1 = 0, h2 = 0, h3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, nf = 0;
 		{
@@ -459,7 +463,8 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 #undef MM2GB_FEW_BUCKET
 #undef MM2GB_FEW_STEP
 #undef MM2GB_FEW_PUT
-	} else {
+	} else if constexpr (!FEW_ONLY) {
+	PassLds &L = *Lp;
 	if (resident) {
 		wave_sync();                                            // (the counts are in registers: the records take their place)
 		// record of a bucket: x = its next position, w = its end
@@ -602,7 +607,11 @@ __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, 
 		atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)(hi - lo));
 		atomicAdd((unsigned long long*)&dbg[5], 1ull);
 	}
-	return true;
+	return 1;
+}
+__device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr, long long *ph = nullptr, FewBuckets *fb = nullptr)
+{
+	return radix_pass_bytes_t<false>(g, lo, hi, shift, &L, L.where, sc, dbg, ph, fb) == 1;
 }
 
 // radix_sort_128x (ksort.h:147-151) of g[0, n) by key, same final element order as the host's.
@@ -1376,10 +1385,11 @@ static_assert(N_TREE_CLASSES == 16, "tree_class takes the top four bits of the h
 
 __global__ __launch_bounds__(POST_THREADS) void k_post_classes(PostBatch b)
 {
-	__shared__ unsigned char s_ring[POST_THREADS / W][CLS_RING];
+	__shared__ int s_ring[POST_THREADS / W][CLS_RING / 4];       // the class ring (bytes); afterwards the histogram of the read's top pass (256 words)
 	__shared__ int s_cnt[POST_THREADS / W][N_TREE_CLASSES];
+	static_assert(CLS_RING / 4 >= 256, "the ring's memory doubles as the 256 counters of the few-bucket pass");
 	const int l = lane(), w = uni(threadIdx.x / W);
-	unsigned char *ring = s_ring[w];
+	unsigned char *ring = (unsigned char*)s_ring[w];
 	int *cnt = s_cnt[w];
 	for (;;) {
 		int q = 0;
@@ -1456,7 +1466,30 @@ __global__ __launch_bounds__(POST_THREADS) void k_post_classes(PostBatch b)
 				if (diff != 0) {
 					int top = 24;                                  // of the key = the score: byte 3 .. 0 (sort_like_host's `top`)
 					while (top > 0 && ((diff >> top) & 255u) == 0) top -= 8;
-					if (l == 0) b.stask[0][atomicAdd(b.cursor + 8, 1)] = make_int4(r, 0, n_z, top);
+					// A long read's top pass right here: its scores take two to four values of their highest byte that differs, and such a pass
+					// needs nothing of the sort's LDS but a histogram (radix_pass_bytes_t<true>: positions in scalar registers, bytes across the
+					// lanes) -- the wave that collected the candidates has them in its caches, and the pass does not wait for the whole batch's
+					// classes.  Its buckets are tasks of the SECOND level; a run that is not of that kind becomes a first-level task as before.
+					int status = 2, shift = top;
+					FewBuckets fb;
+					if (n_z > LINE_STORE_BYTES) {
+						wave_sync();
+						const SortScratch sc = { b.sort_s + off, b.sort_perm + off, b.sort_tmp + off };
+						for (status = 0; shift >= 0 && status == 0; shift -= 8) { fb.n = 0; status = radix_pass_bytes_t<true>(z, 0, n_z, shift, nullptr, s_ring[w], sc, b.dbg ? b.dbg + 24 : nullptr, nullptr, &fb); }
+						// (shift is one byte below the pass that ran last)
+					}
+					if (status == 1) {
+						if (shift >= 0) {
+#pragma unroll
+							for (int j = 0; j < 4; ++j) {
+								if (j < fb.n) {
+									const int first = fb.start[j], n_j = fb.end[j] - fb.start[j];
+									if (n_j > SMALL_RUN) { if (l == 0) b.stask[1][atomicAdd(b.cursor + 9, 1)] = make_int4(r, first, n_j, shift); }
+									else if (n_j > 1) small_run_sort<ZElem>(z, first, n_j);
+								}
+							}
+						}
+					} else if (status == 2) { if (l == 0) b.stask[0][atomicAdd(b.cursor + 8, 1)] = make_int4(r, 0, n_z, n_z > LINE_STORE_BYTES ? shift + 8 : top); }
 				}
 			} else if (n_z > 1) small_run_sort<ZElem>(z, 0, n_z);
 		}
