@@ -296,3 +296,22 @@ def test_the_forms_of_the_post_pass_agree(engine):
         o = orc.lchain_dp(a[off[r]:off[r + 1]], prm, want_fp=False)
         got = _chains_under({}, a[off[r]:off[r + 1]], np.array([0, off[r + 1] - off[r]], dtype=np.int64), prm)
         assert np.array_equal(got[0][0], o["u"]) and np.array_equal(got[0][1], o["a_out"])
+
+
+def test_scores_beyond_24_bits_reach_the_fourth_level(engine):
+    """A chain of 1.3 M anchors scores past 2^24: the candidates' keys then differ in their top byte, the sort by levels runs all four of its launches
+    (key bytes 3 .. 0) and the top pass has few values of its byte (the form that runs where the candidates are collected); next to it reads whose top
+    byte takes many values (a first-level task of the ordinary kind) and a short read.  Against the host post-pass, element for element."""
+    prm = orc.default_param()
+    big = sc.sort_by_x(np.concatenate([sc.colinear(1_300_000, 31, r0=1_000_000, max_gap=20), sc.repeat_block(6000, 32, r0=9_000_000, xwin=3000, ywin=4000)]))
+    parts = [big, sc.read_like(40_000, 33), sc.colinear(90, 34)]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    engine.set_misc(misc_from(prm))
+    f, _, _ = engine.score(a, off)
+    assert int(f[:len(big)].max()) >= 1 << 24, "the test's chain is too short to score past 2^24"
+    res, _ = engine.chain_gpu(a, off)
+    host, _ = engine.chain(a, off, threads=8)
+    for r in range(len(parts)):
+        assert np.array_equal(res[r][0], host[r][0]) and np.array_equal(res[r][1], host[r][1]), f"read {r}"
