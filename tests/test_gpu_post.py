@@ -299,11 +299,11 @@ def test_the_forms_of_the_post_pass_agree(engine):
 
 
 def test_scores_beyond_24_bits_reach_the_fourth_level(engine):
-    """A chain of 1.3 M anchors scores past 2^24: the candidates' keys then differ in their top byte, the sort by levels runs all four of its launches
+    """A chain of 1.5 M anchors scores past 2^24: the candidates' keys then differ in their top byte, the sort by levels runs all four of its launches
     (key bytes 3 .. 0) and the top pass has few values of its byte (the form that runs where the candidates are collected); next to it reads whose top
     byte takes many values (a first-level task of the ordinary kind) and a short read.  Against the host post-pass, element for element."""
     prm = orc.default_param()
-    big = sc.sort_by_x(np.concatenate([sc.colinear(1_300_000, 31, r0=1_000_000, max_gap=20), sc.repeat_block(6000, 32, r0=9_000_000, xwin=3000, ywin=4000)]))
+    big = sc.sort_by_x(np.concatenate([sc.colinear(1_500_000, 31, r0=1_000_000, max_gap=33), sc.repeat_block(6000, 32, r0=9_000_000, xwin=3000, ywin=4000)]))
     parts = [big, sc.read_like(40_000, 33), sc.colinear(90, 34)]
     off = np.zeros(len(parts) + 1, dtype=np.int64)
     off[1:] = np.cumsum([len(x) for x in parts])
