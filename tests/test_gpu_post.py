@@ -176,6 +176,16 @@ def test_sliced_call_overlaps_copies_and_kernels_same_chains(engine, monkeypatch
     got, _ = engine.chain_gpu(a, off)
     for r in range(len(want)):
         assert np.array_equal(got[r][0], want[r][0]) and np.array_equal(got[r][1], want[r][1]), r
+    # a batch with empty reads, a read without chains and a last slice of one short read, sliced per read
+    parts = [a[off[r]:off[r + 1]] for r in range(6)]
+    parts = [parts[0], parts[1][:0], sc.noise(50, 5), parts[2], parts[3][:0], parts[4], parts[5][:3]]
+    off2 = np.zeros(len(parts) + 1, dtype=np.int64)
+    off2[1:] = np.cumsum([len(x) for x in parts])
+    a2 = np.concatenate(parts)
+    want2, _ = engine.chain(a2, off2, threads=2)
+    got2, _ = engine.chain_gpu(a2, off2)
+    for r in range(len(parts)):
+        assert np.array_equal(got2[r][0], want2[r][0]) and np.array_equal(got2[r][1], want2[r][1]), r
 
 
 def test_a_further_engine_on_the_device_has_two_streams_and_the_same_chains(engine, monkeypatch):
