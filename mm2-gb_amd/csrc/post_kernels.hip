@@ -1022,28 +1022,35 @@ __device__ __forceinline__ void post_walk_read(const PostBatch &b, const int64_t
 						for (int k = 0; k < 3; ++k) if (k < ((l >> 2) & 3) && t >= 0) { const int rj = up4[t]; t = rj ? t - rj : -1; }
 						for (int k = 0; k < 3; ++k) if (k < (l & 3) && t >= 0) { const int rj = fpw[2 * t + 1] & ~TAKEN; t = rj ? t - rj : -1; }
 						const bool valid = t >= 0;
-						const int pt = valid ? fpw[2 * t + 1] & ~TAKEN : 0, next = pt ? t - pt : -1;
+						// Every lane loads the record of ITS anchor, once: its link is the lane's step, and score and mark of the anchor the step
+						// arrives at are the NEXT lane's record (lane l + 1 holds p^(l+1) = the predecessor of lane l's anchor) -- a shuffle instead
+						// of a second load behind the first.  The round's last lane only lends its record: a round decides rw - 1 steps.
+						const int rd = rw - 1;
+						int2 own = make_int2(0, TAKEN);
+						if (valid) own = fp[t];
+						const int pt = valid ? own.y & ~TAKEN : 0, next = pt ? t - pt : -1;
 						if (n_rounds == 1) { t_first = t; pt_first = pt; }
+						const int nx_f = __shfl_down(own.x, 1), nx_y = __shfl_down(own.y, 1);
 						int s = top, m = 1;
-						if (next >= 0) { const int2 rec = fp[next]; s = top - rec.x; m = bits ? taken(next) : rec.y < 0; }
+						if (next >= 0) { s = top - nx_f; m = bits ? (int)taken(next) : (int)(nx_y < 0); }
 						// best prefix BEFORE this lane's step
-						int inc = valid ? s : INT_MIN;
+						int inc = valid && l < rd ? s : INT_MIN;
 						for (int o = 1; o < W; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc = max(inc, v); }
 						int before = __shfl_up(inc, 1);
 						before = l == 0 ? best : max(best, before);
 						const bool newmax = valid && s > before;
 						const bool ends = !valid || (!newmax && before - s > b.max_drop) || m != 0;
-						const unsigned long long endm = __ballot(ends && l < rw);
-						const int jb = endm ? first_set(endm) : rw;            // the step that ends the walk (all of it is still taken)
-						if (valid && l <= jb) picked[n_v + visited + l] = t;
-						const unsigned long long nm = __ballot(newmax && l <= jb);
+						const unsigned long long endm = __ballot(ends && l < rd);
+						const int jb = endm ? first_set(endm) : rd;            // the step that ends the walk (all of it is still taken)
+						if (valid && l <= jb && l < rd) picked[n_v + visited + l] = t;
+						const unsigned long long nm = __ballot(newmax && l <= jb && l < rd);
 						if (nm) {
 							const int last = 63 - first_set_from_top(nm);
 							best = __shfl(s, last);
 							kept = visited + last + 1;
 						}
-						if (jb < rw) { visited += jb + 1; ended = true; }
-						else { visited += rw; cur = __shfl(next, rw - 1); rw = W; }
+						if (jb < rd) { visited += jb + 1; ended = true; }
+						else { visited += rd; cur = __shfl(t, rd); rw = W; }
 					}
 					wave_sync();
 					if (n_rounds == 1 && !bits) {
