@@ -692,6 +692,8 @@ int Engine::enqueue_post(int64_t n_reads, const int64_t *d_offsets, const mm2gb_
 	}
 	b.walk_grid_waves = n_cu * 4 * 8;
 	if (const char *v = getenv("MM2GB_WALK_WAVES")) b.walk_grid_waves = std::max(4, atoi(v));
+	b.sort_pairs = 1;
+	if (const char *v = getenv("MM2GB_SORT_PAIRS")) b.sort_pairs = atoi(v) != 0;
 	b.dbg = debug_phases ? (long long*)((char*)post_misc.ptr + 1024) : nullptr;
 	if (debug_phases) { MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024, 0, 512, stream)); MM2GB_HIP(hipMemsetAsync((char*)post_misc.ptr + 1024 + 22 * 8, 0xff, 8, stream)); }   // ([22]: a minimum)
 	b.dbg_reads = nullptr;
@@ -1405,6 +1407,7 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 		const size_t n_t = (size_t)std::min<long long>(t[42], 262144);
 		std::vector<long long> tk(n_t * 4);
 		if (hipMemcpy(tk.data(), post_dbg_stasks.ptr, tk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			auto ph12 = [](long long v) { return (double)((v & 511) << (2 * (v >> 9 & 7))); };   // ticks of a phase as k_post_sort_level packed them
 			for (int lv = 0; lv < 4; ++lv) {
 				std::vector<size_t> idx;
 				long long first = LLONG_MAX, last = 0, sum = 0;
@@ -1415,7 +1418,22 @@ void Engine::print_post_debug(int64_t n_reads, const int64_t *d_offsets)
 				for (size_t k = 0; k < std::min<size_t>(idx.size(), 6); ++k) {
 					const long long phv = tk[4 * idx[k] + 3];
 					fprintf(stderr, "  %lld | %.2f | %.2f (histogram %.2f, set-up %.2f, walk %.2f of %lld steps, move %.2f)", tk[4 * idx[k] + 2] & 0xffffffffLL, (tk[4 * idx[k]] - first) / 1e5, (tk[4 * idx[k] + 1] - tk[4 * idx[k]]) / 1e5,
-					        (phv & 4095) * 0.01024, (phv >> 12 & 4095) * 0.01024, (phv >> 24 & 4095) * 0.01024, phv >> 48 & 0xfffff, (phv >> 36 & 4095) * 0.01024);
+					        ph12(phv) / 1e5, ph12(phv >> 12) / 1e5, ph12(phv >> 24) / 1e5, phv >> 48 & 0xfffff, ph12(phv >> 36) / 1e5);
+				}
+				{
+					// by size: tasks, elements, steps, and where the waves' time went
+					const long long edge[4] = { 1792, 3584, 7168, LLONG_MAX };
+					const char *name[4] = { "up to 1 792 elements", "up to 3 584", "up to 7 168 (resident)", "longer" };
+					for (int c = 0; c < 4; ++c) {
+						long long sdt = 0, sel = 0, sst = 0, sp[4] = { 0, 0, 0, 0 }; size_t nn = 0;
+						for (size_t k : idx) {
+							const long long len = tk[4 * k + 2] & 0xffffffffLL, dt = tk[4 * k + 1] - tk[4 * k], phv = tk[4 * k + 3];
+							if (len > edge[c] || (c > 0 && len <= edge[c - 1])) continue;
+							++nn; sdt += dt; sel += len; sst += phv >> 48 & 0xfffff;
+							for (int q = 0; q < 4; ++q) sp[q] += ph12(phv >> (12 * q));
+						}
+						if (nn) fprintf(stderr, "\n    %s: %zu tasks, %lld elements, %lld steps, %.1f ms summed (histogram %.1f, set-up %.1f, walk %.1f, move %.1f)", name[c], nn, sel, sst, sdt / 1e5, sp[0] / 1e5, sp[1] / 1e5, sp[2] / 1e5, sp[3] / 1e5);
+					}
 				}
 				fprintf(stderr, "\n    tasks in flight at 14 points of its time:");
 				for (int kb = 0; kb < 14; ++kb) { const double at = first + (double)(last - first) * (kb + 0.5) / 14; int busy = 0; for (size_t k : idx) if (tk[4 * k] <= at && at < tk[4 * k + 1]) ++busy; fprintf(stderr, " %d", busy); }

@@ -56,6 +56,7 @@ struct PostBatch {
 	int4     *stask[2];        // two lists (a level reads one and fills the other): read, first candidate, length, key byte's shift; counts in cursor[8 + level], work cursors in cursor[16 + level]
 	int32_t  *stask_order;     // the tasks of the level that runs, longest first
 	int       walk_grid_waves; // waves of k_post_walk (it holds no LDS: more fit than of the sort)
+	int       sort_pairs;      // 1: k_post_sort_level walks two short runs side by side (MM2GB_SORT_PAIRS=0: one at a time)
 	long long *dbg_stasks;     // optional (MM2GB_DEBUG_PHASES): per sort task (up to 262144, in the order finished; count in dbg[40]) 4 values: start tick, end tick, level << 32 | length, steps of its pass
 	long long *dbg_tasks;      // optional (MM2GB_DEBUG_PHASES): per walk task (in the order taken) 4 values: start tick, end tick, read << 4 | class, candidates
 };

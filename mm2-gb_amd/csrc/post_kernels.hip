@@ -471,6 +471,16 @@ __device__ __forceinline__ int radix_pass_bytes_t(unsigned long long *g, int lo,
 #pragma unroll
 		for (int q = 0; q < 4; ++q) { rec[4 * l + q] = make_int4(at, 0, 0, at + c[q]); at += c[q]; }
 		wave_sync();
+		// the map of the elements that are not in their bucket (one bit per position, in the line slots' owner bytes): what the walking lane looks
+		// for -- with it the lane finds a bucket's next element to move by itself, and the other 63 are not asked 256 times over
+		for (int base = 0; base < len; base += W) {
+			const int i = base + l;
+			bool out = false;
+			if (i < len) { const int4 r = rec[lineb[i]]; out = lo + i < r.x || lo + i >= r.w; }
+			const unsigned long long m = __ballot(out);
+			if (l == 0) { ((unsigned*)L.owner)[base / 32] = (unsigned)m; ((unsigned*)L.owner)[base / 32 + 1] = (unsigned)(m >> 32); }
+		}
+		wave_sync();
 	} else {
 		// line slots: one each, the spare ones by share of the keys
 		constexpr int SPARE = GROUPS - 256;
@@ -500,16 +510,49 @@ __device__ __forceinline__ int radix_pass_bytes_t(unsigned long long *g, int lo,
 		fetch_all_byte_lines(sc.S, used, L);
 	}
 	phase(1);
+	if (resident) {
+		// the whole walk on lane 0 (ksort.h:128-139): bucket by bucket, the next element out of place from the map, its cycle -- the next position of
+		// the bucket arrived at, the byte of its occupant, the position advanced, a perm entry per step.  (Tried: the occupant's byte kept in the
+		// bucket's record, refreshed off the dependent chain -- one dependent LDS read per step instead of two, twice the instructions: slower.)
+		int steps = 0, cycles = 0;
+		if (l == 0) {
+			const unsigned *bm = (const unsigned*)L.owner;
+			for (int k = 0; k < 256; ++k) {
+				const int4 rk = rec[k];
+				int i = rk.x - lo;
+				const int end = rk.w - lo;
+				while (i < end) {
+					const unsigned w = bm[i >> 5] >> (i & 31);
+					if (w == 0) { i = (i | 31) + 1; continue; }
+					i += __builtin_ctz(w);
+					if (i >= end) break;
+					const int home = lo + i;
+					int d = lineb[i], src = home;
+					++cycles;
+					do {
+						const int pos = rec[d].x;
+						const int nb = lineb[pos - lo];
+						sc.perm[src] = pos;
+						rec[d].x = pos + 1;
+						src = pos; d = nb; ++steps;
+					} while (d != k);
+					sc.perm[src] = home;
+					++i;
+				}
+			}
+		}
+		d_steps = uni(steps); d_cycles = uni(cycles);
+	} else
 	for (int k = 0; k < 256; ++k) {
 		if (!((full[k & 3] >> (k >> 2)) & 1)) continue;
 		const int4 rk = rec[k];
-		int hk = uni(resident ? rk.x : rk.y);
+		int hk = uni(rk.y);
 		const int tk = uni(rk.w);
 		int by4[4];
 		for (int hq = hk; hq < tk; hq += 4 * W) {
 			// the bucket's bytes, four blocks of 64 per round trip (they never change during the pass: read ahead at will)
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int i = min(hq + u * W + l, tk - 1); by4[u] = resident ? (int)lineb[i - lo] : (int)sc.S[i]; }
+			for (int u = 0; u < 4; ++u) { const int i = min(hq + u * W + l, tk - 1); by4[u] = (int)sc.S[i]; }
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			hk = hq + u * W;
@@ -524,27 +567,6 @@ __device__ __forceinline__ int radix_pass_bytes_t(unsigned long long *g, int lo,
 				++d_cycles;
 				const int home = hk + skip;
 				int d = __builtin_amdgcn_readlane(by, skip), src = home;
-				if (resident) {
-					// the cycle on lane 0: a record, a byte, a record back, a perm entry per step
-					// the cycle on lane 0: the next position of the bucket arrived at, the byte of its occupant, the position advanced, a perm
-					// entry.  (Tried: the occupant's byte kept in the bucket's record, refreshed off the dependent chain -- one dependent LDS
-					// read per step instead of two, twice the instructions: 12.0 -> 14.2 s of wave time at the lowest level.  A lone lane's
-					// step is bound by how fast one wave issues dependent instructions, not by the LDS.)
-					int steps = 0;
-					if (l == 0) {
-						for (;;) {
-							const int pos = rec[d].x;
-							const int nb = lineb[pos - lo];
-							sc.perm[src] = pos;
-							rec[d].x = pos + 1;
-							src = pos; d = nb; ++steps;
-							if (d == k) break;
-						}
-						sc.perm[src] = home;
-					}
-					d_steps += uni(steps);
-					continue;
-				}
 				for (;;) {
 					// the cycle on lane 0, until it closes or a line runs out
 					int status = 0, steps = 0;                // 0 closed, 1 line of bucket d empty
@@ -612,6 +634,136 @@ __device__ __forceinline__ int radix_pass_bytes_t(unsigned long long *g, int lo,
 __device__ __forceinline__ bool radix_pass_bytes(unsigned long long *g, int lo, int hi, int shift, PassLds &L, const SortScratch &sc, long long *dbg = nullptr, long long *ph = nullptr, FewBuckets *fb = nullptr)
 {
 	return radix_pass_bytes_t<false>(g, lo, hi, shift, &L, L.where, sc, dbg, ph, fb) == 1;
+}
+
+// ---- TWO short runs walked side by side (round 6) ---------------------------------------------------------------------------------------
+// A pass's walk is one lane's chain of dependent LDS reads: 63 lanes wait.  Runs of up to half the lines' bytes are taken in PAIRS: their histograms,
+// byte sequences and records go into one wave's LDS side by side (2 KB of records, 3 584 bytes and a 448-byte map of the elements that are not in
+// their bucket, each), lane 0 walks the first run and lane 1 the second at the same time -- the same instructions, each on its own run -- and the
+// elements of both follow their permutations with all lanes afterwards.  The walk is the reference's (ksort.h:128-139) on each run, so the
+// arrays come out the same; what differs from the single form is only that a bucket's elements which must move are found from the map, bit by
+// bit, by the walking lane itself (the single form's wave looks at 64 positions at a time).
+constexpr int PAIR_MAX = LINE_STORE_BYTES / 2;
+static_assert(PAIR_MAX % 64 == 0 && PAIR_MAX / 8 * 2 <= LINE_STORE_BYTES / 8, "two maps of PAIR_MAX bits fit in PassLds::owner");
+struct PairRun { unsigned long long *g; int len, shift; SortScratch sc; };
+// returns bit j set when run j was moved by its pass (clear: all its keys share the byte -- nothing was done to it)
+__device__ __forceinline__ int radix_pass_pair(const PairRun &A, const PairRun &B, PassLds &L, long long *dbg)
+{
+	const int l = lane();
+	int moved = 0;
+	int d_steps = 0, d_cycles = 0;
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		const PairRun &R = j == 0 ? A : B;
+		int *cnt = L.where + 512 * j;
+		int2 *rec = (int2*)cnt;
+		unsigned char *lb = (unsigned char*)L.line + PAIR_MAX * j;
+		unsigned *bm = (unsigned*)L.owner + (PAIR_MAX / 32) * j;
+		const int len = R.len;
+		for (int k = l; k < 256; k += W) cnt[k] = 0;
+		wave_sync();
+		for (int base = 0; base < len; base += 8 * W) {
+			int byte[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) byte[u] = (int)(ZElem::key(R.g[min(base + u * W + l, len - 1)]) >> R.shift) & 255;
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int i = base + u * W + l;
+				if (i < len) { atomicAdd(&cnt[byte[u]], 1); lb[i] = (unsigned char)byte[u]; R.sc.perm[i] = i; }
+			}
+		}
+		wave_sync();
+		const int c[4] = { cnt[4 * l], cnt[4 * l + 1], cnt[4 * l + 2], cnt[4 * l + 3] };
+		const bool same = __ballot(c[0] == len || c[1] == len || c[2] == len || c[3] == len) != 0;
+		int inc = c[0] + c[1] + c[2] + c[3];
+		const int own = inc;
+		for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(inc, off); if (l >= off) inc += o; }
+		int at = inc - own;
+		wave_sync();                                            // (the counts are in registers: the records take their place)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { rec[4 * l + q] = make_int2(at, at + c[q]); at += c[q]; }
+		wave_sync();
+		// the map: an element is where it belongs when its position lies inside its own bucket
+		for (int base = 0; base < len; base += W) {
+			const int i = base + l;
+			bool out = false;
+			if (i < len) { const int2 r = rec[lb[i]]; out = i < r.x || i >= r.y; }
+			const unsigned long long m = __ballot(out);
+			if (l == 0) { bm[base / 32] = (unsigned)m; bm[base / 32 + 1] = (unsigned)(m >> 32); }
+		}
+		wave_sync();
+		if (!same) moved |= 1 << j;
+	}
+	// the two walks, lane j on run j
+	if (l < 2 && ((moved >> l) & 1)) {
+		int2 *rec = (int2*)(L.where + 512 * l);
+		const unsigned char *lb = (const unsigned char*)L.line + PAIR_MAX * l;
+		const unsigned *bm = (const unsigned*)L.owner + (PAIR_MAX / 32) * l;
+		int32_t *perm = l == 0 ? A.sc.perm : B.sc.perm;
+		int steps = 0, cycles = 0;
+		for (int k = 0; k < 256; ++k) {
+			const int2 rk = rec[k];
+			int i = rk.x;
+			const int end = rk.y;
+			while (i < end) {
+				const unsigned w = bm[i >> 5] >> (i & 31);
+				if (w == 0) { i = (i | 31) + 1; continue; }
+				i += __builtin_ctz(w);
+				if (i >= end) break;
+				const int home = i;
+				int d = lb[home], src = home;
+				++cycles;
+				do {
+					const int pos = rec[d].x;
+					const int nb = lb[pos];
+					perm[src] = pos;
+					rec[d].x = pos + 1;
+					src = pos; d = nb; ++steps;
+				} while (d != k);
+				perm[src] = home;
+				i = home + 1;
+			}
+		}
+		d_steps = steps; d_cycles = cycles;
+	}
+	wave_sync();
+	// the elements follow the permutations: out of place first, then back (all lanes)
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		if (!((moved >> j) & 1)) continue;
+		const PairRun &R = j == 0 ? A : B;
+		for (int base = 0; base < R.len; base += 8 * W) {
+			unsigned long long e[8]; int to[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const int i = min(base + u * W + l, R.len - 1); e[u] = R.g[i]; to[u] = R.sc.perm[i]; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) if (base + u * W + l < R.len) R.sc.tmp[to[u]] = e[u];
+		}
+	}
+	wave_sync();
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		if (!((moved >> j) & 1)) continue;
+		const PairRun &R = j == 0 ? A : B;
+		for (int base = 0; base < R.len; base += 8 * W) {
+			unsigned long long e[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) e[u] = R.sc.tmp[min(base + u * W + l, R.len - 1)];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) if (base + u * W + l < R.len) R.g[base + u * W + l] = e[u];
+		}
+	}
+	wave_sync();
+	if (dbg) {
+		const int s0 = __builtin_amdgcn_readlane(d_steps, 0) + __builtin_amdgcn_readlane(d_steps, 1), c0 = __builtin_amdgcn_readlane(d_cycles, 0) + __builtin_amdgcn_readlane(d_cycles, 1);
+		if (l == 0) {
+			atomicAdd((unsigned long long*)&dbg[0], (unsigned long long)s0);
+			atomicAdd((unsigned long long*)&dbg[3], (unsigned long long)c0);
+			atomicAdd((unsigned long long*)&dbg[4], (unsigned long long)((moved & 1 ? A.len : 0) + (moved & 2 ? B.len : 0)));
+			atomicAdd((unsigned long long*)&dbg[5], (unsigned long long)__popc(moved));
+		}
+	}
+	return moved;
 }
 
 // radix_sort_128x (ksort.h:147-151) of g[0, n) by key, same final element order as the host's.
@@ -1326,12 +1478,63 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort
 	const int4 *list = b.stask[level & 1];
 	int4 *next = b.stask[(level + 1) & 1];
 	const int lvl = level < 3 ? level : 2;
+	const bool pairs = b.sort_pairs != 0;
 	for (;;) {
 		int q = 0;
 		if (l == 0) q = atomicAdd(b.cursor + 16 + level, 1);
 		q = uni(q);
 		if (q >= n_t) break;
-		const int4 t = list[uni(b.stask_order[q])];
+		int4 todo[2];
+		todo[0] = list[uni(b.stask_order[q])];
+		int n_todo = 1;
+		if (pairs && uni(todo[0].z) <= PAIR_MAX) {
+			// a short run: it is walked beside the next one when that is short too (the tasks come longest first, so it nearly always is)
+			int q2 = 0;
+			if (l == 0) q2 = atomicAdd(b.cursor + 16 + level, 1);
+			q2 = uni(q2);
+			if (q2 < n_t) {
+				todo[1] = list[uni(b.stask_order[q2])];
+				n_todo = 2;
+				if (uni(todo[1].z) <= PAIR_MAX) {
+					const long long t0 = b.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+					PairRun R[2];
+#pragma unroll
+					for (int j = 0; j < 2; ++j) {
+						const int64_t off = b.offsets[uni(todo[j].x)] + uni(todo[j].y);
+						R[j].g = b.z + off; R[j].len = uni(todo[j].z); R[j].shift = uni(todo[j].w);
+						R[j].sc = SortScratch{ b.sort_s + off, b.sort_perm + off, b.sort_tmp + off };
+					}
+					const int moved = radix_pass_pair(R[0], R[1], L, b.dbg ? b.dbg + 24 + 6 * lvl : nullptr);
+					n_todo = 0;
+					int d_small = 0;
+					for (int j = 0; j < 2; ++j) {
+						const int4 t = j == 0 ? todo[0] : todo[1];
+						const int r = uni(t.x), lo = uni(t.y), len = uni(t.z), shift = uni(t.w) - 8;
+						if (shift < 0) continue;
+						if (!((moved >> j) & 1)) { const int4 again = make_int4(r, lo, len, shift); if (n_todo == 0) todo[0] = again; else todo[1] = again; ++n_todo; continue; }
+						d_small += sort_level<ZElem>(j == 0 ? R[0].g : R[1].g, len, shift, [&](int first, int end) {
+							if (l == 0) next[atomicAdd(b.cursor + 8 + level + 1, 1)] = make_int4(r, lo + first, end - first, shift);
+						});
+					}
+					if (b.dbg && l == 0) {
+						const long long t1 = (long long)__builtin_amdgcn_s_memrealtime();
+						atomicAdd((unsigned long long*)&b.dbg[13 + lvl], (unsigned long long)(t1 - t0));
+						atomicAdd((unsigned long long*)&b.dbg[1], (unsigned long long)(t1 - t0));
+						atomicMax((unsigned long long*)&b.dbg[4], (unsigned long long)(t1 - t0));
+						atomicAdd((unsigned long long*)&b.dbg[17], 2ull);
+						atomicAdd((unsigned long long*)&b.dbg[18], (unsigned long long)(R[0].len + R[1].len));
+						atomicAdd((unsigned long long*)&b.dbg[19], (unsigned long long)d_small);
+						if (b.dbg_stasks) {
+							const unsigned long long at = atomicAdd((unsigned long long*)&b.dbg[42], 1ull);
+							if (at < 262144) { b.dbg_stasks[4 * at] = t0; b.dbg_stasks[4 * at + 1] = t1; b.dbg_stasks[4 * at + 2] = (long long)level << 32 | (R[0].len + R[1].len); b.dbg_stasks[4 * at + 3] = 0; }
+						}
+					}
+					wave_sync();
+				}
+			}
+		}
+		for (int k = 0; k < n_todo; ++k) {
+		const int4 t = k == 0 ? todo[0] : todo[1];
 		const int r = uni(t.x), lo = uni(t.y), len = uni(t.z);
 		const int64_t off = b.offsets[r];
 		unsigned long long *g = b.z + off + lo;
@@ -1368,13 +1571,14 @@ __global__ __launch_bounds__(POST_THREADS, POST_WAVES_PER_SIMD) void k_post_sort
 			atomicAdd((unsigned long long*)&b.dbg[19], (unsigned long long)d_small);
 			if (b.dbg_stasks) {
 				const unsigned long long at = atomicAdd((unsigned long long*)&b.dbg[42], 1ull);
-				// [3]: ticks of the pass's phases, 12 bits of 10.24 us each: histogram | set-up | walk | the elements' move; the rest: the children
-				auto q12 = [](long long v) { const long long u = v >> 10; return u > 4095 ? 4095LL : u; };
+				// [3]: ticks of the pass's phases, 12 bits each (9 of value, 3 of exponent: value << 2 * exponent): histogram | set-up | walk | the elements' move
+				auto q12 = [](long long v) { int e = 0; while ((v >> (2 * e)) > 511 && e < 7) ++e; const long long m = v >> (2 * e); return (m > 511 ? 511LL : m) | (long long)e << 9; };
 				if (at < 262144) { b.dbg_stasks[4 * at] = t0; b.dbg_stasks[4 * at + 1] = t1; b.dbg_stasks[4 * at + 2] = (long long)level << 32 | len;
 				                   b.dbg_stasks[4 * at + 3] = q12(ph[0]) | q12(ph[1]) << 12 | q12(ph[2]) << 24 | q12(ph[3]) << 36 | (ph[5] & 0xfffff) << 48; }
 			}
 		}
 		wave_sync();
+		}
 	}
 }
 
