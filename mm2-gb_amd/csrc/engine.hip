@@ -911,7 +911,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			}
 		}
 		rb.skey_in = rb.skey = nullptr; rb.sa = nullptr; rb.srange = nullptr; rb.sort_tmp = nullptr; rb.sort_tmp_bytes = 0;
-		const RmqParams rp0 = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
+		const RmqParams rp0 = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip, 0 };
 		rb.strip_shift = rmq_strip_shift(rp0);
 		{
 			// scratch of the batch's key sorts (ranks by y; the strip order), and -- tile kernel, MM2GB_RMQ_STRIPS=0 turns it off for A/B runs and
@@ -939,7 +939,8 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			MM2GB_HIP(hipMemsetAsync(rmq_dbg_reads.ptr, 0, (size_t)std::max<int64_t>(n_reads, 1) * 64, stream));
 			rb.dbg_reads = (long long*)rmq_dbg_reads.ptr;
 		}
-		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip };
+		const char *ties = getenv("MM2GB_RMQ_TIES");                   // strict: every tie counts (A/B runs, and what the one-anchor-per-step kernel always does)
+		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip, ties && !strcmp(ties, "strict") ? 0 : 1 };
 		if (launch_rmq_fill(rb, rp, stream)) { (void)hipStreamSynchronize(stream); return fail("mm2gb_rmq_chain_gpu: the segmented sort of the batch's keys failed"); }
 		MM2GB_HIP(hipGetLastError());
 		last.n_anchors += n; last.n_reads += n_reads;

@@ -65,7 +65,8 @@ constexpr int N_TREE_CLASSES = 16;
 void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 
 // RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369) of reads whose anchors are already chained once: score fill on the device.
-struct RmqParams { int max_dist, max_dist_inner, bw, cap_rmq_size; float pen_gap, pen_skip; };
+struct RmqParams { int max_dist, max_dist_inner, bw, cap_rmq_size; float pen_gap, pen_skip;
+                   int weigh_ties; };   // tile form: a tie on the smallest priority counts (n_tied) only if its holders differ in what they leave the anchor with; 0: every tie counts
 struct RmqBatch {
 	const uint4   *raw;        // anchors, sorted by x within each read
 	const int64_t *offsets;

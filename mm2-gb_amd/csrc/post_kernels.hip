@@ -2499,6 +2499,67 @@ __device__ __forceinline__ int tile_pair_score(unsigned xi, int yi, unsigned xj,
 	return sc - (((dd != 0) | (dq > q_span_j)) ? pen : 0);
 }
 
+
+// Several anchors hold the smallest priority of an anchor's query, and which of them the reference returns follows from the shape of its
+// tree.  That need not be known where every holder leaves the anchor with the same score and predecessor: the tree's content does not
+// depend on the pick (priorities come from f[] alone) and -- there is no skip limit here -- neither does the inner walk, whose result is
+// the first candidate, in walking order, to reach the walk's largest score wherever the walk started from below that.  So: the anchor's
+// whole inner window for its best (nothing passed over on the strength of one holder's score), then every holder of the key in the
+// anchor's window and rank interval followed through lchain.c:316-341 and compared with what the tile made of the anchor.  Rare (a few
+// anchors in a hundred thousand), so by the plain means: the whole wave, 64 anchors of the window at a time, from memory; the tile's own
+// anchors below the one in question are still in registers, one per lane (lanes < n_own).  Returns the same in every lane.
+// (csrc/rmq_host.cpp weighs its ties the same way; the oracle counts them: orc_rmq_last_ties_that_decide.)
+__device__ __noinline__ bool rmq_tie_decides(const uint4 *a, const int32_t *f, const int4 *meta, double half_gap, RmqParams P, int max_inner,
+                                             unsigned xt, int yt, int q_t, long long key_t, int rk_lo, int rk_hi, int st, int st_in, int i0, int res_f, int res_j,
+                                             int tb, int n_own, uint4 A_own, int f_own, long long k_own, int rk_own)
+{
+	const int l = lane();
+	const bool inner_there = max_inner > 0 && st_in < i0 && yt > 0;
+	const int y_top = yt - 1, y_bot = yt - max_inner, mem_end = min(i0, tb);
+	TileInner best; best.s = 0; best.y = 0; best.j = -1;
+	if (inner_there) {
+		for (int base = st_in; base < mem_end; base += W) {
+			const int j = base + l;
+			if (j < mem_end) {
+				const uint4 e = a[j];
+				int ex, wd;
+				const int s2 = f[j] + tile_pair_score(xt, yt, e.x, (int)e.z, (int)(e.w & 0xffu), P, ex, wd);
+				tile_offer_inner(best, ((int)e.z <= y_top) & ((int)e.z >= y_bot) & (wd <= P.bw), s2, (int)e.z, j);
+			}
+		}
+		{
+			const int j = tb + l;
+			int ex, wd;
+			const int s2 = f_own + tile_pair_score(xt, yt, A_own.x, (int)A_own.z, (int)(A_own.w & 0xffu), P, ex, wd);
+			tile_offer_inner(best, (l < n_own) & (j >= st_in) & (j < i0) & ((int)A_own.z <= y_top) & ((int)A_own.z >= y_bot) & (wd <= P.bw), s2, (int)A_own.z, j);
+		}
+		for (int o = W / 2; o > 0; o >>= 1) tile_offer_inner(best, __shfl_xor(best.j, o) >= 0, __shfl_xor(best.s, o), __shfl_xor(best.y, o), __shfl_xor(best.j, o));
+	}
+	bool differs = false;
+	auto weigh = [&](bool holds, unsigned xj, int yj, int sj, int fj, int j) {
+		int ex, wd;
+		const int sc = fj + tile_pair_score(xt, yt, xj, yj, sj, P, ex, wd);
+		int o_f = q_t, o_j = -1;
+		if (wd <= P.bw && sc > o_f) { o_f = sc; o_j = j; }
+		if (!ex && inner_there && best.j >= 0 && best.s > o_f) { o_f = best.s; o_j = best.j; }
+		differs |= holds & ((o_f != res_f) | (o_j != res_j));
+	};
+	for (int base = st; base < mem_end; base += W) {
+		const int j = base + l;
+		if (j < mem_end) {
+			const uint4 e = a[j];
+			const int fj = f[j], rk = meta[j].x;
+			const long long kj = key_order((double)fj + half_gap * (double)((int)e.x + (int)e.z));
+			weigh((kj == key_t) & (rk >= rk_lo) & (rk <= rk_hi), e.x, (int)e.z, (int)(e.w & 0xffu), fj, j);
+		}
+	}
+	{
+		const int j = tb + l;
+		weigh((l < n_own) & (j >= st) & (j < i0) & (k_own == key_t) & (rk_own >= rk_lo) & (rk_own <= rk_hi), A_own.x, (int)A_own.z, (int)(A_own.w & 0xffu), f_own, j);
+	}
+	return __ballot(differs) != 0;
+}
+
 } // namespace
 
 // per anchor: its window starts and the start of its run of equal x, closed forms of the carried values of lchain.c:279-310 (the
@@ -2853,10 +2914,16 @@ __device__ __forceinline__ void rmq_fill_read_tiles(const RmqBatch &b, const Rmq
 				}
 				const bool use_in = inner_on & (in.j >= 0) & (in.s > max_f);
 				max_f = use_in ? in.s : max_f; max_j = use_in ? in.j : max_j;
+				bool counts = __builtin_amdgcn_readlane((int)(has && c.tie), t) != 0;
+				if (counts && P.weigh_ties)
+					counts = rmq_tie_decides(a, f, meta, half_gap, P, max_inner, (unsigned)__builtin_amdgcn_readlane((int)xi, t), __builtin_amdgcn_readlane(yi, t), __builtin_amdgcn_readlane(q_i, t),
+					                         (long long)readlane64((unsigned long long)c.key, t), __builtin_amdgcn_readlane(M.y, t), __builtin_amdgcn_readlane(M.z, t),
+					                         __builtin_amdgcn_readlane(Wn.x, t), __builtin_amdgcn_readlane(Wn.y, t), __builtin_amdgcn_readlane(Wn.z, t),
+					                         __builtin_amdgcn_readlane(max_f, t), __builtin_amdgcn_readlane(max_j, t), tb, t, A, f_l, k_l, M.x);
 				if (l == t) {
 					f_l = max_f; p_l = max_j < 0 ? 0 : i - max_j;
 					k_l = key_order((double)max_f + half_gap * (double)((int)xi + yi));
-					tied += has && c.tie;
+					tied += counts;
 				}
 				// lane t's anchor to the lanes above it
 				const int j = tb + t;
@@ -3029,10 +3096,16 @@ __device__ __forceinline__ void team_steps(const RmqBatch &b, const RmqParams &P
 			}
 			const bool use_in = inner_on & (in.j >= 0) & (in.s > max_f);
 			max_f = use_in ? in.s : max_f; max_j = use_in ? in.j : max_j;
+			bool counts = __builtin_amdgcn_readlane((int)(has && c.tie), t) != 0;
+			if (counts && P.weigh_ties)
+				counts = rmq_tie_decides(R.a, R.f, R.meta, R.half_gap, P, max_inner, (unsigned)__builtin_amdgcn_readlane((int)xi, t), __builtin_amdgcn_readlane(yi, t), __builtin_amdgcn_readlane(q_i, t),
+				                         (long long)readlane64((unsigned long long)c.key, t), __builtin_amdgcn_readlane(M.y, t), __builtin_amdgcn_readlane(M.z, t),
+				                         __builtin_amdgcn_readlane(Wn.x, t), __builtin_amdgcn_readlane(Wn.y, t), __builtin_amdgcn_readlane(Wn.z, t),
+				                         __builtin_amdgcn_readlane(max_f, t), __builtin_amdgcn_readlane(max_j, t), tb, t, A, f_l, k_l, M.x);
 			if (l == t) {
 				f_l = max_f; p_l = max_j < 0 ? 0 : i - max_j;
 				k_l = key_order((double)max_f + R.half_gap * (double)((int)xi + yi));
-				tied += has && c.tie;
+				tied += counts;
 			}
 			// lane t's anchor to the lanes above it
 			const int j = tb + t;

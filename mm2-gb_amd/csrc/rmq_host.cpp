@@ -14,6 +14,7 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -312,6 +313,26 @@ struct RankTree {
 		*tied = best.tie != 0;
 		return best.who;
 	}
+	// every anchor of i's interval that holds the priority `pri` (the smallest one, when lowest_for reported a tie): in (y, index) order
+	void holders_of(int i, double pri, std::vector<int> &out) const
+	{
+		out.clear();
+		if (q_lo[(size_t)i] > q_hi[(size_t)i]) return;
+		const size_t first = (size_t)base + (size_t)q_lo[(size_t)i], last = (size_t)base + (size_t)q_hi[(size_t)i];
+		below(1, (size_t)base, first, last, pri, out);
+	}
+private:
+	void below(size_t at, size_t width, size_t first, size_t last, double pri, std::vector<int> &out) const
+	{
+		// node `at` covers leaves [lo, lo + width)
+		size_t depth = 0; for (size_t v = at; v > 1; v >>= 1) ++depth;
+		const size_t lo = (at << (size_t)(__builtin_ctzll((unsigned long long)base) - depth));
+		if (lo > last || lo + width - 1 < first || t[at].pri > pri) return;        // a subtree whose smallest priority is above `pri` holds none (one that reaches outside the interval may go below it)
+		if (width == 1) { if (t[at].pri == pri) out.push_back(t[at].who); return; }
+		below(at * 2, width / 2, first, last, pri, out);
+		below(at * 2 + 1, width / 2, first, last, pri, out);
+	}
+public:
 };
 
 struct InnerCand { int32_t y, j, x, f; int32_t span; };
@@ -406,7 +427,7 @@ __attribute__((target("avx2"))) void scan_bucket_avx2(const InnerBucket &v, int 
 }
 #endif
 
-struct FillScratch { ShapeTree tree; RankTree flat; InnerWindow inner; std::vector<int32_t> seen; };   // seen: the reference's t[] (lchain.c:333-338)
+struct FillScratch { ShapeTree tree; RankTree flat; InnerWindow inner; std::vector<int32_t> seen; std::vector<int> holders; long long ties_met = 0, ties_that_decide = 0; };   // seen: the reference's t[] (lchain.c:333-338)
 
 // f[n], p_rel[n] (i - predecessor, 0 = none) of one read
 // pen: (int)(gap * dd + .5 * mg_log2(dd + 1)) for dd = 0 .. bw when chn_pen_skip == 0 (the penalty then depends on dd alone), else null
@@ -422,6 +443,7 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 	const bool use_avx2 = __builtin_cpu_supports("avx2") && !getenv("MM2GB_RMQ_NO_SIMD");   // (MM2GB_RMQ_NO_SIMD: the scalar scan, for A/B runs and tests; read once per read)
 #endif
 	auto &tree = [&]() -> auto& { if constexpr (EXACT_SHAPE) return ws.tree; else return ws.flat; }();
+	const int weigh_ties = []() { const char *v = getenv("MM2GB_RMQ_TIES"); return v && !strcmp(v, "strict") ? 0 : 1; }();   // strict: every tie sends the read to the reference's tree (A/B runs, tests; read once per read)
 	if constexpr (EXACT_SHAPE) tree.reset(a, n); else tree.reset(a, n, max_dist);
 	ws.seen.assign((size_t)n, 0);
 	if (max_inner > 0 && n > 0) {
@@ -450,61 +472,91 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 				++st_in;
 			}
 		int max_f = q_i, max_j = -1;
+		// lchain.c:320-341: the inner window's anchors with y in [yi - max_inner, yi - 1], from the largest (y, index) down; a strictly better
+		// score replaces the best; the walk gives up after max_chn_skip anchors whose own predecessor chain this anchor has already been
+		// offered (the marks in seen[], lchain.c:333-338)
+		const bool inner_there = max_inner > 0 && ws.inner.count > 0 && yi > 0;
+		auto inner_scan = [&](int &max_f, int &max_j) {
+			int n_skip = 0;
+			const bool exhaustive = P.max_chn_skip == INT32_MAX;
+			const int y_top = yi - 1, y_bot = yi - max_inner;
+			const int xi = (int32_t)a[i].x;
+			const int b_top = std::min<int>((int)ws.inner.bucket.size() - 1, (std::max(y_top, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT);
+			const int b_bot = (std::max(y_bot, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT;
+			bool stop = y_top < ws.inner.y0;
+			for (int b = b_top; b >= b_bot && !stop; --b) {
+				const InnerBucket &v = ws.inner.bucket[(size_t)b];
+				// without a skip limit a candidate matters only if it beats the best so far, and none of this bucket can
+				if (exhaustive && ws.inner.top[(size_t)b] <= max_f) continue;
+#if defined(__x86_64__)
+				if (exhaustive && pen && use_avx2) { scan_bucket_avx2(v, xi, yi, y_top, y_bot, P.bw, pen, max_f, max_j); continue; }
+#endif
+				for (size_t at = v.size(); at-- > 0;) {
+					const int cy = v.y[at];
+					if (cy > y_top) continue;
+					if (cy < y_bot) break;
+					// comput_sc_simple (lchain.c:232-248) on the copies
+					const int cj = v.j[at], cspan = v.span[at];
+					const int dq = yi - cy, dr = xi - v.x[at], dd = dr > dq ? dr - dq : dq - dr;
+					if (dd > P.bw) continue;
+					const int dg = dr < dq ? dr : dq;
+					int sc = cspan < dg ? cspan : dg;
+					if (dd || dq > cspan) {
+						if (pen) sc -= pen[dd];
+						else {
+							const float lin = P.chn_pen_gap * (float)dd + P.chn_pen_skip * (float)dg;
+							const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
+							sc -= (int)(lin + .5f * lg);
+						}
+					}
+					const int s2 = v.f[at] + sc;
+					if (exhaustive) {                          // no skip limit: the marks of lchain.c:333-338 decide nothing -- no look at p[] and seen[] per candidate
+						if (s2 > max_f) { max_f = s2; max_j = cj; }
+						continue;
+					}
+					if (s2 > max_f) { max_f = s2; max_j = cj; if (n_skip > 0) --n_skip; }
+					else if (ws.seen[(size_t)cj] == i) { if (++n_skip > P.max_chn_skip) { stop = true; break; } }
+					if (p_rel[cj]) ws.seen[(size_t)(cj - p_rel[cj])] = i;
+				}
+			}
+		};
 		// lchain.c:311-315: the closed interval [(yi - max_dist, INT32_MAX), (yi, 0)] of (y, index)
 		int j;
+		bool weighed = false;
 		if constexpr (EXACT_SHAPE) j = tree.lowest_between(yi - max_dist, INT32_MAX, yi, 0);
-		else { bool tied = false; j = tree.lowest_for(i, &tied); if (tied) return false; }
-		if (j >= 0) {
+		else {
+			bool tied = false;
+			j = tree.lowest_for(i, &tied);
+			if (tied) {
+				// Several anchors hold the smallest priority and the reference's pick follows from the shape of its tree.  It need not be known
+				// when every one of them leaves this anchor with the same score and predecessor: the tree's content does not depend on the
+				// pick (priorities come from f[] alone), and without a skip limit neither does the inner walk -- its best is the first
+				// candidate, in walking order, to reach the walk's largest score, wherever the walk started from below that.
+				++ws.ties_met;
+				if (P.max_chn_skip != INT32_MAX || weigh_ties == 0) { ++ws.ties_that_decide; return false; }
+				int in_f = q_i, in_j = -1;
+				if (inner_there) inner_scan(in_f, in_j);
+				tree.holders_of(i, -((double)f[j] + half_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y)), ws.holders);
+				bool first = true, same = true;
+				int res_f = q_i, res_j = -1;
+				for (int q : ws.holders) {
+					bool exact; int width;
+					const int sc = f[q] + pair_score(a[i], a[q], P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
+					int o_f = q_i, o_j = -1;
+					if (width <= P.bw && sc > o_f) { o_f = sc; o_j = q; }
+					if (!exact && inner_there && in_f > o_f) { o_f = in_f; o_j = in_j; }
+					if (first) { res_f = o_f; res_j = o_j; first = false; }
+					else if (o_f != res_f || o_j != res_j) { same = false; break; }
+				}
+				if (!same || first) { ++ws.ties_that_decide; return false; }
+				max_f = res_f; max_j = res_j; weighed = true;
+			}
+		}
+		if (j >= 0 && !weighed) {
 			bool exact; int width;
 			const int sc = f[j] + pair_score(a[i], a[j], P.chn_pen_gap, P.chn_pen_skip, &exact, &width);
 			if (width <= P.bw && sc > max_f) { max_f = sc; max_j = j; }
-			if (!exact && max_inner > 0 && ws.inner.count > 0 && yi > 0) {
-				// lchain.c:320-341: the inner window's anchors with y in [yi - max_inner, yi - 1], from the largest (y, index) down; a
-				// strictly better score replaces the best; the walk gives up after max_chn_skip anchors whose own predecessor chain
-				// this anchor has already been offered (the marks in seen[], lchain.c:333-338)
-				int n_skip = 0;
-				const bool exhaustive = P.max_chn_skip == INT32_MAX;
-				const int y_top = yi - 1, y_bot = yi - max_inner;
-				const int xi = (int32_t)a[i].x;
-				const int b_top = std::min<int>((int)ws.inner.bucket.size() - 1, (std::max(y_top, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT);
-				const int b_bot = (std::max(y_bot, ws.inner.y0) - ws.inner.y0) >> InnerWindow::SHIFT;
-				bool stop = y_top < ws.inner.y0;
-				for (int b = b_top; b >= b_bot && !stop; --b) {
-					const InnerBucket &v = ws.inner.bucket[(size_t)b];
-					// without a skip limit a candidate matters only if it beats the best so far, and none of this bucket can
-					if (exhaustive && ws.inner.top[(size_t)b] <= max_f) continue;
-#if defined(__x86_64__)
-					if (exhaustive && pen && use_avx2) { scan_bucket_avx2(v, xi, yi, y_top, y_bot, P.bw, pen, max_f, max_j); continue; }
-#endif
-					for (size_t at = v.size(); at-- > 0;) {
-						const int cy = v.y[at];
-						if (cy > y_top) continue;
-						if (cy < y_bot) break;
-						// comput_sc_simple (lchain.c:232-248) on the copies
-						const int cj = v.j[at], cspan = v.span[at];
-						const int dq = yi - cy, dr = xi - v.x[at], dd = dr > dq ? dr - dq : dq - dr;
-						if (dd > P.bw) continue;
-						const int dg = dr < dq ? dr : dq;
-						int sc = cspan < dg ? cspan : dg;
-						if (dd || dq > cspan) {
-							if (pen) sc -= pen[dd];
-							else {
-								const float lin = P.chn_pen_gap * (float)dd + P.chn_pen_skip * (float)dg;
-								const float lg = dd >= 1 ? log2_fit((float)(dd + 1)) : 0.0f;
-								sc -= (int)(lin + .5f * lg);
-							}
-						}
-						const int s2 = v.f[at] + sc;
-						if (exhaustive) {                          // no skip limit: the marks of lchain.c:333-338 decide nothing -- no look at p[] and seen[] per candidate
-							if (s2 > max_f) { max_f = s2; max_j = cj; }
-							continue;
-						}
-						if (s2 > max_f) { max_f = s2; max_j = cj; if (n_skip > 0) --n_skip; }
-						else if (ws.seen[(size_t)cj] == i) { if (++n_skip > P.max_chn_skip) { stop = true; break; } }
-						if (p_rel[cj]) ws.seen[(size_t)(cj - p_rel[cj])] = i;
-					}
-				}
-			}
+			if (!exact && inner_there) inner_scan(max_f, max_j);
 		}
 		f[i] = max_f;
 		p_rel[i] = max_j < 0 ? 0 : i - max_j;
@@ -553,6 +605,7 @@ static int rmq_chain_host_impl(const mm2gb_rmq_param_t *prm, int64_t n_reads, co
 	if (n_tied) for (int64_t r = 0; r < n_reads; ++r) n_tied[r] = 0;   // becomes 1 for a read that met a tie and was done with the reference's tree
 	const char *force = getenv("MM2GB_RMQ_TREE");
 	const bool exact_only = reference_tree_only || (force && !strcmp(force, "avl"));   // MM2GB_RMQ_TREE=avl: the reference's tree for every read
+	std::atomic<long long> ties_met(0), ties_that_decide(0);
 	auto work = [&]() {
 		FillScratch ws;
 		BacktrackScratch bs;
@@ -572,10 +625,17 @@ static int rmq_chain_host_impl(const mm2gb_rmq_param_t *prm, int64_t n_reads, co
 			nu_of[(size_t)r] = backtrack_compact(misc, n, anchors + offsets[r], f.data(), p.data(), libc_mem, bs, &u_of[(size_t)r], &a_of[(size_t)r]);
 			for (int c = 0; c < nu_of[(size_t)r]; ++c) na_of[(size_t)r] += (uint32_t)u_of[(size_t)r][c];
 		}
+		ties_met += ws.ties_met; ties_that_decide += ws.ties_that_decide;
 	};
 	const int nt = std::max(1, n_threads);
 	if (nt == 1) work();
 	else { std::vector<std::thread> pool; for (int t = 0; t < nt; ++t) pool.emplace_back(work); for (auto &th : pool) th.join(); }
+	if (getenv("MM2GB_DEBUG_PHASES") && !exact_only) {
+		long long redone = 0;
+		if (n_tied) for (int64_t r = 0; r < n_reads; ++r) redone += n_tied[r];
+		fprintf(stderr, "[mm2gb rmq host] %lld reads: %lld ties met (several anchors on the smallest priority), %lld of them decide something; %lld reads done again with the reference's tree\n",
+		        (long long)n_reads, ties_met.load(), ties_that_decide.load(), redone);
+	}
 	out->u_off = (int64_t*)malloc((R + 1) * 8);
 	out->a_off = (int64_t*)malloc((R + 1) * 8);
 	if (!out->u_off || !out->a_off) { mm2gb_chains_free(out); return fail("mm2gb_rmq_chain_host: out of memory"); }

@@ -462,10 +462,53 @@ static int rmq_cand_desc(const void *pa, const void *pb)
 	return a->j < b->j ? 1 : a->j > b->j ? -1 : 0;
 }
 
+/* Does the pick among several holders of the smallest priority change anything for anchor i?  Each holder is followed through
+ * lchain.c:316-341 as if it were the one the tree returned; without a skip limit the inner walk's result is the first candidate, in
+ * walking order, to reach the walk's largest score -- whatever the walk started from below that -- so one walk (from q_span) serves
+ * every holder.  With a skip limit the marks of lchain.c:333-338 depend on where the walk started: every tie is taken to decide. */
+static int rmq_tie_decides(const orc_rmq_param_t *prm, const orc_anchor_t *a, const int32_t *f, int64_t i, int64_t st, int64_t st_inner, int64_t i0,
+                           int32_t max_dist, int32_t max_dist_inner, double best_key, rmq_cand_t *cand)
+{
+	const int32_t yi = (int32_t)a[i].y, q_span = a_qspan(&a[i]);
+	const int inner_there = max_dist_inner > 0 && st_inner < i0 && yi > 0;
+	int32_t in_f = q_span, width, exact, sc, res_f = 0;
+	int64_t in_j = -1, res_j = -1, j, nc = 0, k;
+	int first = 1;
+	if (prm->max_chn_skip != INT32_MAX) return 1;
+	if (inner_there) {
+		for (j = st_inner; j < i0; ++j) {
+			const int32_t yj = (int32_t)a[j].y;
+			if (yj <= yi - 1 && yj >= yi - max_dist_inner) { cand[nc].y = yj; cand[nc].j = j; ++nc; }
+		}
+		qsort(cand, nc, sizeof(rmq_cand_t), rmq_cand_desc);
+		for (k = 0; k < nc; ++k) {
+			j = cand[k].j;
+			sc = f[j] + orc_rmq_pair_score(&a[i], &a[j], prm->pen_gap, prm->pen_skip, 0, &width);
+			if (width <= prm->bw && sc > in_f) in_f = sc, in_j = j;
+		}
+	}
+	for (j = st; j < i0; ++j) {
+		const int32_t yj = (int32_t)a[j].y;
+		int32_t o_f = q_span;
+		int64_t o_j = -1;
+		if (!((yj > yi - max_dist && yj < yi) || (yj == yi && j == 0))) continue;
+		if (f[j] + 0.5 * prm->pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y) != best_key) continue;
+		sc = f[j] + orc_rmq_pair_score(&a[i], &a[j], prm->pen_gap, prm->pen_skip, &exact, &width);
+		if (width <= prm->bw && sc > o_f) o_f = sc, o_j = j;
+		if (!exact && inner_there && in_f > o_f) o_f = in_f, o_j = in_j;
+		if (first) res_f = o_f, res_j = o_j, first = 0;
+		else if (o_f != res_f || o_j != res_j) return 1;
+	}
+	return 0;
+}
+
+static int64_t g_rmq_ties_that_decide;            /* of the last orc_rmq_fill (one thread at a time: test infrastructure) */
+int64_t orc_rmq_last_ties_that_decide(void) { return g_rmq_ties_that_decide; }
+
 int64_t orc_rmq_fill(const orc_rmq_param_t *prm, int64_t n, const orc_anchor_t *a, int32_t *f, int64_t *p, int64_t *n_tied)
 {
 	int32_t max_dist = prm->max_dist, max_dist_inner = prm->max_dist_inner;
-	int64_t i, i0 = 0, st = 0, st_inner = 0, n_scored = 0, tied = 0;
+	int64_t i, i0 = 0, st = 0, st_inner = 0, n_scored = 0, tied = 0, decide = 0;
 	int32_t *t = (int32_t*)calloc(n > 0 ? n : 1, sizeof(int32_t));
 	rmq_cand_t *cand = (rmq_cand_t*)malloc((n > 0 ? n : 1) * sizeof(rmq_cand_t));
 	if (max_dist < prm->bw) max_dist = prm->bw;                                                   /* lchain.c:264 */
@@ -493,7 +536,7 @@ int64_t orc_rmq_fill(const orc_rmq_param_t *prm, int64_t n, const orc_anchor_t *
 			}
 			if (best_j >= 0) {
 				int32_t sc, exact, width, n_skip = 0;
-				if (n_best > 1) ++tied;
+				if (n_best > 1) { ++tied; decide += rmq_tie_decides(prm, a, f, i, st, st_inner, i0, max_dist, max_dist_inner, best_key, cand); }
 				j = best_j;
 				sc = f[j] + orc_rmq_pair_score(&a[i], &a[j], prm->pen_gap, prm->pen_skip, &exact, &width);
 				++n_scored;
@@ -526,6 +569,7 @@ int64_t orc_rmq_fill(const orc_rmq_param_t *prm, int64_t n, const orc_anchor_t *
 	}
 	free(t); free(cand);
 	if (n_tied) *n_tied = tied;
+	g_rmq_ties_that_decide = decide;
 	return n_scored;
 }
 

@@ -210,7 +210,8 @@ def lchain_rmq(a, prm):
         L.orc_free(u_ptr)
     if out:
         L.orc_free(out)
-    return dict(u=u, a_out=a_out, f=f, p=p, n_tied=tied.value)
+    L.orc_rmq_last_ties_that_decide.restype = C.c_int64
+    return dict(u=u, a_out=a_out, f=f, p=p, n_tied=tied.value, n_decide=int(L.orc_rmq_last_ties_that_decide()))
 
 
 def gen_regs(u, a_out, qlen, hash_, is_qstrand=0):

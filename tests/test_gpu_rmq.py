@@ -39,9 +39,17 @@ def test_reference_vectors(engine, path):
     if g["prm"].max_chn_skip != orc.INT32_MAX:
         pytest.skip("recorded with a finite max_chn_skip; the device path is exhaustive by contract")
     res, tied, _ = engine.rmq_chain(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]))
-    assert int(tied[0]) == g["tied"]
-    if g["tied"] == 0:
+    o = orc.lchain_rmq(g["a"], g["prm"])
+    assert o["n_tied"] == g["tied"] and int(tied[0]) == o["n_decide"]
+    if o["n_decide"] == 0:
+        # no tie, or only ties whose holders all leave the anchor with the same score and predecessor: the reference's chains, whatever its tree picked
         assert np.array_equal(res[0][0], g["u"]) and np.array_equal(res[0][1], g["a_out"])
+
+
+def counted(o, kernel="tiles"):
+    """What the device reports in n_tied: the tile form weighs a tie (it counts where the holders of the smallest priority differ in what they
+    leave the anchor with -- orc_rmq_last_ties_that_decide); the one-anchor-per-step kernel counts every tie."""
+    return o["n_decide"] if kernel.startswith("tiles") else o["n_tied"]
 
 
 @pytest.mark.parametrize("kernel", ["tiles", "steps", "tiles, whole workgroups on the first 5 reads", "tiles, whole workgroups on every read"])
@@ -67,7 +75,7 @@ def test_batch_against_the_oracle(engine, monkeypatch, kernel):
         n_with_ties = 0
         for r, x in enumerate(reads):
             o = orc.lchain_rmq(x, prm)
-            assert int(tied[r]) == o["n_tied"], (kw, r)
+            assert int(tied[r]) == counted(o, kernel), (kw, r)
             n_with_ties += o["n_tied"] > 0
             assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r)
         assert n_with_ties >= 1 and st["ms_post"] > 0
@@ -164,7 +172,7 @@ def test_tile_kernel_on_odd_shapes(engine, monkeypatch, team_reads, strips):
         res, tied, _ = engine.rmq_chain(allr, o2, to_lib(prm))
         for r, x in enumerate(reads):
             o = orc.lchain_rmq(x, prm)
-            assert int(tied[r]) == o["n_tied"], (kw, r, len(x))
+            assert int(tied[r]) == counted(o), (kw, r, len(x))
             assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r, len(x))
 
 
@@ -207,11 +215,62 @@ def test_fuzz_random_reads_and_parameters(engine, monkeypatch):
         kw = dict(max_dist=max_dist, bw=bw, max_dist_inner=int(rng.choice([0, 90, 200, 1000, 3000])), cap_rmq_size=int(rng.choice([0, 50, 100000])),
                   pen_gap=np.float32(rng.choice([0.12, 0.3, 0.8])), pen_skip=np.float32(rng.choice([0.0, 0.05])))
         prm = orc.default_rmq_param(**kw)
-        monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles" if rng.random() < 0.8 else "steps")
+        kernel = "tiles" if rng.random() < 0.8 else "steps"
+        monkeypatch.setenv("MM2GB_RMQ_KERNEL", kernel)
         monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", str(int(rng.choice([0, 2, 1000000]))))
         monkeypatch.setenv("MM2GB_RMQ_STRIPS", str(int(rng.random() < 0.7)))
         res, tied, _ = engine.rmq_chain(allr, o2, to_lib(prm))
         for r, x in enumerate(reads):
             o = orc.lchain_rmq(x, prm)
-            assert int(tied[r]) == o["n_tied"], (seed, it, kw, r, len(x))
+            assert int(tied[r]) == counted(o, kernel), (seed, it, kw, r, len(x))
             assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (seed, it, kw, r, len(x))
+
+
+def test_every_tie_counts_when_asked(engine, monkeypatch):
+    """MM2GB_RMQ_TIES=strict: the tile form counts every anchor whose smallest priority has several holders, like the one-anchor-per-step
+    kernel and the oracle's n_tied; the default counts fewer, never more, and never on a read without a tie."""
+    rng = np.random.default_rng(5)
+    reads = [orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(n, 1), np.zeros(n, np.int64), 1000 + rng.integers(0, w, n), 100 + rng.integers(0, w, n)))) for n, w in ((900, 150), (3000, 600), (5000, 2500))]
+    a1, o1 = mm.synth_reads(53, 0, 6, 20_000, 90_000)
+    reads += [first_pass(a1[o1[r]:o1[r + 1]]) for r in range(6)]
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    prm = orc.default_rmq_param()
+    monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles")
+    for team in ("0", "1000000"):
+        monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", team)
+        monkeypatch.setenv("MM2GB_RMQ_TIES", "strict")
+        _, strict, _ = engine.rmq_chain(allr, o2, to_lib(prm))
+        monkeypatch.delenv("MM2GB_RMQ_TIES")
+        _, weighed, _ = engine.rmq_chain(allr, o2, to_lib(prm))
+        for r, x in enumerate(reads):
+            o = orc.lchain_rmq(x, prm)
+            assert int(strict[r]) == o["n_tied"] and int(weighed[r]) == o["n_decide"] <= o["n_tied"], (team, r)
+        assert (strict > 0).sum() >= 3
+
+
+@pytest.mark.skipif(not orc.ref_available(), reason="needs the reference build (oracle/_ref, made where /root/reference exists)")
+@pytest.mark.parametrize("team_reads", ["0", "1000000"])
+def test_reads_whose_ties_decide_nothing_equal_the_reference(engine, monkeypatch, team_reads):
+    """The point of weighing ties: a read that meets ties but none that decides is NOT done again with the reference's tree -- so the device's
+    chains for it must be the compiled reference's (mg_lchain_rmq itself, oracle/_ref), whatever its tree picked at those anchors."""
+    monkeypatch.setenv("MM2GB_RMQ_KERNEL", "tiles")
+    monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", team_reads)
+    a1, o1 = mm.synth_reads(61, 0, 60, 30_000, 150_000)
+    reads = [first_pass(a1[o1[r]:o1[r + 1]]) for r in range(60)]
+    rng = np.random.default_rng(9)
+    reads += [orc.radix_sort_x(sc.sort_by_x(sc.pack(np.full(n, 1), np.zeros(n, np.int64), 1000 + rng.integers(0, w, n), 100 + rng.integers(0, w, n)))) for n, w in ((400, 4000), (1500, 9000), (3000, 20000))]
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    prm = orc.default_rmq_param()
+    res, tied, _ = engine.rmq_chain(np.concatenate(reads), o2, to_lib(prm))
+    spared = 0
+    for r, x in enumerate(reads):
+        if len(x) == 0 or tied[r] != 0:
+            continue
+        ref = orc.ref_lchain_rmq(x, prm)
+        assert np.array_equal(res[r][0], ref["u"]) and np.array_equal(res[r][1], ref["a_out"]), r
+        spared += orc.lchain_rmq(x, prm)["n_tied"] > 0
+    print("reads with ties that decide nothing:", spared)
+    assert spared >= 1

@@ -103,3 +103,28 @@ def test_vector_and_scalar_inner_scans_agree(monkeypatch):
         slow, _ = mm.rmq_chain_host(allr, o2, prm, threads=4)
         for r in range(len(reads)):
             assert np.array_equal(fast[r][0], slow[r][0]) and np.array_equal(fast[r][1], slow[r][1]), (kw, r)
+
+
+def test_ties_are_weighed_before_a_read_is_done_again(monkeypatch):
+    """The tournament tree cannot say which holder of a shared smallest priority the reference's tree returns -- but where every holder leaves the
+    anchor with the same score and predecessor it need not (rmq_fill_one): the read is done again with the reference's tree exactly when the
+    oracle finds a tie that decides (orc_rmq_last_ties_that_decide), and with MM2GB_RMQ_TIES=strict whenever it finds a tie at all.  The chains
+    are the same either way."""
+    reads = batch_of_reads()
+    o2 = np.zeros(len(reads) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum([len(x) for x in reads])
+    allr = np.concatenate(reads)
+    fewer = 0
+    for kw in PARAMS:
+        prm = orc.default_rmq_param(**kw)
+        monkeypatch.delenv("MM2GB_RMQ_TIES", raising=False)
+        res, again = mm.rmq_chain_host(allr, o2, to_lib(prm), threads=4)
+        monkeypatch.setenv("MM2GB_RMQ_TIES", "strict")
+        res_s, again_s = mm.rmq_chain_host(allr, o2, to_lib(prm), threads=4)
+        for r, x in enumerate(reads):
+            o = orc.lchain_rmq(x, prm)
+            assert (again[r] != 0) == (o["n_decide"] > 0) and (again_s[r] != 0) == (o["n_tied"] > 0), (kw, r)
+            assert o["n_decide"] <= o["n_tied"] and (prm.max_chn_skip == orc.INT32_MAX or o["n_decide"] == o["n_tied"])
+            assert np.array_equal(res[r][0], res_s[r][0]) and np.array_equal(res[r][1], res_s[r][1]), (kw, r)
+        fewer += int(again_s.sum() - again.sum())
+    assert fewer >= 3
