@@ -13,6 +13,7 @@ struct DevParams {
 	int   lut_base;          // LDS byte address of the table's entry 0: LUT_LDS_TOTAL - 4 * (lut_last + 1), so that it ends where LDS ends
 	int   lut_clamp;         // 1: the sweeps clamp the table index to lut_last; 0: an index beyond it reads beyond LDS, i.e. 0 = reject
 	int   free_sweep;        // 1 (only without lut_clamp): source blocks whose every pair has bw < dr <= dq_lim - bw are swept without range test
+	int   edge_prefix;       // 1: edge blocks of tiles whose window starts rise from lane to lane take their window test from a scalar prefix mask (sweep_block_lut_edge_sorted); only with MM2GB_EDGE=new
 	float gap, skip;
 };
 

@@ -67,6 +67,9 @@ __device__ __forceinline__ bool in_reach(const DevBatch &b, int j, int hi_i, uns
 
 constexpr int WIN_SAMPLE = 32;                         // anchors per sample = ints per 128-byte line
 constexpr int WIN_MAX_SAMPLES = 512;                   // look-back of 16 K anchors; a larger max_iter probes memory beyond it
+// (Tried, round 6: the 1 024 anchors right before the block in LDS as well, so that the probes between two samples are LDS reads instead of
+// dependent trips to L2 -- 24 KB of LDS per workgroup instead of 16, 8 KB more to load per block: the step went from 48.8 to 49.3 ms at
+// 500 M anchors and from 3.33 to 3.44 ms on 10-30 kb reads.  The kernel is not waiting for those probes.)
 
 // Read that owns the first anchor of every planning block: one bisection of the read offsets per block, all blocks at once
 // (done by the first thread of each k_window workgroup it put ~13 dependent loads in front of every workgroup).
@@ -106,6 +109,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	const int64_t base = (int64_t)blk * PLAN_BLOCK;
 	const unsigned dist = (unsigned)P.max_dist_x;
 	const int n_samples = (int)min((int64_t)WIN_MAX_SAMPLES, min(base, (int64_t)P.max_iter + WIN_SAMPLE - 1) / WIN_SAMPLE);
+	// (the block's first read and its bounds are asked for before the anchors: two dependent loads that every thread's first search waited for)
+	const int64_t rd_first = b.blk_read[blk];
+	const int64_t rd_first_s = b.offsets[rd_first], rd_first_e = b.offsets[rd_first + 1];
 	bool any_seg = false, big_y = false;
 	for (int k = threadIdx.x; k < PLAN_BLOCK; k += PLAN_THREADS) {
 		const int64_t g = base + k;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 	constexpr int PER = PLAN_BLOCK / PLAN_THREADS;
 	const int64_t i_first = base + (int64_t)threadIdx.x * PER;
 	const int base32 = (int)base;
-	int64_t rd = b.blk_read[blk];                     // read of the current anchor
+	int64_t rd = rd_first;                            // read of the current anchor
 	int rs = 0, re = 0, st_prev = 0;
 	int win[PER];
 #pragma unroll
@@ -148,6 +154,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 		if (k == 0 || i >= re) {
 			// read that owns anchor i: last r with offsets[r] <= i (gallop forward from the last known read, then bisect)
 			int64_t lo = rd, hi = b.n_reads;
+			if (k == 0 && rd_first_e > i64) { rs = (int)rd_first_s; re = (int)rd_first_e; fresh = true; }
+			else {
 			if (b.offsets[lo + 1] > i64) hi = lo + 1;
 			else {
 				int64_t step = 1;
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 			}
 			rd = lo; rs = (int)b.offsets[lo]; re = (int)b.offsets[lo + 1];
 			fresh = true;
+			}
 		}
 		int lb = i - P.max_iter;                      // may be negative
 		if (lb < rs) lb = rs;
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_window(DevBatch b, DevParams P
 				}
 				while (h - l > 1) {
 					const int mid = (l + h) >> 1;
-					if (reach_at(mid)) h = mid; else l = mid;
+					if (in_reach(b, mid, hi_i, x_i, dist)) h = mid; else l = mid;
 				}
 			}
 			st = h;
@@ -841,6 +850,68 @@ __device__ __forceinline__ void sweep_block_lut_edge(int t_st, int tx4, int ty4,
 		}
 	}
 }
+// The same block where the targets' window starts do not fall from lane to lane -- every tile of a chunk (anchors come sorted by position, a
+// window start never moves back; dead lanes sit at the end with INT_MAX) --: the lanes whose window holds source k are then a PREFIX of the
+// wave, so "source inside this target's window" needs no vector compare per source: how many lanes hold source k is found for all 64 sources
+// at once (lane k bisects the lanes' starts, six LDS permutes), four counts are packed per register, and the execution mask of a source is
+// made from its count by scalar instructions, which issue beside another wave's vector ones.  What is left per source: the two distances,
+// the table address, min3, shift-add, add, the query distance's range straight into the mask, max -- 8 vector instructions (11 above; the
+// narrow-window regime, 10-30 kb reads, is made of these blocks).  The caller checks the order of the starts (edge_starts_sorted).
+__device__ __forceinline__ bool edge_starts_sorted(int t_st)
+{
+	const int before = __shfl_up(t_st, 1);
+	return __ballot(lane_id() > 0 && t_st < before) == 0;
+}
+__device__ __forceinline__ void sweep_block_lut_edge_sorted(int t_st, int tx4, int ty4, int jb, int k_from, const int4 *stage, const DevParams &P, int &bestv, const int k_to = WAVE)
+{
+	constexpr int G = 4;
+	const unsigned base = (unsigned)P.lut_base, lim4 = (unsigned)P.dq_lim << 2;
+	// lane k: how many lanes' windows hold source jb + k
+	int c = 0;
+	{
+		const int j = jb + lane_id();
+#pragma unroll
+		for (int step = WAVE / 2; step > 0; step >>= 1) c += __shfl(t_st, c + step - 1) <= j ? step : 0;
+		c += __shfl(t_st, c) <= j ? 1 : 0;                        // (c <= 63 here)
+	}
+	// four counts per register: lane 4 m holds those of sources 4 m .. 4 m + 3
+	unsigned packed = (unsigned)c;
+	packed |= (unsigned)__builtin_amdgcn_update_dpp(0, c, 0x101, 0xf, 0xf, true) << 8;     // row_shl:1: lane i takes lane i + 1's
+	packed |= (unsigned)__builtin_amdgcn_update_dpp(0, c, 0x102, 0xf, 0xf, true) << 16;
+	packed |= (unsigned)__builtin_amdgcn_update_dpp(0, c, 0x103, 0xf, 0xf, true) << 24;
+	for (int kg = k_from & ~(G - 1); kg < k_to; kg += G) {
+		int4 s4[G];
+		int dqm[G], drm[G], pen[G], v[G];
+		unsigned long long m[G];
+		const unsigned c4 = (unsigned)__builtin_amdgcn_readlane((int)packed, kg);
+#pragma unroll
+		for (int u = 0; u < G; ++u) s4[u] = stage[kg + u];
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			dqm[u] = ty4 - s4[u].w; drm[u] = tx4 - s4[u].z;
+			pen[u] = *(lds_i32_ptr)(uintptr_t)lut_address(drm[u], dqm[u], base);     // (a query distance <= 0 may read anything: its lane is masked below)
+			const unsigned cu = (c4 >> (8 * u)) & 0xffu;
+			m[u] = cu ? ~0ull >> (64u - cu) : 0ull;                 // the first cu lanes
+		}
+#pragma unroll
+		for (int u = 0; u < G; ++u) {
+			const int dg = drm[u] < dqm[u] ? drm[u] : dqm[u];
+			v[u] = ((s4[u].y < dg ? s4[u].y : dg) << 5) + s4[u].x;
+			asm("" : "+v"(v[u]));
+			v[u] += pen[u];
+		}
+		unsigned long long saved;
+		asm volatile("s_mov_b64 %[sv], exec\n\t"
+		             "s_mov_b64 exec, %[m0]\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[q0]\n\tv_max_i32_e32 %[b], %[v0], %[b]\n\t"
+		             "s_mov_b64 exec, %[m1]\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[q1]\n\tv_max_i32_e32 %[b], %[v1], %[b]\n\t"
+		             "s_mov_b64 exec, %[m2]\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[q2]\n\tv_max_i32_e32 %[b], %[v2], %[b]\n\t"
+		             "s_mov_b64 exec, %[m3]\n\tv_cmpx_gt_u32_e32 vcc, %[lim], %[q3]\n\tv_max_i32_e32 %[b], %[v3], %[b]\n\t"
+		             "s_mov_b64 exec, %[sv]"
+		             : [b] "+v"(bestv), [sv] "=&s"(saved)
+		             : [lim] "s"(lim4), [q0] "v"(dqm[0]), [q1] "v"(dqm[1]), [q2] "v"(dqm[2]), [q3] "v"(dqm[3]), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+		               [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]) : "vcc");
+	}
+}
 __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_from, bool no_check, bool free_block, const int4 *stage, const DevParams &P,
                                                  int &best, int &arg, bool far_block = false, int d0 = 0)
 {
@@ -848,7 +919,10 @@ __device__ __forceinline__ void sweep_staged_lut(const TileXY &T, int jb, int k_
 	int bestv = best << 7;
 	if (far_block) sweep_block_lut_free<true>(tx4, ty4, stage, (unsigned)P.lut_base, d0, bestv);
 	else if (free_block) sweep_block_lut_free<false>(tx4, ty4, stage, (unsigned)P.lut_base, 0, bestv);
-	else if (!no_check && !P.lut_clamp) sweep_block_lut_edge(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
+	else if (!no_check && !P.lut_clamp) {
+		if (P.edge_prefix && edge_starts_sorted(T.st)) sweep_block_lut_edge_sorted(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
+		else sweep_block_lut_edge(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
+	}
 	else if (P.lut_clamp) {
 		if (no_check) sweep_block_lut<false, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
 		else sweep_block_lut<true, true>(T.st, tx4, ty4, jb, k_from, stage, P, bestv);
@@ -1681,7 +1755,8 @@ __device__ __forceinline__ void sweep_block_by_quarters(const DevBatch &b, const
 		if (lo >= hi) continue;
 		stage_block_lut(xs, ys, sf_of(), sq, stage);          // (the quarters that are not out yet hold stale scores: nobody reads them)
 		int bestv = best << 7;
-		sweep_block_lut_edge(T.st, tx4, ty4, jb, lo, stage, P, bestv, hi);
+		if (P.edge_prefix && edge_starts_sorted(T.st)) sweep_block_lut_edge_sorted(T.st, tx4, ty4, jb, lo, stage, P, bestv, hi);
+		else sweep_block_lut_edge(T.st, tx4, ty4, jb, lo, stage, P, bestv, hi);
 		const int won = bestv & 127;
 		arg = (unsigned)(won - 1) < (unsigned)WAVE ? jb + won - 1 : arg;
 		best = bestv >> 7;

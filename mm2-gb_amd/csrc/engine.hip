@@ -260,7 +260,7 @@ static DevParams make_params(const mm2gb_misc_t &m)
 	if (P.max_dist_y < P.bw && !m.is_cdna) P.max_dist_y = P.bw;        // lchain.c:161
 	P.max_iter = m.max_iter; P.n_seg = m.n_seg; P.is_cdna = m.is_cdna;
 	P.dq_lim = std::min(P.max_dist_x, P.max_dist_y);
-	P.lut_last = P.bw + 1; P.lut_base = LUT_LDS_TOTAL - 4 * (P.lut_last + 1); P.lut_clamp = 1; P.free_sweep = 0;
+	P.lut_last = P.bw + 1; P.lut_base = LUT_LDS_TOTAL - 4 * (P.lut_last + 1); P.lut_clamp = 1; P.free_sweep = 0; P.edge_prefix = 0;
 	P.gap = m.chn_pen_gap; P.skip = m.chn_pen_skip;
 	return P;
 }
@@ -344,9 +344,10 @@ int Engine::configure_score()
 	// Penalty table: bw + 1 entries and a rejecting one, ending where the workgroup's LDS ends (chain_dev.h).  On a device that reads 0
 	// beyond a workgroup's LDS (probed in init) the index is not clamped -- a distance beyond bw is an address beyond LDS -- and source
 	// blocks far enough inside a window are swept without any range test (MM2GB_FREE_SWEEP=0 turns that off, for A/B runs).
-	params.lut_last = params.bw + 1; params.lut_base = LUT_LDS_TOTAL - 4 * (params.lut_last + 1); params.lut_clamp = 1; params.free_sweep = 0;
+	params.lut_last = params.bw + 1; params.lut_base = LUT_LDS_TOTAL - 4 * (params.lut_last + 1); params.lut_clamp = 1; params.free_sweep = 0; params.edge_prefix = 0;
 	if (launch.host_mode == SCORE_MODE_LUT && lds_contract_ok && !getenv("MM2GB_LUT_CLAMP")) {
 		params.lut_clamp = 0;
+		{ const char *e = getenv("MM2GB_EDGE"); params.edge_prefix = e && !strcmp(e, "new"); }   // MM2GB_EDGE=new: the window test of edge blocks from a scalar prefix mask (measured: +1 % on 10-30 kb reads, -1 % on 30-100 kb: profiles/r06_narrow_ab.txt; off)
 		const char *v = getenv("MM2GB_FREE_SWEEP");
 		params.free_sweep = !(v && atoi(v) == 0) && params.dq_lim > 2 * params.bw;
 	}

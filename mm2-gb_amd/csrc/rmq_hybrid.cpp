@@ -152,11 +152,14 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		// four, sixteen calls at once share the chip in the drop-in, and a rule built on comparing the two estimates read by read -- a team only
 		// where one wave would take longer than the call's longest team read -- left reads to single waves that then took 1.0-1.2 s: the
 		// single-wave estimate is not that good.  The rule stays.)
-		else if (!getenv("MM2GB_RMQ_NO_TEAMS"))
+		else if (!getenv("MM2GB_RMQ_NO_TEAMS")) {
+			int64_t team_from = INT64_MAX;                       // experiment: every read of at least this many anchors is a whole workgroup's
+			if (const char *tv = getenv("MM2GB_RMQ_TEAM_MIN_ANCHORS")) team_from = atoll(tv);
 			for (size_t r = 0; r < R; ++r) {
 				const double n = (double)(offsets[r + 1] - offsets[r]);
-				if (cost[r].dev > 5e-3 && 0.07e-6 * cost[r].s_in >= 0.5 * 1.37e-6 * n && cost[r].dev_team < cost[r].dev) { cost[r].dev = cost[r].dev_team; cost[r].team = true; }
+				if ((cost[r].dev > 5e-3 && 0.07e-6 * cost[r].s_in >= 0.5 * 1.37e-6 * n && cost[r].dev_team < cost[r].dev) || (offsets[r + 1] - offsets[r] >= team_from)) { cost[r].dev = std::min(cost[r].dev, cost[r].dev_team); cost[r].team = true; }
 			}
+		}
 	}
 	double cal_dev = 1.0, cal_host = 1.0;
 	// (only for callers whose host threads have nothing else to do while the call runs -- the drop-in's finishers, engine.h rmq_calibrate: where
