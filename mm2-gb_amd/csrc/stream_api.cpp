@@ -898,7 +898,10 @@ void free_stream_gpu(int n_threads)
 		}
 		(void)slot->eng.sync();
 		for (HostStage &st : slot->stage) {
-			mm2gb_chains_free(&st.ch);                                    // a batch the host never came back for
+			// a batch the host never came back for: what its finisher ran into is still said (the host is about to exit; nothing is thrown away silently)
+			if (!st.err.empty()) fprintf(stderr, "[Error] free_stream_gpu: a batch that was launched and never collected had failed: %s\n", st.err.c_str());
+			st.err.clear();
+			mm2gb_chains_free(&st.ch);
 			for (size_t r = 0; r < st.u_of.size(); ++r) { free(st.u_of[r]); free(st.a_of[r]); }
 			st.u_of.clear(); st.a_of.clear(); st.nu_of.clear();
 			st.ahead.clear(); st.have_ahead = false;
