@@ -154,8 +154,10 @@ int  mm2gb_post_device_digest(mm2gb_engine_t *eng, int64_t n_reads, uint64_t *di
  *      on the anchors the first chaining kept, sorted by x).  Parameters in the order of mg_lchain_rmq's argument list.
  *      mm2gb_rmq_chain_gpu: a batch of reads; score fill, backtrack and compaction all on the device.  The reference resolves
  *      ties between equal range-minimum priorities by the shape of its AVL tree (krmq.h:110-147), which no closed form
- *      reproduces: n_tied[r] (optional) counts the anchors of read r where that happened; the chains of a read with
- *      n_tied[r] != 0 may differ from the reference's and are for the caller to discard (mm2gb_lchain_rmq does).
+ *      reproduces: n_tied[r] (optional) counts the anchors of read r where that happened AND the tied elements do not all leave
+ *      the anchor with the same score and predecessor (the tile kernel weighs a tie on the spot; the one-anchor-per-step
+ *      kernel and MM2GB_RMQ_TIES=strict count every tie); the chains of a read with n_tied[r] != 0 may differ from the reference's
+ *      and are for the caller to discard (mm2gb_lchain_rmq does).
  *      max_chn_skip is ignored: the device path is exhaustive (== INT32_MAX), like mm2gb_lchain_dp.
  *      mm2gb_rmq_chain: the batch call that is exact for EVERY read with the device carrying the load (csrc/rmq_hybrid.cpp): reads are
  *      dealt between the kernel form and the host form by estimated cost so that both finish together (a read inside a tandem array is
@@ -181,8 +183,9 @@ int  mm2gb_rmq_chain(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t 
                      int n_threads, mm2gb_chains_t *out, int32_t *where, mm2gb_rmq_deal_t *deal);
 /* The same on host threads, O(log n) per anchor, the reference's answer for EVERY read at any max_chn_skip (csrc/rmq_host.cpp): a read
  * is first done with a tournament tree of fixed shape over its anchors' (y, index) ranks, which gives the reference's answer as long as
- * one anchor in range holds the smallest priority; at the first tie (which element the reference returns then follows from its tree's
- * shape) the read is done again with the reference's own tree -- an AVL tree with krmq.h's insertion, deletion, rotation and
+ * one anchor in range holds the smallest priority, or all that hold it leave the anchor with the same score and predecessor; at the
+ * first tie that decides something (which element the reference returns then follows from its tree's shape; with a skip limit: at the
+ * first tie) the read is done again with the reference's own tree -- an AVL tree with krmq.h's insertion, deletion, rotation and
  * subtree-minimum rules, on arrays (MM2GB_RMQ_TREE=avl: that tree for every read).  n_tied[r] (may be NULL) = 1 for a read that was
  * done again, else 0: information only, the chains are exact either way. */
 int  mm2gb_rmq_chain_host(const mm2gb_rmq_param_t *prm, int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, int n_threads,

@@ -252,11 +252,16 @@ struct ShapeTree {
 // ancestor it does not change).  Where several anchors share the smallest priority the reference's answer depends on the shape of its
 // tree: this one only reports the tie, and the read is done again with ShapeTree.
 struct RankTree {
-	struct Node { double pri; int who, tie; };
-	std::vector<Node> t;
+	// Round 6: eight children per node instead of two -- six levels for a read of 100 000 anchors where the binary tree had seventeen, and a
+	// node's children sit side by side in memory (an update or a query touched ~70 nodes of a 5 MB tree before, a cache line each: 0.4 us an anchor).
+	// Level 0 = the priorities by rank; a node of level k >= 1 sums up its eight children of level k - 1: smallest priority, the rank of ONE
+	// leaf that holds it (the first), and whether several leaves below it do.
+	static constexpr int FAN_LOG = 3, FAN = 1 << FAN_LOG;
+	struct Sum { double pri; int at, tie; };
+	std::vector<double> leaf;                       // level 0, padded to a multiple of FAN with EMPTY
+	std::vector<std::vector<Sum>> up;               // up[k - 1] = level k
 	std::vector<uint64_t> by_y;
 	std::vector<int> rank, q_lo, q_hi;
-	int base = 1;
 	unsigned held = 0;
 	static constexpr double EMPTY = 1e300;
 
@@ -264,7 +269,7 @@ struct RankTree {
 	{
 		by_y.resize((size_t)n); rank.resize((size_t)n); q_lo.resize((size_t)n); q_hi.resize((size_t)n);
 		for (int j = 0; j < n; ++j) by_y[(size_t)j] = (uint64_t)(uint32_t)(int32_t)a[j].y << 32 | (uint32_t)j;
-		std::sort(by_y.begin(), by_y.end());
+		sort_by_y();
 		for (int r = 0; r < n; ++r) rank[(size_t)(uint32_t)by_y[(size_t)r]] = r;
 		// the closed interval [(y - max_dist, INT32_MAX), (y, 0)] of (y, index) (lchain.c:311-313) in ranks: y' in (y - max_dist, y), and
 		// anchor 0 -- the first of its y -- when its y is y
@@ -277,60 +282,92 @@ struct RankTree {
 			const int j = (int)(uint32_t)by_y[(size_t)r];
 			q_lo[(size_t)j] = lo; q_hi[(size_t)j] = hi - 1 + (y0 == y ? 1 : 0);
 		}
-		base = 1;
-		while (base < n) base <<= 1;
-		t.assign((size_t)base * 2, Node{ EMPTY, -1, 0 });
+		size_t width = ((size_t)std::max(n, 1) + FAN - 1) & ~(size_t)(FAN - 1);
+		leaf.assign(width, EMPTY);
+		size_t levels = 0;
+		for (size_t w = width; w > 1; w = ((w >> FAN_LOG) + FAN - 1) & ~(size_t)(FAN - 1)) { if (up.size() <= levels) up.emplace_back(); up[levels++].assign(((w >> FAN_LOG) + FAN - 1) & ~(size_t)(FAN - 1), Sum{ EMPTY, -1, 0 }); if ((w >> FAN_LOG) <= 1) break; }
+		up.resize(levels);
 		held = 0;
 	}
-	static Node lower_of(const Node &u, const Node &v)
+	// the keys are (y << 32 | index) with the indices already rising: a stable sort on y alone, least significant byte first, skipping the
+	// bytes every y shares (query positions are below 2^31 and mostly below 2^24; std::sort took 55 ns an anchor of the fill's 470)
+	void sort_by_y()
+	{
+		const size_t n = by_y.size();
+		if (n < 256) { std::sort(by_y.begin(), by_y.end()); return; }
+		uint32_t all_or = 0, all_and = ~0u;
+		for (size_t k = 0; k < n; ++k) { const uint32_t y = (uint32_t)(by_y[k] >> 32); all_or |= y; all_and &= y; }
+		sort_tmp.resize(n);
+		uint64_t *src = by_y.data(), *dst = sort_tmp.data();
+		for (int byte = 0; byte < 4; ++byte) {
+			const int shift = 32 + 8 * byte;
+			if ((((all_or ^ all_and) >> (8 * byte)) & 0xffu) == 0) continue;        // the same in every key
+			size_t count[257] = { 0 };
+			for (size_t k = 0; k < n; ++k) ++count[((src[k] >> shift) & 0xff) + 1];
+			for (int v = 0; v < 256; ++v) count[v + 1] += count[v];
+			for (size_t k = 0; k < n; ++k) dst[count[(src[k] >> shift) & 0xff]++] = src[k];
+			std::swap(src, dst);
+		}
+		if (src != by_y.data()) memcpy(by_y.data(), src, n * sizeof(uint64_t));
+	}
+	std::vector<uint64_t> sort_tmp;
+	static Sum lower_of(const Sum &u, const Sum &v)
 	{
 		if (v.pri < u.pri) return v;
-		if (v.pri == u.pri && v.pri != EMPTY) return Node{ u.pri, u.who, 1 };
+		if (v.pri == u.pri && v.pri != EMPTY) return Sum{ u.pri, u.at, 1 };
 		return u;
 	}
-	void settle(size_t at)
+	Sum sum_of(size_t level, size_t at) const { return level == 0 ? Sum{ leaf[at], (int)at, 0 } : up[level - 1][at]; }
+	void settle(size_t pos)
 	{
-		for (at >>= 1; at >= 1; at >>= 1) {
-			const Node now = lower_of(t[at * 2], t[at * 2 + 1]);
-			Node &was = t[at];
-			if (now.pri == was.pri && now.who == was.who && now.tie == was.tie) break;
+		size_t at = pos;
+		for (size_t level = 1; level <= up.size(); ++level) {
+			at >>= FAN_LOG;
+			const size_t first = at << FAN_LOG;
+			Sum now{ EMPTY, -1, 0 };
+			if (level == 1) { for (size_t c = first; c < first + FAN; ++c) now = lower_of(now, Sum{ leaf[c], (int)c, 0 }); }
+			else { const Sum *kid = up[level - 2].data() + first; for (int c = 0; c < FAN; ++c) now = lower_of(now, kid[c]); }
+			Sum &was = up[level - 1][at];
+			if (now.pri == was.pri && now.at == was.at && now.tie == was.tie) break;
 			was = now;
 		}
 	}
-	void insert(int j, double priority) { const size_t at = (size_t)base + (size_t)rank[(size_t)j]; t[at] = Node{ priority, j, 0 }; ++held; settle(at); }
-	void erase(int j) { const size_t at = (size_t)base + (size_t)rank[(size_t)j]; t[at] = Node{ EMPTY, -1, 0 }; --held; settle(at); }
+	void insert(int j, double priority) { const size_t pos = (size_t)rank[(size_t)j]; leaf[pos] = priority; ++held; settle(pos); }
+	void erase(int j) { const size_t pos = (size_t)rank[(size_t)j]; leaf[pos] = EMPTY; --held; settle(pos); }
 	unsigned size() const { return held; }
+	// the nodes that tile the ranks [lo, hi]: at every level the few at either end that do not fill a parent, then one level up
+	template <class F> void tiles(size_t lo, size_t hi, F &&visit) const
+	{
+		size_t l = lo, r = hi + 1;
+		for (size_t level = 0; l < r; ++level) {
+			if (level == up.size()) { for (; l < r; ++l) visit(level, l); break; }
+			while (l < r && (l & (FAN - 1))) visit(level, l++);
+			while (l < r && (r & (FAN - 1))) visit(level, --r);
+			l >>= FAN_LOG; r >>= FAN_LOG;
+		}
+	}
 	// the anchor of smallest priority in anchor i's interval, -1 if none; *tied when several hold it
 	int lowest_for(int i, bool *tied) const
 	{
-		size_t l = (size_t)base + (size_t)q_lo[(size_t)i], r = (size_t)base + (size_t)(q_hi[(size_t)i] + 1);
-		Node best{ EMPTY, -1, 0 };
 		if (q_lo[(size_t)i] > q_hi[(size_t)i]) return -1;
-		for (; l < r; l >>= 1, r >>= 1) {
-			if (l & 1) best = lower_of(best, t[l++]);
-			if (r & 1) best = lower_of(best, t[--r]);
-		}
+		Sum best{ EMPTY, -1, 0 };
+		tiles((size_t)q_lo[(size_t)i], (size_t)q_hi[(size_t)i], [&](size_t level, size_t at) { best = lower_of(best, sum_of(level, at)); });
 		*tied = best.tie != 0;
-		return best.who;
+		return best.at < 0 ? -1 : (int)(uint32_t)by_y[(size_t)best.at];
 	}
-	// every anchor of i's interval that holds the priority `pri` (the smallest one, when lowest_for reported a tie): in (y, index) order
+	// every anchor of i's interval that holds the priority `pri` (the smallest one, when lowest_for reported a tie)
 	void holders_of(int i, double pri, std::vector<int> &out) const
 	{
 		out.clear();
 		if (q_lo[(size_t)i] > q_hi[(size_t)i]) return;
-		const size_t first = (size_t)base + (size_t)q_lo[(size_t)i], last = (size_t)base + (size_t)q_hi[(size_t)i];
-		below(1, (size_t)base, first, last, pri, out);
+		tiles((size_t)q_lo[(size_t)i], (size_t)q_hi[(size_t)i], [&](size_t level, size_t at) { below(level, at, pri, out); });
 	}
 private:
-	void below(size_t at, size_t width, size_t first, size_t last, double pri, std::vector<int> &out) const
+	void below(size_t level, size_t at, double pri, std::vector<int> &out) const
 	{
-		// node `at` covers leaves [lo, lo + width)
-		size_t depth = 0; for (size_t v = at; v > 1; v >>= 1) ++depth;
-		const size_t lo = (at << (size_t)(__builtin_ctzll((unsigned long long)base) - depth));
-		if (lo > last || lo + width - 1 < first || t[at].pri > pri) return;        // a subtree whose smallest priority is above `pri` holds none (one that reaches outside the interval may go below it)
-		if (width == 1) { if (t[at].pri == pri) out.push_back(t[at].who); return; }
-		below(at * 2, width / 2, first, last, pri, out);
-		below(at * 2 + 1, width / 2, first, last, pri, out);
+		if (sum_of(level, at).pri != pri) return;                // (the node lies inside the interval: its smallest priority is pri or above it)
+		if (level == 0) { out.push_back((int)(uint32_t)by_y[at]); return; }
+		for (size_t c = at << FAN_LOG; c < (at << FAN_LOG) + FAN; ++c) below(level - 1, c, pri, out);
 	}
 public:
 };
@@ -339,8 +376,9 @@ struct InnerCand { int32_t y, j, x, f; int32_t span; };
 // a bucket's anchors in (y, index) order, one array per field: the scan below reads eight candidates per instruction where AVX2 is there
 struct InnerBucket {
 	std::vector<int32_t> y, j, x, f, span;
+	size_t gone = 0;                 // entries whose anchor has left the window (InnerWindow::erase)
 	size_t size() const { return y.size(); }
-	void clear() { y.clear(); j.clear(); x.clear(); f.clear(); span.clear(); }
+	void clear() { y.clear(); j.clear(); x.clear(); f.clear(); span.clear(); gone = 0; }
 };
 struct InnerWindow {
 	static constexpr int SHIFT = 6;
@@ -360,26 +398,43 @@ struct InnerWindow {
 		const size_t b = (size_t)((c.y - y0) >> SHIFT);
 		InnerBucket &v = bucket[b];
 		size_t at = v.size();
-		while (at > 0 && !(v.y[at - 1] != c.y ? v.y[at - 1] < c.y : v.j[at - 1] < c.j)) --at;       // arrivals come in order of x; within a bucket that is mostly near the end
+		while (at > 0 && !(v.y[at - 1] != c.y ? v.y[at - 1] < c.y : v.j[at - 1] < c.j)) --at;       // arrivals come in order of x; within a bucket that is mostly near the end (an entry that has gone carries index -1: it sorts first among its y, which is as good as anywhere)
 		v.y.insert(v.y.begin() + (ptrdiff_t)at, c.y); v.j.insert(v.j.begin() + (ptrdiff_t)at, c.j); v.x.insert(v.x.begin() + (ptrdiff_t)at, c.x);
 		v.f.insert(v.f.begin() + (ptrdiff_t)at, c.f); v.span.insert(v.span.begin() + (ptrdiff_t)at, c.span);
 		top[b] = std::max(top[b], c.f + c.span);
 		++count;
 	}
+	// An anchor that leaves is not taken out at once: its index becomes -1 (the scans pass such entries over) and a bucket is packed when
+	// half of it has gone -- taking one element out of five arrays and finding the bucket's largest f + span again was 60 ns an anchor.
+	// `top` stays what it was until then: an upper bound.
 	void erase(int y, int j)
 	{
 		const size_t b = (size_t)((y - y0) >> SHIFT);
 		InnerBucket &v = bucket[b];
-		for (size_t at = 0; at < v.size(); ++at)
-			if (v.j[at] == j) {
-				v.y.erase(v.y.begin() + (ptrdiff_t)at); v.j.erase(v.j.begin() + (ptrdiff_t)at); v.x.erase(v.x.begin() + (ptrdiff_t)at);
-				v.f.erase(v.f.begin() + (ptrdiff_t)at); v.span.erase(v.span.begin() + (ptrdiff_t)at);
+		const size_t n = v.size();
+		const int32_t *vj = v.j.data();
+		for (size_t at = 0; at < n; ++at)
+			if (vj[at] == j) {
+				v.j[at] = -1;
 				--count;
-				int32_t t = INT32_MIN;
-				for (size_t k = 0; k < v.size(); ++k) t = std::max(t, v.f[k] + v.span[k]);
-				top[b] = t;
+				if (++v.gone * 2 > n) pack(b);
 				return;
 			}
+	}
+	void pack(size_t b)
+	{
+		InnerBucket &v = bucket[b];
+		size_t to = 0;
+		int32_t t = INT32_MIN;
+		for (size_t at = 0; at < v.size(); ++at)
+			if (v.j[at] >= 0) {
+				v.y[to] = v.y[at]; v.j[to] = v.j[at]; v.x[to] = v.x[at]; v.f[to] = v.f[at]; v.span[to] = v.span[at];
+				t = std::max(t, v.f[to] + v.span[to]);
+				++to;
+			}
+		v.y.resize(to); v.j.resize(to); v.x.resize(to); v.f.resize(to); v.span.resize(to);
+		v.gone = 0;
+		top[b] = t;
 	}
 };
 
@@ -396,8 +451,9 @@ __attribute__((target("avx2"))) void scan_bucket_avx2(const InnerBucket &v, int 
 		const size_t lo = hi >= 8 ? hi - 8 : 0, cnt = hi - lo;
 		// lanes 0 .. cnt-1 hold candidates lo .. hi-1 in ascending (y, index) order: the first met going down is the HIGHEST lane
 		const __m256i lane = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
-		const __m256i have = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)cnt), lane);
-		const __m256i cy = _mm256_maskload_epi32(v.y.data() + lo, have), cx = _mm256_maskload_epi32(v.x.data() + lo, have);
+		const __m256i in_array = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)cnt), lane);
+		const __m256i cy = _mm256_maskload_epi32(v.y.data() + lo, in_array), cx = _mm256_maskload_epi32(v.x.data() + lo, in_array);
+		const __m256i have = _mm256_andnot_si256(_mm256_cmpgt_epi32(zero, _mm256_maskload_epi32(v.j.data() + lo, in_array)), in_array);   // (index -1: the anchor has left the window)
 		const __m256i cf = _mm256_maskload_epi32(v.f.data() + lo, have), cs = _mm256_maskload_epi32(v.span.data() + lo, have);
 		const __m256i dq = _mm256_sub_epi32(vyi, cy), dr = _mm256_sub_epi32(vxi, cx);
 		const __m256i dd = _mm256_abs_epi32(_mm256_sub_epi32(dr, dq)), dg = _mm256_min_epi32(dr, dq);
@@ -405,7 +461,7 @@ __attribute__((target("avx2"))) void scan_bucket_avx2(const InnerBucket &v, int 
 		__m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi32(cy, vtop), have);
 		ok = _mm256_andnot_si256(_mm256_cmpgt_epi32(vbot, cy), ok);
 		ok = _mm256_andnot_si256(_mm256_cmpgt_epi32(dd, vbw), ok);
-		if (_mm256_testz_si256(ok, ok)) { if (_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_and_si256(have, _mm256_cmpgt_epi32(vbot, cy)))) == (int)((1u << cnt) - 1)) return; hi = lo; continue; }
+		if (_mm256_testz_si256(ok, ok)) { if (_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_and_si256(in_array, _mm256_cmpgt_epi32(vbot, cy)))) == (int)((1u << cnt) - 1)) return; hi = lo; continue; }   // (entries that have gone keep their y: the order stands)
 		const __m256i p = _mm256_mask_i32gather_epi32(zero, pen, dd, ok, 4);
 		// sc = min(span, dg) - (dd != 0 || dq > span ? pen[dd] : 0)
 		const __m256i charged = _mm256_or_si256(_mm256_xor_si256(_mm256_cmpeq_epi32(dd, zero), _mm256_set1_epi32(-1)), _mm256_cmpgt_epi32(dq, cs));
@@ -497,6 +553,7 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 					if (cy < y_bot) break;
 					// comput_sc_simple (lchain.c:232-248) on the copies
 					const int cj = v.j[at], cspan = v.span[at];
+					if (cj < 0) continue;                      // has left the window (InnerWindow::erase)
 					const int dq = yi - cy, dr = xi - v.x[at], dd = dr > dq ? dr - dq : dq - dr;
 					if (dd > P.bw) continue;
 					const int dg = dr < dq ? dr : dq;
