@@ -149,6 +149,9 @@ int  mm2gb_post_device_totals(mm2gb_engine_t *eng, int64_t *n_chains, int64_t *n
 /* a digest of the chains the last post-pass on this engine left on the device (offsets of chains, offsets of anchors, chains, anchors: four
  * position-dependent sums folded on the host), for comparing two settings or builds on batches too large for the oracle */
 int  mm2gb_post_device_digest(mm2gb_engine_t *eng, int64_t n_reads, uint64_t *digest);
+/* for tests and debugging: the per-anchor scores f[] and predecessor distances p[] (i - predecessor, 0 = none) that the engine's LAST
+ * mm2gb_chain_gpu / mm2gb_rmq_chain_gpu call left on the device (n = that call's anchors) */
+int  mm2gb_debug_last_fill(mm2gb_engine_t *eng, int64_t n, int32_t *f, int32_t *p);
 
 /* ---- RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369, called per read from post_chaining_helper, map.c:444-456,
  *      on the anchors the first chaining kept, sorted by x).  Parameters in the order of mg_lchain_rmq's argument list.
@@ -158,7 +161,9 @@ int  mm2gb_post_device_digest(mm2gb_engine_t *eng, int64_t n_reads, uint64_t *di
  *      the anchor with the same score and predecessor (the tile kernel weighs a tie on the spot; the one-anchor-per-step
  *      kernel and MM2GB_RMQ_TIES=strict count every tie); the chains of a read with n_tied[r] != 0 may differ from the reference's
  *      and are for the caller to discard (mm2gb_lchain_rmq does).
- *      max_chn_skip is ignored: the device path is exhaustive (== INT32_MAX), like mm2gb_lchain_dp.
+ *      max_chn_skip: at or above cap_rmq_size (or INT32_MAX) the inner walk can never be cut short (lchain.c:329-333) and either kernel
+ *      form fills the batch; below it the one-anchor-per-step kernel does, whose inner walk meets the candidates in the reference's
+ *      order and keeps the skip counter and its marks (round 6; MM2GB_RMQ_SKIP=ignore: exhaustive whatever the value, as before).
  *      mm2gb_rmq_chain: the batch call that is exact for EVERY read with the device carrying the load (csrc/rmq_hybrid.cpp): reads are
  *      dealt between the kernel form and the host form by estimated cost so that both finish together (a read inside a tandem array is
  *      a hundred times the median and would be one wave's alone), both run at the same time, and reads the kernel reports a tie for

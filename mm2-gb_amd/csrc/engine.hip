@@ -866,6 +866,17 @@ int Engine::chain_gpu_sliced(int64_t n_reads, const int64_t *offsets, const mm2g
 
 // Whole batch from host buffers to chains with every stage on the device: H2D of the anchors, score kernels, post-pass
 // kernels, then only offsets + chains + compacted anchors come back (the host post-pass path returns 8 B per anchor).
+// lchain.c:329-333: the skip counter grows by at most one per element of the inner tree visited, and that tree never holds more than
+// cap_rmq_size elements when it is walked (lchain.c:301-310): a limit at or above the cap can never end a walk -- INT32_MAX then, the
+// exhaustive walk both kernels have; anything below is the limit the one-anchor-per-step kernel keeps.  MM2GB_RMQ_SKIP=ignore: always
+// exhaustive, as the device path was defined through round 5 (A/B runs).
+static int rmq_skip_limit(const mm2gb_rmq_param_t &p)
+{
+	static const bool ignore = [] { const char *v = getenv("MM2GB_RMQ_SKIP"); return v && !strcmp(v, "ignore"); }();
+	if (ignore || p.max_chn_skip == INT32_MAX || (p.cap_rmq_size > 0 && p.max_chn_skip >= p.cap_rmq_size)) return INT32_MAX;
+	return p.max_chn_skip < 0 ? 0 : p.max_chn_skip;
+}
+
 int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_anchor_t *anchors, mm2gb_chains_t *out,
                       const mm2gb_rmq_param_t *rmq, int32_t *n_tied)
 {
@@ -904,7 +915,8 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 		{
 			// tile form (k_rmq_fill_tiles) unless MM2GB_RMQ_KERNEL=steps asks for the one-anchor-per-step kernel (A/B runs, tests)
 			const char *v = getenv("MM2GB_RMQ_KERNEL");
-			const bool steps = v ? !strcmp(v, "steps") : rmq_kernel == 1;
+			// (a skip limit below the size cap can end an inner walk early, lchain.c:329-333: only the one-anchor-per-step kernel walks in the reference's order)
+			const bool steps = rmq_skip_limit(*rmq) != INT32_MAX || (v ? !strcmp(v, "steps") : rmq_kernel == 1);
 			rmq_tiles_last = !steps;
 			if (!steps) {
 				if (rmq_win.ensure(nn * 16) || rmq_tree.ensure(nn * 32)) return -1;
@@ -912,7 +924,8 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			}
 		}
 		rb.skey_in = rb.skey = nullptr; rb.sa = nullptr; rb.srange = nullptr; rb.sort_tmp = nullptr; rb.sort_tmp_bytes = 0;
-		const RmqParams rp0 = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip, 0 };
+		rb.rk_a = nullptr; rb.rk_f = rb.rk_p = rb.rk_mark = nullptr; rb.rk_in = nullptr;
+		const RmqParams rp0 = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip, 0, INT32_MAX };
 		rb.strip_shift = rmq_strip_shift(rp0);
 		{
 			// scratch of the batch's key sorts (ranks by y; the strip order), and -- tile kernel, MM2GB_RMQ_STRIPS=0 turns it off for A/B runs and
@@ -924,6 +937,13 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			if (rb.tree && rb.strip_shift > 0 && !(v && atoi(v) == 0)) {
 				if (rmq_sa.ensure(nn * 16) || rmq_srange.ensure(nn * 16)) return -1;
 				rb.sa = (uint4*)rmq_sa.ptr; rb.srange = (int4*)rmq_srange.ptr;
+			}
+			if (!rb.tree && rmq_skip_limit(*rmq) != INT32_MAX) {
+				// the skip-limited walk's arrays by rank, in the tile form's scratch (not in use here): anchors in `sa`'s, scores and predecessors'
+				// ranks where the sort's input keys were (free once the (y, index) order stands), marks and walk ranges in `srange`'s
+				if (rmq_sa.ensure(nn * 16) || rmq_srange.ensure(nn * 16)) return -1;
+				rb.rk_a = (uint4*)rmq_sa.ptr; rb.rk_f = (int32_t*)rmq_skey_in.ptr; rb.rk_p = (int32_t*)rmq_skey_in.ptr + nn;
+				rb.rk_in = (int2*)rmq_srange.ptr; rb.rk_mark = (int32_t*)((char*)rmq_srange.ptr + nn * 8);
 			}
 		}
 		rb.cursor = (int32_t*)((char*)post_misc.ptr + 24); rb.grid_waves = n_cu * 32;
@@ -941,7 +961,7 @@ int Engine::chain_gpu(int64_t n_reads, const int64_t *offsets, const mm2gb_ancho
 			rb.dbg_reads = (long long*)rmq_dbg_reads.ptr;
 		}
 		const char *ties = getenv("MM2GB_RMQ_TIES");                   // strict: every tie counts (A/B runs, and what the one-anchor-per-step kernel always does)
-		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip, ties && !strcmp(ties, "strict") ? 0 : 1 };
+		const RmqParams rp = { rmq->max_dist, rmq->max_dist_inner, rmq->bw, rmq->cap_rmq_size, rmq->chn_pen_gap, rmq->chn_pen_skip, ties && !strcmp(ties, "strict") ? 0 : 1, rmq_skip_limit(*rmq) };
 		if (launch_rmq_fill(rb, rp, stream)) { (void)hipStreamSynchronize(stream); return fail("mm2gb_rmq_chain_gpu: the segmented sort of the batch's keys failed"); }
 		MM2GB_HIP(hipGetLastError());
 		last.n_anchors += n; last.n_reads += n_reads;
@@ -1537,6 +1557,18 @@ int mm2gb_post_device_totals(mm2gb_engine_t *eng, int64_t *n_chains, int64_t *n_
 // A digest of what the last post-pass on this engine left on the device (u_off, a_off, u[], a[] of result set 0), for comparing two builds or two
 // settings of the post-pass on batches too large to take through the oracle: copied to the host and folded there (position-dependent, so a
 // permutation of chains or anchors changes it).  digest[0..3]: offsets of chains, offsets of anchors, chains, anchors.
+// for tests and debugging: the scores and predecessor distances (i - p, 0 = none) the engine's LAST mm2gb_chain_gpu / mm2gb_rmq_chain_gpu call left on the device
+int mm2gb_debug_last_fill(mm2gb_engine_t *eng, int64_t n, int32_t *f, int32_t *p)
+{
+	if (!eng || n < 0 || (n > 0 && (!f || !p))) return fail("mm2gb_debug_last_fill: null argument");
+	Engine &e = eng->e;
+	const IoSet &s = e.io[(e.io_seq - 1) & 1];
+	if (e.io_seq == 0 || !s.f.ptr || !s.p.ptr) return fail("mm2gb_debug_last_fill: no call has run on this engine");
+	if (hipSetDevice(e.device) != hipSuccess || hipMemcpy(f, s.f.ptr, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(p, s.p.ptr, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+		return fail("mm2gb_debug_last_fill: copy failed");
+	return 0;
+}
+
 int mm2gb_post_device_digest(mm2gb_engine_t *eng, int64_t n_reads, uint64_t *digest)
 {
 	if (!eng || !digest) return fail("mm2gb: null argument");

@@ -66,7 +66,8 @@ void launch_post(const PostBatch &b, hipStream_t s, hipStream_t aux = nullptr, h
 
 // RMQ re-chaining (mg_lchain_rmq, lchain.c:250-369) of reads whose anchors are already chained once: score fill on the device.
 struct RmqParams { int max_dist, max_dist_inner, bw, cap_rmq_size; float pen_gap, pen_skip;
-                   int weigh_ties; };   // tile form: a tie on the smallest priority counts (n_tied) only if its holders differ in what they leave the anchor with; 0: every tie counts
+                   int weigh_ties;      // tile form: a tie on the smallest priority counts (n_tied) only if its holders differ in what they leave the anchor with; 0: every tie counts
+                   int max_skip; };     // INT_MAX: the inner walk is exhaustive (both kernels); else lchain.c:329-333's limit, one-anchor-per-step kernel only (RmqBatch::rk_*)
 struct RmqBatch {
 	const uint4   *raw;        // anchors, sorted by x within each read
 	const int64_t *offsets;
@@ -96,6 +97,12 @@ struct RmqBatch {
 	long long *dbg_reads;      // optional (MM2GB_DEBUG_PHASES), tile form: per read 8 values: anchors, waves, ticks whole / tree update / queries / broadcasts / in-tile steps, anchors broadcast (wave 0 of a team)
 	int      abandon_tied;     // tile form: a read is given up at the first tile that met a tie (its f / p are cleared: the post-pass finds nothing in it; n_tied != 0 tells the caller, who redoes the read anyway)
 	int      n_team;           // tile form: the first n_team reads of the batch are filled by a whole workgroup each (k_rmq_fill_tiles)
+	// one-anchor-per-step kernel with a skip limit (RmqParams::max_skip): the inner walk goes through the candidates in the reference's order,
+	// (y, index) downwards, so every read's anchors and what the walk needs of them are kept BY RANK (null: no skip limit)
+	uint4   *rk_a;             // scratch, n: (x, y, q_span, index) of the anchor at every rank
+	int32_t *rk_f, *rk_p;      // scratch, n each: its score and the RANK of its predecessor (-1: none), written when the anchor is settled
+	int32_t *rk_mark;          // scratch, n: lchain.c:333-338's t[], by rank: the anchor whose walk last offered this one's chain
+	int2    *rk_in;            // scratch, n: per anchor (by index) the first and last rank of its inner walk: y in [y_i - max_dist_inner, y_i - 1]
 };
 int  launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s);   // -1: a library sort refused (nothing usable was launched after it)
 size_t rmq_strip_sort_temp_bytes(int64_t n, int64_t n_reads);   // what RmqBatch::sort_tmp must hold

@@ -2095,6 +2095,34 @@ __device__ __forceinline__ uint4 rmq_block_summary(int blk, int n, int st, const
 	return e;
 }
 
+// ---- the inner walk with a skip limit (lchain.c:328-341), 64 candidates at a time in walking order (lane 0 first) ----
+// largest value among the lanes BELOW this one (INT_MIN for lane 0)
+__device__ __forceinline__ int wave_max_below(int v)
+{
+	const int l = lane();
+	for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(v, off); if (l >= off) v = max(v, o); }
+	const int ex = __shfl_up(v, 1);
+	return l == 0 ? INT_MIN : ex;
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
+{
+	for (int o = W / 2; o > 0; o >>= 1) v |= (unsigned long long)__shfl_xor((long long)v, o);
+	return v;
+}
+// The skip counter is a chain of x -> max(x - 1, 0) (a better score was met), x -> x + 1 (a candidate whose chain had been offered) and
+// x -> x: all of the form x -> max(x + a, b), closed under composition -- (a1, b1) then (a2, b2) is (a1 + a2, max(b1 + a2, b2)) --, so the
+// counter after every lane comes from a prefix scan of the lanes' (a, b).  NONE stands for "no lower bound" (far below any count).
+constexpr int SKIP_NONE = INT_MIN / 4;
+__device__ __forceinline__ int wave_skip_counts(int a, int bnd, int before)
+{
+	const int l = lane();
+	for (int off = 1; off < W; off <<= 1) {
+		const int oa = __shfl_up(a, off), ob = __shfl_up(bnd, off);
+		if (l >= off) { bnd = max(ob + a, bnd); a = oa + a; }        // the earlier lanes' step first, then this one's
+	}
+	return max(before + a, max(bnd, SKIP_NONE));
+}
+
 } // namespace
 
 // ---- preparation, one thread per anchor: the (y, index) order of every read, and what each anchor's query looks like in it ----
@@ -2148,6 +2176,32 @@ __global__ __launch_bounds__(256) void k_rmq_prep_ranges(RmqBatch b, int max_dis
 	}
 }
 
+// with a skip limit: the anchors by rank, and every anchor's inner walk as a range of ranks (k_rmq_fill)
+__global__ __launch_bounds__(256) void k_rmq_prep_skip(RmqBatch b, int max_inner)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < b.n; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r = rmq_read_of(b.offsets, b.n_reads, g);
+		const int64_t off = b.offsets[r];
+		const int n = (int)(b.offsets[r + 1] - off);
+		const ulonglong2 *z = b.by_y + off;
+		{	// g as a rank of read r
+			const int idx = (int)(unsigned)b.by_y[g].x;
+			const uint4 e = b.raw[off + idx];
+			b.rk_a[g] = make_uint4(e.x, e.z, e.w & 0xffu, (unsigned)idx);
+			b.rk_f[g] = 0; b.rk_p[g] = -1; b.rk_mark[g] = -1;
+		}
+		{	// g as an anchor of read r
+			const int yi = (int)b.raw[g].z;
+			auto first_not_below = [&](long long y) {
+				int lo = 0, hi = n;
+				while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)(z[mid].x >> 32) < y) lo = mid + 1; else hi = mid; }
+				return lo;
+			};
+			b.rk_in[g] = make_int2(first_not_below((long long)yi - max_inner), first_not_below((long long)yi) - 1);
+		}
+	}
+}
+
 // One WAVE per read, one anchor per step.  The reference's tree is ordered by (y, index) and answers "smallest priority with y in a
 // range"; here every read's anchors are ranked in that order beforehand, key[] holds the (negated) priorities by RANK -- set when an
 // anchor enters the tree -- and l1[] the largest key of every 64 consecutive ranks with its holder.  A query reads the two blocks of
@@ -2178,6 +2232,11 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 		long long *key = (long long*)b.key + off;
 		uint4 *l1 = b.l1 + (off >> 6) + r;                 // n / 64 + 1 entries of this read
 		int32_t *bound = b.bound + (off >> 6) + r;
+		const bool skip_limit = P.max_skip != INT_MAX && b.rk_a != nullptr;
+		const uint4 *rk_a = skip_limit ? b.rk_a + off : nullptr;
+		int32_t *rk_f = skip_limit ? b.rk_f + off : nullptr, *rk_p = skip_limit ? b.rk_p + off : nullptr, *rk_mark = skip_limit ? b.rk_mark + off : nullptr;
+		const int2 *rk_in = skip_limit ? b.rk_in + off : nullptr;
+		int2 cin = make_int2(0, -1);                       // current block: first and last rank of the inner walk (skip limit only)
 		int i0 = 0, st = 0, st_in = 0, ins = 0, tied = 0;
 		int d_late = 0, d_stale = 0, d_check = 0, d_l1 = 0, d_inner = 0, d_far = 0, d_evict = 0;   // MM2GB_DEBUG_PHASES
 		unsigned x0_lo = 0, x0_hi = 0;                     // x of anchor i0
@@ -2199,6 +2258,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 				}
 				ca = i + l < n ? a[i + l] : make_uint4(0, 0, 0, 0);
 				cm = i + l < n ? meta[i + l] : make_int4(0, 0, 0, 0);
+				if (skip_limit) cin = i + l < n ? rk_in[i + l] : make_int2(0, -1);
 				cf = 0; cp = 0; ck = 0;
 			}
 			const unsigned xi_lo = (unsigned)__builtin_amdgcn_readlane((int)ca.x, k), xi_hi = (unsigned)__builtin_amdgcn_readlane((int)ca.y, k);
@@ -2262,7 +2322,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 				else { e_rank = __builtin_amdgcn_readlane(prank, src); e_key = (long long)readlane64((unsigned long long)pk, src); }
 				e_sum = l1[e_rank >> 6];
 			}
-			int max_f = q_i, max_j = -1;
+			int max_f = q_i, max_j = -1, max_rank = -1;
 			RmqCand c;
 			c.ord = RMQ_NONE; c.j = -1; c.rank = -1; c.tie = 0; c.check = -1;
 			{	// not yet in the tree's arrays: straight from the registers
@@ -2339,7 +2399,7 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 					const int rr = wave_max_i32(c.ord == top ? c.rank : -1);
 					win = __ballot(c.ord == top && c.rank == rr);
 				}
-				const int bj = __builtin_amdgcn_readlane(c.j, first_set(win));
+				const int bj = __builtin_amdgcn_readlane(c.j, first_set(win)), brank = __builtin_amdgcn_readlane(c.rank, first_set(win));
 				unsigned xj; int yj, sj, fj;
 				if ((bj >> 6) == B) {
 					const int s = bj & 63;
@@ -2356,11 +2416,51 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 				}
 				bool exact; int width;
 				const int sc = fj + rmq_pair_score(xi_lo, yi, xj, yj, sj, P, exact, width);
-				if (width <= P.bw && sc > max_f) { max_f = sc; max_j = bj; }
-				max_f = uni(max_f); max_j = uni(max_j);
+				if (width <= P.bw && sc > max_f) { max_f = sc; max_j = bj; max_rank = brank; }
+				max_f = uni(max_f); max_j = uni(max_j); max_rank = uni(max_rank);
 				inner = uni((int)(!exact && max_inner > 0 && st_in < i0 && yi > 0)) != 0;
 			}
-			if (inner) {
+			if (inner && skip_limit) {
+				// lchain.c:320-341 as written: the inner tree's elements with y in [yi - max_inner, yi - 1] from the largest (y, index) down -- ranks
+				// [r_lo, r_hi] downwards, 64 per round, lane 0 the first met; those still in the inner tree (index in [st_in, i0)) and inside the
+				// band take part.  A strictly better score replaces the best and takes one off the skip counter; a candidate that does not, and whose
+				// chain this anchor has been offered already (the mark: some candidate met earlier has it as predecessor), adds one, and the walk
+				// ends when the counter passes the limit; every candidate that takes part marks its predecessor.  All of that per round by scans
+				// over the lanes (the counter: wave_skip_counts; marks inside the round: one 64-bit mask; marks for later rounds: rk_mark).
+				const int r_lo = __builtin_amdgcn_readlane(cin.x, k), r_hi = __builtin_amdgcn_readlane(cin.y, k);
+				int n_skip = 0;
+				for (int top = r_hi; top >= r_lo; top -= W) {
+					const int rk = top - l;
+					const bool have = rk >= r_lo;
+					const uint4 e = have ? rk_a[rk] : make_uint4(0, 0, 0, 0);
+					// (these three change under the walk: read past the CU's cache -- a line of it that was loaded in an earlier step does not see
+					// what this wave has stored since, and a candidate settled a dozen steps ago came back with the score it was initialised to)
+					const int fj = have ? __hip_atomic_load(rk_f + rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+					const int pr = have ? __hip_atomic_load(rk_p + rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+					const int mk = have ? __hip_atomic_load(rk_mark + rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+					const int j = (int)e.w;
+					bool ex2; int w2;
+					const int s2 = fj + rmq_pair_score(xi_lo, yi, e.x, (int)e.y, (int)e.z, P, ex2, w2);
+					const bool part = have && j >= st_in && j < i0 && w2 <= P.bw;
+					const int below = wave_max_below(part ? s2 : INT_MIN);         // (every lane takes part in the scan: not inside a short-circuit)
+					const bool better = part && s2 > max(max_f, below);
+					const int to = top - pr;                                       // the lane of this round that holds the predecessor (if any: to > l)
+					const unsigned long long offered = wave_or_u64(part && pr >= 0 && to < W ? 1ull << to : 0ull);
+					const bool again = part && !better && (mk == i || ((offered >> l) & 1));
+					const int count = wave_skip_counts(better ? -1 : again ? 1 : 0, better ? 0 : SKIP_NONE, n_skip);
+					const unsigned long long ends = __ballot(again && count > P.max_skip);
+					const int upto = ends ? first_set(ends) : W;                   // lanes below `upto` were met before the walk ended
+					const unsigned long long got = __ballot(better) & (upto < W ? (1ull << upto) - 1 : ~0ull);
+					if (got) {
+						const int last = 63 - first_set_from_top(got);             // every better one replaced the one before: the last stands
+						max_f = __builtin_amdgcn_readlane(s2, last); max_j = __builtin_amdgcn_readlane(j, last); max_rank = __builtin_amdgcn_readlane(rk, last);
+					}
+					if (ends) break;
+					n_skip = __builtin_amdgcn_readlane(count, W - 1);
+					if (part && pr >= 0 && to >= W) __hip_atomic_store(rk_mark + pr, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a predecessor has a lower rank: it comes in a later round, or never)
+					wave_sync();
+				}
+			} else if (inner) {
 				// lchain.c:320-341: every inner-tree element with y in [yi - max_inner, yi - 1], from the largest (y, index) down; strict '>'
 				// keeps the first of equal scores, i.e. the largest (y, index), and nothing replaces the outer result without beating it
 				int bs = max_f, cj = -1, cy = 0;
@@ -2418,6 +2518,10 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 				cf = max_f;
 				cp = max_j < 0 ? 0 : i - max_j;
 				ck = key_order((double)max_f + half_gap * (double)((int)xi_lo + yi));
+				if (skip_limit) {                                                                      // (the next step's loads come after a wave_sync)
+					__hip_atomic_store(rk_f + cm.x, max_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(rk_p + cm.x, max_j < 0 ? -1 : max_rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			}
 		}
 		if (n > 0) {
@@ -3802,7 +3906,14 @@ int launch_rmq_fill(const RmqBatch &b, const RmqParams &P, hipStream_t s)
 		const int64_t singles = std::max<int64_t>(0, b.n_reads - b.n_team);
 		const unsigned grid_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>((singles + per_t - 1) / per_t, b.n_team), (int64_t)b.grid_waves / per_t));   // a workgroup per team read
 		hipLaunchKernelGGL(k_rmq_fill_tiles, dim3(grid_t), dim3(RMQ_THREADS), 0, s, b, P);
-	} else hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);   // one anchor per step (MM2GB_RMQ_KERNEL=steps)
+	} else {
+		// one anchor per step (MM2GB_RMQ_KERNEL=steps; and every call with a skip limit: its inner walk goes through the candidates by rank)
+		if (P.max_skip != INT_MAX && b.rk_a) {
+			const int max_inner = (P.max_dist_inner <= 0 || P.max_dist_inner >= max_dist) ? 0 : P.max_dist_inner;
+			hipLaunchKernelGGL(k_rmq_prep_skip, dim3(wide), dim3(256), 0, s, b, max_inner);
+		}
+		hipLaunchKernelGGL(k_rmq_fill, dim3(grid), dim3(POST_THREADS), 0, s, b, P);
+	}
 	return 0;
 }
 

@@ -15,6 +15,7 @@
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include "engine.h"
@@ -52,7 +53,10 @@ bool rechain_ahead_is_exact(const mm2gb_mapopt_head_t &opt)
 	// lchain.c:329-333: n_skip grows by at most one per element of the inner tree visited, and that tree never holds more than cap_rmq_size
 	// elements when it is queried (lchain.c:296-304): with max_chn_skip >= the cap the break cannot happen and the scan is exhaustive, which
 	// is what the kernel computes.  (--max-chain-skip=infinity parses to 0 in the reference, SURVEY F2: not exact, answered per call by the host form.)
-	return opt.rmq_size_cap > 0 && opt.max_chain_skip >= opt.rmq_size_cap;
+	// Round 6: below the cap the one-anchor-per-step kernel keeps the counter (its inner walk goes through the candidates in the reference's
+	// order, post_kernels.hip k_rmq_fill), so a batch is answered ahead at any max_chain_skip; MM2GB_RMQ_SKIP=ignore takes that walk away again.
+	static const bool no_limit_walk = [] { const char *v = getenv("MM2GB_RMQ_SKIP"); return v && !strcmp(v, "ignore"); }();
+	return !no_limit_walk || (opt.rmq_size_cap > 0 && opt.max_chain_skip >= opt.rmq_size_cap);
 }
 
 int rechain_ahead(mm2gb_engine_t *eng, const mm2gb_mapopt_head_t &opt, const mm2gb_misc_t &misc, const RechainRead *reads, int n_reads,

@@ -590,7 +590,9 @@ bool rmq_fill_one(const mm2gb_rmq_param_t &P, int64_t n64, const mm2gb_anchor_t 
 				// pick (priorities come from f[] alone), and without a skip limit neither does the inner walk -- its best is the first
 				// candidate, in walking order, to reach the walk's largest score, wherever the walk started from below that.
 				++ws.ties_met;
-				if (P.max_chn_skip != INT32_MAX || weigh_ties == 0) { ++ws.ties_that_decide; return false; }
+				// (a skip limit that can end a walk -- one below the tree's size cap, lchain.c:301-310, 329-333 -- makes the walk depend on where it started)
+				const bool limit_can_end_a_walk = P.max_chn_skip != INT32_MAX && !(P.cap_rmq_size > 0 && P.max_chn_skip >= P.cap_rmq_size);
+				if (limit_can_end_a_walk || weigh_ties == 0) { ++ws.ties_that_decide; return false; }
 				int in_f = q_i, in_j = -1;
 				if (inner_there) inner_scan(in_f, in_j);
 				tree.holders_of(i, -((double)f[j] + half_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y)), ws.holders);

@@ -143,7 +143,10 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 	// device's share; with them the tile kernel takes 1.8 s and more of the reads, profiles/r03_rmq_teams.txt.)
 	{
 		const char *v = getenv("MM2GB_RMQ_KERNEL");
-		const bool use_steps = v && !strcmp(v, "steps");
+		// a skip limit that can end an inner walk (below the size cap, lchain.c:329-333): the one-anchor-per-step kernel, which keeps the counter
+		const char *sk = getenv("MM2GB_RMQ_SKIP");
+		const bool limited = !(sk && !strcmp(sk, "ignore")) && prm->max_chn_skip != INT32_MAX && !(prm->cap_rmq_size > 0 && prm->max_chn_skip >= prm->cap_rmq_size);
+		const bool use_steps = limited || (v && !strcmp(v, "steps"));
 		if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
 		// tile kernel: the reads that would set the device's pace get a whole workgroup each (there are far fewer reads than the chip holds waves)
 		// -- those whose time is the sweeps and inner scans, which a team's helpers share.  Measured on the mapper's reads: the slowest

@@ -474,7 +474,9 @@ static int rmq_tie_decides(const orc_rmq_param_t *prm, const orc_anchor_t *a, co
 	int32_t in_f = q_span, width, exact, sc, res_f = 0;
 	int64_t in_j = -1, res_j = -1, j, nc = 0, k;
 	int first = 1;
-	if (prm->max_chn_skip != INT32_MAX) return 1;
+	/* (a limit at or above the tree's size cap can never end a walk: the counter grows by at most one per element visited, and the inner tree
+	 * holds at most cap_rmq_size elements when it is walked, lchain.c:301-310) */
+	if (prm->max_chn_skip != INT32_MAX && !(prm->cap_rmq_size > 0 && prm->max_chn_skip >= prm->cap_rmq_size)) return 1;
 	if (inner_there) {
 		for (j = st_inner; j < i0; ++j) {
 			const int32_t yj = (int32_t)a[j].y;

@@ -236,9 +236,10 @@ def test_rechaining_answered_ahead_for_the_whole_batch(tmp_path, threads, post):
 
 
 @needs_host
-def test_rechaining_ahead_stays_off_at_a_finite_max_chain_skip(tmp_path):
-    """max_chain_skip below the tree's size cap: the reference's skip counter can end an inner scan early (lchain.c:329-333), which the
-    exhaustive device form does not reproduce -- the calls are answered one by one by the host form, as before."""
+def test_rechaining_ahead_at_a_finite_max_chain_skip(tmp_path):
+    """max_chain_skip below the tree's size cap (minimap2's default is 25): the reference's skip counter can end an inner walk early (lchain.c:329-333).
+    Round 6: the one-anchor-per-step kernel keeps the counter, so a batch's calls are answered ahead here too -- the PAF equals the one of a run in
+    which every call is answered on the spot by the host form --, and with MM2GB_RMQ_SKIP=ignore (no such walk on the device) nothing is answered ahead."""
     import json
     import re
     import sim_reads
@@ -246,8 +247,18 @@ def test_rechaining_ahead_stays_off_at_a_finite_max_chain_skip(tmp_path):
     meta = json.load(open(os.path.join(GOLD, "sim160.json")))
     ref, reads = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
     sim_reads.simulate(ref, reads, seed=meta["seed"], n_reads=48, len_lo=meta["len_lo"], len_hi=meta["len_hi"], tandem=meta["tandem"])
-    env = dict(os.environ, MM2GB_REPORT="1", MM2GB_PRECHAIN="1")
-    r = subprocess.run([host_rmq, "-t", "1", "--max-chain-skip=25", "--gpu-chain", "--gpu-cfg", CFG, ref, reads], capture_output=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    m = re.search(r"in (\d+) calls \| re-chaining ahead of the callback [0-9.]+ s for (\d+) reads, (\d+) calls answered from it", r.stderr.decode())
-    assert m and int(m.group(1)) > 10 and int(m.group(2)) == 0 and int(m.group(3)) == 0
+    pat = r"in (\d+) calls \| re-chaining ahead of the callback [0-9.]+ s for (\d+) reads, (\d+) calls answered from it"
+    out = {}
+    for flag in ("--max-chain-skip=25", "--max-chain-skip=0"):
+        for mode in ("ahead", "off"):
+            env = dict(os.environ, MM2GB_REPORT="1", MM2GB_PRECHAIN="1")
+            if mode == "off":
+                env["MM2GB_RMQ_SKIP"] = "ignore"
+            r = subprocess.run([host_rmq, "-t", "1", flag, "--gpu-chain", "--gpu-cfg", CFG, ref, reads], capture_output=True, timeout=900, env=env)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            m = re.search(pat, r.stderr.decode())
+            assert m and int(m.group(1)) > 10, r.stderr.decode()[-800:]
+            out[flag, mode] = (r.stdout.decode(), int(m.group(1)), int(m.group(2)), int(m.group(3)))
+        assert out[flag, "off"][2] == 0 and out[flag, "off"][3] == 0
+        assert out[flag, "ahead"][3] >= 0.9 * out[flag, "ahead"][1]
+        assert out[flag, "ahead"][0] == out[flag, "off"][0]

@@ -36,10 +36,10 @@ def first_pass(a):
 @pytest.mark.parametrize("path", CASES, ids=golden_io.case_ids(CASES))
 def test_reference_vectors(engine, path):
     g = golden_io.load_rmq(path)
-    if g["prm"].max_chn_skip != orc.INT32_MAX:
-        pytest.skip("recorded with a finite max_chn_skip; the device path is exhaustive by contract")
     res, tied, _ = engine.rmq_chain(g["a"], np.array([0, len(g["a"])], np.int64), to_lib(g["prm"]))
     o = orc.lchain_rmq(g["a"], g["prm"])
+    # (a vector recorded with a skip limit is filled by the one-anchor-per-step kernel, which keeps the limit and counts every tie -- as the oracle's
+    # n_decide does under a limit)
     assert o["n_tied"] == g["tied"] and int(tied[0]) == o["n_decide"]
     if o["n_decide"] == 0:
         # no tie, or only ties whose holders all leave the anchor with the same score and predecessor: the reference's chains, whatever its tree picked
@@ -69,13 +69,15 @@ def test_batch_against_the_oracle(engine, monkeypatch, kernel):
     o2 = np.zeros(len(reads) + 1, dtype=np.int64)
     o2[1:] = np.cumsum([len(x) for x in reads])
     allr = np.concatenate(reads)
-    for kw in (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05))):
+    for kw in (dict(), dict(cap_rmq_size=64), dict(max_dist_inner=0), dict(bw=300, max_dist=1500, max_dist_inner=200), dict(pen_gap=np.float32(0.3), pen_skip=np.float32(0.05)),
+               dict(max_chn_skip=25), dict(max_chn_skip=3, bw=300, max_dist=1500, max_dist_inner=200), dict(max_chn_skip=0), dict(max_chn_skip=1, cap_rmq_size=64)):
         prm = orc.default_rmq_param(**kw)
         res, tied, st = engine.rmq_chain(allr, o2, to_lib(prm))
         n_with_ties = 0
+        limited = "max_chn_skip" in kw                  # a skip limit below the size cap: the one-anchor-per-step kernel whatever was asked for
         for r, x in enumerate(reads):
             o = orc.lchain_rmq(x, prm)
-            assert int(tied[r]) == counted(o, kernel), (kw, r)
+            assert int(tied[r]) == counted(o, "steps" if limited else kernel), (kw, r)
             n_with_ties += o["n_tied"] > 0
             assert np.array_equal(res[r][0], o["u"]) and np.array_equal(res[r][1], o["a_out"]), (kw, r)
         assert n_with_ties >= 1 and st["ms_post"] > 0
@@ -213,10 +215,13 @@ def test_fuzz_random_reads_and_parameters(engine, monkeypatch):
         max_dist = int(rng.choice([300, 1500, 5000, 20000, 70000]))
         bw = int(rng.choice([100, 500, 2000, 20000]))
         kw = dict(max_dist=max_dist, bw=bw, max_dist_inner=int(rng.choice([0, 90, 200, 1000, 3000])), cap_rmq_size=int(rng.choice([0, 50, 100000])),
-                  pen_gap=np.float32(rng.choice([0.12, 0.3, 0.8])), pen_skip=np.float32(rng.choice([0.0, 0.05])))
+                  pen_gap=np.float32(rng.choice([0.12, 0.3, 0.8])), pen_skip=np.float32(rng.choice([0.0, 0.05])),
+                  max_chn_skip=int(rng.choice([orc.INT32_MAX, orc.INT32_MAX, 0, 1, 5, 25, 60])))
         prm = orc.default_rmq_param(**kw)
         kernel = "tiles" if rng.random() < 0.8 else "steps"
         monkeypatch.setenv("MM2GB_RMQ_KERNEL", kernel)
+        if kw["max_chn_skip"] != orc.INT32_MAX and not (kw["cap_rmq_size"] > 0 and kw["max_chn_skip"] >= kw["cap_rmq_size"]):
+            kernel = "steps"                             # a skip limit that can end a walk: the one-anchor-per-step kernel takes the call
         monkeypatch.setenv("MM2GB_RMQ_TEAM_READS", str(int(rng.choice([0, 2, 1000000]))))
         monkeypatch.setenv("MM2GB_RMQ_STRIPS", str(int(rng.random() < 0.7)))
         res, tied, _ = engine.rmq_chain(allr, o2, to_lib(prm))
