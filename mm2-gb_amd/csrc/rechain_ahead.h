@@ -29,8 +29,9 @@ struct RechainRead { const mm2gb_anchor_t *a; const uint64_t *u; int n_u, n_seg,
 // map.c:444-446: does post_chaining_helper re-chain this read?  (single-segment long reads whose best chain covers little of the read)
 bool rechain_wanted(const mm2gb_mapopt_head_t &opt, const RechainRead &rd);
 
-// True when the device form of the fill gives mg_lchain_rmq's answer for these options: it is exhaustive (max_chn_skip = infinity), and the
-// reference's skip counter (lchain.c:329-333) can never pass a max_chain_skip that is at least the tree's size cap.
+// True when the device form of the fill gives mg_lchain_rmq's answer for these options.  Round 6: always -- the reference's skip counter
+// (lchain.c:329-333) can never pass a max_chain_skip that is at least the tree's size cap (the exhaustive walk, either kernel), and below
+// the cap the one-anchor-per-step kernel keeps the counter -- unless MM2GB_RMQ_SKIP=ignore takes that walk away.
 bool rechain_ahead_is_exact(const mm2gb_mapopt_head_t &opt);
 
 // Decide, gather, sort as the host will (radix_sort_128x order, equal keys included), then ONE mm2gb_rmq_chain for the batch

@@ -147,7 +147,12 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		const char *sk = getenv("MM2GB_RMQ_SKIP");
 		const bool limited = !(sk && !strcmp(sk, "ignore")) && prm->max_chn_skip != INT32_MAX && !(prm->cap_rmq_size > 0 && prm->max_chn_skip >= prm->cap_rmq_size);
 		const bool use_steps = limited || (v && !strcmp(v, "steps"));
-		if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
+		if (limited) {
+			// the skip-limited walk ends after a few dozen candidates whatever the window holds: a step is the kernel's base cost and a round or two
+			// of 64 ranks -- 9 us an anchor on the longest read of profiles/experiments/rmq_skip_rate.py (the exhaustive one-anchor-per-step form: 7.5),
+			// and the host form is a quarter slower with the marks (0.62 against 0.48 us an anchor)
+			for (size_t r = 0; r < R; ++r) { cost[r].dev = 9.0e-6 * (double)(offsets[r + 1] - offsets[r]); cost[r].host *= 1.25; }
+		} else if (use_steps) for (size_t r = 0; r < R; ++r) cost[r].dev = cost[r].dev_steps;
 		// tile kernel: the reads that would set the device's pace get a whole workgroup each (there are far fewer reads than the chip holds waves)
 		// -- those whose time is the sweeps and inner scans, which a team's helpers share.  Measured on the mapper's reads: the slowest
 		// single-wave reads spend 1.5-1.9 s of 1.6-1.9 s in them (2-4 M anchors each, profiles/r03_rmq_teams.txt).  (Round 5: a team also
