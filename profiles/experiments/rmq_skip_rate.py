@@ -13,9 +13,10 @@ with mm.Engine() as e:
     reads = [orc.radix_sort_x(x[1]) if len(x[1]) else x[1] for x in first]
     o2 = np.zeros(len(reads) + 1, np.int64); o2[1:] = np.cumsum([len(x) for x in reads])
     allr = np.concatenate(reads)
-    for kernel, skip in (("tiles", orc.INT32_MAX), ("steps", orc.INT32_MAX), ("steps", 25), ("steps", 0), ("steps", 1000)):
+    for kernel, skip, kw in (("tiles", orc.INT32_MAX, {}), ("steps", orc.INT32_MAX, {}), ("steps", 25, {}), ("steps", 0, {}), ("steps", 1000, {}), ("steps", 25, dict(max_dist_inner=0)), ("tiles", orc.INT32_MAX, dict(max_dist_inner=0))):
         os.environ["MM2GB_RMQ_KERNEL"] = kernel
-        prm = mm.default_rmq_param(max_chn_skip=skip)
+        prm = mm.default_rmq_param(max_chn_skip=skip, **kw)
+        if kw: print(kw, end=" ")
         best = None
         for _ in range(2):
             res, tied, st = e.rmq_chain(allr, o2, prm)
