@@ -2096,30 +2096,46 @@ __device__ __forceinline__ uint4 rmq_block_summary(int blk, int n, int st, const
 }
 
 // ---- the inner walk with a skip limit (lchain.c:328-341), 64 candidates at a time in walking order (lane 0 first) ----
+// Its scans over the lanes go by DPP inside the rows of 16 lanes (a shift is a vector instruction, not a trip through the LDS crossbar -- a round of
+// the walk had ~30 of those behind each other) and by three scalar reads of the rows' last lanes across them.
+template <int CTRL> __device__ __forceinline__ int dpp_or(int v, int otherwise) { return __builtin_amdgcn_update_dpp(otherwise, v, CTRL, 0xf, 0xf, false); }   // lanes without a source keep `otherwise`
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138;
 // largest value among the lanes BELOW this one (INT_MIN for lane 0)
 __device__ __forceinline__ int wave_max_below(int v)
 {
-	const int l = lane();
-	for (int off = 1; off < W; off <<= 1) { const int o = __shfl_up(v, off); if (l >= off) v = max(v, o); }
-	const int ex = __shfl_up(v, 1);
-	return l == 0 ? INT_MIN : ex;
+	v = max(v, dpp_or<DPP_ROW_SHR + 1>(v, INT_MIN)); v = max(v, dpp_or<DPP_ROW_SHR + 2>(v, INT_MIN));
+	v = max(v, dpp_or<DPP_ROW_SHR + 4>(v, INT_MIN)); v = max(v, dpp_or<DPP_ROW_SHR + 8>(v, INT_MIN));
+	const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = max(t0, __builtin_amdgcn_readlane(v, 31)), t2 = max(t1, __builtin_amdgcn_readlane(v, 47));
+	const int row = lane() >> 4;
+	v = max(v, row == 0 ? INT_MIN : row == 1 ? t0 : row == 2 ? t1 : t2);
+	return dpp_or<DPP_WAVE_SHR1>(v, INT_MIN);
 }
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned x)
 {
-	for (int o = W / 2; o > 0; o >>= 1) v |= (unsigned long long)__shfl_xor((long long)v, o);
-	return v;
+	int v = (int)x;
+	v |= dpp_or<DPP_ROW_SHR + 1>(v, 0); v |= dpp_or<DPP_ROW_SHR + 2>(v, 0); v |= dpp_or<DPP_ROW_SHR + 4>(v, 0); v |= dpp_or<DPP_ROW_SHR + 8>(v, 0);
+	return (unsigned)(__builtin_amdgcn_readlane(v, 15) | __builtin_amdgcn_readlane(v, 31) | __builtin_amdgcn_readlane(v, 47) | __builtin_amdgcn_readlane(v, 63));
 }
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) { return (unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32 | wave_or_u32((unsigned)v); }
 // The skip counter is a chain of x -> max(x - 1, 0) (a better score was met), x -> x + 1 (a candidate whose chain had been offered) and
 // x -> x: all of the form x -> max(x + a, b), closed under composition -- (a1, b1) then (a2, b2) is (a1 + a2, max(b1 + a2, b2)) --, so the
 // counter after every lane comes from a prefix scan of the lanes' (a, b).  NONE stands for "no lower bound" (far below any count).
 constexpr int SKIP_NONE = INT_MIN / 4;
 __device__ __forceinline__ int wave_skip_counts(int a, int bnd, int before)
 {
-	const int l = lane();
-	for (int off = 1; off < W; off <<= 1) {
-		const int oa = __shfl_up(a, off), ob = __shfl_up(bnd, off);
-		if (l >= off) { bnd = max(ob + a, bnd); a = oa + a; }        // the earlier lanes' step first, then this one's
-	}
+	// (the earlier lanes' step first, then this one's)
+#define MM2GB_SKIP_STEP(N) { const int oa = dpp_or<DPP_ROW_SHR + N>(a, 0), ob = dpp_or<DPP_ROW_SHR + N>(bnd, SKIP_NONE); bnd = max(ob + a, bnd); a = oa + a; }
+	MM2GB_SKIP_STEP(1) MM2GB_SKIP_STEP(2) MM2GB_SKIP_STEP(4) MM2GB_SKIP_STEP(8)
+#undef MM2GB_SKIP_STEP
+	// the rows before this lane's: their last lanes' (a, b), composed in order
+	const int a0 = __builtin_amdgcn_readlane(a, 15), b0 = __builtin_amdgcn_readlane(bnd, 15);
+	const int ra1 = __builtin_amdgcn_readlane(a, 31), rb1 = __builtin_amdgcn_readlane(bnd, 31);
+	const int ra2 = __builtin_amdgcn_readlane(a, 47), rb2 = __builtin_amdgcn_readlane(bnd, 47);
+	const int a1 = a0 + ra1, b1 = max(b0 + ra1, rb1);               // rows 0 and 1
+	const int a2 = a1 + ra2, b2 = max(b1 + ra2, rb2);               // rows 0 .. 2
+	const int row = lane() >> 4;
+	const int pa = row == 0 ? 0 : row == 1 ? a0 : row == 2 ? a1 : a2, pb = row == 0 ? SKIP_NONE : row == 1 ? b0 : row == 2 ? b1 : b2;
+	bnd = max(pb + a, bnd); a = pa + a;
 	return max(before + a, max(bnd, SKIP_NONE));
 }
 
@@ -2432,9 +2448,9 @@ __global__ __launch_bounds__(POST_THREADS) void k_rmq_fill(RmqBatch b, RmqParams
 				for (int top = r_hi; top >= r_lo; top -= W) {
 					const int rk = top - l;
 					const bool have = rk >= r_lo;
+					// (scores, predecessors and marks change under the walks: they are read past the CU's cache.  Tried: the first round's four loads
+					// asked for at the start of the step, under the outer query -- 266 -> 264 ms on profiles/experiments/rmq_skip_rate.py: not kept)
 					const uint4 e = have ? rk_a[rk] : make_uint4(0, 0, 0, 0);
-					// (these three change under the walk: read past the CU's cache -- a line of it that was loaded in an earlier step does not see
-					// what this wave has stored since, and a candidate settled a dozen steps ago came back with the score it was initialised to)
 					const int fj = have ? __hip_atomic_load(rk_f + rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 					const int pr = have ? __hip_atomic_load(rk_p + rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
 					const int mk = have ? __hip_atomic_load(rk_mark + rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
