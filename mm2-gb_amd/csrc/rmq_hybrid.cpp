@@ -137,16 +137,15 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 		work();
 		for (auto &th : pool) th.join();
 	}
+	// (a skip limit that can end an inner walk -- below the size cap, lchain.c:329-333 --: the one-anchor-per-step kernel, which keeps the counter)
+	const bool limited = [&] { const char *sk = getenv("MM2GB_RMQ_SKIP"); return !(sk && !strcmp(sk, "ignore")) && prm->max_chn_skip != INT32_MAX && !(prm->cap_rmq_size > 0 && prm->max_chn_skip >= prm->cap_rmq_size); }();
+	const bool steps_kernel = [&] { const char *kv = getenv("MM2GB_RMQ_KERNEL"); return limited || (kv && !strcmp(kv, "steps")); }();
 	// Which device form: the tile kernel (64 anchors per step of a wave, a whole workgroup on the reads whose inner windows hold thousands of
 	// anchors) unless MM2GB_RMQ_KERNEL=steps asks for the one-anchor-per-step kernel.  (Round 3, before the workgroup reads: the step kernel won
 	// on the mapper's batches -- windows of many hundreds of anchors, every chain of a read interleaved along x -- 2.25 s against 2.5 s for the
 	// device's share; with them the tile kernel takes 1.8 s and more of the reads, profiles/r03_rmq_teams.txt.)
 	{
-		const char *v = getenv("MM2GB_RMQ_KERNEL");
-		// a skip limit that can end an inner walk (below the size cap, lchain.c:329-333): the one-anchor-per-step kernel, which keeps the counter
-		const char *sk = getenv("MM2GB_RMQ_SKIP");
-		const bool limited = !(sk && !strcmp(sk, "ignore")) && prm->max_chn_skip != INT32_MAX && !(prm->cap_rmq_size > 0 && prm->max_chn_skip >= prm->cap_rmq_size);
-		const bool use_steps = limited || (v && !strcmp(v, "steps"));
+		const bool use_steps = steps_kernel;
 		if (limited) {
 			// the skip-limited walk ends after a few dozen candidates whatever the window holds: a step is the kernel's base cost and a round or two
 			// of 64 ranks -- 9 us an anchor on the longest read of profiles/experiments/rmq_skip_rate.py (the exhaustive one-anchor-per-step form: 7.5),
@@ -196,7 +195,7 @@ int rmq_chain_impl(mm2gb_engine_t *eng, const mm2gb_rmq_param_t *prm, int64_t n_
 			++n_host;
 		}
 	const double est_host_s = std::max(host_max, host_sum / nt), est_dev_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0;
-	if (deal) { memset(deal, 0, sizeof(*deal)); { const char *kv = getenv("MM2GB_RMQ_KERNEL"); deal->device_kernel = kv && !strcmp(kv, "steps") ? 1 : 0; } deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
+	if (deal) { memset(deal, 0, sizeof(*deal)); deal->device_kernel = steps_kernel ? 1 : 0; deal->n_host_cost = (int64_t)n_host; deal->n_device = (int64_t)(R - n_host); deal->est_host_s = std::max(host_max, host_sum / nt); deal->est_device_s = n_host < R ? launch_s + std::max(cost[(size_t)by_dev[n_host]].dev, dev_sum / slots) : 0; }
 
 	const double s_estimate = seconds_since(t0);
 	double s_gather = 0, s_merge = 0;
