@@ -614,6 +614,32 @@ def test_unchecked_sweep_rejects_what_the_range_test_would(monkeypatch, kw):
         check_batch(e, a, off, prm)
 
 
+def test_edge_blocks_with_the_window_test_from_a_prefix_mask(monkeypatch):
+    """MM2GB_EDGE=new (off by default: profiles/r06_narrow_ab.txt): edge blocks of tiles whose window starts rise from lane to lane take "source inside this
+    target's window" from a scalar prefix mask per source instead of a vector compare (chain_kernels.hip, sweep_block_lut_edge_sorted).  Narrow windows --
+    every block of a 60-anchor window is an edge block --, several reads per chunk (starts jump), runs of equal positions, and the dense clouds of the
+    test above: same f / p as the default build, and both equal the oracle's."""
+    a1, o1 = mm.synth_reads(71, 0, 60, 10_000, 30_000)
+    parts = [a1[o1[r]:o1[r + 1]] for r in range(60)]
+    parts += [band_cloud(9000, 321, xwin=9000, jitter=700), band_cloud(6000, 323, xwin=900, jitter=250, r0=7_000_000), sc.read_like(9000, 324),
+              sc.sort_by_x(np.concatenate([sc.repeat_block(5000, 325), sc.colinear(600, 326)]))]
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    a = np.concatenate(parts)
+    prm = orc.default_param()
+    with mm.Engine() as e:
+        check_batch(e, a, off, prm)
+        f0, p0, _ = e.score(a, off)
+    monkeypatch.setenv("MM2GB_EDGE", "new")
+    for no_coop in (False, True):
+        if no_coop:
+            monkeypatch.setenv("MM2GB_NO_COOP", "1")                  # every chunk by one wave
+        with mm.Engine() as e:
+            check_batch(e, a, off, prm)
+            f1, p1, _ = e.score(a, off)
+        assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
+
+
 def test_without_the_lds_contract_the_checked_builds_run(monkeypatch):
     """Engine::init probes what the unchecked sweeps rely on (reads beyond a workgroup's LDS return 0, v_sad_u32 clamp saturates).
     MM2GB_LDS_PROBE=0 stands for a device where the probe fails: clamped table, every range test, same results."""
